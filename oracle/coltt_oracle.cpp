@@ -1,0 +1,941 @@
+// coltt_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A plain C++ restatement of the reference's (sjy-dv/coltt @ 2025-03-28) ANN search hot path.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+// the product (libcoltt_gpu.so) never links, loads or calls it.
+//
+// PARITY PIN: the reference's own tests pin no numerical search result (SURVEY.md §0 finding 10,
+// §8c), the Go toolchain is absent, so the Go path cannot be run here.  What IS pinned:
+//   * the distance kernels (orc_l2 / orc_cosine, order=avx|sse) are checked bit-for-bit against the
+//     reference's own pkg/distance/simd/cpp/{avx,sse}.cpp compiled from where they lie
+//     (oracle/_ref/libcoltt_ref_simd.so, recipe oracle/Makefile) — tests/test_oracle_ref.py;
+//   * the codecs are checked against IEEE binary16 (numpy float16) over all 65 536 codes / random f32;
+//   * FNV-1a against Python's own restatement of hash/fnv.
+// Everything above that (heaps, FLAT scan, HNSW) is a line-by-line restatement with the reference
+// file:line cited on every function; for those layers parity is "unpinned by the reference" and the
+// golden fixtures under tests/golden/ are produced by this oracle.
+//
+// Build: see oracle/Makefile  (-O2 -mavx -mno-fma -ffp-contract=off : same instruction mix and
+// summation order as pkg/distance/simd/avx/AVX_amd64.s).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#if defined(__clang__) || defined(__GNUC__)
+typedef float v8f __attribute__((vector_size(32)));
+typedef float v4f __attribute__((vector_size(16)));
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// pkg/distance — summation orders
+// ------------------------------------------------------------------------------------------------
+enum { ORDER_AVX = 0, ORDER_SSE = 1, ORDER_NATIVE = 2 };
+
+// _sum_vector for __m256: hadd,hadd, lane0+lane4  (pkg/distance/simd/cpp/avx.cpp:4-8)
+static inline float hsum8(const v8f& v) {
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+// _sum_vector for __m128: v0+v1+v2+v3 left to right (pkg/distance/simd/cpp/sse.cpp:3-6)
+static inline float hsum4(const v4f& v) { return ((v[0] + v[1]) + v[2]) + v[3]; }
+
+static inline v8f ld8(const float* p) { v8f r; std::memcpy(&r, p, 32); return r; }
+static inline v4f ld4(const float* p) { v4f r; std::memcpy(&r, p, 16); return r; }
+
+// euclidean_distance_squared (avx.cpp:15-32 / sse.cpp:13-33); native_impl.go:23-30
+static float l2sq(int order, const float* a, const float* b, size_t len) {
+  if (order == ORDER_AVX) {
+    v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0, n8 = (len / 8) * 8;
+    for (; i < n8; i += 8) { v8f d = ld8(a + i) - ld8(b + i); v8f m = d * d; acc = acc + m; }
+    float r = hsum8(acc);
+    for (; i < len; i++) { float d = a[i] - b[i]; r += d * d; }
+    return r;
+  } else if (order == ORDER_SSE) {
+    v4f acc = {0, 0, 0, 0};
+    size_t i = 0, n4 = (len / 4) * 4;
+    for (; i < n4; i += 4) { v4f d = ld4(a + i) - ld4(b + i); v4f m = d * d; acc = acc + m; }
+    float r = hsum4(acc);
+    for (; i < len; i++) { float d = a[i] - b[i]; r += d * d; }
+    return r;
+  }
+  float r = 0;
+  for (size_t i = 0; i < len; i++) { float d = a[i] - b[i]; r += d * d; }
+  return r;
+}
+
+// cosine_similarity_dot_norm (avx.cpp:51-75 / sse.cpp:54-82); native_impl.go:41-52
+static void cos_parts(int order, const float* a, const float* b, size_t len, float* dot, float* na,
+                      float* nb) {
+  if (order == ORDER_AVX) {
+    v8f d = {0, 0, 0, 0, 0, 0, 0, 0}, x = d, y = d;
+    size_t i = 0, n8 = (len / 8) * 8;
+    for (; i < n8; i += 8) {
+      v8f v1 = ld8(a + i), v2 = ld8(b + i);
+      v8f p = v1 * v2; d = d + p;
+      v8f q = v1 * v1; x = x + q;
+      v8f r = v2 * v2; y = y + r;
+    }
+    float ds = hsum8(d), xs = hsum8(x), ys = hsum8(y);
+    for (; i < len; i++) { ds += a[i] * b[i]; xs += a[i] * a[i]; ys += b[i] * b[i]; }
+    *dot = ds; *na = xs; *nb = ys;
+  } else if (order == ORDER_SSE) {
+    v4f d = {0, 0, 0, 0}, x = d, y = d;
+    size_t i = 0, n4 = (len / 4) * 4;
+    for (; i < n4; i += 4) {
+      v4f v1 = ld4(a + i), v2 = ld4(b + i);
+      v4f p = v1 * v2; d = d + p;
+      v4f q = v1 * v1; x = x + q;
+      v4f r = v2 * v2; y = y + r;
+    }
+    float ds = hsum4(d), xs = hsum4(x), ys = hsum4(y);
+    for (; i < len; i++) { ds += a[i] * b[i]; xs += a[i] * a[i]; ys += b[i] * b[i]; }
+    *dot = ds; *na = xs; *nb = ys;
+  } else {
+    float ds = 0, xs = 0, ys = 0;
+    for (size_t i = 0; i < len; i++) { ds += a[i] * b[i]; xs += a[i] * a[i]; ys += b[i] * b[i]; }
+    *dot = ds; *na = xs; *nb = ys;
+  }
+}
+
+// gomath.Sqrt: float32(math.Sqrt(float64(x)))  (pkg/gomath/math.go:48-50)
+static inline float go_sqrt(float x) { return (float)std::sqrt((double)x); }
+// gomath.Abs: float32(math.Abs(float64(x)))     (pkg/gomath/math.go:35-37)
+static inline float go_abs(float x) { return (float)std::fabs((double)x); }
+
+// Euclidean.Distance -> impl.EuclideanDistance (space.go:61-63; AVX_amd64.go:28-32; native_impl.go:23-30)
+static float dist_l2(int order, const float* a, const float* b, size_t len) {
+  return go_sqrt(l2sq(order, a, b, len));
+}
+// Cosine.Distance = Abs(impl.CosineDistance) (space.go:93-95; AVX_amd64.go:46-52; native_impl.go:41-52)
+static float dist_cos(int order, const float* a, const float* b, size_t len) {
+  float dot, na, nb;
+  cos_parts(order, a, b, len, &dot, &na, &nb);
+  float d;
+  if (order == ORDER_NATIVE) d = 1.0f - dot / (go_sqrt(na) * go_sqrt(nb));
+  else { float nsq = na * nb; d = 1.0f - dot / go_sqrt(nsq); }
+  return go_abs(d);
+}
+enum { METRIC_COS = 0, METRIC_L2 = 1 };  // edgepb.Distance order (idl/proto/v4/edge.proto:70-73)
+static inline float dist(int metric, int order, const float* a, const float* b, size_t len) {
+  return metric == METRIC_COS ? dist_cos(order, a, b, len) : dist_l2(order, a, b, len);
+}
+
+// Normalize (edge/vectorstore.go:173-189 == core/vectorindex/metadata.go:107-123)
+static void normalize(const float* v, float* out, size_t len) {
+  float norm = 0;
+  for (size_t i = 0; i < len; i++) norm += v[i] * v[i];
+  if (norm == 0) { for (size_t i = 0; i < len; i++) out[i] = 0; return; }
+  norm = go_sqrt(norm);
+  for (size_t i = 0; i < len; i++) out[i] = v[i] / norm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pkg/compresshelper — codecs
+// ------------------------------------------------------------------------------------------------
+static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// f16bitsToF32bits (float16.go:237-272) == BF16bitsToF32bits (bf16.go:233-268)
+static uint32_t f16bits_to_f32bits(uint16_t in) {
+  uint32_t sign = (uint32_t)(in & 0x8000) << 16;
+  uint32_t exp = (uint32_t)(in & 0x7c00) >> 10;
+  uint32_t coef = (uint32_t)(in & 0x03ff) << 13;
+  if (exp == 0x1f) {
+    if (coef == 0) return sign | 0x7f800000u | coef;
+    return sign | 0x7fc00000u | coef;
+  }
+  if (exp == 0) {
+    if (coef == 0) return sign;
+    exp++;
+    while ((coef & 0x7f800000u) == 0) { coef <<= 1; exp--; }
+    coef &= 0x007fffffu;
+  }
+  return sign | ((exp + (0x7f - 0xf)) << 23) | coef;
+}
+// f32bitsToF16bits (float16.go:276-321) == f32bitsToBF16bits (bf16.go:272-317)
+static uint16_t f32bits_to_f16bits(uint32_t u32) {
+  uint32_t sign = u32 & 0x80000000u, exp = u32 & 0x7f800000u, coef = u32 & 0x007fffffu;
+  if (exp == 0x7f800000u) {
+    uint32_t nanBit = coef != 0 ? 0x0200u : 0u;
+    return (uint16_t)((sign >> 16) | 0x7c00u | nanBit | (coef >> 13));
+  }
+  uint32_t halfSign = sign >> 16;
+  int32_t unbiasedExp = (int32_t)(exp >> 23) - 127;
+  int32_t halfExp = unbiasedExp + 15;
+  if (halfExp >= 0x1f) return (uint16_t)(halfSign | 0x7c00u);
+  if (halfExp <= 0) {
+    if (14 - halfExp > 24) return (uint16_t)halfSign;
+    uint32_t c = coef | 0x00800000u;
+    uint32_t halfCoef = c >> (uint32_t)(14 - halfExp);
+    uint32_t roundBit = 1u << (uint32_t)(13 - halfExp);
+    if ((c & roundBit) != 0 && (c & (3 * roundBit - 1)) != 0) halfCoef++;
+    return (uint16_t)(halfSign | halfCoef);
+  }
+  uint32_t uHalfExp = (uint32_t)halfExp << 10;
+  uint32_t halfCoef = coef >> 13;
+  uint32_t roundBit = 0x00001000u;
+  if ((coef & roundBit) != 0 && (coef & (3 * roundBit - 1)) != 0)
+    return (uint16_t)((halfSign | uHalfExp | halfCoef) + 1);
+  return (uint16_t)(halfSign | uHalfExp | halfCoef);
+}
+// F8bitsToF32bits (float8.go:233-266).  NB `(in&0x7c)>>10` is always 0 and the subnormal loop runs on
+// a uint32 `exp` that wraps — restated with the same unsigned arithmetic.
+static uint32_t f8bits_to_f32bits(uint8_t in) {
+  uint32_t sign = (uint32_t)(in & 0x80) << 8;
+  uint32_t exp = (uint32_t)(in & 0x7c) >> 10;
+  uint32_t coef = (uint32_t)(in & 0x03) << 13;
+  if (exp == 0x1f) {
+    if (coef == 0) return sign | 0x7f800000u | coef;
+    return sign | 0x7fc00000u | coef;
+  }
+  if (exp == 0) {
+    if (coef == 0) return sign;
+    exp++;
+    while ((coef & 0x7f800000u) == 0) { coef <<= 1; exp--; }
+    coef &= 0x007fffffu;
+  }
+  return sign | ((exp + (0x7f - 0xf)) << 23) | coef;
+}
+// f32bitsToF8bits (float8.go:270-313): the fp16 algorithm with `sign = u32 & 0x800000` and every
+// return truncated to uint8.
+static uint8_t f32bits_to_f8bits(uint32_t u32) {
+  uint32_t sign = u32 & 0x800000u, exp = u32 & 0x7f800000u, coef = u32 & 0x007fffffu;
+  if (exp == 0x7f800000u) {
+    uint32_t nanBit = coef != 0 ? 0x0200u : 0u;
+    return (uint8_t)((sign >> 8) | 0x7cu | nanBit | (coef >> 13));
+  }
+  uint32_t halfSign = sign >> 8;
+  int32_t unbiasedExp = (int32_t)(exp >> 23) - 127;
+  int32_t halfExp = unbiasedExp + 15;
+  if (halfExp >= 0x1f) return (uint8_t)(halfSign | 0x7cu);
+  if (halfExp <= 0) {
+    if (14 - halfExp > 24) return (uint8_t)halfSign;
+    uint32_t c = coef | 0x00800000u;
+    uint32_t halfCoef = c >> (uint32_t)(14 - halfExp);
+    uint32_t roundBit = 1u << (uint32_t)(13 - halfExp);
+    if ((c & roundBit) != 0 && (c & (3 * roundBit - 1)) != 0) halfCoef++;
+    return (uint8_t)(halfSign | halfCoef);
+  }
+  uint32_t uHalfExp = (uint32_t)halfExp << 10;
+  uint32_t halfCoef = coef >> 13;
+  uint32_t roundBit = 0x00001000u;
+  if ((coef & roundBit) != 0 && (coef & (3 * roundBit - 1)) != 0)
+    return (uint8_t)((halfSign | uHalfExp | halfCoef) + 1);
+  return (uint8_t)(halfSign | uHalfExp | halfCoef);
+}
+
+enum { Q_NONE = 0, Q_F16 = 1, Q_F8 = 2, Q_BF16 = 3 };  // edgepb.Quantization (edge.proto:75-80)
+static inline size_t quant_bytes(int q) { return q == Q_NONE ? 4 : (q == Q_F8 ? 1 : 2); }
+
+// Quantization.Lower (edge/quantization.go:47-49; f16_quantization.go:47-53; f8_…:45-51; bf16_…:45-51)
+static void lower(int q, const float* v, size_t len, uint8_t* out) {
+  if (q == Q_NONE) { std::memcpy(out, v, len * 4); return; }
+  if (q == Q_F8) { for (size_t i = 0; i < len; i++) out[i] = f32bits_to_f8bits(f2u(v[i])); return; }
+  uint16_t* o = (uint16_t*)out;
+  for (size_t i = 0; i < len; i++) o[i] = f32bits_to_f16bits(f2u(v[i]));
+}
+// the decode half of Quantization.Similarity (f16_quantization.go:35-45 etc.)
+static void raise(int q, const uint8_t* in, size_t len, float* out) {
+  if (q == Q_NONE) { std::memcpy(out, in, len * 4); return; }
+  if (q == Q_F8) { for (size_t i = 0; i < len; i++) out[i] = u2f(f8bits_to_f32bits(in[i])); return; }
+  const uint16_t* p = (const uint16_t*)in;
+  for (size_t i = 0; i < len; i++) out[i] = u2f(f16bits_to_f32bits(p[i]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// pkg/sharding
+// ------------------------------------------------------------------------------------------------
+// ShardVertex (pkg/sharding/shard.go:34-41): hash/fnv New64a over the 8 little-endian bytes of id.
+static uint64_t shard_vertex(uint64_t x, uint64_t c) {
+  uint64_t h = 14695981039346656037ull;
+  for (int i = 0; i < 8; i++) { h ^= (x >> (8 * i)) & 0xff; h *= 1099511628211ull; }
+  return h % c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pkg/distancepq — avo-generated FMA kernels (asm/dot.s:7-55, asm/euclidean.s:7-65)
+// ------------------------------------------------------------------------------------------------
+static float pq_dot(const float* x, const float* y, size_t len) {
+  float acc[4][8] = {};
+  size_t i = 0;
+  for (; len - i >= 32; i += 32)
+    for (int r = 0; r < 4; r++)
+      for (int j = 0; j < 8; j++) acc[r][j] = std::fmaf(x[i + 8 * r + j], y[i + 8 * r + j], acc[r][j]);
+  float tail = 0;  // X4 lane 0; VFMADD231SS
+  for (; i < len; i++) tail = std::fmaf(x[i], y[i], tail);
+  float s[8];
+  for (int j = 0; j < 8; j++) s[j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+  float t[4];
+  for (int j = 0; j < 4; j++) t[j] = s[j] + s[j + 4];  // VEXTRACTF128 + VADDPS
+  t[0] = t[0] + tail;                                  // VADDPS X0, X4 (X4 = {tail,0,0,0})
+  t[1] = t[1] + 0.0f; t[2] = t[2] + 0.0f; t[3] = t[3] + 0.0f;
+  float h0 = t[0] + t[1], h1 = t[2] + t[3];            // VHADDPS
+  return h0 + h1;                                      // VHADDPS
+}
+static float pq_l2sq(const float* x, const float* y, size_t len) {
+  float acc[4][8] = {};
+  size_t i = 0;
+  for (; len - i >= 32; i += 32)
+    for (int r = 0; r < 4; r++)
+      for (int j = 0; j < 8; j++) {
+        float d = x[i + 8 * r + j] - y[i + 8 * r + j];
+        acc[r][j] = std::fmaf(d, d, acc[r][j]);
+      }
+  float tail = 0;
+  for (; i < len; i++) { float d = x[i] - y[i]; tail = std::fmaf(d, d, tail); }
+  float s[8];
+  for (int j = 0; j < 8; j++) s[j] = ((acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j];
+  float t[4];
+  for (int j = 0; j < 4; j++) t[j] = s[j] + s[j + 4];
+  t[0] = t[0] + tail; t[1] = t[1] + 0.0f; t[2] = t[2] + 0.0f; t[3] = t[3] + 0.0f;
+  float h0 = t[0] + t[1], h1 = t[2] + t[3];
+  return h0 + h1;
+}
+// puredist.go:20-35
+static float pq_dot_pure(const float* x, const float* y, size_t len) {
+  float s = 0; for (size_t i = 0; i < len; i++) s += x[i] * y[i]; return s;
+}
+static float pq_l2sq_pure(const float* x, const float* y, size_t len) {
+  float s = 0; for (size_t i = 0; i < len; i++) { float d = x[i] - y[i]; s += d * d; } return s;
+}
+// hammingDistance / jaccardDistance (pkg/distancepq/distance.go:62-84)
+static float pq_hamming(const uint64_t* x, const uint64_t* y, size_t n) {
+  long d = 0; for (size_t i = 0; i < n; i++) d += __builtin_popcountll(x[i] ^ y[i]); return (float)d;
+}
+static float pq_jaccard(const uint64_t* x, const uint64_t* y, size_t n) {
+  long in = 0, un = 0;
+  for (size_t i = 0; i < n; i++) { in += __builtin_popcountll(x[i] & y[i]); un += __builtin_popcountll(x[i] | y[i]); }
+  if (un == 0) return 0;
+  return 1 - (float)in / (float)un;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Go container/heap (go1.23 src/container/heap/heap.go) — Init/Push/Pop/up/down restated.
+// Call sites: core/vectorindex/priority_queue.go:57-99; edge/priorityqueue/priority_queue.go:57-98.
+// ------------------------------------------------------------------------------------------------
+struct PQItem { float prio; int64_t val; };
+template <bool MAX> struct GoHeap {
+  std::vector<PQItem> a;
+  // minPriorityQueue.Less: a[i].prio < a[j].prio ; maxPriorityQueue.Less: > (priority_queue.go:161-163,183-185)
+  inline bool less(int i, int j) const { return MAX ? a[i].prio > a[j].prio : a[i].prio < a[j].prio; }
+  void up(int j) {
+    for (;;) {
+      int i = (j - 1) / 2;
+      if (i == j || !less(j, i)) break;
+      std::swap(a[i], a[j]);
+      j = i;
+    }
+  }
+  bool down(int i0, int n) {
+    int i = i0;
+    for (;;) {
+      int j1 = 2 * i + 1;
+      if (j1 >= n || j1 < 0) break;
+      int j = j1;
+      int j2 = j1 + 1;
+      if (j2 < n && less(j2, j1)) j = j2;
+      if (!less(j, i)) break;
+      std::swap(a[i], a[j]);
+      i = j;
+    }
+    return i > i0;
+  }
+  void init() { int n = (int)a.size(); for (int i = n / 2 - 1; i >= 0; i--) down(i, n); }
+  void push(PQItem x) { a.push_back(x); up((int)a.size() - 1); }
+  PQItem pop() {
+    int n = (int)a.size() - 1;
+    std::swap(a[0], a[n]);
+    down(0, n);
+    PQItem x = a.back();
+    a.pop_back();
+    return x;
+  }
+  const PQItem& peek() const { return a[0]; }  // Peek = ToSlice()[0] (priority_queue.go:101-107)
+  int len() const { return (int)a.size(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Canonical total order used wherever the reference's outcome depends on Go map iteration order or
+// on heap/sort tie handling: key = (score bits as f32 compare, then 64-bit tiebreak).
+// ------------------------------------------------------------------------------------------------
+struct Scored { float score; uint64_t tie; };
+static inline bool scored_less(const Scored& x, const Scored& y) {
+  if (x.score < y.score) return true;
+  if (y.score < x.score) return false;
+  return x.tie < y.tie;
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge FLAT store  (edge/none_vectorstore.go, f16_/f8_/bf16_vectorstore.go)
+// ------------------------------------------------------------------------------------------------
+struct Flat {
+  uint32_t dim; int metric; int quant; int order;
+  // vertices[shard] : id -> stored (lowered) vector bytes.  std::map gives the canonical
+  // ascending-id iteration that stands in for Go's random map order.
+  std::map<uint64_t, std::vector<uint8_t>> shards[16];
+};
+
+// {none,f16,f8,bf16}VecSpace.ChangedVertex, vector part (none_vectorstore.go:86-101; f16_…:87-105)
+static int flat_upsert(Flat* f, uint64_t id, const float* vec) {
+  std::vector<float> tmp(f->dim);
+  const float* v = vec;
+  if (f->metric == METRIC_COS) { normalize(vec, tmp.data(), f->dim); v = tmp.data(); }
+  std::vector<uint8_t> low(f->dim * quant_bytes(f->quant));
+  lower(f->quant, v, f->dim, low.data());
+  f->shards[shard_vertex(id, 16)][id] = std::move(low);
+  return 0;
+}
+
+// Quantization.Similarity (quantization.go:43-45; f16_quantization.go:35-45): decode BOTH, then Distance
+static float flat_similarity(const Flat* f, const uint8_t* x, const uint8_t* y, float* bx, float* by) {
+  if (f->quant == Q_NONE) return dist(f->metric, f->order, (const float*)x, (const float*)y, f->dim);
+  raise(f->quant, x, f->dim, bx);
+  raise(f->quant, y, f->dim, by);
+  return dist(f->metric, f->order, bx, by, f->dim);
+}
+
+// edge.PriorityQueue (edge/priority_queue.go:33-69): min-heap, pop-min when over capacity => keeps the
+// K LARGEST scores; ToSlice sorts ascending.  `nearest` flips to a max-heap (the useful direction; not
+// reference behaviour).
+struct EdgePQ {
+  GoHeap<false> mn; GoHeap<true> mx; int maxSize; bool nearest;
+  void add(float score, uint64_t id) {
+    if (!nearest) { mn.push({score, (int64_t)id}); if (mn.len() > maxSize) mn.pop(); }
+    else { mx.push({score, (int64_t)id}); if (mx.len() > maxSize) mx.pop(); }
+  }
+  std::vector<PQItem> to_slice() const {
+    std::vector<PQItem> r = nearest ? mx.a : mn.a;
+    // sort.Slice is an unstable pdqsort; tie order is unspecified in the reference.  stable_sort here.
+    std::stable_sort(r.begin(), r.end(), [](const PQItem& x, const PQItem& y) { return x.prio < y.prio; });
+    return r;
+  }
+};
+
+// mode 0: literal, highCpu=false (none_vectorstore.go:135-147)
+// mode 1: literal, highCpu=true  (none_vectorstore.go:148-178): 16 local queues -> global queue
+// mode 2: canonical closed form: the K extreme (score,id) pairs, ascending — what the GPU computes.
+// cand/n_cand != null: FilterableVertexSearch's candidate walk (none_vectorstore.go:192-252)
+static int flat_search(const Flat* f, const float* query, int topK, int nearest, int mode, bool use_cand,
+                       const uint64_t* cand, size_t n_cand, uint64_t* out_ids, float* out_scores) {
+  std::vector<float> q(f->dim), bx(f->dim), by(f->dim);
+  if (f->metric == METRIC_COS) normalize(query, q.data(), f->dim);
+  else std::memcpy(q.data(), query, f->dim * 4);
+  std::vector<uint8_t> low(f->dim * quant_bytes(f->quant));
+  lower(f->quant, q.data(), f->dim, low.data());  // f16_vectorstore.go:136 — the QUERY is lowered too
+
+  std::vector<std::vector<uint64_t>> shard_cand(16);
+  if (use_cand) for (size_t i = 0; i < n_cand; i++) shard_cand[shard_vertex(cand[i], 16)].push_back(cand[i]);
+
+  auto scan_shard = [&](int s, auto&& emit) {
+    if (use_cand) {
+      for (uint64_t id : shard_cand[s]) {
+        auto it = f->shards[s].find(id);
+        if (it == f->shards[s].end()) continue;
+        emit(id, flat_similarity(f, low.data(), it->second.data(), bx.data(), by.data()));
+      }
+    } else {
+      for (auto& kv : f->shards[s])
+        emit(kv.first, flat_similarity(f, low.data(), kv.second.data(), bx.data(), by.data()));
+    }
+  };
+
+  std::vector<PQItem> res;
+  if (mode == 2) {
+    std::vector<Scored> all;
+    for (int s = 0; s < 16; s++) scan_shard(s, [&](uint64_t id, float sc) { all.push_back({sc, id}); });
+    std::sort(all.begin(), all.end(), scored_less);
+    size_t n = all.size(), k = std::min((size_t)std::max(topK, 0), n);
+    size_t lo = nearest ? 0 : n - k;
+    for (size_t i = 0; i < k; i++) res.push_back({all[lo + i].score, (int64_t)all[lo + i].tie});
+  } else if (mode == 0) {
+    EdgePQ pq; pq.maxSize = topK; pq.nearest = nearest;
+    for (int s = 0; s < 16; s++) scan_shard(s, [&](uint64_t id, float sc) { pq.add(sc, id); });
+    res = pq.to_slice();
+  } else {
+    EdgePQ pq; pq.maxSize = topK; pq.nearest = nearest;
+    std::vector<std::vector<PQItem>> local(16);
+    for (int s = 0; s < 16; s++) {
+      EdgePQ lp; lp.maxSize = topK; lp.nearest = nearest;
+      scan_shard(s, [&](uint64_t id, float sc) { lp.add(sc, id); });
+      local[s] = lp.to_slice();
+    }
+    for (int s = 0; s < 16; s++) for (auto& it : local[s]) pq.add(it.prio, (uint64_t)it.val);
+    res = pq.to_slice();
+  }
+  for (size_t i = 0; i < res.size(); i++) { out_ids[i] = (uint64_t)res[i].val; out_scores[i] = res[i].prio; }
+  return (int)res.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+// core/vectorindex HNSW
+// ------------------------------------------------------------------------------------------------
+struct HnswCfg {  // hnsw_config.go:135-162
+  int32_t m, mMax, mMax0, ef, efConstruction, algo /*0 simple,1 heuristic*/;
+  float levelMultiplier;
+  int32_t extendCandidates, keepPruned;
+};
+struct Edge { int32_t to; float d; };  // hnswEdgeSet entry (hnsw_vertex.go:27)
+struct Vertex {                          // hnswVertex (hnsw_vertex.go:29-39)
+  uint64_t id; int level; bool deleted;
+  std::vector<float> own;                // reference-shaped: one heap allocation per vector
+  const float* vec;                      // == own.data(), or a view into a caller-owned matrix
+  // edges[l]: kept sorted by `to` (insertion index) — the canonical stand-in for Go map order.
+  std::vector<std::vector<Edge>> edges;
+};
+struct HnswStats { uint64_t n_dist, n_exp, n_hops; };
+struct Hnsw {
+  uint32_t dim; int metric; int order; HnswCfg cfg;
+  std::vector<Vertex> v;                         // slot = insertion index (never reused)
+  std::unordered_map<uint64_t, int32_t> by_id;   // live vertices only (the 16 sharded maps, hnsw.go:49-50)
+  int32_t entry = -1; uint64_t len = 0;
+  bool canon_build = false;  // Insert/prune use the canonical closed forms (what the GPU builder runs)
+  HnswStats st{};
+  float D(const float* a, const float* b) { st.n_dist++; return dist(metric, order, a, b, dim); }
+};
+
+static void edge_set(std::vector<Edge>& es, int32_t to, float d) {  // map[k]=v
+  auto it = std::lower_bound(es.begin(), es.end(), to, [](const Edge& e, int32_t t) { return e.to < t; });
+  if (it != es.end() && it->to == to) it->d = d; else es.insert(it, {to, d});
+}
+static void edge_del(std::vector<Edge>& es, int32_t to) {
+  auto it = std::lower_bound(es.begin(), es.end(), to, [](const Edge& e, int32_t t) { return e.to < t; });
+  if (it != es.end() && it->to == to) es.erase(it);
+}
+
+// greedyClosestNeighbor (hnsw.go:320-343)
+static void greedy(Hnsw* h, const float* q, int32_t& ep, float& minD, int level) {
+  for (;;) {
+    int32_t closest = -1;
+    for (const Edge& e : h->v[ep].edges[level]) {
+      const Vertex& n = h->v[e.to];
+      if (n.deleted) continue;
+      float d = h->D(q, n.vec);
+      if (d < minD) { minD = d; closest = e.to; }
+    }
+    h->st.n_hops++;
+    if (closest < 0) break;
+    ep = closest;
+  }
+}
+
+// searchLevel (hnsw.go:345-389), literal: Go heaps, stale lowerBound, canonical neighbour order.
+static GoHeap<true> search_level_literal(Hnsw* h, const float* q, int32_t ep, int ef, int level) {
+  float epd = h->D(q, h->v[ep].vec);
+  GoHeap<false> cand; GoHeap<true> res;
+  cand.push({epd, ep}); res.push({epd, ep});
+  std::unordered_set<int32_t> visited; visited.reserve((size_t)ef * h->cfg.mMax0);
+  visited.insert(ep);
+  while (cand.len() > 0) {
+    PQItem c = cand.pop();
+    float lowerBound = res.peek().prio;
+    if (c.prio > lowerBound) break;
+    h->st.n_exp++;
+    for (const Edge& e : h->v[c.val].edges[level]) {
+      const Vertex& n = h->v[e.to];
+      if (n.deleted) continue;
+      if (!visited.insert(e.to).second) continue;
+      float d = h->D(q, n.vec);
+      if (d < lowerBound || res.len() < ef) {
+        cand.push({d, e.to}); res.push({d, e.to});
+        if (res.len() > ef) res.pop();
+      }
+    }
+  }
+  return res;
+}
+
+// searchLevel, canonical closed form: result set = sorted array with an `expanded`
+// flag, key (distance, slot); the candidate queue is "the unexpanded members of the result set";
+// per popped candidate, in canonical neighbour order, the first (ef-len0) eligible neighbours are
+// admitted unconditionally, the rest iff d < lowerBound sampled before the loop; then keep the ef
+// smallest.  This is the algorithm the HIP kernel runs.  Equal to the literal form whenever no two
+// distinct vertices have bit-equal distances to the query.
+struct RItem { float d; int32_t slot; bool expanded; };
+static inline bool ritem_less(const RItem& a, const RItem& b) {
+  if (a.d < b.d) return true;
+  if (b.d < a.d) return false;
+  return a.slot < b.slot;
+}
+static std::vector<RItem> search_level_canon(Hnsw* h, const float* q, int32_t ep, int ef, int level) {
+  std::vector<RItem> res;
+  res.push_back({h->D(q, h->v[ep].vec), ep, false});
+  std::unordered_set<int32_t> visited; visited.insert(ep);
+  std::vector<RItem> adm;
+  for (;;) {
+    int ci = -1;
+    for (int i = 0; i < (int)res.size(); i++) if (!res[i].expanded) { ci = i; break; }
+    if (ci < 0) break;
+    res[ci].expanded = true;
+    float lowerBound = res.back().d;
+    int len0 = (int)res.size();
+    int32_t c = res[ci].slot;
+    h->st.n_exp++;
+    adm.clear();
+    int free_slots = ef - len0;
+    for (const Edge& e : h->v[c].edges[level]) {
+      const Vertex& n = h->v[e.to];
+      if (n.deleted) continue;
+      if (!visited.insert(e.to).second) continue;
+      float d = h->D(q, n.vec);
+      if (free_slots > 0) { adm.push_back({d, e.to, false}); free_slots--; }
+      else if (d < lowerBound) adm.push_back({d, e.to, false});
+    }
+    for (auto& a : adm) res.insert(std::upper_bound(res.begin(), res.end(), a, ritem_less), a);
+    if ((int)res.size() > ef) res.resize(ef);
+  }
+  return res;
+}
+
+// selectNeighbors (hnsw.go:391-397)
+static void select_simple(GoHeap<true>& nb, int k) { while (nb.len() > k) nb.pop(); }
+
+// selectNeighborsHeuristic (hnsw.go:399-447) with extendCandidates=false (true is rejected: the
+// reference's Reverse() aliases the backing array — SURVEY.md §0 finding 8).  candidateVertices =
+// neighbors.Reverse(): the SAME array re-typed as a min-heap and heap.Init'ed (priority_queue.go:109-122).
+static GoHeap<true> select_heuristic(GoHeap<true>& nb, int k, bool keepPruned) {
+  GoHeap<false> cand; cand.a = nb.a; cand.init();
+  GoHeap<true> result;
+  while (cand.len() > 0 && result.len() < k) result.push(cand.pop());
+  if (keepPruned) { while (cand.len() > 0) { if (result.len() >= k) break; result.push(cand.pop()); } }
+  return result;
+}
+
+// pruneNeighbors (hnsw.go:449-474)
+static void prune(Hnsw* h, int32_t vi, int k, int level) {
+  if (h->canon_build) {  // k nearest by (stored distance, slot); Simple == Heuristic(extend=false)
+    std::vector<RItem> all;
+    for (const Edge& e : h->v[vi].edges[level]) { if (h->v[e.to].deleted) continue; all.push_back({e.d, e.to, false}); }
+    std::sort(all.begin(), all.end(), ritem_less);
+    if ((int)all.size() > k) all.resize(k);
+    std::vector<Edge> ne;
+    for (auto& r : all) ne.push_back({r.slot, r.d});
+    std::sort(ne.begin(), ne.end(), [](const Edge& a, const Edge& b) { return a.to < b.to; });
+    h->v[vi].edges[level] = std::move(ne);
+    return;
+  }
+  GoHeap<true> nq;
+  for (const Edge& e : h->v[vi].edges[level]) { if (h->v[e.to].deleted) continue; nq.push({e.d, e.to}); }
+  if (h->cfg.algo == 0) select_simple(nq, k); else nq = select_heuristic(nq, k, h->cfg.keepPruned);
+  std::vector<Edge> ne;
+  for (auto& it : nq.a) ne.push_back({(int32_t)it.val, it.prio});
+  std::sort(ne.begin(), ne.end(), [](const Edge& a, const Edge& b) { return a.to < b.to; });
+  h->v[vi].edges[level] = std::move(ne);
+}
+
+// Hnsw.Insert (hnsw.go:104-167).  Returns 0 ok, -2 ItemAlreadyExistsError (hnsw.go:293-295).
+static int hnsw_insert(Hnsw* h, uint64_t id, const float* value, int vertexLevel, bool view) {
+  if (h->by_id.count(id)) return -2;
+  Vertex nv; nv.id = id; nv.deleted = false;
+  if (h->metric == METRIC_COS || !view) {
+    nv.own.resize(h->dim);
+    if (h->metric == METRIC_COS) normalize(value, nv.own.data(), h->dim);
+    else std::memcpy(nv.own.data(), value, h->dim * 4);
+  }
+  int32_t vi = (int32_t)h->v.size();
+  if (h->entry < 0) {  // first vertex is forced to level 0 (hnsw.go:108-117)
+    nv.level = 0; nv.edges.resize(1);
+    h->v.push_back(std::move(nv));
+    h->v[vi].vec = h->v[vi].own.empty() ? value : h->v[vi].own.data();
+    h->by_id[id] = vi; h->len++; h->entry = vi;
+    return 0;
+  }
+  nv.level = vertexLevel; nv.edges.resize(vertexLevel + 1);
+  h->v.push_back(std::move(nv));
+  h->v[vi].vec = h->v[vi].own.empty() ? value : h->v[vi].own.data();
+  h->by_id[id] = vi; h->len++;
+  const float* vec = h->v[vi].vec;
+
+  int32_t ep = h->entry;
+  float minD = h->D(vec, h->v[ep].vec);
+  for (int l = h->v[ep].level; l > vertexLevel; l--) greedy(h, vec, ep, minD, l);
+
+  for (int l = std::min(h->v[ep].level, vertexLevel); l >= 0; l--) {
+    GoHeap<true> nb;
+    if (h->canon_build) {
+      std::vector<RItem> r = search_level_canon(h, vec, ep, h->cfg.efConstruction, l);
+      if ((int)r.size() > h->cfg.m) r.resize(h->cfg.m);
+      for (auto& x : r) nb.a.push_back({x.d, x.slot});  // ascending array; popped back-to-front below
+    } else nb = search_level_literal(h, vec, ep, h->cfg.efConstruction, l);
+    if (h->canon_build) {
+      int mMaxc = l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
+      for (int i = (int)nb.a.size() - 1; i >= 0; i--) {  // farthest first, nearest last (next entrypoint)
+        int32_t ni = (int32_t)nb.a[i].val; ep = ni;
+        edge_set(h->v[vi].edges[l], ni, nb.a[i].prio);
+        edge_set(h->v[ni].edges[l], vi, nb.a[i].prio);
+        if ((int)h->v[ni].edges[l].size() > mMaxc) prune(h, ni, mMaxc, l);
+      }
+      continue;
+    }
+    if (h->cfg.algo == 0) select_simple(nb, h->cfg.m); else nb = select_heuristic(nb, h->cfg.m, h->cfg.keepPruned);
+    int mMax = l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
+    while (nb.len() > 0) {
+      PQItem it = nb.pop();
+      int32_t ni = (int32_t)it.val;
+      ep = ni;
+      edge_set(h->v[vi].edges[l], ni, it.prio);
+      edge_set(h->v[ni].edges[l], vi, it.prio);
+      if ((int)h->v[ni].edges[l].size() > mMax) prune(h, ni, mMax, l);
+    }
+  }
+  if (h->entry >= 0 && h->v[vi].level > h->v[h->entry].level) h->entry = vi;
+  return 0;
+}
+
+// Hnsw.Remove (hnsw.go:191-241).  Returns 0 ok, -3 ItemNotFoundError.
+static int hnsw_remove(Hnsw* h, uint64_t id) {
+  auto it = h->by_id.find(id);
+  if (it == h->by_id.end()) return -3;
+  int32_t vi = it->second;
+  h->by_id.erase(it); h->len--; h->v[vi].deleted = true;  // removeVertex (hnsw.go:304-318)
+  if (h->entry == vi) {
+    float minD = 3.40282346638528859811704183484516925440e+38f;  // gomath.MaxFloat
+    int32_t closest = -1;
+    for (int l = h->v[vi].level; l >= 0; l--) {
+      for (const Edge& e : h->v[vi].edges[l]) if (e.d < minD) { minD = e.d; closest = e.to; }
+      if (closest >= 0) break;
+    }
+    h->entry = closest;
+  }
+  for (int l = h->v[vi].level; l >= 0; l--) {
+    int mMax = l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
+    std::vector<int32_t> nbs;
+    for (const Edge& e : h->v[vi].edges[l]) nbs.push_back(e.to);
+    for (int32_t ni : nbs) { edge_del(h->v[ni].edges[l], vi); prune(h, ni, mMax, l); }
+  }
+  return 0;
+}
+
+// Hnsw.Search (hnsw.go:243-278).  mode 0 literal, 1 canonical.  Result ascending by distance.
+static int hnsw_search(Hnsw* h, const float* query, int k, int mode, int ef_override,
+                       uint64_t* out_ids, float* out_scores, int32_t* out_slots) {
+  std::vector<float> qn;
+  const float* q = query;
+  if (h->metric == METRIC_COS) { qn.resize(h->dim); normalize(query, qn.data(), h->dim); q = qn.data(); }
+  if (h->entry < 0) return 0;
+  int32_t ep = h->entry;
+  float minD = h->D(q, h->v[ep].vec);
+  for (int l = h->v[ep].level; l > 0; l--) greedy(h, q, ep, minD, l);
+  int ef = std::max(ef_override > 0 ? ef_override : h->cfg.ef, k);
+  int n = 0;
+  if (mode == 0) {
+    GoHeap<true> nb = search_level_literal(h, q, ep, ef, 0);
+    if (h->cfg.algo == 0) select_simple(nb, k); else nb = select_heuristic(nb, k, h->cfg.keepPruned);
+    n = std::min(k, nb.len());
+    for (int i = n - 1; i >= 0; i--) {
+      PQItem it = nb.pop();
+      out_ids[i] = h->v[it.val].id; out_scores[i] = it.prio; if (out_slots) out_slots[i] = (int32_t)it.val;
+    }
+  } else {
+    std::vector<RItem> res = search_level_canon(h, q, ep, ef, 0);
+    n = std::min(k, (int)res.size());
+    for (int i = 0; i < n; i++) {
+      out_ids[i] = h->v[res[i].slot].id; out_scores[i] = res[i].d; if (out_slots) out_slots[i] = res[i].slot;
+    }
+  }
+  return n;
+}
+
+static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
+  const uint8_t* b = (const uint8_t*)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// splitmix64 counter RNG
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C API (ctypes)
+// ================================================================================================
+extern "C" {
+
+float orc_l2(int order, const float* a, const float* b, size_t d) { return dist_l2(order, a, b, d); }
+float orc_cosine(int order, const float* a, const float* b, size_t d) { return dist_cos(order, a, b, d); }
+float orc_l2sq(int order, const float* a, const float* b, size_t d) { return l2sq(order, a, b, d); }
+void orc_cosine_parts(int order, const float* a, const float* b, size_t d, float* dot, float* na, float* nb) {
+  cos_parts(order, a, b, d, dot, na, nb);
+}
+void orc_normalize(const float* v, float* out, size_t d) { normalize(v, out, d); }
+// one query against n contiguous rows (the contiguous CPU-baseline shape)
+void orc_dist_rows(int metric, int order, const float* q, const float* rows, size_t n, size_t d, float* out) {
+  for (size_t i = 0; i < n; i++) out[i] = dist(metric, order, q, rows + i * d, d);
+}
+
+void orc_f16_encode(const float* in, uint16_t* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = f32bits_to_f16bits(f2u(in[i])); }
+void orc_f16_decode(const uint16_t* in, float* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = u2f(f16bits_to_f32bits(in[i])); }
+void orc_f8_encode(const float* in, uint8_t* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = f32bits_to_f8bits(f2u(in[i])); }
+void orc_f8_decode(const uint8_t* in, float* out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = u2f(f8bits_to_f32bits(in[i])); }
+void orc_lower(int quant, const float* v, size_t d, uint8_t* out) { lower(quant, v, d, out); }
+void orc_raise(int quant, const uint8_t* in, size_t d, float* out) { raise(quant, in, d, out); }
+
+uint64_t orc_shard_vertex(uint64_t id, uint64_t c) { return shard_vertex(id, c); }
+
+float orc_pq_dot(const float* x, const float* y, size_t n) { return pq_dot(x, y, n); }
+float orc_pq_l2sq(const float* x, const float* y, size_t n) { return pq_l2sq(x, y, n); }
+float orc_pq_dot_pure(const float* x, const float* y, size_t n) { return pq_dot_pure(x, y, n); }
+float orc_pq_l2sq_pure(const float* x, const float* y, size_t n) { return pq_l2sq_pure(x, y, n); }
+float orc_pq_hamming(const uint64_t* x, const uint64_t* y, size_t n) { return pq_hamming(x, y, n); }
+float orc_pq_jaccard(const uint64_t* x, const uint64_t* y, size_t n) { return pq_jaccard(x, y, n); }
+
+// Go container/heap trace: ops[i] >= 0 -> Push(prios[ops[i]] , value ops[i]); ops[i] == -1 -> Pop.
+// Writes the popped values to out_vals (in pop order) then the final array order to out_final.
+int orc_heap_trace(int is_max, const float* prios, const int32_t* ops, size_t n_ops, int32_t* out_pops,
+                   int32_t* out_final, int32_t* n_final) {
+  int np = 0;
+  if (is_max) {
+    GoHeap<true> hp;
+    for (size_t i = 0; i < n_ops; i++) { if (ops[i] >= 0) hp.push({prios[ops[i]], ops[i]}); else if (hp.len()) out_pops[np++] = (int32_t)hp.pop().val; }
+    for (int i = 0; i < hp.len(); i++) out_final[i] = (int32_t)hp.a[i].val;
+    *n_final = hp.len();
+  } else {
+    GoHeap<false> hp;
+    for (size_t i = 0; i < n_ops; i++) { if (ops[i] >= 0) hp.push({prios[ops[i]], ops[i]}); else if (hp.len()) out_pops[np++] = (int32_t)hp.pop().val; }
+    for (int i = 0; i < hp.len(); i++) out_final[i] = (int32_t)hp.a[i].val;
+    *n_final = hp.len();
+  }
+  return np;
+}
+
+// Deterministic synthetic data, integer-exact so that any host/device restatement is bit-identical:
+// element e of stream `seed` = (sum of twelve 16-bit uniforms - 393210) * 2^-16  (Irwin–Hall ~ N(0,1)).
+void orc_fill_normal(uint64_t seed, uint64_t first, float* out, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    uint64_t e = first + i;
+    uint64_t a = splitmix64(seed ^ (e * 3 + 0)), b = splitmix64(seed ^ (e * 3 + 1) ^ 0x5555555555555555ull),
+             c = splitmix64(seed ^ (e * 3 + 2) ^ 0xAAAAAAAAAAAAAAAAull);
+    uint32_t s = 0;
+    for (int k = 0; k < 4; k++) { s += (a >> (16 * k)) & 0xffff; s += (b >> (16 * k)) & 0xffff; s += (c >> (16 * k)) & 0xffff; }
+    out[i] = ((float)(int32_t)s - 393210.0f) * (1.0f / 65536.0f);
+  }
+}
+// HNSW level draw: floor(-ln(U) * mult) (hnsw.go:280-282; gomath/rand.go:42-44; math.go:52-54,60-62)
+// with U = (24 random bits + 1) / 2^24 in (0,1] from the counter stream (the reference uses the
+// auto-seeded global math/rand, so no sequence is reproducible there).
+int orc_level(uint64_t seed, uint64_t i, float mult) {
+  uint64_t r = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+  float u = (float)((r >> 40) + 1) * (1.0f / 16777216.0f);
+  float lg = (float)std::log((double)u);
+  float x = -lg * mult;
+  return (int)std::floor((double)x);
+}
+
+// ---- FLAT ----
+void* orc_flat_create(uint32_t dim, int metric, int quant, int order) {
+  Flat* f = new Flat(); f->dim = dim; f->metric = metric; f->quant = quant; f->order = order; return f;
+}
+void orc_flat_destroy(void* h) { delete (Flat*)h; }
+int orc_flat_upsert(void* h, const uint64_t* ids, const float* vecs, size_t n) {
+  Flat* f = (Flat*)h; for (size_t i = 0; i < n; i++) flat_upsert(f, ids[i], vecs + i * f->dim); return 0;
+}
+int orc_flat_remove(void* h, const uint64_t* ids, size_t n) {
+  Flat* f = (Flat*)h; for (size_t i = 0; i < n; i++) f->shards[shard_vertex(ids[i], 16)].erase(ids[i]); return 0;
+}
+uint64_t orc_flat_len(void* h) { Flat* f = (Flat*)h; uint64_t n = 0; for (auto& s : f->shards) n += s.size(); return n; }
+int orc_flat_get(void* h, uint64_t id, uint8_t* out) {
+  Flat* f = (Flat*)h; auto& s = f->shards[shard_vertex(id, 16)]; auto it = s.find(id);
+  if (it == s.end()) return -3;
+  std::memcpy(out, it->second.data(), it->second.size());
+  return 0;
+}
+int orc_flat_search(void* h, const float* query, int topK, int nearest, int mode, const uint64_t* cand,
+                    size_t n_cand, int use_cand, uint64_t* out_ids, float* out_scores) {
+  return flat_search((Flat*)h, query, topK, nearest, mode, use_cand != 0, cand, n_cand, out_ids, out_scores);
+}
+
+// ---- HNSW ----
+void* orc_hnsw_create(uint32_t dim, int metric, int order, const HnswCfg* cfg) {
+  Hnsw* h = new Hnsw(); h->dim = dim; h->metric = metric; h->order = order; h->cfg = *cfg;
+  if (h->cfg.levelMultiplier == -1) h->cfg.levelMultiplier = 1.0f / (float)std::log((double)(float)h->cfg.m);
+  if (h->cfg.mMax == -1) h->cfg.mMax = h->cfg.m;
+  if (h->cfg.mMax0 == -1) h->cfg.mMax0 = 2 * h->cfg.m;
+  return h;
+}
+void orc_hnsw_destroy(void* h) { delete (Hnsw*)h; }
+void orc_hnsw_get_cfg(void* h, HnswCfg* out) { *out = ((Hnsw*)h)->cfg; }
+int orc_hnsw_insert(void* h, uint64_t id, const float* vec, int level) {
+  Hnsw* x = (Hnsw*)h;
+  if (x->cfg.algo == 1 && x->cfg.extendCandidates) return -4;
+  return hnsw_insert(x, id, vec, level, false);
+}
+void orc_hnsw_set_canonical(void* h, int on) { ((Hnsw*)h)->canon_build = on != 0; }
+int orc_hnsw_remove(void* h, uint64_t id) { return hnsw_remove((Hnsw*)h, id); }
+uint64_t orc_hnsw_len(void* h) { return ((Hnsw*)h)->len; }
+int64_t orc_hnsw_slots(void* h) { return (int64_t)((Hnsw*)h)->v.size(); }
+int32_t orc_hnsw_entry(void* h) { return ((Hnsw*)h)->entry; }
+int orc_hnsw_search(void* h, const float* q, int k, int mode, int ef_override, uint64_t* out_ids,
+                    float* out_scores, int32_t* out_slots, uint64_t* stats3) {
+  Hnsw* x = (Hnsw*)h; x->st = HnswStats{};
+  int n = hnsw_search(x, q, k, mode, ef_override, out_ids, out_scores, out_slots);
+  if (stats3) { stats3[0] = x->st.n_dist; stats3[1] = x->st.n_exp; stats3[2] = x->st.n_hops; }
+  return n;
+}
+// Export: per-slot arrays + CSR over (slot, level) in canonical (ascending slot) neighbour order.
+// Pass null pointers to query sizes: returns total edge count; max_level via *out_max_level.
+int64_t orc_hnsw_export(void* h, uint64_t* ids, int32_t* levels, uint8_t* deleted, float* vectors,
+                        int64_t* row_offsets /* n_rows+1 where rows = sum(level+1) in slot-major, level-minor order */,
+                        int32_t* nbr, float* nbr_dist, int32_t* out_max_level) {
+  Hnsw* x = (Hnsw*)h; int64_t ne = 0, row = 0; int32_t ml = 0;
+  if (row_offsets) row_offsets[0] = 0;
+  for (size_t i = 0; i < x->v.size(); i++) {
+    const Vertex& v = x->v[i];
+    if (ids) ids[i] = v.id;
+    if (levels) levels[i] = v.level;
+    if (deleted) deleted[i] = v.deleted;
+    if (vectors) std::memcpy(vectors + i * x->dim, v.vec, x->dim * 4);
+    ml = std::max(ml, (int32_t)v.level);
+    for (int l = 0; l <= v.level; l++) {
+      for (const Edge& e : v.edges[l]) { if (nbr) nbr[ne] = e.to; if (nbr_dist) nbr_dist[ne] = e.d; ne++; }
+      row++;
+      if (row_offsets) row_offsets[row] = ne;
+    }
+  }
+  if (out_max_level) *out_max_level = ml;
+  return ne;
+}
+// Import a graph (same layout as export).  view != 0: `vectors` is NOT copied (caller keeps it alive) —
+// the "contiguous" CPU-baseline variant; vectors must already be normalised for cosine.
+int orc_hnsw_import(void* h, int64_t n, const uint64_t* ids, const int32_t* levels, const uint8_t* deleted,
+                    const float* vectors, const int64_t* row_offsets, const int32_t* nbr, const float* nbr_dist,
+                    int32_t entry, int view) {
+  Hnsw* x = (Hnsw*)h; x->v.clear(); x->by_id.clear(); x->len = 0;
+  x->v.resize(n); int64_t row = 0;
+  for (int64_t i = 0; i < n; i++) {
+    Vertex& v = x->v[i]; v.id = ids[i]; v.level = levels[i]; v.deleted = deleted ? deleted[i] : 0;
+    if (view) v.vec = vectors + i * x->dim;
+    else { v.own.assign(vectors + i * x->dim, vectors + (i + 1) * x->dim); v.vec = v.own.data(); }
+    v.edges.resize(v.level + 1);
+    for (int l = 0; l <= v.level; l++, row++) {
+      for (int64_t e = row_offsets[row]; e < row_offsets[row + 1]; e++) v.edges[l].push_back({nbr[e], nbr_dist ? nbr_dist[e] : 0.f});
+      std::sort(v.edges[l].begin(), v.edges[l].end(), [](const Edge& a, const Edge& b) { return a.to < b.to; });
+    }
+    if (!v.deleted) { x->by_id[v.id] = (int32_t)i; x->len++; }
+  }
+  x->entry = entry;
+  return 0;
+}
+uint64_t orc_hnsw_graph_hash(void* h) {
+  Hnsw* x = (Hnsw*)h; uint64_t hs = 14695981039346656037ull;
+  hs = fnv_mix(hs, &x->entry, 4);
+  for (auto& v : x->v) {
+    hs = fnv_mix(hs, &v.id, 8); int32_t lv = v.level; hs = fnv_mix(hs, &lv, 4); uint8_t d = v.deleted; hs = fnv_mix(hs, &d, 1);
+    for (auto& es : v.edges) { int32_t c = (int32_t)es.size(); hs = fnv_mix(hs, &c, 4); for (auto& e : es) { hs = fnv_mix(hs, &e.to, 4); hs = fnv_mix(hs, &e.d, 4); } }
+  }
+  return hs;
+}
+
+}  // extern "C"

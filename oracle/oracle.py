@@ -1,0 +1,329 @@
+"""ctypes binding of the CPU oracle (oracle/libcoltt_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
+product package (coltt_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libcoltt_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libcoltt_ref_simd.so")
+
+ORDER_AVX, ORDER_SSE, ORDER_NATIVE = 0, 1, 2
+COSINE, L2 = 0, 1
+Q_NONE, Q_F16, Q_F8, Q_BF16 = 0, 1, 2, 3
+QUANT_DTYPE = {Q_NONE: np.float32, Q_F16: np.uint16, Q_F8: np.uint8, Q_BF16: np.uint16}
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "coltt_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "libcoltt_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/pkg/distance/simd/cpp/avx.cpp") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class HnswCfg(C.Structure):
+    _fields_ = [("m", C.c_int32), ("mMax", C.c_int32), ("mMax0", C.c_int32), ("ef", C.c_int32),
+                ("efConstruction", C.c_int32), ("algo", C.c_int32), ("levelMultiplier", C.c_float),
+                ("extendCandidates", C.c_int32), ("keepPruned", C.c_int32)]
+
+
+def default_cfg(**kw):
+    """newHnswConfig defaults (core/vectorindex/hnsw_config.go:135-162)."""
+    c = HnswCfg(16, -1, -1, 20, 200, 0, -1.0, 0, 1)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+_lib = None
+_ref = None
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+_vp = C.c_void_p
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_l2.restype = C.c_float
+        L.orc_cosine.restype = C.c_float
+        L.orc_l2sq.restype = C.c_float
+        for n in ("orc_pq_dot", "orc_pq_l2sq", "orc_pq_dot_pure", "orc_pq_l2sq_pure", "orc_pq_hamming",
+                  "orc_pq_jaccard"):
+            getattr(L, n).restype = C.c_float
+        L.orc_shard_vertex.restype = C.c_uint64
+        L.orc_shard_vertex.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_flat_create.restype = _vp
+        L.orc_flat_len.restype = C.c_uint64
+        L.orc_hnsw_create.restype = _vp
+        L.orc_hnsw_len.restype = C.c_uint64
+        L.orc_hnsw_slots.restype = C.c_int64
+        L.orc_hnsw_entry.restype = C.c_int32
+        L.orc_hnsw_export.restype = C.c_int64
+        L.orc_hnsw_graph_hash.restype = C.c_uint64
+        L.orc_level.argtypes = [C.c_uint64, C.c_uint64, C.c_float]
+        L.orc_fill_normal.argtypes = [C.c_uint64, C.c_uint64, _vp, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's own avx.cpp / sse.cpp (oracle/_ref), or None when it was never built."""
+    global _ref
+    if _ref is None:
+        build()
+        if not os.path.exists(_REF):
+            return None
+        _ref = C.CDLL(_REF)
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ------------------------------------------------------------------ kernels
+def l2(a, b, order=ORDER_AVX):
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_l2(order, _p(a), _p(b), C.c_size_t(a.size)))
+
+
+def cosine(a, b, order=ORDER_AVX):
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_cosine(order, _p(a), _p(b), C.c_size_t(a.size)))
+
+
+def l2sq(a, b, order=ORDER_AVX):
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_l2sq(order, _p(a), _p(b), C.c_size_t(a.size)))
+
+
+def cosine_parts(a, b, order=ORDER_AVX):
+    a, b = _f32(a), _f32(b)
+    o = (C.c_float * 3)()
+    lib().orc_cosine_parts(order, _p(a), _p(b), C.c_size_t(a.size), C.byref(o, 0), C.byref(o, 4), C.byref(o, 8))
+    return np.float32(o[0]), np.float32(o[1]), np.float32(o[2])
+
+
+def dist_rows(metric, q, rows, order=ORDER_AVX):
+    q, rows = _f32(q), _f32(rows)
+    out = np.empty(rows.shape[0], np.float32)
+    lib().orc_dist_rows(metric, order, _p(q), _p(rows), C.c_size_t(rows.shape[0]), C.c_size_t(rows.shape[1]), _p(out))
+    return out
+
+
+def normalize(v):
+    v = _f32(v)
+    out = np.empty_like(v)
+    if v.ndim == 1:
+        lib().orc_normalize(_p(v), _p(out), C.c_size_t(v.size))
+    else:
+        for i in range(v.shape[0]):
+            lib().orc_normalize(_p(v[i]), _p(out[i]), C.c_size_t(v.shape[1]))
+    return out
+
+
+def f16_encode(x):
+    x = _f32(x); o = np.empty(x.shape, np.uint16); lib().orc_f16_encode(_p(x), _p(o), C.c_size_t(x.size)); return o
+
+
+def f16_decode(x):
+    x = np.ascontiguousarray(x, np.uint16); o = np.empty(x.shape, np.float32)
+    lib().orc_f16_decode(_p(x), _p(o), C.c_size_t(x.size)); return o
+
+
+def f8_encode(x):
+    x = _f32(x); o = np.empty(x.shape, np.uint8); lib().orc_f8_encode(_p(x), _p(o), C.c_size_t(x.size)); return o
+
+
+def f8_decode(x):
+    x = np.ascontiguousarray(x, np.uint8); o = np.empty(x.shape, np.float32)
+    lib().orc_f8_decode(_p(x), _p(o), C.c_size_t(x.size)); return o
+
+
+def lower(quant, v):
+    v = _f32(v); o = np.empty(v.shape, QUANT_DTYPE[quant])
+    if v.ndim == 1:
+        lib().orc_lower(quant, _p(v), C.c_size_t(v.size), _p(o))
+    else:
+        for i in range(v.shape[0]):
+            lib().orc_lower(quant, _p(v[i]), C.c_size_t(v.shape[1]), _p(o[i]))
+    return o
+
+
+def shard_vertex(i, c=16):
+    return int(lib().orc_shard_vertex(int(i), int(c)))
+
+
+def pq_dot(x, y, pure=False):
+    x, y = _f32(x), _f32(y)
+    return np.float32((lib().orc_pq_dot_pure if pure else lib().orc_pq_dot)(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def pq_l2sq(x, y, pure=False):
+    x, y = _f32(x), _f32(y)
+    return np.float32((lib().orc_pq_l2sq_pure if pure else lib().orc_pq_l2sq)(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def pq_hamming(x, y):
+    x, y = np.ascontiguousarray(x, np.uint64), np.ascontiguousarray(y, np.uint64)
+    return np.float32(lib().orc_pq_hamming(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def pq_jaccard(x, y):
+    x, y = np.ascontiguousarray(x, np.uint64), np.ascontiguousarray(y, np.uint64)
+    return np.float32(lib().orc_pq_jaccard(_p(x), _p(y), C.c_size_t(x.size)))
+
+
+def heap_trace(is_max, prios, ops):
+    prios = _f32(prios); ops = np.ascontiguousarray(ops, np.int32)
+    pops = np.empty(len(ops), np.int32); fin = np.empty(len(ops), np.int32); nf = C.c_int32(0)
+    n = lib().orc_heap_trace(int(is_max), _p(prios), _p(ops), C.c_size_t(len(ops)), _p(pops), _p(fin), C.byref(nf))
+    return pops[:n].copy(), fin[:nf.value].copy()
+
+
+def fill_normal(seed, shape, first=0):
+    out = np.empty(shape, np.float32)
+    lib().orc_fill_normal(int(seed), int(first), _p(out), C.c_size_t(out.size))
+    return out
+
+
+def level(seed, i, mult):
+    return int(lib().orc_level(int(seed), int(i), C.c_float(mult)))
+
+
+def levels(seed, n, m=16):
+    mult = np.float32(1.0) / np.float32(np.log(np.float64(np.float32(m))))
+    return np.array([level(seed, i, mult) for i in range(n)], np.int32)
+
+
+# ------------------------------------------------------------------ FLAT
+class Flat:
+    """edge.{none,f16,f8,bf16}VecSpace restated (edge/none_vectorstore.go etc.)."""
+
+    def __init__(self, dim, metric=COSINE, quant=Q_NONE, order=ORDER_AVX):
+        self.dim, self.metric, self.quant = dim, metric, quant
+        self.h = _vp(lib().orc_flat_create(dim, metric, quant, order))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_flat_destroy(self.h); self.h = None
+
+    def upsert(self, ids, vecs):
+        ids = np.ascontiguousarray(ids, np.uint64); vecs = _f32(vecs)
+        assert vecs.shape == (len(ids), self.dim)
+        lib().orc_flat_upsert(self.h, _p(ids), _p(vecs), C.c_size_t(len(ids)))
+
+    def remove(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint64)
+        lib().orc_flat_remove(self.h, _p(ids), C.c_size_t(len(ids)))
+
+    def __len__(self):
+        return int(lib().orc_flat_len(self.h))
+
+    def get(self, id_):
+        o = np.empty(self.dim, QUANT_DTYPE[self.quant])
+        return o if lib().orc_flat_get(self.h, C.c_uint64(int(id_)), _p(o)) == 0 else None
+
+    def search(self, query, k, nearest=False, mode=2, cand=None):
+        """mode 0 literal (highCpu=false), 1 literal (highCpu=true), 2 canonical (score,id) order."""
+        q = _f32(query)
+        ids = np.empty(max(k, 1), np.uint64); sc = np.empty(max(k, 1), np.float32)
+        if cand is not None:
+            cand = np.ascontiguousarray(cand, np.uint64)
+            n = lib().orc_flat_search(self.h, _p(q), int(k), int(nearest), mode, _p(cand), C.c_size_t(len(cand)), 1, _p(ids), _p(sc))
+        else:
+            n = lib().orc_flat_search(self.h, _p(q), int(k), int(nearest), mode, None, C.c_size_t(0), 0, _p(ids), _p(sc))
+        return ids[:n].copy(), sc[:n].copy()
+
+
+# ------------------------------------------------------------------ HNSW
+class Hnsw:
+    """core/vectorindex.Hnsw restated (core/vectorindex/hnsw.go)."""
+
+    def __init__(self, dim, metric=COSINE, cfg=None, order=ORDER_AVX, canonical_build=False):
+        self.dim, self.metric = dim, metric
+        cfg = cfg or default_cfg()
+        self.h = _vp(lib().orc_hnsw_create(dim, metric, order, C.byref(cfg)))
+        self.cfg = HnswCfg(); lib().orc_hnsw_get_cfg(self.h, C.byref(self.cfg))
+        if canonical_build:
+            lib().orc_hnsw_set_canonical(self.h, 1)
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_hnsw_destroy(self.h); self.h = None
+
+    def insert(self, id_, vec, level):
+        v = _f32(vec)
+        return lib().orc_hnsw_insert(self.h, C.c_uint64(int(id_)), _p(v), int(level))
+
+    def insert_many(self, ids, vecs, lvls):
+        vecs = _f32(vecs)
+        for i in range(len(ids)):
+            rc = lib().orc_hnsw_insert(self.h, C.c_uint64(int(ids[i])), _p(vecs[i]), int(lvls[i]))
+            assert rc == 0, rc
+
+    def remove(self, id_):
+        return lib().orc_hnsw_remove(self.h, C.c_uint64(int(id_)))
+
+    def __len__(self):
+        return int(lib().orc_hnsw_len(self.h))
+
+    @property
+    def entry(self):
+        return int(lib().orc_hnsw_entry(self.h))
+
+    @property
+    def slots(self):
+        return int(lib().orc_hnsw_slots(self.h))
+
+    def search(self, q, k, mode=1, ef=0, with_stats=False):
+        q = _f32(q)
+        ids = np.empty(max(k, 1), np.uint64); sc = np.empty(max(k, 1), np.float32); sl = np.empty(max(k, 1), np.int32)
+        st = (C.c_uint64 * 3)()
+        n = lib().orc_hnsw_search(self.h, _p(q), int(k), mode, int(ef), _p(ids), _p(sc), _p(sl), st)
+        if with_stats:
+            return ids[:n].copy(), sc[:n].copy(), {"n_dist": st[0], "n_exp": st[1], "n_hops": st[2]}
+        return ids[:n].copy(), sc[:n].copy()
+
+    def graph_hash(self):
+        return int(lib().orc_hnsw_graph_hash(self.h))
+
+    def export(self, with_vectors=True):
+        n = self.slots
+        ml = C.c_int32(0)
+        ne = lib().orc_hnsw_export(self.h, None, None, None, None, None, None, None, C.byref(ml))
+        ids = np.empty(n, np.uint64); lv = np.empty(n, np.int32); dl = np.empty(n, np.uint8)
+        vec = np.empty((n, self.dim), np.float32) if with_vectors else None
+        lib().orc_hnsw_export(self.h, _p(ids), _p(lv), _p(dl), None, None, None, None, C.byref(ml))
+        rows = int((lv.astype(np.int64) + 1).sum())
+        off = np.empty(rows + 1, np.int64); nb = np.empty(ne, np.int32); nd = np.empty(ne, np.float32)
+        lib().orc_hnsw_export(self.h, _p(ids), _p(lv), _p(dl), _p(vec) if with_vectors else None, _p(off), _p(nb), _p(nd),
+                              C.byref(ml))
+        return {"ids": ids, "levels": lv, "deleted": dl, "vectors": vec, "row_offsets": off, "nbr": nb,
+                "nbr_dist": nd, "entry": self.entry, "max_level": ml.value}
+
+    def load(self, g, view=False):
+        """import a graph dict (export() layout).  view=True keeps a reference to g['vectors'] (no copy)."""
+        vec = _f32(g["vectors"])
+        ids = np.ascontiguousarray(g["ids"], np.uint64); lv = np.ascontiguousarray(g["levels"], np.int32)
+        dl = np.ascontiguousarray(g["deleted"], np.uint8) if g.get("deleted") is not None else None
+        off = np.ascontiguousarray(g["row_offsets"], np.int64); nb = np.ascontiguousarray(g["nbr"], np.int32)
+        nd = np.ascontiguousarray(g["nbr_dist"], np.float32) if g.get("nbr_dist") is not None else None
+        if view:
+            self._keep = (vec,)
+        lib().orc_hnsw_import(self.h, C.c_int64(len(ids)), _p(ids), _p(lv), _p(dl) if dl is not None else None, _p(vec),
+                              _p(off), _p(nb), _p(nd) if nd is not None else None, int(g["entry"]), int(view))
