@@ -1,0 +1,57 @@
+"""ctypes loader for libcoltt_gpu.so — the C-ABI declared in include/coltt_gpu.h."""
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+COSINE, EUCLIDEAN = 0, 1
+Q_NONE, Q_F16, Q_F8, Q_BF16 = 0, 1, 2, 3
+SELECT_REFERENCE, SELECT_NEAREST = 0, 1
+MODE_EXACT, MODE_MFMA = 0, 1
+
+_lib = None
+
+
+class ColttError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"coltt_gpu error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "libcoltt_gpu.so")
+
+
+def declared_symbols():
+    """Every function name include/coltt_gpu.h declares."""
+    hdr = open(os.path.join(HERE, "..", "include", "coltt_gpu.h")).read()
+    return sorted(set(re.findall(r"\b(coltt_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def lib():
+    """Load the HIP extension.  There is no fallback: a missing .so is an error."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ColttError(-5, f"{p} is missing — build it with `python -m coltt_amd.build` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(p)
+        L.coltt_last_error.restype = C.c_char_p
+        L.coltt_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ColttError(rc, lib().coltt_last_error().decode("utf-8", "replace"))
+
+
+def vp(a):
+    """numpy array / int address / None -> c_void_p"""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)

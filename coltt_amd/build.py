@@ -1,0 +1,64 @@
+"""Build libcoltt_gpu.so (hipcc, gfx950) in-tree.  `python -m coltt_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libcoltt_gpu.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+# -ffp-contract=off : the exact-order kernels must never fuse a*b+c (the reference's AVX code has no FMA).
+# denormals are kept (no -fgpu-flush-denormals-to-zero): the "f8" codec decodes to an f32 denormal.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.sep not in c or os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(HERE, "..", "include", "coltt_gpu.h"))
+    jobs = []
+    for s in sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s[:-4] + ".o")
+        if force or _stale(obj, [src] + headers):
+            jobs.append((src, obj))
+
+    def cc(job):
+        cmd = [_hipcc()] + FLAGS + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, s[:-4] + ".o") for s in sources()]
+    if force or jobs or _stale(OUT, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

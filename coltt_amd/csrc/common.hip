@@ -1,0 +1,89 @@
+// common.hip — registry, error string, device selection.
+#include "common.hpp"
+
+namespace coltt {
+
+thread_local std::string g_last_error;
+static int g_device = -1;
+static std::mutex g_dev_mu;
+
+Registry& Registry::get() {
+  static Registry r;
+  return r;
+}
+coltt_handle_t Registry::add(std::shared_ptr<Object> o) {
+  std::lock_guard<std::mutex> g(mu_);
+  coltt_handle_t h = next_++;
+  map_[h] = std::move(o);
+  return h;
+}
+std::shared_ptr<Object> Registry::find(coltt_handle_t h) {
+  std::lock_guard<std::mutex> g(mu_);
+  auto it = map_.find(h);
+  return it == map_.end() ? nullptr : it->second;
+}
+bool Registry::erase(coltt_handle_t h) {
+  std::shared_ptr<Object> keep;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = map_.find(h);
+    if (it == map_.end()) return false;
+    keep = it->second;
+    map_.erase(it);
+  }
+  std::lock_guard<std::mutex> g2(keep->mu);  // wait for an in-flight call
+  return true;
+}
+
+// cgo calls arrive on arbitrary OS threads; the HIP "current device" is per thread.
+int ensure_device() {
+  int dev;
+  {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (g_device < 0) {
+      int n = 0;
+      hipError_t e = hipGetDeviceCount(&n);
+      if (e != hipSuccess || n <= 0)
+        return fail(COLTT_E_DEVICE, "libcoltt_gpu: no HIP device visible (%s) — this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+      g_device = 0;
+    }
+    dev = g_device;
+  }
+  COLTT_HIP(hipSetDevice(dev));
+  return COLTT_OK;
+}
+
+hipStream_t main_stream() { return nullptr; }  // per-object streams are created by the objects themselves
+
+}  // namespace coltt
+
+using namespace coltt;
+
+extern "C" {
+
+int coltt_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(COLTT_E_DEVICE, "coltt_init: no HIP device visible (%s) — this library has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(COLTT_E_INVALID, "coltt_init: device %d out of range [0,%d)", device, n);
+  {
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    g_device = device;
+  }
+  COLTT_HIP(hipSetDevice(device));
+  return COLTT_OK;
+}
+
+int coltt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* coltt_last_error(void) { return g_last_error.c_str(); }
+const char* coltt_version(void) { return "coltt_gpu 0.1 (gfx950)"; }
+
+}  // extern "C"

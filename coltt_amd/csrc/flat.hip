@@ -1,0 +1,631 @@
+// flat.hip — edge FLAT store on the GPU: replaces {none,f16,f8,bf16}VecSpace's vector half
+// (edge/none_vectorstore.go:66-253, edge/f16_vectorstore.go:67-262 and the f8/bf16 twins).
+//
+// HBM layout (one store = one collection shard on one GPU):
+//   rows   [cap][row_stride]  stored ("lowered") vectors, dense in slot order, row_stride = dim*s rounded to 16 B
+//   norms  [cap] f32          ||row||^2 in AVX order (the reference recomputes it per pair; same bits)
+//   ids    [cap] u64          slot -> id           (absent in dense-id mode: id = dense_base + slot)
+// Removal swaps the last row into the hole, so a scan is always over the dense prefix [0, n).
+//
+// Kernels: prep_rows (Normalize + Lower), row_norms, prep_queries, flat_scan (exact-order distances for a
+// tile of QB queries per row read, threshold-filtered candidate emission), flat_select (radix-select +
+// rank-sort of the candidates by the canonical (score, id) order).
+#include <algorithm>
+
+#include "common.hpp"
+#include "exact.hpp"
+#include "prep.hpp"
+
+using namespace coltt;
+using namespace coltt::dev;
+
+namespace {
+
+constexpr int QB = 8;             // queries per row read in the exact scan
+constexpr uint32_t K_MAX = 2048;  // largest top-k served by flat_select's LDS rank sort
+
+// ---------------------------------------------------------------------------------------------------
+// Exact-order scan: the hot loop of VertexSearch (none_vectorstore.go:136-147) for QB queries at once.
+// Each wave owns 32 rows per iteration (lane pair per row); every row chunk read from HBM is used for
+// all QB queries (queries broadcast from LDS).  Survivors of the per-query threshold are appended to a
+// candidate list as (score_key << 32 | slot).
+// ---------------------------------------------------------------------------------------------------
+template <int METRIC, int QUANT, bool GATHER>
+__global__ __launch_bounds__(256) void flat_scan_kernel(
+    const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms,
+    const uint32_t* __restrict__ gather, uint64_t begin, uint64_t end, const float* __restrict__ q_eff,
+    const float* __restrict__ qnorms, int nq_grp, int dim, const uint32_t* __restrict__ thr, int nearest,
+    unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // [QB][dim]
+  for (int i = threadIdx.x; i < QB * dim; i += blockDim.x) qs[i] = (i / dim) < nq_grp ? q_eff[i] : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane & 1, p = lane >> 1;
+  float qn[QB];
+  uint32_t th[QB];
+#pragma unroll
+  for (int q = 0; q < QB; q++) { qn[q] = q < nq_grp ? qnorms[q] : 0.f; th[q] = q < nq_grp ? thr[q] : 0u; }
+  const uint64_t ngroups = (end - begin + 31) / 32;
+  const int n8 = dim >> 3;
+  for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += (uint64_t)gridDim.x * 4) {
+    uint64_t pos = begin + g * 32 + p;
+    bool valid = pos < end;
+    uint32_t slot = GATHER ? gather[valid ? pos : begin] : (uint32_t)(valid ? pos : begin);
+    const uint8_t* row = rows + (size_t)slot * stride;
+    f32x4 acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    const int nb = n8 / U;
+    f32x4 cur[U], nxt[U];
+    if (nb > 0) {
+#pragma unroll
+      for (int u = 0; u < U; u++) cur[u] = load4<QUANT>(row, 8 * u + 4 * half);
+    }
+    for (int b = 0; b < nb; b++) {
+      if (b + 1 < nb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) nxt[u] = load4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float* qp = qs + 8 * (b * U + u) + 4 * half;
+#pragma unroll
+        for (int q = 0; q < QB; q++) {
+          f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dim);
+          if constexpr (METRIC == M_COS) { f32x4 pr = qq * cur[u]; acc[q] = acc[q] + pr; }
+          else { f32x4 d = qq - cur[u]; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    for (int t = nb * U; t < n8; t++) {
+      f32x4 r = load4<QUANT>(row, 8 * t + 4 * half);
+      const float* qp = qs + 8 * t + 4 * half;
+#pragma unroll
+      for (int q = 0; q < QB; q++) {
+        f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dim);
+        if constexpr (METRIC == M_COS) { f32x4 pr = qq * r; acc[q] = acc[q] + pr; }
+        else { f32x4 d = qq - r; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
+      }
+    }
+    float rn = 0.f;
+    if constexpr (METRIC == M_COS) rn = norms[slot];
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      float s = pair_hsum(acc[q], half);
+      for (int e = n8 * 8; e < dim; e++) {
+        float r = load1<QUANT>(row, e);
+        if constexpr (METRIC == M_COS) s += qs[q * dim + e] * r;
+        else { float d = qs[q * dim + e] - r; s += d * d; }
+      }
+      float score;
+      if constexpr (METRIC == M_COS) score = cos_epilogue(s, qn[q], rn);
+      else score = go_sqrt(s);
+      uint32_t sk = score_key(score);
+      bool pass = valid && half == 0 && q < nq_grp && (nearest ? sk <= th[q] : sk >= th[q]);
+      if (pass) {
+        uint32_t idx = atomicAdd(&cnt[q], 1u);
+        if (idx < cap) cand[(size_t)q * cap + idx] = ((unsigned long long)sk << 32) | slot;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Selection: the bounded queue + ToSlice of edge.PriorityQueue (edge/priority_queue.go:39-69) in closed
+// form.  REFERENCE keeps the K LARGEST (score,id) keys, NEAREST the K smallest; output ascending.
+// One block per query: radix-select on the score key (4 x 8 bits), a second radix-select on the id among
+// boundary ties only when they do not all fit, then an LDS rank sort of the <= K survivors.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t slot_id(const uint64_t* ids, uint64_t dense_base, uint32_t slot) {
+  return ids ? ids[slot] : dense_base + slot;
+}
+
+__global__ __launch_bounds__(256) void flat_select_kernel(
+    unsigned long long* __restrict__ cand_all, uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all,
+    uint32_t cap, uint32_t k, int nearest, const uint64_t* __restrict__ ids, uint64_t dense_base,
+    uint32_t* __restrict__ overflow, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+    uint32_t* __restrict__ out_counts) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sel_key[K_MAX];
+  __shared__ uint32_t sel_slot[K_MAX];
+  __shared__ uint64_t sel_id[K_MAX];
+  __shared__ uint32_t s_digit, s_need, s_nsel;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  unsigned long long* cand = cand_all + (size_t)q * cap;
+  uint32_t c = cnt_all[q];
+  if (c > cap) { if (tid == 0) atomicOr(overflow, 1u); c = cap; }
+  const uint32_t kk = k < c ? k : c;
+  if (kk == 0) {
+    if (tid == 0) { out_counts[q] = 0; cnt_all[q] = 0; thr_all[q] = nearest ? 0xffffffffu : 0u; }
+    return;
+  }
+  const uint32_t flip = nearest ? 0u : 0xffffffffu;  // key' = key ^ flip : we want the kk smallest key'
+  // ---- pass 1: radix-select the kk-th smallest key'
+  uint32_t prefix = 0, mask = 0, need = kk;
+  for (int pass = 3; pass >= 0; pass--) {
+    const int shift = pass * 8;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < c; i += 256) {
+      uint32_t kp = (uint32_t)(cand[i] >> 32) ^ flip;
+      if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cum = 0, b = 0;
+      for (; b < 256; b++) { if (cum + hist[b] >= need) break; cum += hist[b]; }
+      s_digit = b; s_need = need - cum;
+    }
+    __syncthreads();
+    prefix |= s_digit << shift; mask |= 255u << shift; need = s_need;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;            // boundary key'
+  const uint32_t ties = hist[s_digit];  // elements with key' == T (last pass histogram)
+  // ---- boundary ties that do not all fit: radix-select on id' among them
+  const uint64_t idflip = nearest ? 0ull : ~0ull;
+  uint64_t idT = ~0ull;  // take ties with id' <= idT
+  if (ties > need) {
+    uint64_t ipre = 0, imask = 0; uint32_t ineed = need;
+    for (int pass = 7; pass >= 0; pass--) {
+      const int shift = pass * 8;
+      __syncthreads();
+      hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < c; i += 256) {
+        unsigned long long e = cand[i];
+        if (((uint32_t)(e >> 32) ^ flip) != T) continue;
+        uint64_t ip = slot_id(ids, dense_base, (uint32_t)e) ^ idflip;
+        if ((ip & imask) == ipre) atomicAdd(&hist[(ip >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, b = 0;
+        for (; b < 256; b++) { if (cum + hist[b] >= ineed) break; cum += hist[b]; }
+        s_digit = b; s_need = ineed - cum;
+      }
+      __syncthreads();
+      ipre |= (uint64_t)s_digit << shift; imask |= 255ull << shift; ineed = s_need;
+    }
+    idT = ipre;
+  }
+  // ---- gather the survivors
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < c; i += 256) {
+    unsigned long long e = cand[i];
+    uint32_t kp = (uint32_t)(e >> 32) ^ flip;
+    if (kp > T) continue;
+    uint64_t ip = slot_id(ids, dense_base, (uint32_t)e) ^ idflip;
+    if (kp == T && ip > idT) continue;
+    uint32_t j = atomicAdd(&s_nsel, 1u);
+    if (j < K_MAX) { sel_key[j] = kp; sel_slot[j] = (uint32_t)e; sel_id[j] = ip; }
+  }
+  __syncthreads();
+  const uint32_t ns = s_nsel < kk ? s_nsel : kk;  // == kk by construction
+  // ---- rank sort by (key', id'); emit ascending by (score, id)
+  for (uint32_t i = tid; i < ns; i += 256) {
+    uint32_t ki = sel_key[i]; uint64_t ii = sel_id[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < ns; j++) {
+      uint32_t kj = sel_key[j]; uint64_t ij = sel_id[j];
+      rank += (kj < ki) || (kj == ki && ij < ii);
+    }
+    uint32_t pos = nearest ? rank : (ns - 1 - rank);
+    uint32_t key = ki ^ flip;
+    out_ids[(size_t)q * k + pos] = ii ^ idflip;
+    out_scores[(size_t)q * k + pos] = key_score(key);
+    cand[pos] = ((unsigned long long)key << 32) | sel_slot[i];
+  }
+  if (tid == 0) {
+    out_counts[q] = ns; cnt_all[q] = ns;
+    thr_all[q] = (ns == k) ? (T ^ flip) : (nearest ? 0xffffffffu : 0u);
+  }
+}
+
+__global__ void init_group_kernel(uint32_t* cnt, uint32_t* thr, uint32_t* overflow, int nearest) {
+  int q = threadIdx.x;
+  if (q < QB) { cnt[q] = 0; thr[q] = nearest ? 0xffffffffu : 0u; }
+  if (q == 0) *overflow = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct Flat : Object {
+  uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
+  uint64_t n = 0, cap = 0;
+  DevBuf rows, norms, ids;
+  bool dense = true; uint64_t dense_base = 0;     // id = dense_base + slot, no map
+  std::unordered_map<uint64_t, uint32_t> id2slot;  // !dense
+  std::vector<uint64_t> h_ids;                     // !dense : slot -> id (host mirror)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
+  // workspaces
+  DevBuf w_raw, w_slots, w_qraw, w_qeff, w_qn, w_cand, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  ~Flat() override {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int reserve(uint64_t rows_needed) {
+    if (rows_needed <= cap) return COLTT_OK;
+    uint64_t ncap = std::max<uint64_t>(rows_needed, cap + cap / 2);
+    ncap = std::max<uint64_t>(ncap, 1024);
+    COLTT_TRY(rows.reserve(ncap * stride, true, stream));
+    COLTT_TRY(norms.reserve(ncap * 4, true, stream));
+    if (!dense) COLTT_TRY(ids.reserve(ncap * 8, true, stream));
+    cap = ncap;
+    return COLTT_OK;
+  }
+  int undense() {  // switch from "id = base + slot" to an explicit id table
+    if (!dense) return COLTT_OK;
+    h_ids.resize(n);
+    id2slot.reserve(n * 2);
+    for (uint64_t s = 0; s < n; s++) { h_ids[s] = dense_base + s; id2slot[dense_base + s] = (uint32_t)s; }
+    dense = false;
+    COLTT_TRY(ids.reserve(std::max<uint64_t>(cap, 1024) * 8, false, stream));
+    if (n) COLTT_HIP(hipMemcpyAsync(ids.p, h_ids.data(), n * 8, hipMemcpyHostToDevice, stream));
+    COLTT_HIP(hipStreamSynchronize(stream));
+    return COLTT_OK;
+  }
+};
+
+template <int QUANT>
+int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_slots, uint64_t slot_base) {
+  if (n == 0) return COLTT_OK;
+  prep_rows_kernel<QUANT><<<ceil_div(n, 128), 128, 0, f->stream>>>(d_raw, n, (int)f->dim, f->metric == COLTT_COSINE,
+                                                                    d_slots, slot_base, f->rows.as<uint8_t>(), f->stride);
+  row_norms_kernel<QUANT><<<ceil_div(n * 2, 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, d_slots,
+                                                                       slot_base, n, (int)f->dim, f->norms.as<float>());
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+int prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_slots, uint64_t slot_base) {
+  switch (f->quant) {
+    case COLTT_Q_NONE: return launch_prep_rows<Q_NONE>(f, d_raw, n, d_slots, slot_base);
+    case COLTT_Q_F8: return launch_prep_rows<Q_F8>(f, d_raw, n, d_slots, slot_base);
+    default: return launch_prep_rows<Q_F16>(f, d_raw, n, d_slots, slot_base);
+  }
+}
+
+template <int METRIC, int QUANT, bool GATHER>
+void launch_scan(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+                 int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+  uint64_t groups = (end - begin + 31) / 32;
+  uint32_t grid = (uint32_t)std::min<uint64_t>((groups + 3) / 4, 256 * 8);
+  size_t lds = (size_t)QB * f->dim * 4;
+  flat_scan_kernel<METRIC, QUANT, GATHER><<<grid, 256, lds, f->stream>>>(
+      f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), gather, begin, end, q_eff, qn, nq_grp, (int)f->dim, thr,
+      nearest, cand, cnt, cap);
+}
+template <bool GATHER>
+void scan_dispatch(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+                   int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+#define COLTT_SCAN(M, Q) launch_scan<M, Q, GATHER>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap)
+  if (f->metric == COLTT_COSINE) {
+    if (f->quant == COLTT_Q_NONE) COLTT_SCAN(M_COS, Q_NONE);
+    else if (f->quant == COLTT_Q_F8) COLTT_SCAN(M_COS, Q_F8);
+    else COLTT_SCAN(M_COS, Q_F16);
+  } else {
+    if (f->quant == COLTT_Q_NONE) COLTT_SCAN(M_L2, Q_NONE);
+    else if (f->quant == COLTT_Q_F8) COLTT_SCAN(M_L2, Q_F8);
+    else COLTT_SCAN(M_L2, Q_F16);
+  }
+#undef COLTT_SCAN
+}
+
+int prep_queries(Flat* f, const float* d_qraw, size_t nq) {
+  COLTT_TRY(f->w_qeff.reserve(nq * f->dim * 4));
+  COLTT_TRY(f->w_qn.reserve(nq * 4));
+  int norm = f->metric == COLTT_COSINE;
+  uint32_t g = ceil_div(nq, 64);
+  if (f->quant == COLTT_Q_NONE) prep_queries_kernel<Q_NONE><<<g, 64, 0, f->stream>>>(d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
+  else if (f->quant == COLTT_Q_F8) prep_queries_kernel<Q_F8><<<g, 64, 0, f->stream>>>(d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
+  else prep_queries_kernel<Q_F16><<<g, 64, 0, f->stream>>>(d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
+  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, f->stream>>>(f->w_qeff.as<float>(), nq, (int)f->dim, f->w_qn.as<float>());
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// Search nq prepared queries over positions [0, total) (rows, or entries of the gather list).
+// Results land in w_out_* ([nq][k]).
+int search_prepared(Flat* f, size_t nq, uint32_t k, int select, const uint32_t* d_gather, uint64_t total,
+                    uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt) {
+  const int nearest = select == COLTT_SELECT_NEAREST;
+  const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
+  COLTT_TRY(f->w_cand.reserve((size_t)QB * cap * 8));
+  COLTT_TRY(f->w_cnt.reserve(256));
+  uint32_t* cnt = f->w_cnt.as<uint32_t>();
+  uint32_t* thr = cnt + QB;
+  uint32_t* ovf = cnt + 2 * QB;
+  unsigned long long* cand = f->w_cand.as<unsigned long long>();
+  const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
+  COLTT_HIP(hipEventRecord(f->ev0, f->stream));
+  for (size_t q0 = 0; q0 < nq; q0 += QB) {
+    int g = (int)std::min<size_t>(QB, nq - q0);
+    const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
+    const float* qn = f->w_qn.as<float>() + q0;
+    uint64_t* oi = d_out_ids + q0 * k; float* os = d_out_sc + q0 * k; uint32_t* oc = d_out_cnt + q0;
+    auto scan = [&](uint64_t b, uint64_t e) {
+      if (d_gather) scan_dispatch<true>(f, d_gather, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
+      else scan_dispatch<false>(f, nullptr, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
+      flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc);
+    };
+    init_group_kernel<<<1, 64, 0, f->stream>>>(cnt, thr, ovf, nearest);
+    if (total == 0) { flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc); continue; }
+    // optimistic: first segment (everything passes, <= cap candidates), then the rest behind the threshold
+    uint64_t s0 = std::min<uint64_t>(total, cap);
+    scan(0, s0);
+    if (s0 < total) scan(s0, total);
+    uint32_t h_ovf = 0;
+    COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
+    COLTT_HIP(hipStreamSynchronize(f->stream));
+    if (h_ovf) {  // adversarial order: redo with segments that cannot overflow (list holds <= k + segment)
+      init_group_kernel<<<1, 64, 0, f->stream>>>(cnt, thr, ovf, nearest);
+      uint64_t seg = cap - std::min<uint32_t>(k, cap / 2);
+      for (uint64_t b = 0; b < total; b += seg) scan(b, std::min<uint64_t>(total, b + seg));
+    }
+  }
+  COLTT_HIP(hipEventRecord(f->ev1, f->stream));
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+int flat_search_common(Flat* f, const float* queries, bool q_on_device, size_t nq, uint32_t k, int select, int mode,
+                       const uint32_t* d_gather, uint64_t total, uint64_t* out_ids, float* out_scores,
+                       uint32_t* out_counts, bool out_on_device) {
+  if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "flat search: k=%u outside [1,%u]", k, K_MAX);
+  if (select != COLTT_SELECT_REFERENCE && select != COLTT_SELECT_NEAREST) return fail(COLTT_E_INVALID, "flat search: bad select %d", select);
+  if (mode != COLTT_MODE_EXACT) return fail(COLTT_E_UNSUPPORTED, "flat search: MFMA mode is not built in this round; use COLTT_MODE_EXACT");
+  if (nq == 0) return COLTT_OK;
+  const float* d_q = queries;
+  if (!q_on_device) {
+    COLTT_TRY(f->w_qraw.reserve(nq * f->dim * 4));
+    COLTT_HIP(hipMemcpyAsync(f->w_qraw.p, queries, nq * f->dim * 4, hipMemcpyHostToDevice, f->stream));
+    d_q = f->w_qraw.as<float>();
+  }
+  COLTT_TRY(prep_queries(f, d_q, nq));
+  uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
+  if (!out_on_device) {
+    COLTT_TRY(f->w_out_ids.reserve(nq * k * 8));
+    COLTT_TRY(f->w_out_sc.reserve(nq * k * 4));
+    COLTT_TRY(f->w_out_cnt.reserve(nq * 4));
+    d_oi = f->w_out_ids.as<uint64_t>(); d_os = f->w_out_sc.as<float>(); d_oc = f->w_out_cnt.as<uint32_t>();
+  }
+  COLTT_TRY(search_prepared(f, nq, k, select, d_gather, total, d_oi, d_os, d_oc));
+  if (!out_on_device) {
+    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, f->stream));
+    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, f->stream));
+    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, f->stream));
+  }
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  (void)hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1);
+  return COLTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out) {
+  if (!out) return fail(COLTT_E_INVALID, "flat_create: out is NULL");
+  if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "flat_create: dim %u outside [1,8192]", dim);
+  if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "flat_create: bad metric %d", metric);
+  if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");  // vectorstore.go:79
+  COLTT_TRY(ensure_device());
+  auto f = std::make_shared<Flat>();
+  f->dim = dim; f->metric = metric; f->quant = quant;
+  f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
+  if ((size_t)QB * dim * 4 > 64 * 1024) return fail(COLTT_E_UNSUPPORTED, "flat_create: dim %u too large for the LDS query tile", dim);
+  COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  COLTT_HIP(hipEventCreate(&f->ev0));
+  COLTT_HIP(hipEventCreate(&f->ev1));
+  *out = Registry::get().add(f);
+  return COLTT_OK;
+}
+
+int coltt_flat_destroy(coltt_handle_t h) {
+  if (!Registry::get().erase(h)) return fail(COLTT_E_NOT_FOUND, "flat_destroy: unknown handle");
+  return COLTT_OK;
+}
+
+int coltt_flat_reserve(coltt_handle_t h, uint64_t n_rows) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_reserve: unknown handle");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  return f->reserve(n_rows);
+}
+
+int coltt_flat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_upsert: unknown handle");
+  if (n == 0) return COLTT_OK;
+  if (!ids || !vecs) return fail(COLTT_E_INVALID, "flat_upsert: NULL input");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  COLTT_TRY(f->undense());
+  // slot assignment: existing id -> overwrite in place; a repeated id inside the batch -> last one wins
+  std::vector<uint32_t> slots(n);
+  uint64_t nn = f->n;
+  for (size_t i = 0; i < n; i++) {
+    auto it = f->id2slot.find(ids[i]);
+    if (it != f->id2slot.end()) slots[i] = it->second;
+    else { slots[i] = (uint32_t)nn; f->id2slot[ids[i]] = (uint32_t)nn; nn++; }
+  }
+  COLTT_TRY(f->reserve(nn));
+  f->h_ids.resize(nn);
+  for (size_t i = 0; i < n; i++) f->h_ids[slots[i]] = ids[i];
+  // last-wins for duplicates inside the batch: keep only the last occurrence of each slot
+  {
+    std::unordered_map<uint32_t, size_t> last;
+    for (size_t i = 0; i < n; i++) last[slots[i]] = i;
+    if (last.size() != n) {
+      // process duplicates serially by uploading only the winning rows
+      std::vector<uint32_t> s2; std::vector<float> v2;
+      s2.reserve(last.size()); v2.reserve(last.size() * f->dim);
+      for (size_t i = 0; i < n; i++) if (last[slots[i]] == i) { s2.push_back(slots[i]); v2.insert(v2.end(), vecs + i * f->dim, vecs + (i + 1) * f->dim); }
+      size_t m = s2.size();
+      COLTT_TRY(f->w_raw.reserve(m * f->dim * 4));
+      COLTT_TRY(f->w_slots.reserve(m * 4));
+      COLTT_HIP(hipMemcpyAsync(f->w_raw.p, v2.data(), m * f->dim * 4, hipMemcpyHostToDevice, f->stream));
+      COLTT_HIP(hipMemcpyAsync(f->w_slots.p, s2.data(), m * 4, hipMemcpyHostToDevice, f->stream));
+      COLTT_TRY(prep_rows(f.get(), f->w_raw.as<float>(), m, f->w_slots.as<uint32_t>(), 0));
+      COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
+      COLTT_HIP(hipStreamSynchronize(f->stream));
+      f->n = nn;
+      return COLTT_OK;
+    }
+  }
+  COLTT_TRY(f->w_raw.reserve(n * f->dim * 4));
+  COLTT_TRY(f->w_slots.reserve(n * 4));
+  COLTT_HIP(hipMemcpyAsync(f->w_raw.p, vecs, n * f->dim * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_TRY(prep_rows(f.get(), f->w_raw.as<float>(), n, f->w_slots.as<uint32_t>(), 0));
+  COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  f->n = nn;
+  return COLTT_OK;
+}
+
+int coltt_flat_upsert_device(coltt_handle_t h, const uint64_t* ids, uint64_t first_id, const float* d_vecs, size_t n) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_upsert_device: unknown handle");
+  if (n == 0) return COLTT_OK;
+  if (!d_vecs) return fail(COLTT_E_INVALID, "flat_upsert_device: NULL vectors");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  if (!ids && f->dense && (f->n == 0 || first_id == f->dense_base + f->n)) {  // append-only dense fast path
+    if (f->n == 0) f->dense_base = first_id;
+    COLTT_TRY(f->reserve(f->n + n));
+    COLTT_TRY(prep_rows(f.get(), d_vecs, n, nullptr, f->n));
+    COLTT_HIP(hipStreamSynchronize(f->stream));
+    f->n += n;
+    return COLTT_OK;
+  }
+  COLTT_TRY(f->undense());
+  std::vector<uint32_t> slots(n);
+  uint64_t nn = f->n;
+  for (size_t i = 0; i < n; i++) {
+    uint64_t id = ids ? ids[i] : first_id + i;
+    auto it = f->id2slot.find(id);
+    if (it != f->id2slot.end()) slots[i] = it->second;
+    else { slots[i] = (uint32_t)nn; f->id2slot[id] = (uint32_t)nn; nn++; }
+  }
+  COLTT_TRY(f->reserve(nn));
+  f->h_ids.resize(nn);
+  for (size_t i = 0; i < n; i++) f->h_ids[slots[i]] = ids ? ids[i] : first_id + i;
+  COLTT_TRY(f->w_slots.reserve(n * 4));
+  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_TRY(prep_rows(f.get(), d_vecs, n, f->w_slots.as<uint32_t>(), 0));
+  COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  f->n = nn;
+  return COLTT_OK;
+}
+
+int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_remove: unknown handle");
+  if (n == 0) return COLTT_OK;
+  if (!ids) return fail(COLTT_E_INVALID, "flat_remove: NULL ids");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  COLTT_TRY(f->undense());
+  for (size_t i = 0; i < n; i++) {
+    auto it = f->id2slot.find(ids[i]);
+    if (it == f->id2slot.end()) continue;  // delete() of a missing key is a no-op in Go
+    uint32_t s = it->second;
+    uint64_t last = f->n - 1;
+    f->id2slot.erase(it);
+    if (s != last) {  // move the last row into the hole
+      uint8_t* R = f->rows.as<uint8_t>();
+      COLTT_HIP(hipMemcpyAsync(R + (size_t)s * f->stride, R + (size_t)last * f->stride, f->stride, hipMemcpyDeviceToDevice, f->stream));
+      COLTT_HIP(hipMemcpyAsync(f->norms.as<float>() + s, f->norms.as<float>() + last, 4, hipMemcpyDeviceToDevice, f->stream));
+      uint64_t moved = f->h_ids[last];
+      f->h_ids[s] = moved;
+      f->id2slot[moved] = s;
+    }
+    f->h_ids.pop_back();
+    f->n--;
+  }
+  if (f->n) COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), f->n * 8, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  return COLTT_OK;
+}
+
+int coltt_flat_len(coltt_handle_t h, uint64_t* out) {
+  auto f = lookup<Flat>(h);
+  if (!f || !out) return fail(COLTT_E_NOT_FOUND, "flat_len: unknown handle");
+  std::lock_guard<std::mutex> g(f->mu);
+  *out = f->n;
+  return COLTT_OK;
+}
+
+int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row) {
+  auto f = lookup<Flat>(h);
+  if (!f || !out_row) return fail(COLTT_E_NOT_FOUND, "flat_get: unknown handle");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  uint64_t slot;
+  if (f->dense) { if (id < f->dense_base || id >= f->dense_base + f->n) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = id - f->dense_base; }
+  else { auto it = f->id2slot.find(id); if (it == f->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = it->second; }
+  COLTT_HIP(hipMemcpy(out_row, f->rows.as<uint8_t>() + slot * f->stride, (size_t)f->dim * quant_bytes(f->quant), hipMemcpyDeviceToHost));
+  return COLTT_OK;
+}
+
+int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search: unknown handle");
+  if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search: NULL buffer");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  return flat_search_common(f.get(), queries, false, nq, k, select, mode, nullptr, f->n, out_ids, out_scores, out_counts, false);
+}
+
+int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, int select, int mode,
+                             uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_device: unknown handle");
+  if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "flat_search_device: NULL buffer");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  return flat_search_common(f.get(), d_queries, true, nq, k, select, mode, nullptr, f->n, d_out_ids, d_out_scores, d_out_counts, true);
+}
+
+int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,
+                          const uint64_t* cand_ids, size_t n_cand, uint64_t* out_ids, float* out_scores,
+                          uint32_t* out_counts) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_ids: unknown handle");
+  if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search_ids: NULL buffer");
+  if (n_cand && !cand_ids) return fail(COLTT_E_INVALID, "flat_search_ids: NULL candidates");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  // id -> slot; ids that are not stored are skipped (none_vectorstore.go:201 `if node, ok := ...; ok`);
+  // a repeated candidate id is scored once (roaring64 ToArray yields a set, pkg/inverted/search.go:113-119)
+  std::vector<uint32_t> slots;
+  slots.reserve(n_cand);
+  for (size_t i = 0; i < n_cand; i++) {
+    uint64_t id = cand_ids[i];
+    if (f->dense) { if (id >= f->dense_base && id < f->dense_base + f->n) slots.push_back((uint32_t)(id - f->dense_base)); }
+    else { auto it = f->id2slot.find(id); if (it != f->id2slot.end()) slots.push_back(it->second); }
+  }
+  std::sort(slots.begin(), slots.end());
+  slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+  COLTT_TRY(f->w_gather.reserve(std::max<size_t>(slots.size(), 1) * 4));
+  if (!slots.empty()) COLTT_HIP(hipMemcpyAsync(f->w_gather.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, f->stream));
+  return flat_search_common(f.get(), queries, false, nq, k, select, COLTT_MODE_EXACT, f->w_gather.as<uint32_t>(), slots.size(),
+                            out_ids, out_scores, out_counts, false);
+}
+
+int coltt_last_kernel_ms_flat(coltt_handle_t h, float* out_ms) {
+  auto f = lookup<Flat>(h);
+  if (!f || !out_ms) return fail(COLTT_E_NOT_FOUND, "last_kernel_ms: unknown handle");
+  *out_ms = f->last_ms;
+  return COLTT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,830 @@
+// hnsw.hip — core/vectorindex.Hnsw on the GPU (core/vectorindex/hnsw.go).
+//
+// HBM layout (one index = one collection shard on one GPU), everything addressed by dense slot (u32 =
+// insertion index, never reused — the oracle uses the same numbering as its canonical order):
+//   rows      [cap][stride]     stored vectors (normalised for cosine; 4/2/1-byte codes)
+//   norms     [cap] f32         ||row||^2 in AVX order
+//   ids       [cap] u64         slot -> id                       (absent in dense-id mode)
+//   adj0      [cap][mMax0] u32  level-0 neighbours, ascending slot, padded 0xffffffff   (+ adj0_d f32 distances)
+//   upper_off [cap] u32         first upper row of the slot (a vertex of level L owns L consecutive rows)
+//   adjU      [ucap][mMax] u32  levels >= 1                                                (+ adjU_d)
+//   del_bits  [cap/32] u32      tombstones (hnswVertex.deleted)
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+#include "exact.hpp"
+#include "hnsw_dev.hpp"
+#include "prep.hpp"
+
+using namespace coltt;
+using namespace coltt::dev;
+
+namespace {
+
+// Hnsw.Search (hnsw.go:243-278) for a batch: one wave per query, queries pulled from a global counter.
+template <int METRIC, int QUANT>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t entry, int32_t entry_level,
+                                                        const float* __restrict__ q_eff, const float* __restrict__ qnorms,
+                                                        uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
+                                                        uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
+                                                        float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                        unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  WaveCtx w;
+  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  w.qs = reinterpret_cast<float*>(smem);
+  w.res[0] = reinterpret_cast<unsigned long long*>(smem + off);
+  w.res[1] = w.res[0] + ef_pad;
+  w.vis = reinterpret_cast<uint32_t*>(w.res[1] + ef_pad);
+  w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
+  for (;;) {
+    uint32_t qi = 0;
+    if (lane == 0) qi = atomicAdd(counter, 1u);
+    qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+    if (qi >= nq) break;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0;
+    __syncthreads();
+    for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    w.qnorm = qnorms[qi];
+    __syncthreads();
+    // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253)
+    uint32_t cur = (uint32_t)entry;
+    float curd = eval_pair<METRIC, QUANT>(g, w, cur, lane & 1);
+    curd = __shfl(curd, 0, 64);
+    w.n_dist += 1;
+    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT>(g, w, cur, curd, l, lane);  // :254-256
+    // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    w.n_dist += 1;
+    uint32_t len; int buf;
+    search_level<METRIC, QUANT>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
+    // selectNeighbors + pop into result[n-1..0] (:261-277) == the k smallest, ascending
+    uint32_t n = len < k ? len : k;
+    const unsigned long long* res = w.res[buf];
+    for (uint32_t i = lane; i < n; i += 64) {
+      unsigned long long e = res[i];
+      uint32_t slot = (uint32_t)e >> 1;
+      out_ids[(size_t)qi * k + i] = g.ids ? g.ids[slot] : (uint64_t)slot;
+      out_scores[(size_t)qi * k + i] = __uint_as_float((uint32_t)(e >> 32));
+    }
+    if (lane == 0) {
+      out_counts[qi] = n;
+      atomicAdd(&stats[0], (unsigned long long)w.n_dist);
+      atomicAdd(&stats[1], (unsigned long long)w.n_exp);
+      atomicAdd(&stats[2], (unsigned long long)w.n_hops);
+      atomicAdd(&stats[3], (unsigned long long)w.n_resets);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Graph construction (Hnsw.Insert, hnsw.go:104-167) for a batch of new vertices against the frozen graph.
+// Phase A (this kernel, one wave per new vertex): greedy descent above the vertex level (:126-130), then per
+// level searchLevel(efConstruction) + the m nearest (:132-140); the vertex's own rows are written here
+// (nobody can reach a new vertex yet: it has no in-edges) and one link request per selected neighbour is
+// queued: req[r] = {row id of the neighbour's level-l row, new slot, distance}, chained per target row through
+// head[]/next[] with atomicExch.
+// ---------------------------------------------------------------------------------------------------
+struct BuildReq { uint32_t rid, from; float d; uint32_t next; };
+
+template <int METRIC, int QUANT>
+__global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int32_t entry, int32_t entry_level, uint32_t base,
+                                                              uint32_t count, const int32_t* __restrict__ levels, uint32_t M,
+                                                              uint32_t efc, uint32_t ef_pad, uint32_t hcap, uint64_t cap_slots,
+                                                              uint32_t* __restrict__ counter, uint32_t* __restrict__ req_count,
+                                                              BuildReq* __restrict__ req, uint32_t* __restrict__ head,
+                                                              unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  WaveCtx w;
+  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  w.qs = reinterpret_cast<float*>(smem);
+  w.res[0] = reinterpret_cast<unsigned long long*>(smem + off);
+  w.res[1] = w.res[0] + ef_pad;
+  w.vis = reinterpret_cast<uint32_t*>(w.res[1] + ef_pad);
+  w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
+  for (;;) {
+    uint32_t bi = 0;
+    if (lane == 0) bi = atomicAdd(counter, 1u);
+    bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi);
+    if (bi >= count) break;
+    const uint32_t vi = base + bi;
+    const int lv = levels[bi];
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0;
+    __syncthreads();
+    {  // the query is the vertex's own stored row, decoded to f32
+      const uint8_t* row = g.rows + (size_t)vi * g.stride;
+      for (int e = lane; e < g.dim; e += 64) w.qs[e] = load1<QUANT>(row, e);
+    }
+    w.qnorm = METRIC == M_COS ? g.norms[vi] : 0.f;
+    __syncthreads();
+    uint32_t cur = (uint32_t)entry;
+    float curd = eval_pair<METRIC, QUANT>(g, w, cur, lane & 1);
+    curd = __shfl(curd, 0, 64);
+    w.n_dist += 1;
+    for (int l = entry_level; l > lv; l--) greedy_level<METRIC, QUANT>(g, w, cur, curd, l, lane);
+    for (int l = entry_level < lv ? entry_level : lv; l >= 0; l--) {
+      uint32_t len; int buf;
+      w.n_dist += 1;
+      search_level<METRIC, QUANT>(g, w, cur, curd, efc, l, lane, len, buf);
+      const unsigned long long* res = w.res[buf];
+      const uint32_t m = len < M ? len : M;
+      // the m nearest, re-ordered by slot (canonical row order)
+      unsigned long long e = (uint32_t)lane < m ? res[lane] : ~0ull;
+      uint32_t myslot = (uint32_t)e >> 1;
+      float myd = __uint_as_float((uint32_t)(e >> 32));
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < m; j++) {
+        uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)j);
+        rank += sj < myslot ? 1u : 0u;
+      }
+      uint32_t width;
+      uint32_t* row = const_cast<uint32_t*>(adj_row(g, vi, l, width));
+      float* drow = (l == 0 ? g.adj0_d + (size_t)vi * g.mMax0 : g.adjU_d + ((size_t)g.upper_off[vi] + (uint32_t)(l - 1)) * g.mMax);
+      uint32_t r0 = 0;
+      if (lane == 0) r0 = atomicAdd(req_count, m);
+      r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+      if ((uint32_t)lane < m) {
+        row[rank] = myslot; drow[rank] = myd;
+        uint32_t rid = l == 0 ? myslot : (uint32_t)cap_slots + g.upper_off[myslot] + (uint32_t)(l - 1);
+        uint32_t r = r0 + lane;
+        uint32_t old = atomicExch(&head[rid], r);
+        req[r].rid = rid; req[r].from = vi; req[r].d = myd; req[r].next = old;
+      }
+      // next level starts from the nearest result (hnsw.go:145 `entrypoint = neighbor`, last popped = nearest)
+      unsigned long long e0 = res[0];
+      cur = (uint32_t)e0 >> 1; curd = __uint_as_float((uint32_t)(e0 >> 32));
+      __syncthreads();
+    }
+    if (lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)w.n_dist);
+      atomicAdd(&stats[1], (unsigned long long)w.n_exp);
+      atomicAdd(&stats[2], (unsigned long long)w.n_hops);
+      atomicAdd(&stats[3], (unsigned long long)w.n_resets);
+    }
+  }
+}
+
+// Phase B: apply the queued links to the neighbours' rows (hnsw.go:151-158: neighbor.addEdge + pruneNeighbors when
+// the row exceeds mMax).  Exactly one request per touched row arrived first (next == NONE): its thread owns the
+// row.  Closed form of "add one by one, prune on overflow" (order-independent): if existing + added <= width the
+// row is the union; otherwise the deleted neighbours are dropped (pruneNeighbors skips them, hnsw.go:454-456) and
+// the `width` nearest by (stored distance, slot) are kept (selectNeighbors, :391-397).  Rows stay sorted by slot.
+constexpr int LINK_W = 64;    // widest row the builder supports
+constexpr int LINK_CH = 64;   // requests merged per round
+__global__ void hnsw_link_kernel(GraphView g, uint64_t cap_slots, const BuildReq* __restrict__ req, uint32_t n_req,
+                                 uint32_t* __restrict__ head) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_req) return;
+  if (req[r].next != NBR_NONE) return;
+  const uint32_t rid = req[r].rid;
+  const bool lvl0 = rid < cap_slots;
+  const uint32_t W = lvl0 ? g.mMax0 : g.mMax;
+  uint32_t* row = lvl0 ? g.adj0 + (size_t)rid * g.mMax0 : g.adjU + (size_t)(rid - cap_slots) * g.mMax;
+  float* drow = lvl0 ? g.adj0_d + (size_t)rid * g.mMax0 : g.adjU_d + (size_t)(rid - cap_slots) * g.mMax;
+  uint32_t s[LINK_W + LINK_CH]; float d[LINK_W + LINK_CH];
+  uint32_t n = 0;
+  for (; n < W && row[n] != NBR_NONE; n++) { s[n] = row[n]; d[n] = drow[n]; }
+  uint32_t cur = head[rid];
+  head[rid] = NBR_NONE;
+  while (cur != NBR_NONE) {
+    uint32_t take = 0;
+    while (cur != NBR_NONE && take < LINK_CH) { s[n + take] = req[cur].from; d[n + take] = req[cur].d; cur = req[cur].next; take++; }
+    uint32_t tot = n + take;
+    if (tot > W) {
+      uint32_t m = 0;  // drop tombstoned neighbours
+      for (uint32_t i = 0; i < tot; i++) if (!is_deleted(g, s[i])) { s[m] = s[i]; d[m] = d[i]; m++; }
+      // insertion sort by (d, slot)
+      for (uint32_t i = 1; i < m; i++) {
+        uint32_t si = s[i]; float di = d[i]; uint32_t j = i;
+        while (j > 0 && (d[j - 1] > di || (d[j - 1] == di && s[j - 1] > si))) { s[j] = s[j - 1]; d[j] = d[j - 1]; j--; }
+        s[j] = si; d[j] = di;
+      }
+      n = m < W ? m : W;
+    } else n = tot;
+  }
+  for (uint32_t i = 1; i < n; i++) {  // back to canonical slot order
+    uint32_t si = s[i]; float di = d[i]; uint32_t j = i;
+    while (j > 0 && s[j - 1] > si) { s[j] = s[j - 1]; d[j] = d[j - 1]; j--; }
+    s[j] = si; d[j] = di;
+  }
+  for (uint32_t i = 0; i < W; i++) { row[i] = i < n ? s[i] : NBR_NONE; drow[i] = i < n ? d[i] : 0.f; }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void add_base_kernel(uint64_t* ids, size_t n, uint64_t base) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] += base;
+}
+
+struct Hnsw : Object {
+  uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
+  coltt_hnsw_cfg cfg{};
+  uint64_t n = 0 /*slots*/, live = 0, cap = 0, n_upper = 0, ucap = 0;
+  int32_t entry = -1, entry_level = 0;
+  bool any_deleted = false;
+  DevBuf rows, norms, ids, adj0, adj0_d, upper_off, adjU, adjU_d, del_bits;
+  bool dense = true; uint64_t dense_base = 0;
+  std::unordered_map<uint64_t, uint32_t> id2slot;
+  std::vector<uint64_t> h_ids;       // !dense
+  std::vector<int32_t> h_levels;     // per slot
+  std::vector<uint32_t> h_upper_off; // per slot
+  std::vector<uint32_t> h_del;       // bitmap mirror
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
+  DevBuf w_raw, w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc;
+  DevBuf b_head, b_req, b_levels; uint64_t head_cap = 0;  // builder scratch
+  coltt_hnsw_stats build_stats{};
+  ~Hnsw() override {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  GraphView view() const {
+    GraphView g;
+    g.rows = rows.as<uint8_t>(); g.stride = stride; g.norms = norms.as<float>();
+    g.ids = dense ? nullptr : ids.as<uint64_t>();
+    g.adj0 = adj0.as<uint32_t>(); g.adj0_d = adj0_d.as<float>(); g.upper_off = upper_off.as<uint32_t>();
+    g.adjU = adjU.as<uint32_t>(); g.adjU_d = adjU_d.as<float>();
+    g.del_bits = any_deleted ? del_bits.as<uint32_t>() : nullptr;
+    g.mMax = (uint32_t)cfg.m_max; g.mMax0 = (uint32_t)cfg.m_max0; g.dim = (int)dim;
+    return g;
+  }
+  int reserve(uint64_t slots, uint64_t upper_rows) {
+    if (slots > cap) {
+      uint64_t nc = std::max<uint64_t>({slots, cap + cap / 2, 1024});
+      COLTT_TRY(rows.reserve(nc * stride, true, stream));
+      COLTT_TRY(norms.reserve(nc * 4, true, stream));
+      if (!dense) COLTT_TRY(ids.reserve(nc * 8, true, stream));
+      COLTT_TRY(adj0.reserve(nc * cfg.m_max0 * 4, true, stream));
+      COLTT_TRY(adj0_d.reserve(nc * cfg.m_max0 * 4, true, stream));
+      COLTT_TRY(upper_off.reserve(nc * 4, true, stream));
+      size_t old_words = (cap + 31) / 32, new_words = (nc + 31) / 32;
+      COLTT_TRY(del_bits.reserve(new_words * 4, true, stream));
+      if (new_words > old_words) COLTT_HIP(hipMemsetAsync(del_bits.as<uint32_t>() + old_words, 0, (new_words - old_words) * 4, stream));
+      cap = nc;
+    }
+    if (upper_rows > ucap) {
+      uint64_t nc = std::max<uint64_t>({upper_rows, ucap + ucap / 2, 256});
+      COLTT_TRY(adjU.reserve(nc * cfg.m_max * 4, true, stream));
+      COLTT_TRY(adjU_d.reserve(nc * cfg.m_max * 4, true, stream));
+      ucap = nc;
+    }
+    return COLTT_OK;
+  }
+};
+
+int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, bool normalize) {
+  if (n == 0) return COLTT_OK;
+  int nrm = normalize ? 1 : 0;
+  uint8_t* R = x->rows.as<uint8_t>();
+  float* N = x->norms.as<float>();
+#define COLTT_PREP(Q)                                                                                                  \
+  do {                                                                                                                 \
+    prep_rows_kernel<Q><<<ceil_div(n, 128), 128, 0, x->stream>>>(d_raw, n, (int)x->dim, nrm, nullptr, slot_base, R, x->stride); \
+    row_norms_kernel<Q><<<ceil_div(n * 2, 256), 256, 0, x->stream>>>(R, x->stride, nullptr, slot_base, n, (int)x->dim, N);     \
+  } while (0)
+  if (x->quant == COLTT_Q_NONE) COLTT_PREP(Q_NONE);
+  else if (x->quant == COLTT_Q_F8) COLTT_PREP(Q_F8);
+  else COLTT_PREP(Q_F16);
+#undef COLTT_PREP
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+int prep_queries_any(Hnsw* x, const float* d_qraw, size_t nq) {
+  COLTT_TRY(x->w_qeff.reserve(nq * x->dim * 4));
+  COLTT_TRY(x->w_qn.reserve(nq * 4));
+  int norm = x->metric == COLTT_COSINE;
+  uint32_t g = ceil_div(nq, 64);
+  float* qe = x->w_qeff.as<float>();
+  if (x->quant == COLTT_Q_NONE) prep_queries_kernel<Q_NONE><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
+  else if (x->quant == COLTT_Q_F8) prep_queries_kernel<Q_F8><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
+  else prep_queries_kernel<Q_F16><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
+  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, x->stream>>>(qe, nq, (int)x->dim, x->w_qn.as<float>());
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; };
+SearchGeom search_geom(const Hnsw* x, uint32_t ef) {
+  SearchGeom s;
+  s.ef = ef;
+  s.ef_pad = (ef + 63) & ~63u;
+  // visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
+  s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
+  s.lds = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8 + (size_t)s.hcap * 4;
+  return s;
+}
+
+template <int METRIC, int QUANT>
+int launch_search(Hnsw* x, const SearchGeom& sg, uint32_t nq, uint32_t k, uint32_t* counter, uint64_t* oi, float* os,
+                  uint32_t* oc, unsigned long long* stats) {
+  auto kern = hnsw_search_kernel<METRIC, QUANT>;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
+  uint32_t grid = std::min<uint32_t>(nq, 256u * per_cu);
+  kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, x->w_qeff.as<float>(), x->w_qn.as<float>(), nq,
+                                        k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
+                  uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats) {
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (nq == 0) return COLTT_OK;
+  if (k == 0) return fail(COLTT_E_INVALID, "hnsw_search: k must be >= 1");
+  uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
+  if (!on_device) {
+    COLTT_TRY(x->w_out_ids.reserve(nq * k * 8));
+    COLTT_TRY(x->w_out_sc.reserve(nq * k * 4));
+    COLTT_TRY(x->w_out_cnt.reserve(nq * 4));
+    d_oi = x->w_out_ids.as<uint64_t>(); d_os = x->w_out_sc.as<float>(); d_oc = x->w_out_cnt.as<uint32_t>();
+  }
+  if (x->entry < 0) {  // empty index => empty result, not an error (hnsw.go:249-251)
+    COLTT_HIP(hipMemsetAsync(d_oc, 0, nq * 4, x->stream));
+    if (!on_device) COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipStreamSynchronize(x->stream));
+    return COLTT_OK;
+  }
+  uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
+  if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: ef=%u > 4096", ef);
+  SearchGeom sg = search_geom(x, ef);
+  if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
+  const float* d_q = queries;
+  if (!on_device) {
+    COLTT_TRY(x->w_qraw.reserve(nq * x->dim * 4));
+    COLTT_HIP(hipMemcpyAsync(x->w_qraw.p, queries, nq * x->dim * 4, hipMemcpyHostToDevice, x->stream));
+    d_q = x->w_qraw.as<float>();
+  }
+  COLTT_TRY(prep_queries_any(x, d_q, nq));
+  COLTT_TRY(x->w_misc.reserve(64));
+  uint32_t* counter = x->w_misc.as<uint32_t>();
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
+  COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 64, x->stream));
+  COLTT_HIP(hipEventRecord(x->ev0, x->stream));
+  int rc;
+#define COLTT_LS(M, Q) rc = launch_search<M, Q>(x, sg, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats)
+  if (x->metric == COLTT_COSINE) {
+    if (x->quant == COLTT_Q_NONE) COLTT_LS(M_COS, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LS(M_COS, Q_F8); else COLTT_LS(M_COS, Q_F16);
+  } else {
+    if (x->quant == COLTT_Q_NONE) COLTT_LS(M_L2, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LS(M_L2, Q_F8); else COLTT_LS(M_L2, Q_F16);
+  }
+#undef COLTT_LS
+  COLTT_TRY(rc);
+  COLTT_HIP(hipEventRecord(x->ev1, x->stream));
+  if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, x->stream>>>(d_oi, nq * k, x->dense_base);
+  unsigned long long h_stats[4] = {0, 0, 0, 0};
+  if (!on_device) {
+    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
+  }
+  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 32, hipMemcpyDeviceToHost, x->stream));
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  (void)hipEventElapsedTime(&x->last_ms, x->ev0, x->ev1);
+  if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }
+  return COLTT_OK;
+}
+
+
+// pruneNeighbors as Remove calls it (hnsw.go:234-236): rebuild the row from its non-deleted entries (<= width, so
+// nothing is trimmed).  One thread per (neighbour, level) row.
+__global__ void hnsw_unlink_kernel(GraphView g, const uint32_t* __restrict__ nbs, const int32_t* __restrict__ lvl, uint32_t n) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t W;
+  uint32_t* row = const_cast<uint32_t*>(adj_row(g, nbs[t], lvl[t], W));
+  float* drow = lvl[t] == 0 ? g.adj0_d + (size_t)nbs[t] * g.mMax0 : g.adjU_d + ((size_t)g.upper_off[nbs[t]] + (uint32_t)(lvl[t] - 1)) * g.mMax;
+  uint32_t m = 0;
+  for (uint32_t i = 0; i < W && row[i] != NBR_NONE; i++) {
+    uint32_t sl = row[i]; float dd = drow[i];
+    if (!is_deleted(g, sl)) { row[m] = sl; drow[m] = dd; m++; }
+  }
+  for (; m < W; m++) { row[m] = NBR_NONE; drow[m] = 0.f; }
+}
+
+int hnsw_undense(Hnsw* x) {
+  if (!x->dense) return COLTT_OK;
+  x->h_ids.resize(x->n);
+  x->id2slot.reserve(x->n * 2);
+  for (uint64_t s = 0; s < x->n; s++) {
+    x->h_ids[s] = x->dense_base + s;
+    if (!(x->h_del.size() > (s >> 5) && ((x->h_del[s >> 5] >> (s & 31)) & 1u))) x->id2slot[x->dense_base + s] = (uint32_t)s;
+  }
+  x->dense = false;
+  COLTT_TRY(x->ids.reserve(std::max<uint64_t>(x->cap, 1024) * 8, false, x->stream));
+  if (x->n) COLTT_HIP(hipMemcpyAsync(x->ids.p, x->h_ids.data(), x->n * 8, hipMemcpyHostToDevice, x->stream));
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  return COLTT_OK;
+}
+
+template <int METRIC, int QUANT>
+int launch_build(Hnsw* x, const SearchGeom& sg, uint32_t base, uint32_t count, const int32_t* d_levels, uint32_t* counter,
+                 uint32_t* req_count, BuildReq* req, uint32_t* head, unsigned long long* stats) {
+  auto kern = hnsw_build_search_kernel<METRIC, QUANT>;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
+  uint32_t grid = std::min<uint32_t>(count, 256u * per_cu);
+  kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, base, count, d_levels, (uint32_t)x->cfg.m,
+                                        sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// n Inserts (hnsw.go:104-167) in order, `batch` at a time against a frozen graph.  d_vecs: raw vectors in HBM.
+int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_vecs, const int32_t* levels, size_t n,
+                uint32_t batch) {
+  if (n == 0) return COLTT_OK;
+  if (batch == 0) batch = 1;
+  if (x->cfg.m_max > LINK_W || x->cfg.m_max0 > LINK_W) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: builder supports mMax, mMax0 <= %d", LINK_W);
+  if (x->cfg.m > 64) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: builder supports m <= 64");
+  if (x->n + n >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: more than 2^31-1 slots");
+  for (size_t i = 0; i < n; i++) if (levels[i] < 0 || levels[i] > 60) return fail(COLTT_E_INVALID, "hnsw insert: level %d out of range", levels[i]);
+  bool dense_ok = !ids && x->dense && (x->n == 0 || first_id == x->dense_base + x->n);
+  if (dense_ok) { if (x->n == 0) x->dense_base = first_id; }
+  else {
+    COLTT_TRY(hnsw_undense(x));
+    std::unordered_map<uint64_t, int> seen;
+    for (size_t i = 0; i < n; i++) {  // storeVertex: ItemAlreadyExistsError (hnsw.go:293-295), checked before any mutation
+      uint64_t id = ids ? ids[i] : first_id + i;
+      if (x->id2slot.count(id) || !seen.emplace(id, 1).second) return fail(COLTT_E_EXISTS, "Item already exists");
+    }
+  }
+  const uint32_t efc = (uint32_t)x->cfg.ef_construction;
+  SearchGeom sg = search_geom(x, efc);
+  if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", sg.lds);
+  COLTT_TRY(x->w_misc.reserve(64));
+  uint32_t* counter = x->w_misc.as<uint32_t>();
+  uint32_t* req_count = counter + 1;
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
+  size_t i = 0;
+  while (i < n) {
+    const bool first = x->entry < 0 && x->live == 0 && x->n == 0;
+    uint32_t b = first ? 1u : (uint32_t)std::min<size_t>(batch, n - i);
+    if (!first && x->entry < 0) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: index lost its entrypoint (all entry neighbours removed)");
+    uint64_t up = 0;
+    for (uint32_t j = 0; j < b; j++) up += first ? 0 : (uint64_t)levels[i + j];
+    const uint64_t base = x->n;
+    COLTT_TRY(x->reserve(base + b, x->n_upper + up));
+    // host mirrors + per-slot tables
+    std::vector<uint32_t> uo(b);
+    std::vector<int32_t> lv(b);
+    uint64_t u = x->n_upper;
+    for (uint32_t j = 0; j < b; j++) {
+      lv[j] = first ? 0 : levels[i + j];  // first vertex is forced to level 0 (hnsw.go:108-110)
+      uo[j] = lv[j] > 0 ? (uint32_t)u : NBR_NONE;
+      u += (uint64_t)lv[j];
+      x->h_levels.push_back(lv[j]);
+      x->h_upper_off.push_back(uo[j]);
+      if (!x->dense) { uint64_t id = ids ? ids[i + j] : first_id + i + j; x->h_ids.push_back(id); x->id2slot[id] = (uint32_t)(base + j); }
+    }
+    x->h_del.resize((base + b + 31) / 32, 0u);
+    COLTT_HIP(hipMemcpyAsync(x->upper_off.as<uint32_t>() + base, uo.data(), (size_t)b * 4, hipMemcpyHostToDevice, x->stream));
+    if (!x->dense) COLTT_HIP(hipMemcpyAsync(x->ids.as<uint64_t>() + base, x->h_ids.data() + base, (size_t)b * 8, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemsetAsync(x->adj0.as<uint32_t>() + base * x->cfg.m_max0, 0xff, (size_t)b * x->cfg.m_max0 * 4, x->stream));
+    COLTT_HIP(hipMemsetAsync(x->adj0_d.as<float>() + base * x->cfg.m_max0, 0, (size_t)b * x->cfg.m_max0 * 4, x->stream));
+    if (up) {
+      COLTT_HIP(hipMemsetAsync(x->adjU.as<uint32_t>() + x->n_upper * x->cfg.m_max, 0xff, (size_t)up * x->cfg.m_max * 4, x->stream));
+      COLTT_HIP(hipMemsetAsync(x->adjU_d.as<float>() + x->n_upper * x->cfg.m_max, 0, (size_t)up * x->cfg.m_max * 4, x->stream));
+    }
+    COLTT_TRY(prep_rows_any(x, d_vecs + i * x->dim, b, base, x->metric == COLTT_COSINE));
+    if (first) {
+      COLTT_HIP(hipStreamSynchronize(x->stream));
+      x->entry = (int32_t)base; x->entry_level = 0;
+      x->n += 1; x->live += 1; i += 1;
+      continue;
+    }
+    // builder scratch: head[] over every adjacency row, request queue sized for the worst case
+    uint64_t need_head = x->cap + x->ucap;
+    if (need_head > x->head_cap) {
+      COLTT_TRY(x->b_head.reserve(need_head * 4));
+      fill_u32_kernel<<<ceil_div(need_head, 256), 256, 0, x->stream>>>(x->b_head.as<uint32_t>(), need_head, NBR_NONE);
+      x->head_cap = need_head;
+    }
+    uint64_t max_req = 0;
+    for (uint32_t j = 0; j < b; j++) max_req += (uint64_t)(std::min<int32_t>(lv[j], x->entry_level) + 1) * (uint64_t)x->cfg.m;
+    COLTT_TRY(x->b_req.reserve(std::max<uint64_t>(max_req, 1) * sizeof(BuildReq)));
+    COLTT_TRY(x->b_levels.reserve((size_t)b * 4));
+    COLTT_HIP(hipMemcpyAsync(x->b_levels.p, lv.data(), (size_t)b * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 64, x->stream));
+    int rc;
+#define COLTT_LB(M, Q) rc = launch_build<M, Q>(x, sg, (uint32_t)base, b, x->b_levels.as<int32_t>(), counter, req_count, \
+                                               x->b_req.as<BuildReq>(), x->b_head.as<uint32_t>(), d_stats)
+    if (x->metric == COLTT_COSINE) {
+      if (x->quant == COLTT_Q_NONE) COLTT_LB(M_COS, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LB(M_COS, Q_F8); else COLTT_LB(M_COS, Q_F16);
+    } else {
+      if (x->quant == COLTT_Q_NONE) COLTT_LB(M_L2, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LB(M_L2, Q_F8); else COLTT_LB(M_L2, Q_F16);
+    }
+#undef COLTT_LB
+    COLTT_TRY(rc);
+    struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[4]; } hm;
+    COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipStreamSynchronize(x->stream));
+    if (hm.n_req) {
+      hnsw_link_kernel<<<ceil_div(hm.n_req, 64), 64, 0, x->stream>>>(x->view(), x->cap, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>());
+      COLTT_HIP(hipGetLastError());
+    }
+    x->build_stats.n_dist += hm.st[0]; x->build_stats.n_exp += hm.st[1]; x->build_stats.n_hops += hm.st[2]; x->build_stats.n_visit_resets += hm.st[3];
+    for (uint32_t j = 0; j < b; j++)  // entrypoint CAS in insertion order (hnsw.go:161-164)
+      if (lv[j] > x->entry_level) { x->entry = (int32_t)(base + j); x->entry_level = lv[j]; }
+    x->n += b; x->live += b; x->n_upper += up; i += b;
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  return COLTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out) {
+  if (!out) return fail(COLTT_E_INVALID, "hnsw_create: out is NULL");
+  if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "hnsw_create: dim %u outside [1,8192]", dim);
+  if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "hnsw_create: bad metric %d", metric);
+  if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");
+  COLTT_TRY(ensure_device());
+  auto x = std::make_shared<Hnsw>();
+  x->dim = dim; x->metric = metric; x->quant = quant;
+  x->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
+  coltt_hnsw_cfg c = cfg ? *cfg : coltt_hnsw_cfg{16, -1, -1, 20, 200, 0, -1.f, 0, 1};
+  if (c.m <= 0) return fail(COLTT_E_INVALID, "hnsw_create: m must be > 0");
+  // newHnswConfig defaults (hnsw_config.go:150-160)
+  if (c.level_multiplier == -1.f) c.level_multiplier = 1.0f / (float)std::log((double)(float)c.m);
+  if (c.m_max == -1) c.m_max = c.m;
+  if (c.m_max0 == -1) c.m_max0 = 2 * c.m;
+  if (c.algo != 0 && c.algo != 1) return fail(COLTT_E_INVALID, "hnsw_create: unknown search algorithm %d", c.algo);
+  if (c.algo == 1 && c.extend_candidates)
+    return fail(COLTT_E_UNSUPPORTED, "hnsw_create: HeuristicExtendCandidates is undefined behaviour in the reference "
+                                     "(priority_queue.go:109-122 aliases the heap array); rejected");
+  if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
+  if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
+  x->cfg = c;
+  COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+  COLTT_HIP(hipEventCreate(&x->ev0));
+  COLTT_HIP(hipEventCreate(&x->ev1));
+  *out = Registry::get().add(x);
+  return COLTT_OK;
+}
+
+int coltt_hnsw_destroy(coltt_handle_t h) {
+  if (!Registry::get().erase(h)) return fail(COLTT_E_NOT_FOUND, "hnsw_destroy: unknown handle");
+  return COLTT_OK;
+}
+
+int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out) {
+  auto x = lookup<Hnsw>(h);
+  if (!x || !out) return fail(COLTT_E_NOT_FOUND, "hnsw_get_cfg: unknown handle");
+  *out = x->cfg;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_len(coltt_handle_t h, uint64_t* out) {
+  auto x = lookup<Hnsw>(h);
+  if (!x || !out) return fail(COLTT_E_NOT_FOUND, "hnsw_len: unknown handle");
+  std::lock_guard<std::mutex> g(x->mu);
+  *out = x->live;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, const int32_t* levels, const uint8_t* deleted,
+                         const float* vectors, const int64_t* row_offsets, const int32_t* nbr, const float* nbr_dist,
+                         int32_t entry_slot) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_bulk_load: unknown handle");
+  if (n && (!levels || !vectors || !row_offsets)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: NULL input");
+  if (n >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw_bulk_load: more than 2^31-1 slots");
+  if (n && (entry_slot < -1 || entry_slot >= (int64_t)n)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: entry slot out of range");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  uint64_t n_upper = 0;
+  for (uint64_t i = 0; i < n; i++) { if (levels[i] < 0) return fail(COLTT_E_INVALID, "hnsw_bulk_load: negative level"); n_upper += (uint64_t)levels[i]; }
+  x->n = 0; x->live = 0; x->cap = 0; x->ucap = 0; x->n_upper = 0;
+  x->dense = (ids == nullptr); x->dense_base = 0; x->id2slot.clear();
+  COLTT_TRY(x->reserve(n, n_upper));
+  std::vector<uint32_t> a0((size_t)n * W0, NBR_NONE), aU((size_t)n_upper * WU, NBR_NONE), uo(n, NBR_NONE);
+  std::vector<float> d0((size_t)n * W0, 0.f), dU((size_t)n_upper * WU, 0.f);
+  x->h_levels.assign(levels, levels + n);
+  x->h_del.assign((n + 31) / 32, 0u);
+  x->any_deleted = false;
+  uint64_t row = 0, up = 0;
+  std::vector<std::pair<uint32_t, float>> tmp;
+  for (uint64_t i = 0; i < n; i++) {
+    bool del = deleted && deleted[i];
+    if (del) { x->h_del[i >> 5] |= 1u << (i & 31); x->any_deleted = true; } else x->live++;
+    if (levels[i] > 0) { uo[i] = (uint32_t)up; }
+    for (int l = 0; l <= levels[i]; l++, row++) {
+      int64_t b = row_offsets[row], e = row_offsets[row + 1];
+      uint32_t W = l == 0 ? W0 : WU;
+      if (e - b > (int64_t)W) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d has %lld edges > width %u", (unsigned long long)i, l, (long long)(e - b), W);
+      tmp.clear();
+      for (int64_t j = b; j < e; j++) {
+        if (nbr[j] < 0 || (uint64_t)nbr[j] >= n) return fail(COLTT_E_INVALID, "hnsw_bulk_load: neighbour slot out of range");
+        tmp.push_back({(uint32_t)nbr[j], nbr_dist ? nbr_dist[j] : 0.f});
+      }
+      std::sort(tmp.begin(), tmp.end());
+      uint32_t* ar = l == 0 ? &a0[(size_t)i * W0] : &aU[(size_t)(up + l - 1) * WU];
+      float* dr = l == 0 ? &d0[(size_t)i * W0] : &dU[(size_t)(up + l - 1) * WU];
+      for (size_t j = 0; j < tmp.size(); j++) { ar[j] = tmp[j].first; dr[j] = tmp[j].second; }
+    }
+    up += (uint64_t)levels[i];
+  }
+  x->h_upper_off = uo;
+  if (!x->dense) {
+    x->h_ids.assign(ids, ids + n);
+    x->id2slot.reserve(n * 2);
+    for (uint64_t i = 0; i < n; i++) if (!(deleted && deleted[i])) x->id2slot[ids[i]] = (uint32_t)i;
+    COLTT_HIP(hipMemcpyAsync(x->ids.p, ids, n * 8, hipMemcpyHostToDevice, x->stream));
+  }
+  if (n) {
+    COLTT_HIP(hipMemcpyAsync(x->adj0.p, a0.data(), a0.size() * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->adj0_d.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->upper_off.p, uo.data(), n * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->del_bits.p, x->h_del.data(), x->h_del.size() * 4, hipMemcpyHostToDevice, x->stream));
+    if (n_upper) {
+      COLTT_HIP(hipMemcpyAsync(x->adjU.p, aU.data(), aU.size() * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(x->adjU_d.p, dU.data(), dU.size() * 4, hipMemcpyHostToDevice, x->stream));
+    }
+    // vectors in chunks through a staging buffer: Normalize (cosine) + Lower, as Insert does (hnsw.go:105-107)
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)x->dim * 4));
+    COLTT_TRY(x->w_raw.reserve(std::min<uint64_t>(chunk, n) * x->dim * 4));
+    for (uint64_t b = 0; b < n; b += chunk) {
+      uint64_t m = std::min<uint64_t>(chunk, n - b);
+      COLTT_HIP(hipMemcpyAsync(x->w_raw.p, vectors + b * x->dim, m * x->dim * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_TRY(prep_rows_any(x.get(), x->w_raw.as<float>(), m, b, x->metric == COLTT_COSINE));
+      COLTT_HIP(hipStreamSynchronize(x->stream));
+    }
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  x->n = n; x->n_upper = n_upper;
+  x->entry = n ? entry_slot : -1;
+  x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, uint32_t ef_override,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search: unknown handle");
+  if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "hnsw_search: NULL buffer");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  return search_common(x.get(), queries, false, nq, k, ef_override, out_ids, out_scores, out_counts, stats);
+}
+
+int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
+                             uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search_device: unknown handle");
+  if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "hnsw_search_device: NULL buffer");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  return search_common(x.get(), d_queries, true, nq, k, ef_override, d_out_ids, d_out_scores, d_out_counts, stats);
+}
+
+
+int coltt_hnsw_insert(coltt_handle_t h, uint64_t id, const float* vec, int32_t level) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert: unknown handle");
+  if (!vec) return fail(COLTT_E_INVALID, "hnsw_insert: NULL vector");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  COLTT_TRY(x->w_raw.reserve((size_t)x->dim * 4));
+  COLTT_HIP(hipMemcpyAsync(x->w_raw.p, vec, (size_t)x->dim * 4, hipMemcpyHostToDevice, x->stream));
+  return insert_core(x.get(), &id, 0, x->w_raw.as<float>(), &level, 1, 1);
+}
+
+int coltt_hnsw_insert_batch_device(coltt_handle_t h, const uint64_t* ids, uint64_t first_id, const float* d_vecs,
+                                   const int32_t* levels, size_t n, uint32_t batch) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert_batch_device: unknown handle");
+  if (n && (!d_vecs || !levels)) return fail(COLTT_E_INVALID, "hnsw_insert_batch_device: NULL input");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  return insert_core(x.get(), ids, first_id, d_vecs, levels, n, batch);
+}
+
+int coltt_hnsw_remove(coltt_handle_t h, uint64_t id) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_remove: unknown handle");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  uint32_t vi;
+  if (x->dense) {
+    if (id < x->dense_base || id >= x->dense_base + x->n) return fail(COLTT_E_NOT_FOUND, "Item not found");
+    vi = (uint32_t)(id - x->dense_base);
+    if ((x->h_del[vi >> 5] >> (vi & 31)) & 1u) return fail(COLTT_E_NOT_FOUND, "Item not found");
+  } else {
+    auto it = x->id2slot.find(id);
+    if (it == x->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "Item not found");  // ItemNotFoundError (hnsw.go:317)
+    vi = it->second;
+    x->id2slot.erase(it);
+  }
+  // removeVertex: delete from the map, set the deleted flag (hnsw.go:304-318)
+  x->h_del[vi >> 5] |= 1u << (vi & 31);
+  x->any_deleted = true; x->live--;
+  COLTT_HIP(hipMemcpyAsync(x->del_bits.as<uint32_t>() + (vi >> 5), &x->h_del[vi >> 5], 4, hipMemcpyHostToDevice, x->stream));
+  // the removed vertex's own rows
+  const int L = x->h_levels[vi];
+  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  std::vector<std::vector<uint32_t>> nb(L + 1);
+  std::vector<std::vector<float>> nd(L + 1);
+  for (int l = 0; l <= L; l++) {
+    uint32_t W = l == 0 ? W0 : WU;
+    nb[l].resize(W); nd[l].resize(W);
+    const uint32_t* src = l == 0 ? x->adj0.as<uint32_t>() + (size_t)vi * W0 : x->adjU.as<uint32_t>() + ((size_t)x->h_upper_off[vi] + l - 1) * WU;
+    const float* dsrc = l == 0 ? x->adj0_d.as<float>() + (size_t)vi * W0 : x->adjU_d.as<float>() + ((size_t)x->h_upper_off[vi] + l - 1) * WU;
+    COLTT_HIP(hipMemcpyAsync(nb[l].data(), src, W * 4, hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipMemcpyAsync(nd[l].data(), dsrc, W * 4, hipMemcpyDeviceToHost, x->stream));
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  if (x->entry == (int32_t)vi) {  // new entrypoint: closest neighbour on the highest level that has any (hnsw.go:197-217)
+    float minD = 3.40282346638528859811704183484516925440e+38f;
+    int32_t closest = -1;
+    for (int l = L; l >= 0; l--) {
+      for (size_t j = 0; j < nb[l].size() && nb[l][j] != NBR_NONE; j++)
+        if (nd[l][j] < minD) { minD = nd[l][j]; closest = (int32_t)nb[l][j]; }
+      if (closest >= 0) break;
+    }
+    x->entry = closest;
+    x->entry_level = closest >= 0 ? x->h_levels[closest] : 0;
+  }
+  // every neighbour drops the back-edge and is re-pruned (hnsw.go:219-238)
+  std::vector<uint32_t> t_nb; std::vector<int32_t> t_lv;
+  for (int l = L; l >= 0; l--)
+    for (size_t j = 0; j < nb[l].size() && nb[l][j] != NBR_NONE; j++) { t_nb.push_back(nb[l][j]); t_lv.push_back(l); }
+  if (!t_nb.empty()) {
+    COLTT_TRY(x->b_req.reserve(t_nb.size() * 8));
+    uint32_t* d_nb = x->b_req.as<uint32_t>();
+    int32_t* d_lv = reinterpret_cast<int32_t*>(d_nb + t_nb.size());
+    COLTT_HIP(hipMemcpyAsync(d_nb, t_nb.data(), t_nb.size() * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(d_lv, t_lv.data(), t_lv.size() * 4, hipMemcpyHostToDevice, x->stream));
+    hnsw_unlink_kernel<<<ceil_div(t_nb.size(), 64), 64, 0, x->stream>>>(x->view(), d_nb, d_lv, (uint32_t)t_nb.size());
+    COLTT_HIP(hipGetLastError());
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  return COLTT_OK;
+}
+
+int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uint64_t* n_edges, uint64_t* ids,
+                      int32_t* levels, uint8_t* deleted, int64_t* row_offsets, int32_t* nbr, float* nbr_dist,
+                      int32_t* entry_slot) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export: unknown handle");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  const uint64_t n = x->n;
+  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  std::vector<uint32_t> a0((size_t)n * W0), aU((size_t)x->n_upper * WU);
+  std::vector<float> d0, dU;
+  if (n) COLTT_HIP(hipMemcpy(a0.data(), x->adj0.p, a0.size() * 4, hipMemcpyDeviceToHost));
+  if (x->n_upper) COLTT_HIP(hipMemcpy(aU.data(), x->adjU.p, aU.size() * 4, hipMemcpyDeviceToHost));
+  if (nbr_dist) {
+    d0.resize(a0.size()); dU.resize(aU.size());
+    if (n) COLTT_HIP(hipMemcpy(d0.data(), x->adj0_d.p, d0.size() * 4, hipMemcpyDeviceToHost));
+    if (x->n_upper) COLTT_HIP(hipMemcpy(dU.data(), x->adjU_d.p, dU.size() * 4, hipMemcpyDeviceToHost));
+  }
+  uint64_t rows = 0, edges = 0;
+  if (row_offsets) row_offsets[0] = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (ids) ids[i] = x->dense ? x->dense_base + i : x->h_ids[i];
+    if (levels) levels[i] = x->h_levels[i];
+    if (deleted) deleted[i] = (x->h_del[i >> 5] >> (i & 31)) & 1u;
+    for (int l = 0; l <= x->h_levels[i]; l++) {
+      uint32_t W = l == 0 ? W0 : WU;
+      const uint32_t* r = l == 0 ? &a0[(size_t)i * W0] : &aU[((size_t)x->h_upper_off[i] + l - 1) * WU];
+      const float* dr = nbr_dist ? (l == 0 ? &d0[(size_t)i * W0] : &dU[((size_t)x->h_upper_off[i] + l - 1) * WU]) : nullptr;
+      for (uint32_t j = 0; j < W && r[j] != NBR_NONE; j++) {
+        if (nbr) nbr[edges] = (int32_t)r[j];
+        if (nbr_dist) nbr_dist[edges] = dr[j];
+        edges++;
+      }
+      rows++;
+      if (row_offsets) row_offsets[rows] = (int64_t)edges;
+    }
+  }
+  if (n_slots) *n_slots = n;
+  if (n_rows) *n_rows = rows;
+  if (n_edges) *n_edges = edges;
+  if (entry_slot) *entry_slot = x->entry;
+  return COLTT_OK;
+}
+
+int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms) {
+  if (!out_ms) return fail(COLTT_E_INVALID, "last_kernel_ms: NULL out");
+  if (auto x = lookup<Hnsw>(h)) { *out_ms = x->last_ms; return COLTT_OK; }
+  extern int coltt_last_kernel_ms_flat(coltt_handle_t, float*);
+  return coltt_last_kernel_ms_flat(h, out_ms);
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// hnsw_dev.hpp — device-side HNSW traversal shared by the search kernel and the graph builder.
+//
+// One wave64 owns one query (or one vertex being inserted).  State in LDS, per wave:
+//   qs   [dim] f32         the query as the distance kernel sees it (normalised / decoded)
+//   res  [2][ef_pad] u64   result set, sorted ascending, double-buffered; entry = d_bits<<32 | slot<<1 | expanded
+//   vis  [hcap] u32        open-addressed visited set (slots), linear probing, EMPTY = 0xffffffff
+//
+// Algorithm = the canonical closed form of Hnsw.searchLevel (core/vectorindex/hnsw.go:345-389) worked out in
+// SURVEY.md §3.2 and restated on the CPU by oracle/coltt_oracle.cpp:search_level_canon:
+//   * the candidate min-heap is "the unexpanded members of the result set" (every candidate is also pushed to
+//     the result heap, hnsw.go:375-377, and a popped candidate worse than the worst result ends the loop, :359-361);
+//   * lowerBound is sampled ONCE per popped candidate (:357) and not refreshed inside the neighbour loop (:374);
+//   * in canonical neighbour order (ascending slot — Go's map order is random), the first (ef - len0) eligible
+//     neighbours are admitted unconditionally, the others iff d < lowerBound; then the ef smallest are kept;
+//   * ties are ordered by (distance, slot).
+// Distances are evaluated 32 neighbours at a time (lane pair per row) in the reference's AVX summation order.
+#pragma once
+#include "exact.hpp"
+
+namespace coltt {
+namespace dev {
+
+constexpr uint32_t VIS_EMPTY = 0xffffffffu;
+constexpr uint32_t NBR_NONE = 0xffffffffu;
+
+struct GraphView {
+  const uint8_t* rows; size_t stride; const float* norms; const uint64_t* ids;
+  uint32_t* adj0; float* adj0_d;      // [cap][mMax0]   level-0 rows, ascending slot, padded with NBR_NONE
+  const uint32_t* upper_off;          // [cap]          first upper row of a slot (levels 1..L consecutive)
+  uint32_t* adjU; float* adjU_d;      // [ucap][mMax]
+  const uint32_t* del_bits;           // tombstones (hnswVertex.deleted, hnsw_vertex.go:70-76) or null when none
+  uint32_t mMax, mMax0;
+  int dim;
+};
+
+struct WaveCtx {
+  float* qs; unsigned long long* res[2]; uint32_t* vis;
+  uint32_t ef_pad, hcap_mask, hcap;
+  float qnorm;
+  // counters (wave-uniform)
+  uint32_t n_dist, n_exp, n_hops, n_resets;
+};
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64);
+  uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { unsigned long long o = shfl_xor_u64(v, m); v = o < v ? o : v; }
+  return v;
+}
+
+__device__ __forceinline__ bool is_deleted(const GraphView& g, uint32_t slot) {
+  return g.del_bits && ((g.del_bits[slot >> 5] >> (slot & 31)) & 1u);
+}
+
+__device__ __forceinline__ const uint32_t* adj_row(const GraphView& g, uint32_t slot, int level, uint32_t& width) {
+  if (level == 0) { width = g.mMax0; return g.adj0 + (size_t)slot * g.mMax0; }
+  width = g.mMax;
+  return g.adjU + ((size_t)g.upper_off[slot] + (uint32_t)(level - 1)) * g.mMax;
+}
+
+__device__ __forceinline__ uint32_t vis_hash(uint32_t slot, uint32_t mask) { return (slot * 2654435761u) >> 7 & mask; }
+
+// test-and-set; true = newly inserted (was unvisited)
+__device__ __forceinline__ bool vis_insert(uint32_t* vis, uint32_t mask, uint32_t slot) {
+  uint32_t h = vis_hash(slot, mask);
+  for (;;) {
+    uint32_t old = atomicCAS(&vis[h], VIS_EMPTY, slot);
+    if (old == VIS_EMPTY) return true;
+    if (old == slot) return false;
+    h = (h + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
+  for (uint32_t i = lane; i < w.hcap; i += 64) w.vis[i] = VIS_EMPTY;
+}
+
+template <int METRIC, int QUANT>
+__device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
+  float rn = 0.f;
+  if constexpr (METRIC == M_COS) rn = g.norms[slot];
+  return pair_distance<METRIC, QUANT, 8>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+}
+
+// greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level,
+                                             int lane) {
+  const int half = lane & 1, p = lane >> 1;
+  for (;;) {
+    uint32_t width;
+    const uint32_t* row = adj_row(g, cur, level, width);
+    unsigned long long best = ~0ull;
+    uint32_t best_slot = NBR_NONE;
+    for (uint32_t c0 = 0; c0 < width; c0 += 32) {
+      uint32_t idx = c0 + p;
+      uint32_t nb = idx < width ? row[idx] : NBR_NONE;
+      bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+      float d = 0.f;
+      if (valid) d = eval_pair<METRIC, QUANT>(g, w, nb, half);
+      w.n_dist += __popcll(__ballot(valid && half == 0));
+      unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;
+      unsigned long long km = wave_min_u64(key);
+      if (km < best) {
+        best = km;
+        int src = (int)(((uint32_t)km - c0) * 2);  // lane of the winning pair in this chunk
+        best_slot = (uint32_t)__builtin_amdgcn_readlane((int)nb, src);
+      }
+    }
+    w.n_hops++;
+    float bd = __uint_as_float((uint32_t)(best >> 32));
+    if (best != ~0ull && bd < curd) { cur = best_slot; curd = bd; }
+    else break;
+  }
+}
+
+// Rebuild the visited set from the current result set (bounded-memory fallback; see search_level).
+__device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* res, uint32_t len, int lane) {
+  vis_clear(w, lane);
+  __syncthreads();
+  for (uint32_t i = lane; i < len; i += 64) vis_insert(w.vis, w.hcap_mask, (uint32_t)res[i] >> 1);
+  __syncthreads();
+}
+
+// searchLevel (hnsw.go:345-389).  On return w.res[buf][0..len) holds the result set ascending by (d, slot).
+// The wave must be the only one in its workgroup (uses __syncthreads as a wave-level LDS fence).
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
+                                             int level, int lane, uint32_t& out_len, int& out_buf) {
+  const int half = lane & 1, p = lane >> 1;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  vis_clear(w, lane);
+  int buf = 0;
+  if (lane == 0) w.res[0][0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
+  __syncthreads();
+  if (lane == 0) vis_insert(w.vis, w.hcap_mask, ep);
+  uint32_t len = 1, vis_count = 1;
+  bool had_reset = false;
+  __syncthreads();
+  for (;;) {
+    unsigned long long* res = w.res[buf];
+    // ---- pop: the smallest unexpanded member
+    int ci = -1;
+    for (uint32_t base = 0; base < len; base += 64) {
+      uint32_t i = base + lane;
+      bool un = i < len && !(res[i] & 1ull);
+      unsigned long long m = __ballot(un);
+      if (m) { ci = (int)base + __builtin_ctzll(m); break; }
+    }
+    if (ci < 0) break;
+    unsigned long long ce = res[ci];
+    float lower_bound = __uint_as_float((uint32_t)(res[len - 1] >> 32));
+    __syncthreads();
+    if (lane == 0) res[ci] = ce | 1ull;
+    const uint32_t cslot = (uint32_t)ce >> 1;
+    uint32_t free_slots = ef - len;  // len <= ef
+    w.n_exp++;
+    if (vis_count + 64 > (w.hcap >> 2) * 3) {  // bounded visited set: forget everything but the result set
+      __syncthreads();
+      vis_reset(w, res, len, lane);
+      vis_count = len; had_reset = true; w.n_resets++;
+    }
+    __syncthreads();
+    uint32_t width;
+    const uint32_t* row = adj_row(g, cslot, level, width);
+    for (uint32_t c0 = 0; c0 < width; c0 += 32) {
+      res = w.res[buf];
+      uint32_t idx = c0 + p;
+      uint32_t nb = idx < width ? row[idx] : NBR_NONE;
+      bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+      int fresh_i = 0;
+      if (valid && half == 0) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+      fresh_i = __shfl(fresh_i, lane & ~1, 64);
+      bool fresh = fresh_i != 0;
+      if (had_reset) {
+        // a forgotten vertex that is still in the result set must not be admitted twice
+        unsigned long long fm = __ballot(fresh && half == 0);
+        while (fm) {
+          int j = __builtin_ctzll(fm); fm &= fm - 1;
+          uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)nb, j);
+          bool hit = false;
+          for (uint32_t base = 0; base < len; base += 64) {
+            uint32_t i = base + lane;
+            hit |= (i < len && ((uint32_t)res[i] >> 1) == sj);
+          }
+          if (__ballot(hit) && (lane >> 1) == (j >> 1)) fresh = false;
+        }
+      }
+      unsigned long long E = __ballot(fresh && half == 0);
+      uint32_t nfresh = __popcll(E);
+      if (nfresh == 0) continue;
+      vis_count += nfresh; w.n_dist += nfresh;
+      float d = 0.f;
+      if (fresh) d = eval_pair<METRIC, QUANT>(g, w, nb, half);
+      uint32_t rank = __popcll(E & lt_mask);
+      bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
+      free_slots = free_slots > nfresh ? free_slots - nfresh : 0;
+      unsigned long long A = __ballot(adm);
+      uint32_t m = __popcll(A);
+      if (m == 0) continue;
+      // ---- merge the m admitted (d, slot) into the sorted result set, keep the ef smallest
+      unsigned long long* dst = w.res[buf ^ 1];
+      unsigned long long mykey = adm ? (((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)nb << 1)) : ~0ull;
+      uint32_t mypos = 0;
+      if (adm) {  // lower_bound over the sorted result set
+        uint32_t lo = 0, hi = len;
+        while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (res[mid] < mykey) lo = mid + 1; else hi = mid; }
+        mypos = lo;
+      }
+      for (uint32_t base = 0; base < len; base += 64) {
+        uint32_t i = base + lane;
+        unsigned long long e = i < len ? res[i] : ~0ull;
+        uint32_t shift = 0;
+        unsigned long long am = A;
+        while (am) {
+          int j = __builtin_ctzll(am); am &= am - 1;
+          unsigned long long kj = readlane_u64(mykey, j);
+          shift += (kj < e) ? 1u : 0u;
+        }
+        uint32_t np = i + shift;
+        if (i < len && np < ef) dst[np] = e;
+      }
+      {
+        unsigned long long am = A;
+        uint32_t myrank = 0;
+        while (am) {
+          int j = __builtin_ctzll(am); am &= am - 1;
+          unsigned long long kj = readlane_u64(mykey, j);
+          myrank += (kj < mykey) ? 1u : 0u;
+        }
+        uint32_t np = mypos + myrank;
+        if (adm && np < ef) dst[np] = mykey;
+      }
+      len = len + m < ef ? len + m : ef;
+      buf ^= 1;
+      __syncthreads();
+    }
+  }
+  out_len = len;
+  out_buf = buf;
+}
+
+}  // namespace dev
+}  // namespace coltt

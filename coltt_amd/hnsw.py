@@ -1,0 +1,114 @@
+"""Hnsw — GPU-backed stand-in for *vectorindex.Hnsw (core/vectorindex/hnsw.go:43-54)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class HnswCfg(C.Structure):
+    """hnswConfig (core/vectorindex/hnsw_config.go:135-162); -1 = derive the default."""
+    _fields_ = [("m", C.c_int32), ("m_max", C.c_int32), ("m_max0", C.c_int32), ("ef", C.c_int32),
+                ("ef_construction", C.c_int32), ("algo", C.c_int32), ("level_multiplier", C.c_float),
+                ("extend_candidates", C.c_int32), ("keep_pruned", C.c_int32)]
+
+    @staticmethod
+    def default(**kw):
+        c = HnswCfg(16, -1, -1, 20, 200, 0, -1.0, 0, 1)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+
+class HnswStats(C.Structure):
+    _fields_ = [("n_dist", C.c_uint64), ("n_exp", C.c_uint64), ("n_hops", C.c_uint64), ("n_visit_resets", C.c_uint64)]
+
+
+class Hnsw:
+    def __init__(self, dim, distance=L.COSINE, cfg=None, quantization=L.Q_NONE):
+        self.dim, self.distance, self.quantization = int(dim), distance, quantization
+        cfg = cfg or HnswCfg.default()
+        h = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_create(C.c_uint32(dim), distance, quantization, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.cfg = HnswCfg()
+        L.check(L.lib().coltt_hnsw_get_cfg(self.h, C.byref(self.cfg)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            L.lib().coltt_hnsw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Len(self):
+        n = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_len(self.h, C.byref(n)))
+        return n.value
+
+    def Dim(self):
+        return self.dim
+
+    # -- Hnsw.Load-shaped bulk import (graph dict in the oracle's export layout; raw vectors in slot order)
+    def BulkLoad(self, g, raw_vectors):
+        v = np.ascontiguousarray(raw_vectors, np.float32)
+        ids = np.ascontiguousarray(g["ids"], np.uint64) if g.get("ids") is not None else None
+        lv = np.ascontiguousarray(g["levels"], np.int32)
+        dl = np.ascontiguousarray(g["deleted"], np.uint8) if g.get("deleted") is not None else None
+        off = np.ascontiguousarray(g["row_offsets"], np.int64)
+        nb = np.ascontiguousarray(g["nbr"], np.int32)
+        nd = np.ascontiguousarray(g["nbr_dist"], np.float32) if g.get("nbr_dist") is not None else None
+        L.check(L.lib().coltt_hnsw_bulk_load(self.h, C.c_uint64(len(lv)), L.vp(ids), L.vp(lv), L.vp(dl), L.vp(v), L.vp(off),
+                                             L.vp(nb), L.vp(nd), C.c_int32(int(g["entry"]))))
+
+    # -- Hnsw.Insert (hnsw.go:104-167)
+    def Insert(self, id_, vector, level):
+        v = np.ascontiguousarray(vector, np.float32).reshape(-1)
+        L.check(L.lib().coltt_hnsw_insert(self.h, C.c_uint64(int(id_)), L.vp(v), C.c_int32(int(level))))
+
+    def InsertBatchDevice(self, d_vecs, n, levels, batch, first_id=0, ids=None):
+        lv = np.ascontiguousarray(levels, np.int32)
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, np.uint64)
+        L.check(L.lib().coltt_hnsw_insert_batch_device(self.h, L.vp(ids), C.c_uint64(first_id), C.c_void_p(d_vecs), L.vp(lv),
+                                                       C.c_size_t(n), C.c_uint32(batch)))
+
+    # -- Hnsw.Remove (hnsw.go:191-241)
+    def Remove(self, id_):
+        L.check(L.lib().coltt_hnsw_remove(self.h, C.c_uint64(int(id_))))
+
+    # -- Hnsw.Search (hnsw.go:243-278) for a batch of queries
+    def Search(self, queries, k, ef=0, with_stats=False):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32); cnt = np.zeros(nq, np.uint32)
+        st = HnswStats()
+        L.check(L.lib().coltt_hnsw_search(self.h, L.vp(q), C.c_size_t(nq), C.c_uint32(k), C.c_uint32(ef), L.vp(ids), L.vp(sc),
+                                          L.vp(cnt), C.byref(st)))
+        if with_stats:
+            return ids, sc, cnt, {"n_dist": st.n_dist, "n_exp": st.n_exp, "n_hops": st.n_hops, "n_visit_resets": st.n_visit_resets}
+        return ids, sc, cnt
+
+    def SearchDevice(self, d_q, nq, k, d_ids, d_scores, d_counts, ef=0):
+        st = HnswStats()
+        L.check(L.lib().coltt_hnsw_search_device(self.h, C.c_void_p(d_q), C.c_size_t(nq), C.c_uint32(k), C.c_uint32(ef),
+                                                 C.c_void_p(d_ids), C.c_void_p(d_scores), C.c_void_p(d_counts), C.byref(st)))
+        return {"n_dist": st.n_dist, "n_exp": st.n_exp, "n_hops": st.n_hops, "n_visit_resets": st.n_visit_resets}
+
+    def Export(self):
+        ns, nr, ne, ent = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        L.check(L.lib().coltt_hnsw_export(self.h, C.byref(ns), C.byref(nr), C.byref(ne), None, None, None, None, None, None, C.byref(ent)))
+        ids = np.empty(ns.value, np.uint64); lv = np.empty(ns.value, np.int32); dl = np.empty(ns.value, np.uint8)
+        off = np.empty(nr.value + 1, np.int64); nb = np.empty(ne.value, np.int32); nd = np.empty(ne.value, np.float32)
+        L.check(L.lib().coltt_hnsw_export(self.h, C.byref(ns), C.byref(nr), C.byref(ne), L.vp(ids), L.vp(lv), L.vp(dl), L.vp(off),
+                                          L.vp(nb), L.vp(nd), C.byref(ent)))
+        return {"ids": ids, "levels": lv, "deleted": dl, "row_offsets": off, "nbr": nb, "nbr_dist": nd, "entry": ent.value}
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,160 @@
+/* coltt_gpu.h — C-ABI of libcoltt_gpu.so: the MI355X-native ANN search hot path of sjy-dv/coltt.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path (it is pure Go + Go
+ * assembly); these entry points are what a cgo shim binds in order to put the GPU behind the
+ * reference's own Go interfaces.  Every function cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; all handles are opaque uint64.
+ *   - the caller owns every input and output buffer; the library copies inputs before returning
+ *     (cgo: no Go pointer is retained, no callbacks into Go).
+ *   - return value: 0 = ok, <0 = error class (COLTT_E_*); message via coltt_last_error() (thread-local).
+ *     Nothing aborts or throws across the boundary.
+ *   - all entry points are thread-safe (cgo calls arrive on arbitrary OS threads).
+ *   - "*_device" variants take pointers that already live in this GPU's HBM (hipMalloc'd or a
+ *     torch.Tensor.data_ptr()); they exist so resident data never crosses PCIe.
+ */
+#ifndef COLTT_GPU_H
+#define COLTT_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t coltt_handle_t;
+
+enum { COLTT_OK = 0, COLTT_E_INVALID = -1, COLTT_E_EXISTS = -2, COLTT_E_NOT_FOUND = -3,
+       COLTT_E_UNSUPPORTED = -4, COLTT_E_DEVICE = -5, COLTT_E_NOMEM = -6 };
+
+/* edgepb.Distance (idl/proto/v4/edge.proto:70-73) */
+enum { COLTT_COSINE = 0, COLTT_EUCLIDEAN = 1 };
+/* edgepb.Quantization (idl/proto/v4/edge.proto:75-80).  NB the reference's "BF16" is IEEE binary16
+ * (pkg/compresshelper/bf16.go:233-317 == float16.go:237-321) and its "F8" decodes to 8 distinct
+ * values (float8.go:233-313); both are reproduced bit-for-bit. */
+enum { COLTT_Q_NONE = 0, COLTT_Q_F16 = 1, COLTT_Q_F8 = 2, COLTT_Q_BF16 = 3 };
+/* top-k direction.  REFERENCE = what edge.PriorityQueue really does: min-heap + pop-min keeps the K
+ * LARGEST distances (edge/priority_queue.go:39-55), returned ascending (:57-69).  NEAREST = K smallest. */
+enum { COLTT_SELECT_REFERENCE = 0, COLTT_SELECT_NEAREST = 1 };
+/* FLAT arithmetic.  EXACT = the reference AVX summation order, bit-identical scores
+ * (pkg/distance/simd/cpp/avx.cpp:15-32,51-75).  MFMA = matrix-core candidate generation followed by an
+ * EXACT re-score of the survivors (returned scores are still bit-exact; the candidate SET is exact
+ * unless two scores differ by less than the MFMA rounding error, ~1e-6 relative). */
+enum { COLTT_MODE_EXACT = 0, COLTT_MODE_MFMA = 1 };
+
+/* ---- process / device ------------------------------------------------------------------------ */
+int coltt_init(int device);                 /* selects the HIP device for the calling process      */
+int coltt_device_count(void);
+const char* coltt_last_error(void);
+const char* coltt_version(void);
+
+/* ---- kernels exposed one-to-one (pkg/distance, pkg/compresshelper, pkg/sharding, pkg/distancepq) --- */
+/* distance.Space.Distance(a,b) for n independent pairs: a,b are row-major [n][dim] host arrays
+ * (pkg/distance/space.go:61-63,93-95).  order: 0 avx (default dispatch on AVX hosts), 1 sse, 2 native
+ * (space.go:40-49). */
+int coltt_distance_pairs(int metric, int order, const float* a, const float* b, size_t n, uint32_t dim,
+                         float* out);
+/* edge.Normalize / vectorindex.Normalize (edge/vectorstore.go:173-189; core/vectorindex/metadata.go:107-123) */
+int coltt_normalize(const float* in, size_t n, uint32_t dim, float* out);
+/* Quantization.Lower: compresshelper.Fromfloat32 / BF16Fromfloat32 / F8Fromfloat32 per element
+ * (edge/f16_quantization.go:47-53; pkg/compresshelper/float16.go:124-126, bf16.go:120-122, float8.go:120-122) */
+int coltt_quant_lower(int quant, const float* in, size_t n_elems, void* out_codes);
+/* Float16.Float32 / BFloat16.Float32 / Float8.Float32 (float16.go:184-187, bf16.go:180-183, float8.go:180-183) */
+int coltt_quant_raise(int quant, const void* codes, size_t n_elems, float* out);
+/* sharding.ShardVertex (pkg/sharding/shard.go:34-41) */
+int coltt_shard_vertex(const uint64_t* ids, size_t n, uint64_t shard_count, uint64_t* out);
+/* distancepq: asm.Dot / asm.SquaredEuclideanDistance (pkg/distancepq/asm/dot.s:7-55, euclidean.s:7-65);
+ * kind 0 dot, 1 squared-L2, 2 cosineDistance (1-dot), 3 dotProductDistance (-dot) (distance.go:36-42);
+ * one query against n rows. */
+int coltt_pq_float_scan(int kind, const float* query, const float* rows, size_t n, uint32_t dim, float* out);
+/* hammingDistance / jaccardDistance (pkg/distancepq/distance.go:62-84); kind 0 hamming, 1 jaccard;
+ * one query of `words` uint64 against n rows. */
+int coltt_pq_bit_scan(int kind, const uint64_t* query, const uint64_t* rows, size_t n, uint32_t words, float* out);
+
+/* ---- edge FLAT store: replaces {none,f16,f8,bf16}VecSpace behind edge.vectorspace
+ *      (edge/vectorstore.go:30-49; constructors selected at edge/vectorstore.go:62-85) ------------- */
+int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out);
+int coltt_flat_destroy(coltt_handle_t h);
+int coltt_flat_reserve(coltt_handle_t h, uint64_t n_rows);
+/* ChangedVertex, vector half (edge/none_vectorstore.go:86-101; f16_vectorstore.go:87-105): applies
+ * Normalize (cosine) and Lower so the stored bits equal the reference's.  Existing ids are overwritten.
+ * A vector whose length != dim is the caller's error (none_vectorstore.go:86-88) — dim is fixed here. */
+int coltt_flat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n);
+/* same, vectors already in HBM; ids == NULL means ids are first_id, first_id+1, ... (append-only fast path) */
+int coltt_flat_upsert_device(coltt_handle_t h, const uint64_t* ids, uint64_t first_id, const float* d_vecs, size_t n);
+/* RemoveVertex, vector half (edge/none_vectorstore.go:118-124).  Unknown ids are ignored as in Go's delete(). */
+int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n);
+int coltt_flat_len(coltt_handle_t h, uint64_t* out);
+/* stored (lowered) bits of one vertex — what SaveVertex serialises (none_vectorstore.go:308-390) */
+int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row);
+/* VertexSearch for a batch of queries (edge/none_vectorstore.go:129-180; f16_vectorstore.go:131-186).
+ * out_ids/out_scores are [nq][k]; out_counts[q] = min(k, len).  Rows ascending by (score, id). */
+int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, int select, int mode,
+                             uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts);
+/* FilterableVertexSearch (edge/none_vectorstore.go:182-253): the candidate ids come from the roaring
+ * index (pkg/inverted/search.go:113-119) on the Go side; ids not present are skipped (:201). */
+int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,
+                          const uint64_t* cand_ids, size_t n_cand,
+                          uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+
+/* ---- core HNSW: replaces *vectorindex.Hnsw (core/vectorindex/hnsw.go:43-54) --------------------- */
+typedef struct coltt_hnsw_cfg {       /* hnswConfig defaults: hnsw_config.go:135-162 */
+  int32_t m;                          /* 16 */
+  int32_t m_max;                      /* -1 -> m */
+  int32_t m_max0;                     /* -1 -> 2m */
+  int32_t ef;                         /* 20 */
+  int32_t ef_construction;            /* 200 */
+  int32_t algo;                       /* 0 HnswSearchSimple, 1 HnswSearchHeuristic */
+  float level_multiplier;             /* -1 -> 1/ln(m) */
+  int32_t extend_candidates;          /* must be 0: the reference's extend path is undefined */
+  int32_t keep_pruned;                /* 1 (dead code in the reference) */
+} coltt_hnsw_cfg;
+
+typedef struct coltt_hnsw_stats {     /* per search call, summed over the batch */
+  uint64_t n_dist;                    /* distance evaluations */
+  uint64_t n_exp;                     /* expanded candidates on level 0 */
+  uint64_t n_hops;                    /* greedy hops on upper levels */
+  uint64_t n_visit_resets;            /* visited-set resets (0 => traversal identical to the oracle's) */
+} coltt_hnsw_stats;
+
+/* NewHnsw(dim, distancer, options...) (hnsw.go:56-73).  quant != NONE stores 2-/1-byte codes and
+ * evaluates distances as the edge quantised stores do (decode both, f32 distance) — an extension the
+ * reference's core does not have (BASELINE.json configs[4]). */
+int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out);
+int coltt_hnsw_destroy(coltt_handle_t h);
+int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out);
+/* Load a graph built elsewhere (the oracle, Hnsw.Load's stream, another shard): slot-major arrays.
+ * vectors are raw (Normalize/Lower are applied here for cosine/quant, as Insert does, hnsw.go:105-107).
+ * rows = sum(level+1); row r of slot s, level l holds nbr[row_offsets[r] .. row_offsets[r+1]).  */
+int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, const int32_t* levels,
+                         const uint8_t* deleted, const float* vectors, const int64_t* row_offsets,
+                         const int32_t* nbr, const float* nbr_dist, int32_t entry_slot);
+/* Hnsw.Insert(id, value, metadata, vertexLevel) (hnsw.go:104-167); COLTT_E_EXISTS = ItemAlreadyExistsError */
+int coltt_hnsw_insert(coltt_handle_t h, uint64_t id, const float* vec, int32_t level);
+/* n Inserts in id order; `batch` vertices are linked against a frozen graph at a time (batch==1 is the
+ * reference's sequential semantics).  d_vecs lives in HBM; ids == NULL means first_id + i. */
+int coltt_hnsw_insert_batch_device(coltt_handle_t h, const uint64_t* ids, uint64_t first_id, const float* d_vecs,
+                                   const int32_t* levels, size_t n, uint32_t batch);
+/* Hnsw.Remove(id) (hnsw.go:191-241); COLTT_E_NOT_FOUND = ItemNotFoundError */
+int coltt_hnsw_remove(coltt_handle_t h, uint64_t id);
+int coltt_hnsw_len(coltt_handle_t h, uint64_t* out);
+/* Hnsw.Search(ctx, query, k) for a batch (hnsw.go:243-278): ef = max(cfg.ef or ef_override, k); rows
+ * ascending by distance; empty index => counts 0, not an error (hnsw.go:249-251). */
+int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, uint32_t ef_override,
+                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats);
+int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
+                             uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats);
+/* graph export in the bulk_load layout (what Hnsw.Commit serialises, hnsw_commit.go:69-162).
+ * Call with NULL arrays to get sizes. */
+int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uint64_t* n_edges, uint64_t* ids,
+                      int32_t* levels, uint8_t* deleted, int64_t* row_offsets, int32_t* nbr, float* nbr_dist,
+                      int32_t* entry_slot);
+/* last kernel timing of the handle's search stream, measured with hipEvents (milliseconds) */
+int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLTT_GPU_H */

@@ -743,6 +743,61 @@ static int hnsw_search(Hnsw* h, const float* query, int k, int mode, int ef_over
   return n;
 }
 
+
+// Batched Insert (what the GPU builder runs).  The reference allows concurrent Inserts
+// (per-vertex RWMutexes, hnsw.go:104-167) with unspecified interleaving; this fixes ONE interleaving:
+// every vertex of the batch searches the graph as it was before the batch (phase A: hnsw.go:124-135 with
+// the canonical searchLevel / k-nearest selection), then all links are applied (phase B: hnsw.go:142-159 —
+// addEdge both ways, pruneNeighbors when a row exceeds mMax; the outcome is independent of the order in which
+// the batch's links are applied).  batch == 1 is exactly the sequential canonical Insert.
+static int hnsw_insert_batch(Hnsw* h, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n) {
+  struct Link { int32_t from; int l; int32_t to; float d; };
+  std::vector<Link> links;
+  size_t i0 = 0;
+  if (h->entry < 0 && n > 0) {  // first vertex: level forced to 0, becomes the entrypoint (hnsw.go:108-117)
+    int rc = hnsw_insert(h, ids[0], vecs, 0, false);
+    if (rc) return rc;
+    i0 = 1;
+  }
+  int32_t base = (int32_t)h->v.size();
+  for (size_t i = i0; i < n; i++) {
+    if (h->by_id.count(ids[i])) return -2;
+    Vertex nv; nv.id = ids[i]; nv.deleted = false; nv.level = levels[i]; nv.edges.resize(levels[i] + 1);
+    nv.own.resize(h->dim);
+    if (h->metric == METRIC_COS) normalize(vecs + i * h->dim, nv.own.data(), h->dim);
+    else std::memcpy(nv.own.data(), vecs + i * h->dim, h->dim * 4);
+    h->v.push_back(std::move(nv));
+    h->v.back().vec = h->v.back().own.data();
+  }
+  for (size_t i = i0; i < n; i++) {  // phase A (frozen graph: new vertices are unreachable, they have no in-edges)
+    int32_t vi = base + (int32_t)(i - i0);
+    const float* vec = h->v[vi].vec;
+    int32_t ep = h->entry;
+    float minD = h->D(vec, h->v[ep].vec);
+    for (int l = h->v[ep].level; l > levels[i]; l--) greedy(h, vec, ep, minD, l);
+    for (int l = std::min(h->v[ep].level, (int)levels[i]); l >= 0; l--) {
+      std::vector<RItem> r = search_level_canon(h, vec, ep, h->cfg.efConstruction, l);
+      if ((int)r.size() > h->cfg.m) r.resize(h->cfg.m);
+      for (auto& x : r) links.push_back({vi, l, x.slot, x.d});
+      ep = r[0].slot;
+    }
+  }
+  for (size_t i = i0; i < n; i++) { int32_t vi = base + (int32_t)(i - i0); h->by_id[ids[i]] = vi; h->len++; }
+  bool save = h->canon_build; h->canon_build = true;
+  for (auto& k : links) {  // phase B
+    int mMax = k.l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
+    edge_set(h->v[k.from].edges[k.l], k.to, k.d);
+    edge_set(h->v[k.to].edges[k.l], k.from, k.d);
+    if ((int)h->v[k.to].edges[k.l].size() > mMax) prune(h, k.to, mMax, k.l);
+  }
+  h->canon_build = save;
+  for (size_t i = i0; i < n; i++) {  // entrypoint CAS in insertion order (hnsw.go:161-164)
+    int32_t vi = base + (int32_t)(i - i0);
+    if (h->v[vi].level > h->v[h->entry].level) h->entry = vi;
+  }
+  return 0;
+}
+
 static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -873,6 +928,9 @@ int orc_hnsw_insert(void* h, uint64_t id, const float* vec, int level) {
   return hnsw_insert(x, id, vec, level, false);
 }
 void orc_hnsw_set_canonical(void* h, int on) { ((Hnsw*)h)->canon_build = on != 0; }
+int orc_hnsw_insert_batch(void* h, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n) {
+  return hnsw_insert_batch((Hnsw*)h, ids, vecs, levels, n);
+}
 int orc_hnsw_remove(void* h, uint64_t id) { return hnsw_remove((Hnsw*)h, id); }
 uint64_t orc_hnsw_len(void* h) { return ((Hnsw*)h)->len; }
 int64_t orc_hnsw_slots(void* h) { return (int64_t)((Hnsw*)h)->v.size(); }

@@ -276,6 +276,16 @@ class Hnsw:
             rc = lib().orc_hnsw_insert(self.h, C.c_uint64(int(ids[i])), _p(vecs[i]), int(lvls[i]))
             assert rc == 0, rc
 
+    def insert_batched(self, ids, vecs, lvls, batch, schedule=None):
+        """GPU-builder semantics: consecutive groups of `batch` vertices are linked against a frozen graph."""
+        ids = np.ascontiguousarray(ids, np.uint64); vecs = _f32(vecs); lvls = np.ascontiguousarray(lvls, np.int32)
+        i = 0
+        while i < len(ids):
+            b = min(batch if schedule is None else schedule(i), len(ids) - i)
+            rc = lib().orc_hnsw_insert_batch(self.h, _p(ids[i:i + b]), _p(vecs[i:i + b]), _p(lvls[i:i + b]), C.c_size_t(b))
+            assert rc == 0, rc
+            i += b
+
     def remove(self, id_):
         return lib().orc_hnsw_remove(self.h, C.c_uint64(int(id_)))
 

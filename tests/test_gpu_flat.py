@@ -1,0 +1,107 @@
+"""FLAT VertexSearch on the GPU vs the oracle's canonical form: bit-exact ids, ranks and scores
+(SURVEY.md §8a rows a8-a11)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import assert_same_results, bits
+
+pytestmark = pytest.mark.gpu
+
+
+def build_pair(gpu, n, d, metric, quant, seed=1):
+    X = O.fill_normal(seed, (n, d))
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919) + np.uint64(1000003)) % np.uint64(1 << 40)
+    of = O.Flat(d, metric, quant); of.upsert(ids, X)
+    gf = gpu.FlatSpace(d, metric, quant); gf.ChangedVertex(ids, X)
+    return X, ids, of, gf
+
+
+@pytest.mark.parametrize("quant", [O.Q_NONE, O.Q_F16, O.Q_F8, O.Q_BF16])
+@pytest.mark.parametrize("metric", [O.COSINE, O.L2])
+def test_flat_search_parity(gpu, metric, quant):
+    n, d = 2048, 128
+    X, ids, of, gf = build_pair(gpu, n, d, metric, quant)
+    assert gf.LoadSize() == n
+    for i in (0, 17, n - 1):  # stored bits == reference Normalize+Lower
+        assert np.array_equal(gf.Stored(ids[i]).view(np.uint8), of.get(ids[i]).view(np.uint8))
+    Q = O.fill_normal(99, (19, d))
+    for k in (1, 10, 100):
+        for select in (gpu.SELECT_REFERENCE, gpu.SELECT_NEAREST):
+            gi, gs, gc = gf.VertexSearch(Q, k, select)
+            for qi in range(len(Q)):
+                wi, ws = of.search(Q[qi], k, nearest=bool(select), mode=2)
+                assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} k{k} sel{select}")
+
+
+def test_flat_768_and_literal_heap(gpu):
+    """config-2 shape at test size; also: the canonical answer equals the literal Go-heap emulation."""
+    n, d = 4096, 768
+    X, ids, of, gf = build_pair(gpu, n, d, O.COSINE, O.Q_NONE, seed=5)
+    Q = O.fill_normal(6, (16, d))
+    gi, gs, gc = gf.VertexSearch(Q, 10, gpu.SELECT_REFERENCE)
+    for qi in range(16):
+        for mode in (0, 1, 2):
+            wi, ws = of.search(Q[qi], 10, nearest=False, mode=mode)
+            assert_same_results(gi[qi], gs[qi], wi, ws, f"mode{mode}")
+
+
+def test_flat_ragged_and_edge_cases(gpu):
+    d = 20  # not a multiple of 8: scalar tail path, padded row stride
+    X, ids, of, gf = build_pair(gpu, 333, d, O.L2, O.Q_F16, seed=8)
+    Q = O.fill_normal(3, (5, d))
+    gi, gs, gc = gf.VertexSearch(Q, 500, gpu.SELECT_NEAREST)  # k > n
+    assert (gc == 333).all()
+    for qi in range(5):
+        wi, ws = of.search(Q[qi], 500, nearest=True, mode=2)
+        assert_same_results(gi[qi, :333], gs[qi, :333], wi, ws)
+    # empty store
+    e = gpu.FlatSpace(d, O.COSINE, O.Q_NONE)
+    _, _, c = e.VertexSearch(Q, 10)
+    assert (c == 0).all()
+    with pytest.raises(ValueError):
+        e.ChangedVertex([1], np.zeros((1, d + 1), np.float32))
+
+
+def test_flat_ties_upsert_remove_filter(gpu):
+    n, d = 600, 64
+    X = O.fill_normal(21, (n, d)); X[100:140] = X[7]  # 40 exact duplicates -> ties at the boundary
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(50)
+    of = O.Flat(d, O.COSINE, O.Q_NONE); gf = gpu.FlatSpace(d, O.COSINE, O.Q_NONE)
+    of.upsert(ids, X); gf.ChangedVertex(ids, X)
+    Q = np.concatenate([X[7:8], O.fill_normal(4, (6, d))])
+
+    def check(tag, cand=None):
+        for k in (5, 25, 60):
+            for select in (0, 1):
+                if cand is None: gi, gs, gc = gf.VertexSearch(Q, k, select)
+                else: gi, gs, gc = gf.FilterableVertexSearch(cand, Q, k, select)
+                for qi in range(len(Q)):
+                    wi, ws = of.search(Q[qi], k, nearest=bool(select), mode=2, cand=cand)
+                    assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"{tag} q{qi} k{k} s{select}")
+    check("ties")
+    # overwrite some ids, add new ones, remove others (incl. unknown ids: no-op like Go's delete)
+    up_ids = np.concatenate([ids[10:30], np.arange(5000, 5040, dtype=np.uint64)]); up = O.fill_normal(77, (60, d))
+    of.upsert(up_ids, up); gf.ChangedVertex(up_ids, up)
+    rm = np.concatenate([ids[200:260], np.array([999999], np.uint64), ids[n - 1:]])
+    of.remove(rm); gf.RemoveVertex(rm)
+    assert gf.LoadSize() == len(of)
+    check("after-mutation")
+    cand = np.concatenate([ids[::3], np.array([424242, 5001, 5003], np.uint64)])  # includes removed + unknown ids
+    check("filtered", cand)
+    check("filtered-empty", np.array([1, 2, 3], np.uint64))
+
+
+def test_flat_adversarial_order_overflow_path(gpu):
+    """rows sorted so every later row beats the threshold: exercises the safe (segmented) selection path."""
+    n, d = 70000, 8
+    base = O.fill_normal(31, d)
+    scale = (1.0 + np.arange(n, dtype=np.float32) / n)[:, None]
+    X = (base[None, :] * scale).astype(np.float32)  # L2 distance to 0 grows with the row index
+    ids = np.arange(n, dtype=np.uint64)
+    of = O.Flat(d, O.L2, O.Q_NONE); gf = gpu.FlatSpace(d, O.L2, O.Q_NONE)
+    of.upsert(ids, X); gf.ChangedVertex(ids, X)
+    q = np.zeros((1, d), np.float32)
+    gi, gs, gc = gf.VertexSearch(q, 10, gpu.SELECT_REFERENCE)
+    wi, ws = of.search(q[0], 10, nearest=False, mode=2)
+    assert_same_results(gi[0], gs[0], wi, ws)

@@ -1,0 +1,171 @@
+"""HNSW search on the GPU vs the oracle on the oracle-built graph: identical ids, ranks, score bits AND identical
+traversal counters."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import assert_same_results
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_index(n, d, metric, seed, cfg=None, remove=0):
+    X = O.fill_normal(seed, (n, d)); lv = O.levels(seed + 1, n)
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(11)
+    h = O.Hnsw(d, metric, cfg or O.default_cfg())
+    h.insert_many(ids, X, lv)
+    rng = np.random.default_rng(seed)
+    for i in rng.choice(n, remove, replace=False):
+        assert h.remove(ids[i]) == 0
+    return X, ids, h
+
+
+@pytest.mark.parametrize("metric", [O.COSINE, O.L2])
+@pytest.mark.parametrize("n,d", [(1000, 128), (3000, 64), (1500, 768)])
+def test_hnsw_search_parity(gpu, metric, n, d):
+    X, ids, oh = oracle_index(n, d, metric, seed=40 + d)
+    g = oh.export(with_vectors=False)
+    gh = gpu.Hnsw(d, metric)
+    gh.BulkLoad(g, X)
+    assert gh.Len() == n
+    Q = O.fill_normal(123, (40, d))
+    for ef in (20, 128):
+        gi, gs, gc, st = gh.Search(Q, 10, ef=ef, with_stats=True)
+        tot = {"n_dist": 0, "n_exp": 0, "n_hops": 0}
+        for qi in range(len(Q)):
+            wi, ws, s = oh.search(Q[qi], 10, mode=1, ef=ef, with_stats=True)
+            li, ls = oh.search(Q[qi], 10, mode=0, ef=ef)  # literal Go-heap restatement agrees with the canonical form
+            assert_same_results(wi, ws, li, ls, "oracle literal vs canonical")
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} ef{ef}")
+            for k in tot: tot[k] += s[k]
+        assert st["n_visit_resets"] == 0
+        assert {k: st[k] for k in tot} == tot, (st, tot)
+
+
+def test_hnsw_with_removed_vertices_and_small_k(gpu):
+    n, d = 1200, 32
+    X, ids, oh = oracle_index(n, d, O.COSINE, seed=7, remove=200)
+    gh = gpu.Hnsw(d, O.COSINE)
+    gh.BulkLoad(oh.export(with_vectors=False), X)
+    assert gh.Len() == len(oh) == n - 200
+    Q = O.fill_normal(5, (30, d))
+    for k, ef in ((1, 20), (10, 64), (50, 20)):  # ef = max(ef, k)
+        gi, gs, gc = gh.Search(Q, k, ef=ef)
+        for qi in range(len(Q)):
+            wi, ws = oh.search(Q[qi], k, mode=1, ef=ef)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} k{k}")
+
+
+def test_hnsw_empty_and_tiny(gpu):
+    d = 16
+    gh = gpu.Hnsw(d, O.L2)
+    _, _, c = gh.Search(np.zeros((3, d), np.float32), 5)
+    assert (c == 0).all()  # empty index => empty result (hnsw.go:249-251)
+    X, ids, oh = oracle_index(3, d, O.L2, seed=1)
+    gh.BulkLoad(oh.export(with_vectors=False), X)
+    gi, gs, gc = gh.Search(X, 5)
+    for qi in range(3):
+        wi, ws = oh.search(X[qi], 5, mode=1)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
+
+
+@pytest.mark.parametrize("quant", [O.Q_F16, O.Q_F8])
+def test_hnsw_quantised_rows(gpu, quant):
+    """2-/1-byte stored codes (BASELINE configs[4]): distances as the edge quantised stores compute them —
+    decode(query') vs decode(row).  Oracle: an f32 index over the decoded vectors gives the same arithmetic."""
+    n, d = 800, 64
+    X = O.fill_normal(3, (n, d)); lv = O.levels(4, n); ids = np.arange(n, dtype=np.uint64)
+    Xs = O.f16_decode(O.lower(quant, X)) if quant != O.Q_F8 else O.f8_decode(O.lower(quant, X))
+    oh = O.Hnsw(d, O.L2); oh.insert_many(ids, Xs, lv)
+    gh = gpu.Hnsw(d, O.L2, quantization=quant); gh.BulkLoad(oh.export(with_vectors=False), X)
+    Q = O.fill_normal(8, (20, d))
+    Qs = O.f16_decode(O.lower(quant, Q)) if quant != O.Q_F8 else O.f8_decode(O.lower(quant, Q))
+    gi, gs, gc = gh.Search(Q, 10, ef=64)
+    for qi in range(20):
+        wi, ws = oh.search(Qs[qi], 10, mode=1, ef=64)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
+
+
+# ---------------------------------------------------------------------------------------------- builder
+def _graph_equal(a, b):
+    for k in ("levels", "deleted", "row_offsets", "nbr"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["nbr_dist"].view(np.uint32), b["nbr_dist"].view(np.uint32)), "edge distances"
+    assert a["entry"] == b["entry"]
+
+
+@pytest.mark.parametrize("metric", [O.COSINE, O.L2])
+def test_hnsw_gpu_build_sequential_equals_reference_insert(gpu, metric):
+    """batch == 1: the GPU builder is Hnsw.Insert; the graph (edges AND stored distances) equals the oracle's."""
+    import torch
+    n, d = 700, 48
+    X = O.fill_normal(61, (n, d)); lv = O.levels(62, n); ids = np.arange(n, dtype=np.uint64) + np.uint64(500)
+    oh = O.Hnsw(d, metric); oh.insert_many(ids, X, lv)          # literal restatement (Go heaps)
+    gh = gpu.Hnsw(d, metric)
+    xd = torch.from_numpy(X).cuda()
+    gh.InsertBatchDevice(xd.data_ptr(), n, lv, batch=1, ids=ids)
+    go = gh.Export(); oo = oh.export(with_vectors=False)
+    assert np.array_equal(go["ids"], oo["ids"])
+    _graph_equal(go, oo)
+    # single host-side Insert + duplicate id
+    v = O.fill_normal(63, d)
+    gh.Insert(10**9, v, 1); assert oh.insert(10**9, v, 1) == 0
+    with pytest.raises(gpu.ColttError) as e:
+        gh.Insert(10**9, v, 0)
+    assert e.value.code == -2  # ItemAlreadyExistsError
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
+
+
+def test_hnsw_gpu_build_batched(gpu):
+    """batch > 1: equals the oracle's batched-insert restatement; recall is checked against exact search."""
+    import torch
+    n, d = 4000, 64
+    X = O.fill_normal(71, (n, d)); lv = O.levels(72, n); ids = np.arange(n, dtype=np.uint64)
+    sched = lambda i: max(1, min(256, i // 16))
+    oh = O.Hnsw(d, O.L2, O.default_cfg(efConstruction=64)); oh.insert_batched(ids, X, lv, 0, schedule=sched)
+    gh = gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(ef_construction=64))
+    xd = torch.from_numpy(X).cuda()
+    i = 0
+    while i < n:
+        b = min(sched(i), n - i)
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i)
+        i += b
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
+    Q = O.fill_normal(73, (64, d))
+    gi, gs, gc = gh.Search(Q, 10, ef=128)
+    fl = gpu.FlatSpace(d, O.L2); fl.ChangedVertex(ids, X)
+    ti, ts, tc = fl.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+    rec = np.mean([len(set(gi[q]) & set(ti[q])) / 10 for q in range(len(Q))])
+    assert rec > 0.9, rec
+
+
+def test_hnsw_remove_parity(gpu):
+    import torch
+    n, d = 500, 32
+    X = O.fill_normal(81, (n, d)); lv = O.levels(82, n); ids = np.arange(n, dtype=np.uint64)
+    oh = O.Hnsw(d, O.COSINE); oh.insert_many(ids, X, lv)
+    gh = gpu.Hnsw(d, O.COSINE); gh.BulkLoad(oh.export(with_vectors=False), X)
+    rng = np.random.default_rng(5)
+    victims = list(rng.choice(n, 120, replace=False))
+    ent = oh.export(with_vectors=False)["entry"]
+    if ent not in victims: victims.insert(3, ent)  # removing the entrypoint re-elects one (hnsw.go:197-217)
+    for v in victims:
+        assert oh.remove(ids[v]) == 0
+        gh.Remove(ids[v])
+    with pytest.raises(gpu.ColttError) as e:
+        gh.Remove(ids[victims[0]])
+    assert e.value.code == -3  # ItemNotFoundError
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
+    assert gh.Len() == len(oh)
+    Q = O.fill_normal(83, (20, d))
+    gi, gs, gc = gh.Search(Q, 10, ef=50)
+    for qi in range(20):
+        wi, ws = oh.search(Q[qi], 10, mode=1, ef=50)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
+    # inserts after removals keep matching
+    Y = O.fill_normal(84, (50, d)); ly = O.levels(85, 50)
+    yd = torch.from_numpy(Y).cuda()
+    nid = np.arange(50, dtype=np.uint64) + np.uint64(10000)
+    for i in range(50): assert oh.insert(nid[i], Y[i], ly[i]) == 0
+    gh.InsertBatchDevice(yd.data_ptr(), 50, ly, batch=1, ids=nid)
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))

@@ -1,0 +1,181 @@
+"""CPU suite: the oracle against (1) the reference's own C++ SIMD kernels built from /root/reference when present
+(oracle/_ref), (2) independent restatements (numpy float16, Python FNV / container-heap), (3) the committed golden
+fixtures.  No GPU needed."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import bits
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+import make_golden as MG  # noqa: E402
+
+
+def test_distance_orders_equal_reference_sources():
+    r = O.ref()
+    if r is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    rng = np.random.default_rng(1)
+    for _ in range(1500):
+        d = int(rng.integers(1, 800))
+        a = rng.standard_normal(d).astype(np.float32); b = rng.standard_normal(d).astype(np.float32)
+        for order in (O.ORDER_AVX, O.ORDER_SSE):
+            res = C.c_float(); dot = C.c_float(); ns = C.c_float()
+            r.ref_l2sq(order, C.c_size_t(d), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(res))
+            r.ref_cos_dot_norm(order, C.c_size_t(d), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(dot), C.byref(ns))
+            p = O.cosine_parts(a, b, order)
+            assert np.float32(res.value).view(np.uint32) == O.l2sq(a, b, order).view(np.uint32)
+            assert np.float32(dot.value).view(np.uint32) == p[0].view(np.uint32)
+            assert np.float32(ns.value).view(np.uint32) == np.float32(p[1] * p[2]).view(np.uint32)
+
+
+def test_codecs_against_ieee_binary16():
+    codes = np.arange(65536, dtype=np.uint16)
+    dec = O.f16_decode(codes); ref = codes.view(np.float16).astype(np.float32)
+    m = ~np.isnan(ref)
+    assert np.array_equal(bits(dec[m]), bits(ref[m])) and np.isnan(dec[~m]).all()
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal(300000) * np.exp(rng.uniform(-25, 11, 300000))).astype(np.float32)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(O.f16_encode(x), x.astype(np.float16).view(np.uint16))
+    # "bf16" is binary16 in the reference, "f8" decodes to 8 values (SURVEY.md §0 findings 2-3)
+    lut = O.f8_decode(np.arange(256, dtype=np.uint8)).view(np.uint32)
+    assert sorted(set(lut.tolist())) == [0, 0x8000, 0x33800000, 0x33808000, 0x34000000, 0x34008000, 0x34400000, 0x34408000]
+
+
+def test_f8_encode_is_low_byte_of_f16_for_finite_non_overflow():
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal(100000) * np.exp(rng.uniform(-20, 8, 100000))).astype(np.float32)
+    x = x[np.abs(x) < 60000]
+    assert np.array_equal(O.f8_encode(x), (O.f16_encode(x) & 0xFF).astype(np.uint8))
+
+
+def test_fnv_shard():
+    def fnv(x, c):
+        h = 14695981039346656037
+        for i in range(8):
+            h ^= (x >> (8 * i)) & 0xFF; h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h % c
+    for i in range(2000):
+        x = (i * 0x9E3779B97F4A7C15 + 77) & 0xFFFFFFFFFFFFFFFF
+        assert O.shard_vertex(x, 16) == fnv(x, 16)
+
+
+def test_go_heap_semantics():
+    """container/heap restated independently in Python (up/down as in go1.23 heap.go)."""
+    def run(is_max, pr, ops):
+        less = (lambda a, b: pr[a] > pr[b]) if is_max else (lambda a, b: pr[a] < pr[b])
+        h, pops = [], []
+        def up(j):
+            while True:
+                i = (j - 1) // 2 if j > 0 else 0
+                if i == j or not less(h[j], h[i]): break
+                h[i], h[j] = h[j], h[i]; j = i
+        def down(i0, n):
+            i = i0
+            while True:
+                j1 = 2 * i + 1
+                if j1 >= n: break
+                j = j1
+                if j1 + 1 < n and less(h[j1 + 1], h[j1]): j = j1 + 1
+                if not less(h[j], h[i]): break
+                h[i], h[j] = h[j], h[i]; i = j
+        for o in ops:
+            if o >= 0: h.append(o); up(len(h) - 1)
+            elif h:
+                n = len(h) - 1; h[0], h[n] = h[n], h[0]; down(0, n); pops.append(h.pop())
+        return pops, h
+    rng = np.random.default_rng(9)
+    for trial in range(50):
+        pr = rng.integers(0, 6, 40).astype(np.float32)  # many ties
+        ops = np.array([i if rng.random() < 0.7 else -1 for i in range(40)], np.int32)
+        for mx in (0, 1):
+            p, f = O.heap_trace(mx, pr, ops); p2, f2 = run(mx, pr, list(ops))
+            assert list(p) == p2 and list(f) == f2
+
+
+def test_edge_queue_keeps_farthest_and_modes_agree():
+    """edge.PriorityQueue is a min-heap that pops the minimum: K LARGEST distances survive (finding 1)."""
+    n, d = 500, 24
+    X = O.fill_normal(3, (n, d)); ids = np.arange(n, dtype=np.uint64)
+    f = O.Flat(d, O.L2); f.upsert(ids, X)
+    q = O.fill_normal(4, d)
+    alld = O.dist_rows(O.L2, q, X)
+    i0, s0 = f.search(q, 7, nearest=False, mode=0)
+    assert np.array_equal(np.sort(alld)[-7:], s0)               # farthest 7, ascending
+    for mode in (1, 2):
+        i, s = f.search(q, 7, nearest=False, mode=mode)
+        assert np.array_equal(i, i0) and np.array_equal(bits(s), bits(s0))
+    i1, s1 = f.search(q, 7, nearest=True, mode=2)
+    assert np.array_equal(np.sort(alld)[:7], s1)
+
+
+def test_hnsw_literal_equals_canonical_and_batched_1():
+    n, d = 800, 40
+    X = O.fill_normal(11, (n, d)); lv = O.levels(12, n); ids = np.arange(n, dtype=np.uint64)
+    a = O.Hnsw(d, O.COSINE); a.insert_many(ids, X, lv)
+    b = O.Hnsw(d, O.COSINE, canonical_build=True); b.insert_many(ids, X, lv)
+    c = O.Hnsw(d, O.COSINE); c.insert_batched(ids, X, lv, 1)
+    assert a.graph_hash() == b.graph_hash() == c.graph_hash()
+    e = O.Hnsw(d, O.COSINE, O.default_cfg(algo=1)); e.insert_many(ids, X, lv)   # Heuristic(extend=false) == Simple
+    assert e.graph_hash() == a.graph_hash()
+    for q in O.fill_normal(13, (25, d)):
+        r0 = a.search(q, 10, mode=0, ef=50, with_stats=True); r1 = a.search(q, 10, mode=1, ef=50, with_stats=True)
+        assert np.array_equal(r0[0], r1[0]) and np.array_equal(bits(r0[1]), bits(r1[1])) and r0[2] == r1[2]
+    assert a.insert(5, X[5], 0) == -2 and a.remove(10**6) == -3
+    # export -> import round trip (the invariant hnsw_commit_test.go:127-181 asserts for Commit/Load)
+    g = a.export(); z = O.Hnsw(d, O.COSINE); z.load(g)
+    assert z.graph_hash() == a.graph_hash() and len(z) == len(a)
+
+
+def test_golden_kernels():
+    g = np.load(os.path.join(GOLD, "kernels.npz"))
+    for d in MG.DIST_DIMS:
+        a = O.fill_normal(100 + d, (8, d)); b = O.fill_normal(200 + d, (8, d))
+        for mname, f in (("cos", O.cosine), ("l2", O.l2)):
+            for order in (0, 1, 2):
+                got = np.array([f(a[i], b[i], order) for i in range(8)], np.float32).view(np.uint32)
+                assert np.array_equal(got, g[f"dist_{mname}_{order}_{d}"]), (mname, order, d)
+        assert np.array_equal(O.normalize(a).view(np.uint32), g[f"norm_{d}"])
+        assert np.array_equal(np.array([O.pq_dot(a[i], b[i]) for i in range(8)], np.float32).view(np.uint32), g[f"pqdot_{d}"])
+        assert np.array_equal(np.array([O.pq_l2sq(a[i], b[i]) for i in range(8)], np.float32).view(np.uint32), g[f"pql2_{d}"])
+    x = g["enc_in"].view(np.float32)
+    assert np.array_equal(O.f16_encode(x), g["f16_encode"]) and np.array_equal(O.f8_encode(x), g["f8_encode"])
+    assert np.array_equal(O.f8_decode(np.arange(256, dtype=np.uint8)).view(np.uint32), g["f8_lut"])
+    assert MG.fnv64(O.f16_decode(np.arange(65536, dtype=np.uint16)).tobytes()) == int(g["f16_decode_hash"][0])
+    assert np.array_equal(np.array([O.pq_hamming(g["bit_q"], r) for r in g["bit_rows"]], np.float32), g["hamming"])
+    for mx in (0, 1):
+        p, f = O.heap_trace(mx, g["heap_prios"], g["heap_ops"])
+        assert np.array_equal(p, g[f"heap_pops_{mx}"]) and np.array_equal(f, g[f"heap_final_{mx}"])
+
+
+def test_golden_flat_and_hnsw():
+    g = np.load(os.path.join(GOLD, "flat_2048x128.npz"))
+    n, d = 2048, 128
+    X = O.fill_normal(1, (n, d)); Q = O.fill_normal(99, (16, d))
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919) + np.uint64(1000003)) % np.uint64(1 << 40)
+    for metric, quant in ((0, 0), (1, 1), (0, 2), (1, 3)):
+        f = O.Flat(d, metric, quant); f.upsert(ids, X)
+        for k, nearest in ((10, 0), (100, 1)):
+            for qi in range(16):
+                i, s = f.search(Q[qi], k, bool(nearest), 2)
+                assert np.array_equal(i, g[f"ids_{metric}_{quant}_{k}_{nearest}"][qi])
+                assert np.array_equal(s.view(np.uint32), g[f"sc_{metric}_{quant}_{k}_{nearest}"][qi])
+    h = np.load(os.path.join(GOLD, "hnsw.npz"))
+    n, d = 1000, 128
+    X = O.fill_normal(40 + d, (n, d)); lv = O.levels(41 + d, n); ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(11)
+    x = O.Hnsw(d, O.COSINE); x.insert_many(ids, X, lv)
+    assert x.graph_hash() == int(h["1000x128_cos_graph_hash"][0])
+    Q = O.fill_normal(123, (40, d))
+    for qi in range(40):
+        i, s, c = x.search(Q[qi], 10, mode=1, ef=128, with_stats=True)
+        assert np.array_equal(i, h["1000x128_cos_ids_128"][qi]) and np.array_equal(s.view(np.uint32), h["1000x128_cos_sc_128"][qi])
+        assert (c["n_dist"], c["n_exp"], c["n_hops"]) == tuple(int(v) for v in h["1000x128_cos_stats_128"][qi])
+    rng = np.random.default_rng(40 + d)
+    for i in rng.choice(n, 200, replace=False): x.remove(ids[i])
+    assert x.graph_hash() == int(h["1000x128_cos_graph_hash_removed"][0])
