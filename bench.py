@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec at recall@10 for HNSW search on MI355X (BASELINE.json metric), one process per GPU.
+
+Workload (config.workload): BASELINE.json configs[3] — core/vectorindex HNSW, M=16 (mMax0=32), efSearch=128,
+10M x 768 float32, cosine, k=10, synthetic random-normal vectors generated in HBM.  A "step" is one call of
+Hnsw.Search for a batch of `--queries` queries (inputs already resident in HBM).  The index is built on the GPU by the
+library's own batched Insert (outside the timed region), searched by the hand-written HIP kernel, and checked:
+recall@10 against the exact FLAT scan (COLTT_SELECT_NEAREST), and a sample of queries bit-for-bit against the CPU
+oracle on the exported graph.
+
+N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), --mode:
+  replica (default): the 10M index fits one GPU (30.7 GB of 288 GB), so every rank holds a replica and searches its
+           own slice of the query stream — no data-path collective; value = total queries / max-over-ranks time.
+  shard  : the collection is partitioned N ways (ids i with i % N == rank), every rank searches every query on its
+           shard, per-shard top-k is exchanged with ONE all-gather (RCCL over xGMI) and merged on the host of rank 0
+           (north-star layout; BASELINE.json configs[4]).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=10_000, help="queries per step (per rank)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--efc", type=int, default=200, help="efConstruction (reference default 200)")
+    ap.add_argument("--build-batch", type=int, default=16384)
+    ap.add_argument("--quant", type=int, default=0, help="0 f32 (configs[3]); 1 f16 codes")
+    ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
+    ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--seed", type=int, default=0xC0177)
+    return ap.parse_args()
+
+
+def build_index(G, torch, dev, n, dim, args, seed, id_base=0):
+    """Generate n random-normal vectors in HBM chunk by chunk and Insert them (batched builder)."""
+    from oracle import oracle as O  # level draw only (host logic: floor(-ln U * 1/ln M))
+    cfg = G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc)
+    h = G.Hnsw(dim, G.COSINE, cfg, quantization=args.quant)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    rng = np.random.default_rng(seed ^ 0x1E7E1)
+    mult = 1.0 / np.log(float(args.m))
+    levels = np.floor(-np.log(1.0 - rng.random(n)) * mult).astype(np.int32)  # RandomExponential (gomath/rand.go:42-44)
+    chunk = min(n, 1 << 20)
+    done = 0
+    t0 = time.time()
+    while done < n:
+        c = min(chunk, n - done)
+        x = torch.randn((c, dim), device=dev, dtype=torch.float32, generator=gen)
+        # batch schedule: grow geometrically so a batch never exceeds 1/32 of the graph it is linked against
+        i = 0
+        while i < c:
+            cur = done + i
+            b = int(min(c - i, max(1, min(args.build_batch, cur // 32))))
+            h.InsertBatchDevice(x.data_ptr() + i * dim * 4, b, levels[cur:cur + b], batch=b, first_id=id_base + cur)
+            i += b
+        done += c
+        del x
+    torch.cuda.synchronize()
+    return h, time.time() - t0, levels
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import coltt_amd as G
+    L = G.lib()
+    assert L.coltt_init(local) == 0, L.coltt_last_error()
+
+    n_total, dim, k = args.n, args.dim, args.k
+    shard = args.mode == "shard" and world > 1
+    n_local = (n_total - rank + world - 1) // world if shard else n_total
+    # replica mode: same seed on every rank => identical replicas; shard mode: rank-specific stream
+    seed = args.seed + (rank * 7919 if shard else 0)
+    h, build_s, levels = build_index(G, torch, dev, n_local, dim, args, seed, id_base=0)
+
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + (0 if shard else rank))
+    nq = args.queries
+    queries = [torch.randn((nq, dim), device=dev, dtype=torch.float32, generator=qgen) for _ in range(min(2, args.steps + args.warmup))]
+    out_ids = torch.empty((nq, k), device=dev, dtype=torch.int64)
+    out_sc = torch.empty((nq, k), device=dev, dtype=torch.float32)
+    out_cnt = torch.empty((nq,), device=dev, dtype=torch.int32)
+    if shard:
+        g_ids = torch.empty((world, nq, k), device=dev, dtype=torch.int64)
+        g_sc = torch.empty((world, nq, k), device=dev, dtype=torch.float32)
+
+    def step(i):
+        q = queries[i % len(queries)]
+        st = h.SearchDevice(q.data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
+        if shard:
+            gid = out_ids * world + rank  # local id -> global id (i % world == rank partition)
+            dist.all_gather_into_tensor(g_ids, gid)
+            dist.all_gather_into_tensor(g_sc, out_sc)
+            if rank == 0:  # host-side final merge of world x k candidates per query (north star)
+                allsc = g_sc.permute(1, 0, 2).reshape(nq, world * k).cpu().numpy()
+                allid = g_ids.permute(1, 0, 2).reshape(nq, world * k).cpu().numpy()
+                order = np.lexsort((allid, allsc), axis=1)[:, :k]
+                np.take_along_axis(allid, order, 1)
+        return st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    kernel_ms = []
+    stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(args.warmup + i)
+        kernel_ms.append(h.last_kernel_ms())  # hipEvent pair recorded on the library's search stream
+        for kk in stats: stats[kk] += st[kk]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_q = args.steps * nq * (1 if shard else world)
+    qps = total_q / dt
+
+    res = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (hnsw_search_kernel): algorithmic bytes per query
+        s_bytes = {0: 4, 1: 2, 2: 1, 3: 2}[args.quant]
+        nd = stats["n_dist"] / (args.steps * nq); ne = stats["n_exp"] / (args.steps * nq)
+        bytes_per_query = nd * dim * s_bytes + ne * (2 * args.m) * 4 + nd * 4
+        launch_s = float(np.mean(kernel_ms)) / 1e3
+        achieved = bytes_per_query * nq / launch_s / 1e9
+        # ---- recall@10 vs the exact scan on a sample
+        rq = min(args.recall_queries, nq)
+        fl = None
+        recall = None
+        try:
+            ids_h = out_ids[:rq].cpu().numpy() if not shard else None
+            if not shard:
+                q = queries[(args.warmup + args.steps - 1) % len(queries)]
+                st = h.SearchDevice(q.data_ptr(), rq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
+                ids_h = out_ids[:rq].cpu().numpy()
+                recall = exact_recall(G, torch, dev, h, args, seed, n_local, dim, q, rq, k, ids_h)
+        except Exception as e:  # recall is reported, never allowed to kill the bench line
+            recall = f"failed: {e}"
+        cpu = None
+        if not args.no_cpu_baseline and not shard:
+            try:
+                cpu = cpu_baseline(G, torch, h, args, dim, queries[0], k, out_ids, out_sc, out_cnt)
+            except Exception as e:
+                cpu = {"error": str(e)}
+        res = {
+            "metric": "queries/sec @ recall@10, 10Mx768 HNSW", "value": qps, "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.quant == 0 else "f16", "data": "synthetic",
+            "config": {"workload": f"core/vectorindex HNSW M={args.m} efSearch={args.ef} efConstruction={args.efc}, "
+                                   f"{n_total}x{dim} {'float32' if args.quant == 0 else 'f16 codes'}, cosine, k={k}, "
+                                   f"{nq} queries/step/rank, mode={'shard+allgather' if shard else ('replica' if world > 1 else 'single')}",
+                       "n": n_total, "dim": dim, "queries_per_step": nq, "ef": args.ef, "build_batch": args.build_batch},
+            "recall_at_10": recall, "build_s": build_s,
+            "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bytes_per_query, "visit_resets": stats["n_visit_resets"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "hnsw_search_kernel", "avg_launch_ms": launch_s * 1e3},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def exact_recall(G, torch, dev, h, args, seed, n, dim, q, rq, k, ann_ids):
+    """recall@k of the HNSW answers against the exact nearest-k from the parity-checked FLAT kernel.  The FLAT store is
+    filled by re-generating the same vectors (same generator stream) so no second copy has to cross PCIe."""
+    fl = G.FlatSpace(dim, G.COSINE, args.quant)
+    fl.Reserve(n)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    chunk = min(n, 1 << 20); done = 0
+    while done < n:
+        c = min(chunk, n - done)
+        x = torch.randn((c, dim), device=dev, dtype=torch.float32, generator=gen)
+        fl.ChangedVertexDevice(x.data_ptr(), c, first_id=done)
+        done += c
+        del x
+    ti = torch.empty((rq, k), device=dev, dtype=torch.int64); ts = torch.empty((rq, k), device=dev, dtype=torch.float32)
+    tc = torch.empty((rq,), device=dev, dtype=torch.int32)
+    fl.VertexSearchDevice(q.data_ptr(), rq, k, ti.data_ptr(), ts.data_ptr(), tc.data_ptr(), select=G.SELECT_NEAREST)
+    truth = ti.cpu().numpy()
+    fl.close()
+    hit = sum(len(set(truth[i].tolist()) & set(ann_ids[i].tolist())) for i in range(rq))
+    return hit / (rq * k)
+
+
+def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
+    """The CPU oracle (a restatement of the reference's Go/AVX path: oracle/coltt_oracle.cpp, 'contiguous' variant)
+    searching the SAME graph on the host cores, on a bounded sample of the same queries; also cross-checks the GPU
+    answers and traversal counters for that sample bit-for-bit."""
+    import psutil
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    Lo = O.lib()
+    g = h.Export()
+    n = len(g["levels"])
+    need = n * dim * 4 * 1.1 + g["nbr"].nbytes * 3
+    if psutil.virtual_memory().available < need:
+        return {"error": f"host RAM too small for a copy of the index ({need / 2**30:.0f} GiB needed)"}
+    if args.quant != 0:
+        return {"error": "cpu baseline implemented for f32 rows"}
+    w0, wu = 2 * args.m, args.m
+    # rebuild the padded arrays the oracle's contiguous search walks (same layout as HBM)
+    lv = g["levels"]; off = g["row_offsets"]; nbr = g["nbr"].astype(np.uint32)
+    rows_of_slot = np.concatenate([[0], np.cumsum(lv.astype(np.int64) + 1)])
+    adj0 = np.full((n, w0), 0xFFFFFFFF, np.uint32)
+    r0 = rows_of_slot[:-1]
+    deg0 = (off[r0 + 1] - off[r0]).astype(np.int64)
+    idx = np.repeat(np.arange(n), deg0); pos = np.arange(deg0.sum()) - np.repeat(np.cumsum(deg0) - deg0, deg0)
+    src = np.repeat(off[r0], deg0) + pos
+    adj0[idx, pos] = nbr[src]
+    n_up = int(lv.sum())
+    upper_off = np.full(n, 0xFFFFFFFF, np.uint32); adjU = np.full((max(n_up, 1), wu), 0xFFFFFFFF, np.uint32)
+    up = 0
+    for s in np.nonzero(lv > 0)[0]:
+        upper_off[s] = up
+        for l in range(1, lv[s] + 1):
+            r = rows_of_slot[s] + l
+            e = nbr[off[r]:off[r + 1]]
+            adjU[up + l - 1, :len(e)] = e
+        up += lv[s]
+    # stored (normalised) vectors: read back from HBM via the FLAT-free path = re-normalise on host is NOT bit-safe, so
+    # fetch the rows the GPU actually searches
+    rows = fetch_rows(G, torch, h, n, dim)
+    ent = int(g["entry"]); ent_lv = int(lv[ent])
+    threads = os.cpu_count() or 1
+    q_host = q_dev.cpu().numpy()
+
+    def run(qs):
+        m = len(qs)
+        sl = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32); cn = np.empty(m, np.int32); st = (C.c_uint64 * 3)()
+        Lo.orc_csr_search(rows.ctypes.data_as(C.c_void_p), adj0.ctypes.data_as(C.c_void_p), upper_off.ctypes.data_as(C.c_void_p),
+                          adjU.ctypes.data_as(C.c_void_p), None, C.c_uint32(w0), C.c_uint32(wu), C.c_uint32(dim), 0, 0, C.c_int32(ent),
+                          C.c_int32(ent_lv), qs.ctypes.data_as(C.c_void_p), C.c_size_t(m), k, args.ef, sl.ctypes.data_as(C.c_void_p),
+                          sc.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p), st)
+        return sl, sc, cn, (st[0], st[1], st[2])
+
+    # calibrate on a few queries, then size the sample for ~cpu-seconds of wall time on all cores
+    t0 = time.perf_counter(); sl1, sc1, cn1, st1 = run(np.ascontiguousarray(q_host[:8])); t1 = (time.perf_counter() - t0) / 8
+    sample = int(max(threads, min(len(q_host), args.cpu_seconds / t1 * threads)))
+    sample -= sample % threads
+    parts = np.array_split(np.ascontiguousarray(q_host[:sample]), threads)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        outs = list(ex.map(run, parts))
+    wall = time.perf_counter() - t0
+    # parity of the sample: GPU answers == oracle answers (slots, score bits)
+    st = h.SearchDevice(q_dev.data_ptr(), sample, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
+    gi = out_ids[:sample].cpu().numpy(); gs = out_sc[:sample].cpu().numpy()
+    ci = np.concatenate([o[0] for o in outs]); cs = np.concatenate([o[1] for o in outs])
+    cstat = np.sum([o[3] for o in outs], axis=0)
+    same = bool(np.array_equal(gi, ci.astype(np.int64)) and np.array_equal(gs.view(np.uint32), cs.view(np.uint32)))
+    same_counters = bool(int(cstat[0]) == st["n_dist"] and int(cstat[1]) == st["n_exp"])
+    return {"value": sample / wall, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} of the step's queries on the full {n}x{dim} index, oracle contiguous variant, {threads} threads "
+                      f"(1 query per thread); single-thread latency {t1 * 1e3:.2f} ms/query",
+            "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
+
+
+def fetch_rows(G, torch, h, n, dim):
+    """stored f32 rows of the index, copied out of HBM"""
+    import ctypes
+    out = np.empty((n, dim), np.float32)
+    L = G.lib()
+    rc = L.coltt_hnsw_fetch_rows(h.h, ctypes.c_uint64(0), ctypes.c_uint64(n), out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError(L.coltt_last_error().decode())
+    return out
+
+
+if __name__ == "__main__":
+    main()

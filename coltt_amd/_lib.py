@@ -32,6 +32,14 @@ def lib():
     """Load the HIP extension.  There is no fallback: a missing .so is an error."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HIP runtimes in one process cannot both own
+        # the GPU ("No HIP GPUs are available"), so when torch is installed it is imported FIRST: the dynamic linker then
+        # resolves this library's NEEDED libamdhip64.so.7 to the copy that is already loaded (SONAME match) and torch
+        # tensors, RCCL and these kernels share one runtime.  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         p = lib_path()
         if not os.path.exists(p):
             raise ColttError(-5, f"{p} is missing — build it with `python -m coltt_amd.build` "

@@ -35,16 +35,17 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
   WaveCtx w;
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
-  w.res[0] = reinterpret_cast<unsigned long long*>(smem + off);
-  w.res[1] = w.res[0] + ef_pad;
-  w.vis = reinterpret_cast<uint32_t*>(w.res[1] + ef_pad);
+  w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
+  w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
   for (;;) {
-    uint32_t qi = 0;
-    if (lane == 0) qi = atomicAdd(counter, 1u);
-    qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+    // dynamic work fetch.  Branch-free on purpose: with `if (lane == 0) t = atomicAdd(..)` hipcc threads the
+    // loop-invariant divergent branch through the back edge, lanes 1..63 re-enter the loop without lane 0 and the
+    // cross-lane broadcast below reads a stale value forever.
+    const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);
+    const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
     if (qi >= nq) break;
-    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
     __syncthreads();
     for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
     w.qnorm = qnorms[qi];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     search_level<METRIC, QUANT>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
     // selectNeighbors + pop into result[n-1..0] (:261-277) == the k smallest, ascending
     uint32_t n = len < k ? len : k;
-    const unsigned long long* res = w.res[buf];
+    const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
     for (uint32_t i = lane; i < n; i += 64) {
       unsigned long long e = res[i];
       uint32_t slot = (uint32_t)e >> 1;
@@ -101,18 +102,16 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
   WaveCtx w;
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
-  w.res[0] = reinterpret_cast<unsigned long long*>(smem + off);
-  w.res[1] = w.res[0] + ef_pad;
-  w.vis = reinterpret_cast<uint32_t*>(w.res[1] + ef_pad);
+  w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
+  w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
   for (;;) {
-    uint32_t bi = 0;
-    if (lane == 0) bi = atomicAdd(counter, 1u);
-    bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bi);
+    const uint32_t bt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free, see hnsw_search_kernel
+    const uint32_t bi = (uint32_t)__shfl((int)bt, 0, 64);
     if (bi >= count) break;
     const uint32_t vi = base + bi;
     const int lv = levels[bi];
-    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
     __syncthreads();
     {  // the query is the vertex's own stored row, decoded to f32
       const uint8_t* row = g.rows + (size_t)vi * g.stride;
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       uint32_t len; int buf;
       w.n_dist += 1;
       search_level<METRIC, QUANT>(g, w, cur, curd, efc, l, lane, len, buf);
-      const unsigned long long* res = w.res[buf];
+      const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
       const uint32_t m = len < M ? len : M;
       // the m nearest, re-ordered by slot (canonical row order)
       unsigned long long e = (uint32_t)lane < m ? res[lane] : ~0ull;
@@ -143,9 +142,8 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       uint32_t width;
       uint32_t* row = const_cast<uint32_t*>(adj_row(g, vi, l, width));
       float* drow = (l == 0 ? g.adj0_d + (size_t)vi * g.mMax0 : g.adjU_d + ((size_t)g.upper_off[vi] + (uint32_t)(l - 1)) * g.mMax);
-      uint32_t r0 = 0;
-      if (lane == 0) r0 = atomicAdd(req_count, m);
-      r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0);
+      const uint32_t rt = atomicAdd(req_count, lane == 0 ? m : 0u);  // branch-free, see hnsw_search_kernel
+      const uint32_t r0 = (uint32_t)__shfl((int)rt, 0, 64);
       if ((uint32_t)lane < m) {
         row[rank] = myslot; drow[rank] = myd;
         uint32_t rid = l == 0 ? myslot : (uint32_t)cap_slots + g.upper_off[myslot] + (uint32_t)(l - 1);
@@ -163,6 +161,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       atomicAdd(&stats[1], (unsigned long long)w.n_exp);
       atomicAdd(&stats[2], (unsigned long long)w.n_hops);
       atomicAdd(&stats[3], (unsigned long long)w.n_resets);
+      if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
     }
   }
 }
@@ -383,15 +382,16 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
   COLTT_TRY(rc);
   COLTT_HIP(hipEventRecord(x->ev1, x->stream));
   if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, x->stream>>>(d_oi, nq * k, x->dense_base);
-  unsigned long long h_stats[4] = {0, 0, 0, 0};
+  unsigned long long h_stats[5] = {0, 0, 0, 0, 0};
   if (!on_device) {
     COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, x->stream));
     COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, x->stream));
     COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
   }
-  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 32, hipMemcpyDeviceToHost, x->stream));
+  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, x->stream));
   COLTT_HIP(hipStreamSynchronize(x->stream));
   (void)hipEventElapsedTime(&x->last_ms, x->ev0, x->ev1);
+  if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_search: traversal watchdog tripped (code %llu)", h_stats[4]);
   if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }
   return COLTT_OK;
 }
@@ -527,9 +527,10 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     }
 #undef COLTT_LB
     COLTT_TRY(rc);
-    struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[4]; } hm;
+    struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[5]; } hm;
     COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
     COLTT_HIP(hipStreamSynchronize(x->stream));
+    if (hm.st[4]) return fail(COLTT_E_DEVICE, "hnsw insert: traversal watchdog tripped (code %llu)", hm.st[4]);
     if (hm.n_req) {
       hnsw_link_kernel<<<ceil_div(hm.n_req, 64), 64, 0, x->stream>>>(x->view(), x->cap, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>());
       COLTT_HIP(hipGetLastError());
@@ -817,6 +818,18 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
   if (n_rows) *n_rows = rows;
   if (n_edges) *n_edges = edges;
   if (entry_slot) *entry_slot = x->entry;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_fetch_rows: unknown handle");
+  if (n == 0) return COLTT_OK;
+  if (!out_rows || first_slot + n > x->n) return fail(COLTT_E_INVALID, "hnsw_fetch_rows: range outside [0,%llu)", (unsigned long long)x->n);
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  const size_t rb = (size_t)x->dim * quant_bytes(x->quant);
+  COLTT_HIP(hipMemcpy2D(out_rows, rb, x->rows.as<uint8_t>() + first_slot * x->stride, x->stride, rb, n, hipMemcpyDeviceToHost));
   return COLTT_OK;
 }
 

@@ -34,12 +34,19 @@ struct GraphView {
 };
 
 struct WaveCtx {
-  float* qs; unsigned long long* res[2]; uint32_t* vis;
+  float* qs; unsigned long long* res0; uint32_t* vis;  // res buffer b = res0 + b * ef_pad
   uint32_t ef_pad, hcap_mask, hcap;
   float qnorm;
   // counters (wave-uniform)
   uint32_t n_dist, n_exp, n_hops, n_resets;
+  uint32_t err;  // watchdog: 1 visited-set probe overflow, 2 expansion budget, 3 greedy hop budget (every loop is bounded)
 };
+
+// hipcc treats `lane`-derived predicates as loop-invariant and may thread such divergent branches through a loop's
+// back edge, which splits the wave around convergent operations (ballot / shuffle / readlane) — observed as an
+// endless loop in the work-fetch of the search kernel.  Re-reading the lane id through an opaque asm at the top of
+// every traversal loop iteration makes the predicates non-invariant and keeps the wave converged.
+__device__ __forceinline__ int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
   uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j);
@@ -72,12 +79,13 @@ __device__ __forceinline__ uint32_t vis_hash(uint32_t slot, uint32_t mask) { ret
 // test-and-set; true = newly inserted (was unvisited)
 __device__ __forceinline__ bool vis_insert(uint32_t* vis, uint32_t mask, uint32_t slot) {
   uint32_t h = vis_hash(slot, mask);
-  for (;;) {
+  for (uint32_t probes = 0; probes <= mask; probes++) {
     uint32_t old = atomicCAS(&vis[h], VIS_EMPTY, slot);
     if (old == VIS_EMPTY) return true;
     if (old == slot) return false;
     h = (h + 1) & mask;
   }
+  return false;  // table full: cannot happen (it is reset at 75 % load); treated as "visited"
 }
 
 __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
@@ -94,9 +102,11 @@ __device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w,
 // greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.
 template <int METRIC, int QUANT>
 __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level,
-                                             int lane) {
-  const int half = lane & 1, p = lane >> 1;
-  for (;;) {
+                                             int lane_in) {
+  for (uint32_t hops = 0;; hops++) {
+    const int lane = opaque_lane(lane_in);
+    const int half = lane & 1, p = lane >> 1;
+    if (hops > (1u << 20)) { w.err |= 4u; break; }
     uint32_t width;
     const uint32_t* row = adj_row(g, cur, level, width);
     unsigned long long best = ~0ull;
@@ -135,19 +145,22 @@ __device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* 
 // The wave must be the only one in its workgroup (uses __syncthreads as a wave-level LDS fence).
 template <int METRIC, int QUANT>
 __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
-                                             int level, int lane, uint32_t& out_len, int& out_buf) {
-  const int half = lane & 1, p = lane >> 1;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+                                             int level, int lane_in, uint32_t& out_len, int& out_buf) {
+  int lane = lane_in;
   vis_clear(w, lane);
   int buf = 0;
-  if (lane == 0) w.res[0][0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
+  if (lane == 0) w.res0[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
   __syncthreads();
   if (lane == 0) vis_insert(w.vis, w.hcap_mask, ep);
   uint32_t len = 1, vis_count = 1;
   bool had_reset = false;
   __syncthreads();
-  for (;;) {
-    unsigned long long* res = w.res[buf];
+  for (uint32_t iters = 0;; iters++) {
+    if (iters > (1u << 22)) { w.err |= 2u; break; }
+    lane = opaque_lane(lane_in);
+    const int half = lane & 1, p = lane >> 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
     // ---- pop: the smallest unexpanded member
     int ci = -1;
     for (uint32_t base = 0; base < len; base += 64) {
@@ -173,7 +186,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     uint32_t width;
     const uint32_t* row = adj_row(g, cslot, level, width);
     for (uint32_t c0 = 0; c0 < width; c0 += 32) {
-      res = w.res[buf];
+      res = w.res0 + (size_t)buf * w.ef_pad;
       uint32_t idx = c0 + p;
       uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
@@ -208,7 +221,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       uint32_t m = __popcll(A);
       if (m == 0) continue;
       // ---- merge the m admitted (d, slot) into the sorted result set, keep the ef smallest
-      unsigned long long* dst = w.res[buf ^ 1];
+      unsigned long long* dst = w.res0 + (size_t)(buf ^ 1) * w.ef_pad;
       unsigned long long mykey = adm ? (((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)nb << 1)) : ~0ull;
       uint32_t mypos = 0;
       if (adm) {  // lower_bound over the sorted result set

@@ -798,6 +798,69 @@ static int hnsw_insert_batch(Hnsw* h, const uint64_t* ids, const float* vecs, co
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "Contiguous" CPU-baseline variant: the same canonical Hnsw.Search over the GPU's own
+// padded-array graph layout (adj0 [n][w0], upper_off [n], adjU [rows][wu], rows [n][dim] f32), so a
+// 10M-vertex index exported from HBM can be timed on the host without re-materialising per-vertex objects.
+// ------------------------------------------------------------------------------------------------
+struct CsrGraph {
+  const float* rows; const uint32_t* adj0; const uint32_t* upper_off; const uint32_t* adjU; const uint32_t* del_bits;
+  uint32_t w0, wu, dim; int metric, order; int32_t entry, entry_level;
+};
+static inline bool csr_deleted(const CsrGraph& g, uint32_t s) { return g.del_bits && ((g.del_bits[s >> 5] >> (s & 31)) & 1u); }
+static inline const uint32_t* csr_row(const CsrGraph& g, uint32_t s, int level, uint32_t& w) {
+  if (level == 0) { w = g.w0; return g.adj0 + (size_t)s * g.w0; }
+  w = g.wu; return g.adjU + ((size_t)g.upper_off[s] + (uint32_t)(level - 1)) * g.wu;
+}
+static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int32_t* out_slots, float* out_scores, uint64_t* st) {
+  std::vector<float> qn; const float* q = query;
+  if (g.metric == METRIC_COS) { qn.resize(g.dim); normalize(query, qn.data(), g.dim); q = qn.data(); }
+  if (g.entry < 0) return 0;
+  uint64_t n_dist = 0, n_exp = 0, n_hops = 0;
+  auto D = [&](uint32_t s) { n_dist++; return dist(g.metric, g.order, q, g.rows + (size_t)s * g.dim, g.dim); };
+  uint32_t ep = (uint32_t)g.entry; float minD = D(ep);
+  for (int l = g.entry_level; l > 0; l--) {
+    for (;;) {
+      int64_t closest = -1; uint32_t w; const uint32_t* row = csr_row(g, ep, l, w);
+      for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
+        if (csr_deleted(g, row[j])) continue;
+        float d = D(row[j]);
+        if (d < minD) { minD = d; closest = row[j]; }
+      }
+      n_hops++;
+      if (closest < 0) break;
+      ep = (uint32_t)closest;
+    }
+  }
+  std::vector<RItem> res; res.push_back({D(ep), (int32_t)ep, false});
+  std::unordered_set<uint32_t> visited; visited.reserve((size_t)ef * g.w0); visited.insert(ep);
+  std::vector<RItem> adm;
+  for (;;) {
+    int ci = -1;
+    for (int i = 0; i < (int)res.size(); i++) if (!res[i].expanded) { ci = i; break; }
+    if (ci < 0) break;
+    res[ci].expanded = true;
+    float lowerBound = res.back().d; int free_slots = ef - (int)res.size(); uint32_t c = (uint32_t)res[ci].slot;
+    n_exp++; adm.clear();
+    uint32_t w; const uint32_t* row = csr_row(g, c, 0, w);
+    for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
+      uint32_t nb = row[j];
+      if (csr_deleted(g, nb)) continue;
+      if (!visited.insert(nb).second) continue;
+      float d = D(nb);
+      if (free_slots > 0) { adm.push_back({d, (int32_t)nb, false}); free_slots--; }
+      else if (d < lowerBound) adm.push_back({d, (int32_t)nb, false});
+    }
+    for (auto& a : adm) res.insert(std::upper_bound(res.begin(), res.end(), a, ritem_less), a);
+    if ((int)res.size() > ef) res.resize(ef);
+  }
+  int n = std::min(k, (int)res.size());
+  for (int i = 0; i < n; i++) { out_slots[i] = res[i].slot; out_scores[i] = res[i].d; }
+  if (st) { st[0] += n_dist; st[1] += n_exp; st[2] += n_hops; }
+  return n;
+}
+
 static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -986,6 +1049,18 @@ int orc_hnsw_import(void* h, int64_t n, const uint64_t* ids, const int32_t* leve
   x->entry = entry;
   return 0;
 }
+
+// nq queries, one after another on the calling thread (call from several threads for the all-cores figure).
+int orc_csr_search(const float* rows, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* adjU,
+                   const uint32_t* del_bits, uint32_t w0, uint32_t wu, uint32_t dim, int metric, int order, int32_t entry,
+                   int32_t entry_level, const float* queries, size_t nq, int k, int ef, int32_t* out_slots, float* out_scores,
+                   int32_t* out_counts, uint64_t* stats3) {
+  CsrGraph g{rows, adj0, upper_off, adjU, del_bits, w0, wu, dim, metric, order, entry, entry_level};
+  for (size_t i = 0; i < nq; i++)
+    out_counts[i] = csr_search(g, queries + i * dim, k, ef, out_slots + i * k, out_scores + i * k, stats3);
+  return 0;
+}
+
 uint64_t orc_hnsw_graph_hash(void* h) {
   Hnsw* x = (Hnsw*)h; uint64_t hs = 14695981039346656037ull;
   hs = fnv_mix(hs, &x->entry, 4);
