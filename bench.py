@@ -57,7 +57,6 @@ def parse():
 
 def build_index(G, torch, dev, n, dim, args, seed, id_base=0):
     """Generate n random-normal vectors in HBM chunk by chunk and Insert them (batched builder)."""
-    from oracle import oracle as O  # level draw only (host logic: floor(-ln U * 1/ln M))
     cfg = G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc)
     h = G.Hnsw(dim, G.COSINE, cfg, quantization=args.quant)
     gen = torch.Generator(device=dev); gen.manual_seed(seed)
@@ -112,22 +111,17 @@ def main():
     out_ids = torch.empty((nq, k), device=dev, dtype=torch.int64)
     out_sc = torch.empty((nq, k), device=dev, dtype=torch.float32)
     out_cnt = torch.empty((nq,), device=dev, dtype=torch.int32)
-    if shard:
-        g_ids = torch.empty((world, nq, k), device=dev, dtype=torch.int64)
-        g_sc = torch.empty((world, nq, k), device=dev, dtype=torch.float32)
+    from coltt_amd import dist as D
+    merged = []
 
     def step(i):
         q = queries[i % len(queries)]
         st = h.SearchDevice(q.data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
         if shard:
-            gid = out_ids * world + rank  # local id -> global id (i % world == rank partition)
-            dist.all_gather_into_tensor(g_ids, gid)
-            dist.all_gather_into_tensor(g_sc, out_sc)
-            if rank == 0:  # host-side final merge of world x k candidates per query (north star)
-                allsc = g_sc.permute(1, 0, 2).reshape(nq, world * k).cpu().numpy()
-                allid = g_ids.permute(1, 0, 2).reshape(nq, world * k).cpu().numpy()
-                order = np.lexsort((allid, allsc), axis=1)[:, :k]
-                np.take_along_axis(allid, order, 1)
+            gid = out_ids * world + rank  # shard-local id -> collection id (ids with id % world == rank live here)
+            gi, gs, gc = D.allgather_topk(gid, out_sc, out_cnt)      # ONE RCCL all-gather per tensor over xGMI
+            if rank == 0:                                             # host-side final merge (north star)
+                merged.append(D.merge_topk(gi.cpu().numpy().astype(np.uint64), gs.cpu().numpy(), gc.cpu().numpy(), k, True))
         return st
 
     def barrier():
@@ -177,7 +171,7 @@ def main():
         except Exception as e:  # recall is reported, never allowed to kill the bench line
             recall = f"failed: {e}"
         cpu = None
-        if not args.no_cpu_baseline and not shard:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 cpu = cpu_baseline(G, torch, h, args, dim, queries[0], k, out_ids, out_sc, out_cnt)
             except Exception as e:
@@ -232,37 +226,17 @@ def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     Lo = O.lib()
-    g = h.Export()
-    n = len(g["levels"])
-    need = n * dim * 4 * 1.1 + g["nbr"].nbytes * 3
+    g = h.ExportRaw()
+    n = g["n"]
+    need = n * dim * 4 * 1.1 + g["adj0"].nbytes * 2
     if psutil.virtual_memory().available < need:
         return {"error": f"host RAM too small for a copy of the index ({need / 2**30:.0f} GiB needed)"}
     if args.quant != 0:
         return {"error": "cpu baseline implemented for f32 rows"}
     w0, wu = 2 * args.m, args.m
-    # rebuild the padded arrays the oracle's contiguous search walks (same layout as HBM)
-    lv = g["levels"]; off = g["row_offsets"]; nbr = g["nbr"].astype(np.uint32)
-    rows_of_slot = np.concatenate([[0], np.cumsum(lv.astype(np.int64) + 1)])
-    adj0 = np.full((n, w0), 0xFFFFFFFF, np.uint32)
-    r0 = rows_of_slot[:-1]
-    deg0 = (off[r0 + 1] - off[r0]).astype(np.int64)
-    idx = np.repeat(np.arange(n), deg0); pos = np.arange(deg0.sum()) - np.repeat(np.cumsum(deg0) - deg0, deg0)
-    src = np.repeat(off[r0], deg0) + pos
-    adj0[idx, pos] = nbr[src]
-    n_up = int(lv.sum())
-    upper_off = np.full(n, 0xFFFFFFFF, np.uint32); adjU = np.full((max(n_up, 1), wu), 0xFFFFFFFF, np.uint32)
-    up = 0
-    for s in np.nonzero(lv > 0)[0]:
-        upper_off[s] = up
-        for l in range(1, lv[s] + 1):
-            r = rows_of_slot[s] + l
-            e = nbr[off[r]:off[r + 1]]
-            adjU[up + l - 1, :len(e)] = e
-        up += lv[s]
-    # stored (normalised) vectors: read back from HBM via the FLAT-free path = re-normalise on host is NOT bit-safe, so
-    # fetch the rows the GPU actually searches
-    rows = fetch_rows(G, torch, h, n, dim)
-    ent = int(g["entry"]); ent_lv = int(lv[ent])
+    adj0, upper_off, adjU = g["adj0"], g["upper_off"], g["adjU"]   # the very arrays the GPU walks, copied out of HBM
+    rows = h.FetchRows()                                            # stored (normalised) f32 rows, copied out of HBM
+    ent, ent_lv = int(g["entry"]), int(g["entry_level"])
     threads = os.cpu_count() or 1
     q_host = q_dev.cpu().numpy()
 
@@ -295,17 +269,6 @@ def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
             "sample": f"{sample} of the step's queries on the full {n}x{dim} index, oracle contiguous variant, {threads} threads "
                       f"(1 query per thread); single-thread latency {t1 * 1e3:.2f} ms/query",
             "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
-
-
-def fetch_rows(G, torch, h, n, dim):
-    """stored f32 rows of the index, copied out of HBM"""
-    import ctypes
-    out = np.empty((n, dim), np.float32)
-    L = G.lib()
-    rc = L.coltt_hnsw_fetch_rows(h.h, ctypes.c_uint64(0), ctypes.c_uint64(n), out.ctypes.data_as(ctypes.c_void_p))
-    if rc != 0:
-        raise RuntimeError(L.coltt_last_error().decode())
-    return out
 
 
 if __name__ == "__main__":

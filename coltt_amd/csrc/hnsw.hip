@@ -821,6 +821,22 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
   return COLTT_OK;
 }
 
+int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper_rows, int32_t* entry_slot,
+                          int32_t* entry_level, uint32_t* adj0, uint32_t* upper_off, uint32_t* adjU) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export_raw: unknown handle");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  if (n_slots) *n_slots = x->n;
+  if (n_upper_rows) *n_upper_rows = x->n_upper;
+  if (entry_slot) *entry_slot = x->entry;
+  if (entry_level) *entry_level = x->entry_level;
+  if (adj0 && x->n) COLTT_HIP(hipMemcpy(adj0, x->adj0.p, (size_t)x->n * x->cfg.m_max0 * 4, hipMemcpyDeviceToHost));
+  if (upper_off && x->n) COLTT_HIP(hipMemcpy(upper_off, x->upper_off.p, (size_t)x->n * 4, hipMemcpyDeviceToHost));
+  if (adjU && x->n_upper) COLTT_HIP(hipMemcpy(adjU, x->adjU.p, (size_t)x->n_upper * x->cfg.m_max * 4, hipMemcpyDeviceToHost));
+  return COLTT_OK;
+}
+
 int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_fetch_rows: unknown handle");

@@ -108,6 +108,24 @@ class Hnsw:
                                           L.vp(nb), L.vp(nd), C.byref(ent)))
         return {"ids": ids, "levels": lv, "deleted": dl, "row_offsets": off, "nbr": nb, "nbr_dist": nd, "entry": ent.value}
 
+    def ExportRaw(self):
+        """adjacency in the HBM layout: adj0 [n, mMax0], upper_off [n], adjU [n_upper, mMax] (0xffffffff padded)."""
+        ns, nu, ent, el = C.c_uint64(0), C.c_uint64(0), C.c_int32(0), C.c_int32(0)
+        L.check(L.lib().coltt_hnsw_export_raw(self.h, C.byref(ns), C.byref(nu), C.byref(ent), C.byref(el), None, None, None))
+        adj0 = np.empty((ns.value, self.cfg.m_max0), np.uint32); uo = np.empty(ns.value, np.uint32)
+        adjU = np.empty((max(nu.value, 1), self.cfg.m_max), np.uint32)
+        L.check(L.lib().coltt_hnsw_export_raw(self.h, C.byref(ns), C.byref(nu), C.byref(ent), C.byref(el), L.vp(adj0), L.vp(uo), L.vp(adjU)))
+        return {"adj0": adj0, "upper_off": uo, "adjU": adjU, "entry": ent.value, "entry_level": el.value, "n": ns.value}
+
+    def FetchRows(self, first=0, n=None):
+        ns = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_export_raw(self.h, C.byref(ns), None, None, None, None, None, None))
+        n = ns.value - first if n is None else n
+        dt = {L.Q_NONE: np.float32, L.Q_F8: np.uint8}.get(self.quantization, np.uint16)
+        out = np.empty((n, self.dim), dt)
+        L.check(L.lib().coltt_hnsw_fetch_rows(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out)))
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

@@ -151,6 +151,10 @@ int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq
 int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uint64_t* n_edges, uint64_t* ids,
                       int32_t* levels, uint8_t* deleted, int64_t* row_offsets, int32_t* nbr, float* nbr_dist,
                       int32_t* entry_slot);
+/* the adjacency exactly as it lives in HBM: adj0 [n][m_max0], upper_off [n], adjU [n_upper][m_max],
+ * padded with 0xffffffff.  NULL arrays => sizes only. */
+int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper_rows, int32_t* entry_slot,
+                          int32_t* entry_level, uint32_t* adj0, uint32_t* upper_off, uint32_t* adjU);
 /* Hnsw.Get(id)-style read-back (hnsw.go:169-178) for a slot range: the stored (normalised / lowered) row bytes. */
 int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows);
 /* last kernel timing of the handle's search stream, measured with hipEvents (milliseconds) */
