@@ -282,11 +282,9 @@ def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
     Lo = O.lib()
     g = h.ExportRaw()
     n = g["n"]
-    need = n * dim * 4 * 1.1 + g["adj0"].nbytes * 2
+    need = n * dim * {0: 4, 1: 2, 2: 1, 3: 2}[args.quant] * 1.1 + g["adj0"].nbytes * 2
     if psutil.virtual_memory().available < need:
         return {"error": f"host RAM too small for a copy of the index ({need / 2**30:.0f} GiB needed)"}
-    if args.quant != 0:
-        return {"error": "cpu baseline implemented for f32 rows"}
     w0, wu = 2 * args.m, args.m
     adj0, upper_off, adjU = g["adj0"], g["upper_off"], g["adjU"]   # the very arrays the GPU walks, copied out of HBM
     rows = h.FetchRows()                                            # stored (normalised) f32 rows, copied out of HBM
@@ -297,7 +295,7 @@ def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
     def run(qs):
         m = len(qs)
         sl = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32); cn = np.empty(m, np.int32); st = (C.c_uint64 * 3)()
-        Lo.orc_csr_search(rows.ctypes.data_as(C.c_void_p), adj0.ctypes.data_as(C.c_void_p), upper_off.ctypes.data_as(C.c_void_p),
+        Lo.orc_csr_search(rows.ctypes.data_as(C.c_void_p), int(args.quant), adj0.ctypes.data_as(C.c_void_p), upper_off.ctypes.data_as(C.c_void_p),
                           adjU.ctypes.data_as(C.c_void_p), None, C.c_uint32(w0), C.c_uint32(wu), C.c_uint32(dim), 0, 0, C.c_int32(ent),
                           C.c_int32(ent_lv), qs.ctypes.data_as(C.c_void_p), C.c_size_t(m), k, args.ef, sl.ctypes.data_as(C.c_void_p),
                           sc.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p), st)
@@ -320,7 +318,7 @@ def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
     same = bool(np.array_equal(gi, ci.astype(np.int64)) and np.array_equal(gs.view(np.uint32), cs.view(np.uint32)))
     same_counters = bool(int(cstat[0]) == st["n_dist"] and int(cstat[1]) == st["n_exp"])
     return {"value": sample / wall, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} of the step's queries on the full {n}x{dim} index, oracle contiguous variant, {threads} threads "
+            "sample": f"{sample} of the step's queries on the full {n}x{dim} index ({'f32 rows' if args.quant == 0 else '2-/1-byte codes decoded per pair'}), oracle contiguous variant, {threads} threads "
                       f"(1 query per thread); single-thread latency {t1 * 1e3:.2f} ms/query",
             "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
 

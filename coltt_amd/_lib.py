@@ -19,7 +19,7 @@ class ColttError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libcoltt_gpu.so")
+    return os.environ.get("COLTT_LIB", os.path.join(HERE, "libcoltt_gpu.so"))
 
 
 def declared_symbols():

@@ -113,6 +113,27 @@ template <int QUANT> __device__ __forceinline__ f32x4 load4(const uint8_t* __res
     return __builtin_convertvector(h, f32x4);
   }
 }
+// Raw (undecoded) 4-element chunk: keeping the RAW bits in the software-pipeline registers and decoding at the point of
+// use is what lets the loads stay in flight — decoding at load time would wait for every load as it is issued.
+template <int QUANT> struct Raw4 { typedef f32x4 type; };
+template <> struct Raw4<Q_F16> { typedef f16x4 type; };
+template <> struct Raw4<Q_BF16> { typedef f16x4 type; };
+template <> struct Raw4<Q_F8> { typedef uint32_t type; };
+template <int QUANT> __device__ __forceinline__ typename Raw4<QUANT>::type load_raw4(const uint8_t* __restrict__ row, int e) {
+  return *reinterpret_cast<const typename Raw4<QUANT>::type*>(row + (size_t)e * elem_bytes<QUANT>());
+}
+template <int QUANT> __device__ __forceinline__ f32x4 decode4(typename Raw4<QUANT>::type v) {
+  if constexpr (QUANT == Q_NONE) return v;
+  else if constexpr (QUANT == Q_F8) {
+    f32x4 r;
+    r.x = __uint_as_float(f8bits_to_f32bits(v & 0xffu));
+    r.y = __uint_as_float(f8bits_to_f32bits((v >> 8) & 0xffu));
+    r.z = __uint_as_float(f8bits_to_f32bits((v >> 16) & 0xffu));
+    r.w = __uint_as_float(f8bits_to_f32bits(v >> 24));
+    return r;
+  } else return __builtin_convertvector(v, f32x4);
+}
+
 template <int QUANT> __device__ __forceinline__ float load1(const uint8_t* __restrict__ row, int e) {
   if constexpr (QUANT == Q_NONE) return *reinterpret_cast<const float*>(row + (size_t)e * 4);
   else if constexpr (QUANT == Q_F8) return __uint_as_float(f8bits_to_f32bits(row[e]));
@@ -167,34 +188,38 @@ __device__ __forceinline__ float pair_sqnorm_f32(const float* __restrict__ v, in
 }
 
 // Distance(query, row) for the pair-owned row; q = f32 query in LDS.  Valid in both lanes of the pair.
-// Loads are software-pipelined U steps deep (U x 16 B per lane in flight while the previous U are consumed).
+// Row loads are software-pipelined in bursts of U steps: the next U raw chunks are requested back to back while the
+// previous U are decoded and consumed (U..2U loads per lane in flight).  The traversal kernels run 4 waves per CU, so
+// bytes in flight per wave are what buys HBM bandwidth (Little's law); U is tuned per element size.
 template <int METRIC, int QUANT, int U = 8>
 __device__ __forceinline__ float pair_distance(const uint8_t* __restrict__ row, const float* __restrict__ q, int dim,
                                                float qnorm, float rnorm, int half) {
+  typedef typename Raw4<QUANT>::type raw_t;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int n8 = dim >> 3;
   const int nb = n8 / U;
-  f32x4 cur[U], nxt[U];
+  raw_t cur[U], nxt[U];
   if (nb > 0) {
 #pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = load4<QUANT>(row, 8 * u + 4 * half);
+    for (int u = 0; u < U; u++) cur[u] = load_raw4<QUANT>(row, 8 * u + 4 * half);
   }
   for (int b = 0; b < nb; b++) {
     if (b + 1 < nb) {
 #pragma unroll
-      for (int u = 0; u < U; u++) nxt[u] = load4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
+      for (int u = 0; u < U; u++) nxt[u] = load_raw4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * (b * U + u) + 4 * half);
-      if constexpr (METRIC == M_COS) { f32x4 p = qq * cur[u]; acc = acc + p; }
-      else { f32x4 d = qq - cur[u]; f32x4 p = d * d; acc = acc + p; }
+      f32x4 r = decode4<QUANT>(cur[u]);
+      if constexpr (METRIC == M_COS) { f32x4 p = qq * r; acc = acc + p; }
+      else { f32x4 d = qq - r; f32x4 p = d * d; acc = acc + p; }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) cur[u] = nxt[u];
   }
   for (int t = nb * U; t < n8; t++) {
-    f32x4 r = load4<QUANT>(row, 8 * t + 4 * half);
+    f32x4 r = decode4<QUANT>(load_raw4<QUANT>(row, 8 * t + 4 * half));
     f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * t + 4 * half);
     if constexpr (METRIC == M_COS) { f32x4 p = qq * r; acc = acc + p; }
     else { f32x4 d = qq - r; f32x4 p = d * d; acc = acc + p; }

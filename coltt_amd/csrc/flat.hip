@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "exact.hpp"
 #include "prep.hpp"
+#include "flat_mfma.hpp"
 
 using namespace coltt;
 using namespace coltt::dev;
@@ -56,24 +57,25 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
     for (int q = 0; q < QB; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
     const int nb = n8 / U;
-    f32x4 cur[U], nxt[U];
+    typename Raw4<QUANT>::type cur[U], nxt[U];  // raw bits stay in the pipeline registers; decoded at use
     if (nb > 0) {
 #pragma unroll
-      for (int u = 0; u < U; u++) cur[u] = load4<QUANT>(row, 8 * u + 4 * half);
+      for (int u = 0; u < U; u++) cur[u] = load_raw4<QUANT>(row, 8 * u + 4 * half);
     }
     for (int b = 0; b < nb; b++) {
       if (b + 1 < nb) {
 #pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = load4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
+        for (int u = 0; u < U; u++) nxt[u] = load_raw4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const float* qp = qs + 8 * (b * U + u) + 4 * half;
+        const f32x4 rc = decode4<QUANT>(cur[u]);
 #pragma unroll
         for (int q = 0; q < QB; q++) {
           f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dim);
-          if constexpr (METRIC == M_COS) { f32x4 pr = qq * cur[u]; acc[q] = acc[q] + pr; }
-          else { f32x4 d = qq - cur[u]; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
+          if constexpr (METRIC == M_COS) { f32x4 pr = qq * rc; acc[q] = acc[q] + pr; }
+          else { f32x4 d = qq - rc; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
         }
       }
 #pragma unroll
@@ -225,9 +227,10 @@ __global__ __launch_bounds__(256) void flat_select_kernel(
   }
 }
 
+// group state: cnt[256] | thr[256] | overflow
 __global__ void init_group_kernel(uint32_t* cnt, uint32_t* thr, uint32_t* overflow, int nearest) {
   int q = threadIdx.x;
-  if (q < QB) { cnt[q] = 0; thr[q] = nearest ? 0xffffffffu : 0u; }
+  if (q < 256) { cnt[q] = 0; thr[q] = nearest ? 0xffffffffu : 0u; }
   if (q == 0) *overflow = 0;
 }
 
@@ -242,7 +245,8 @@ struct Flat : Object {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
   // workspaces
-  DevBuf w_raw, w_slots, w_qraw, w_qeff, w_qn, w_cand, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  DevBuf w_raw, w_slots, w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  uint64_t mfma_groups = 0, mfma_fallbacks = 0;  // statistics: groups served by the MFMA path / sent back to the exact path
   ~Flat() override {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -328,43 +332,122 @@ int prep_queries(Flat* f, const float* d_qraw, size_t nq) {
   return COLTT_OK;
 }
 
+// One group of <= QB prepared queries [q0, q0+g) over positions [0, total) (rows, or entries of the gather list), exact order.
+int search_group_exact(Flat* f, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total,
+                       uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt, uint32_t cap) {
+  uint32_t* cnt = f->w_cnt.as<uint32_t>();
+  uint32_t* thr = cnt + 256;
+  uint32_t* ovf = cnt + 512;
+  unsigned long long* cand = f->w_cand.as<unsigned long long>();
+  const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
+  const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
+  const float* qn = f->w_qn.as<float>() + q0;
+  uint64_t* oi = d_out_ids + q0 * k; float* os = d_out_sc + q0 * k; uint32_t* oc = d_out_cnt + q0;
+  auto scan = [&](uint64_t b, uint64_t e) {
+    if (d_gather) scan_dispatch<true>(f, d_gather, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
+    else scan_dispatch<false>(f, nullptr, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
+    flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc);
+  };
+  init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
+  if (total == 0) { flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc); return COLTT_OK; }
+  // optimistic: first segment (everything passes, <= cap candidates), then the rest behind the threshold
+  uint64_t s0 = std::min<uint64_t>(total, cap);
+  scan(0, s0);
+  if (s0 < total) scan(s0, total);
+  uint32_t h_ovf = 0;
+  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  if (h_ovf) {  // adversarial order: redo with segments that cannot overflow (list holds <= k + segment)
+    init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
+    uint64_t seg = cap - std::min<uint32_t>(k, cap / 2);
+    for (uint64_t b = 0; b < total; b += seg) scan(b, std::min<uint64_t>(total, b + seg));
+  }
+  return COLTT_OK;
+}
+
+template <int BN>
+int launch_mfma_scan(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
+                     unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+  auto kern = flat_mfma_cos_f16_kernel<BN>;
+  const size_t lds = mfma_lds_bytes<BN>();
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
+  kern<<<grid, 256, lds, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+                                      nearest, cand, cnt, cap);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
+int search_group_mfma(Flat* f, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
+                      uint32_t* d_out_cnt, uint32_t cap, bool* used_fallback) {
+  uint32_t* cnt = f->w_cnt.as<uint32_t>();
+  uint32_t* thr = cnt + 256;
+  uint32_t* ovf = cnt + 512;
+  unsigned long long* cur = f->w_cand.as<unsigned long long>();
+  unsigned long long* oth = f->w_cand2.as<unsigned long long>();
+  const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
+  const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
+  const float* qn = f->w_qn.as<float>() + q0;
+  _Float16* q16 = f->w_q16.as<_Float16>();
+  const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
+  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, f->stream>>>(qe, g, BN, (int)f->dim, q16);
+  init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
+  auto scan = [&](uint64_t b, uint64_t e) -> int {
+    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    else COLTT_TRY(launch_mfma_scan<256>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    flat_pick_kernel<<<g, 256, 0, f->stream>>>(cur, oth, cnt, thr, cap, k, nearest, MF_MARGIN, ovf);
+    std::swap(cur, oth);
+    return COLTT_OK;
+  };
+  // first segment unfiltered (it seeds the threshold), the rest runs behind the threshold
+  uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(8192, 128ull * k)});
+  COLTT_TRY(scan(0, s0));
+  if (s0 < total) COLTT_TRY(scan(s0, total));
+  struct { uint32_t cnt[256]; } hc;
+  uint32_t h_ovf = 0;
+  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
+  COLTT_HIP(hipMemcpyAsync(hc.cnt, cnt, 256 * 4, hipMemcpyDeviceToHost, f->stream));
+  COLTT_HIP(hipStreamSynchronize(f->stream));
+  if (h_ovf) { *used_fallback = true; return COLTT_OK; }  // candidate list overflowed: caller re-runs the group in exact mode
+  uint32_t maxc = 0;
+  for (int i = 0; i < g; i++) maxc = std::max(maxc, hc.cnt[i]);
+  if (maxc) {
+    dim3 grid(ceil_div(maxc, 32), g);
+    if (f->quant == COLTT_Q_NONE) flat_rescore_kernel<Q_NONE><<<grid, 64, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
+    else flat_rescore_kernel<Q_F16><<<grid, 64, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
+  }
+  flat_select_kernel<<<g, 256, 0, f->stream>>>(cur, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, d_out_ids + q0 * k, d_out_sc + q0 * k, d_out_cnt + q0);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
 // Search nq prepared queries over positions [0, total) (rows, or entries of the gather list).
-// Results land in w_out_* ([nq][k]).
-int search_prepared(Flat* f, size_t nq, uint32_t k, int select, const uint32_t* d_gather, uint64_t total,
+int search_prepared(Flat* f, size_t nq, uint32_t k, int select, int mode, const uint32_t* d_gather, uint64_t total,
                     uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt) {
   const int nearest = select == COLTT_SELECT_NEAREST;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
-  COLTT_TRY(f->w_cand.reserve((size_t)QB * cap * 8));
-  COLTT_TRY(f->w_cnt.reserve(256));
-  uint32_t* cnt = f->w_cnt.as<uint32_t>();
-  uint32_t* thr = cnt + QB;
-  uint32_t* ovf = cnt + 2 * QB;
-  unsigned long long* cand = f->w_cand.as<unsigned long long>();
-  const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
+  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && f->metric == COLTT_COSINE &&
+                    (f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
+  const size_t gq = mfma ? 256 : QB;
+  COLTT_TRY(f->w_cand.reserve((size_t)gq * cap * 8));
+  if (mfma) { COLTT_TRY(f->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(f->w_q16.reserve((size_t)256 * f->dim * 2)); }
+  COLTT_TRY(f->w_cnt.reserve(4096));
   COLTT_HIP(hipEventRecord(f->ev0, f->stream));
-  for (size_t q0 = 0; q0 < nq; q0 += QB) {
-    int g = (int)std::min<size_t>(QB, nq - q0);
-    const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
-    const float* qn = f->w_qn.as<float>() + q0;
-    uint64_t* oi = d_out_ids + q0 * k; float* os = d_out_sc + q0 * k; uint32_t* oc = d_out_cnt + q0;
-    auto scan = [&](uint64_t b, uint64_t e) {
-      if (d_gather) scan_dispatch<true>(f, d_gather, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
-      else scan_dispatch<false>(f, nullptr, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
-      flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc);
-    };
-    init_group_kernel<<<1, 64, 0, f->stream>>>(cnt, thr, ovf, nearest);
-    if (total == 0) { flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc); continue; }
-    // optimistic: first segment (everything passes, <= cap candidates), then the rest behind the threshold
-    uint64_t s0 = std::min<uint64_t>(total, cap);
-    scan(0, s0);
-    if (s0 < total) scan(s0, total);
-    uint32_t h_ovf = 0;
-    COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
-    COLTT_HIP(hipStreamSynchronize(f->stream));
-    if (h_ovf) {  // adversarial order: redo with segments that cannot overflow (list holds <= k + segment)
-      init_group_kernel<<<1, 64, 0, f->stream>>>(cnt, thr, ovf, nearest);
-      uint64_t seg = cap - std::min<uint32_t>(k, cap / 2);
-      for (uint64_t b = 0; b < total; b += seg) scan(b, std::min<uint64_t>(total, b + seg));
+  for (size_t q0 = 0; q0 < nq; q0 += gq) {
+    int g = (int)std::min<size_t>(gq, nq - q0);
+    if (mfma) {
+      bool fb = false;
+      COLTT_TRY(search_group_mfma(f, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, &fb));
+      f->mfma_groups++;
+      if (!fb) continue;
+      f->mfma_fallbacks++;
+      for (size_t s = 0; s < (size_t)g; s += QB)
+        COLTT_TRY(search_group_exact(f, q0 + s, (int)std::min<size_t>(QB, g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+    } else {
+      COLTT_TRY(search_group_exact(f, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     }
   }
   COLTT_HIP(hipEventRecord(f->ev1, f->stream));
@@ -377,7 +460,7 @@ int flat_search_common(Flat* f, const float* queries, bool q_on_device, size_t n
                        uint32_t* out_counts, bool out_on_device) {
   if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "flat search: k=%u outside [1,%u]", k, K_MAX);
   if (select != COLTT_SELECT_REFERENCE && select != COLTT_SELECT_NEAREST) return fail(COLTT_E_INVALID, "flat search: bad select %d", select);
-  if (mode != COLTT_MODE_EXACT) return fail(COLTT_E_UNSUPPORTED, "flat search: MFMA mode is not built in this round; use COLTT_MODE_EXACT");
+  if (mode != COLTT_MODE_EXACT && mode != COLTT_MODE_MFMA) return fail(COLTT_E_INVALID, "flat search: bad mode %d", mode);
   if (nq == 0) return COLTT_OK;
   const float* d_q = queries;
   if (!q_on_device) {
@@ -393,7 +476,7 @@ int flat_search_common(Flat* f, const float* queries, bool q_on_device, size_t n
     COLTT_TRY(f->w_out_cnt.reserve(nq * 4));
     d_oi = f->w_out_ids.as<uint64_t>(); d_os = f->w_out_sc.as<float>(); d_oc = f->w_out_cnt.as<uint32_t>();
   }
-  COLTT_TRY(search_prepared(f, nq, k, select, d_gather, total, d_oi, d_os, d_oc));
+  COLTT_TRY(search_prepared(f, nq, k, select, mode, d_gather, total, d_oi, d_os, d_oc));
   if (!out_on_device) {
     COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, f->stream));
     COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, f->stream));

@@ -92,11 +92,19 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
   for (uint32_t i = lane; i < w.hcap; i += 64) w.vis[i] = VIS_EMPTY;
 }
 
+#ifndef COLTT_U_F32
+#define COLTT_U_F32 16
+#endif
+#ifndef COLTT_U_Q
+#define COLTT_U_Q 24
+#endif
 template <int METRIC, int QUANT>
 __device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
   float rn = 0.f;
   if constexpr (METRIC == M_COS) rn = g.norms[slot];
-  return pair_distance<METRIC, QUANT, 8>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  // burst depth, tuned on MI355X at 2M x 768 (f32: U=8 5.5, 12 6.06, 16 6.15 TB/s; f16: U=16 3.9, 24 4.8, 32 4.6 TB/s)
+  constexpr int U = QUANT == Q_NONE ? COLTT_U_F32 : COLTT_U_Q;
+  return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
 // greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.

@@ -805,8 +805,8 @@ static int hnsw_insert_batch(Hnsw* h, const uint64_t* ids, const float* vecs, co
 // 10M-vertex index exported from HBM can be timed on the host without re-materialising per-vertex objects.
 // ------------------------------------------------------------------------------------------------
 struct CsrGraph {
-  const float* rows; const uint32_t* adj0; const uint32_t* upper_off; const uint32_t* adjU; const uint32_t* del_bits;
-  uint32_t w0, wu, dim; int metric, order; int32_t entry, entry_level;
+  const uint8_t* rows; const uint32_t* adj0; const uint32_t* upper_off; const uint32_t* adjU; const uint32_t* del_bits;
+  uint32_t w0, wu, dim; int metric, order; int32_t entry, entry_level; int quant;
 };
 static inline bool csr_deleted(const CsrGraph& g, uint32_t s) { return g.del_bits && ((g.del_bits[s >> 5] >> (s & 31)) & 1u); }
 static inline const uint32_t* csr_row(const CsrGraph& g, uint32_t s, int level, uint32_t& w) {
@@ -814,11 +814,22 @@ static inline const uint32_t* csr_row(const CsrGraph& g, uint32_t s, int level, 
   w = g.wu; return g.adjU + ((size_t)g.upper_off[s] + (uint32_t)(level - 1)) * g.wu;
 }
 static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int32_t* out_slots, float* out_scores, uint64_t* st) {
-  std::vector<float> qn; const float* q = query;
-  if (g.metric == METRIC_COS) { qn.resize(g.dim); normalize(query, qn.data(), g.dim); q = qn.data(); }
+  std::vector<float> qn(g.dim), rowbuf(g.dim); const float* q = query;
+  if (g.metric == METRIC_COS) { normalize(query, qn.data(), g.dim); q = qn.data(); }
+  std::vector<uint8_t> qlow;
+  if (g.quant != Q_NONE) {  // the query is lowered too, then both operands are decoded per pair (f16_vectorstore.go:136, f16_quantization.go:35-45)
+    qlow.resize((size_t)g.dim * quant_bytes(g.quant)); lower(g.quant, q, g.dim, qlow.data());
+    raise(g.quant, qlow.data(), g.dim, qn.data()); q = qn.data();
+  }
   if (g.entry < 0) return 0;
   uint64_t n_dist = 0, n_exp = 0, n_hops = 0;
-  auto D = [&](uint32_t s) { n_dist++; return dist(g.metric, g.order, q, g.rows + (size_t)s * g.dim, g.dim); };
+  const size_t rb = (size_t)g.dim * quant_bytes(g.quant);
+  auto D = [&](uint32_t s) {
+    n_dist++;
+    if (g.quant == Q_NONE) return dist(g.metric, g.order, q, (const float*)(g.rows + (size_t)s * rb), g.dim);
+    raise(g.quant, g.rows + (size_t)s * rb, g.dim, rowbuf.data());
+    return dist(g.metric, g.order, q, rowbuf.data(), g.dim);
+  };
   uint32_t ep = (uint32_t)g.entry; float minD = D(ep);
   for (int l = g.entry_level; l > 0; l--) {
     for (;;) {
@@ -1051,11 +1062,11 @@ int orc_hnsw_import(void* h, int64_t n, const uint64_t* ids, const int32_t* leve
 }
 
 // nq queries, one after another on the calling thread (call from several threads for the all-cores figure).
-int orc_csr_search(const float* rows, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* adjU,
+int orc_csr_search(const void* rows, int quant, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* adjU,
                    const uint32_t* del_bits, uint32_t w0, uint32_t wu, uint32_t dim, int metric, int order, int32_t entry,
                    int32_t entry_level, const float* queries, size_t nq, int k, int ef, int32_t* out_slots, float* out_scores,
                    int32_t* out_counts, uint64_t* stats3) {
-  CsrGraph g{rows, adj0, upper_off, adjU, del_bits, w0, wu, dim, metric, order, entry, entry_level};
+  CsrGraph g{(const uint8_t*)rows, adj0, upper_off, adjU, del_bits, w0, wu, dim, metric, order, entry, entry_level, quant};
   for (size_t i = 0; i < nq; i++)
     out_counts[i] = csr_search(g, queries + i * dim, k, ef, out_slots + i * k, out_scores + i * k, stats3);
   return 0;

@@ -105,3 +105,40 @@ def test_flat_adversarial_order_overflow_path(gpu):
     gi, gs, gc = gf.VertexSearch(q, 10, gpu.SELECT_REFERENCE)
     wi, ws = of.search(q[0], 10, nearest=False, mode=2)
     assert_same_results(gi[0], gs[0], wi, ws)
+
+
+@pytest.mark.parametrize("quant", [O.Q_F16, O.Q_BF16])
+def test_flat_mfma_mode_equals_exact_mode(gpu, quant):
+    """COLTT_MODE_MFMA: matrix-core candidate generation + exact re-score returns the SAME ids, ranks and score bits as
+    the exact-order scan (and hence as the oracle), for every batch size / k / direction."""
+    n, d = 6000, 128
+    X, ids, of, gf = build_pair(gpu, n, d, O.COSINE, quant, seed=17)
+    for nq in (3, 70, 200, 300):
+        Q = O.fill_normal(1000 + nq, (nq, d))
+        for k in (1, 10, 100):
+            for select in (gpu.SELECT_REFERENCE, gpu.SELECT_NEAREST):
+                ei, es, ec = gf.VertexSearch(Q, k, select, gpu.MODE_EXACT)
+                mi, ms, mc = gf.VertexSearch(Q, k, select, gpu.MODE_MFMA)
+                assert np.array_equal(ec, mc) and np.array_equal(ei, mi), (nq, k, select)
+                assert np.array_equal(bits(es), bits(ms)), (nq, k, select)
+        wi, ws = of.search(Q[0], 10, nearest=True, mode=2)
+        mi, ms, mc = gf.VertexSearch(Q[:1], 10, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
+        assert_same_results(mi[0], ms[0], wi, ws, "mfma vs oracle")
+
+
+def test_flat_mfma_768_duplicates_and_fallbacks(gpu):
+    n, d = 9000, 768
+    X = O.fill_normal(23, (n, d)); X[500:540] = X[3]       # exact duplicates: boundary ties go through the margin logic
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(7)
+    gf = gpu.FlatSpace(d, O.COSINE, O.Q_F16); gf.ChangedVertex(ids, X)
+    Q = np.concatenate([X[3:4], O.fill_normal(24, (99, d))])
+    for k, select in ((10, 1), (25, 1), (60, 0)):
+        ei, es, ec = gf.VertexSearch(Q, k, select, gpu.MODE_EXACT)
+        mi, ms, mc = gf.VertexSearch(Q, k, select, gpu.MODE_MFMA)
+        assert np.array_equal(ei, mi) and np.array_equal(bits(es), bits(ms)), (k, select)
+    # combinations the MFMA kernel does not cover (f32 rows, L2, dim % 64 != 0) are served by the exact path: same answer
+    for metric, quant, dd in ((O.L2, O.Q_F16, 128), (O.COSINE, O.Q_NONE, 128), (O.COSINE, O.Q_F16, 72)):
+        Y = O.fill_normal(5, (700, dd)); g2 = gpu.FlatSpace(dd, metric, quant); g2.ChangedVertex(np.arange(700, dtype=np.uint64), Y)
+        q = O.fill_normal(6, (5, dd))
+        a = g2.VertexSearch(q, 7, 1, gpu.MODE_EXACT); b = g2.VertexSearch(q, 7, 1, gpu.MODE_MFMA)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))

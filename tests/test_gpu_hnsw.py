@@ -169,3 +169,25 @@ def test_hnsw_remove_parity(gpu):
     for i in range(50): assert oh.insert(nid[i], Y[i], ly[i]) == 0
     gh.InsertBatchDevice(yd.data_ptr(), 50, ly, batch=1, ids=nid)
     _graph_equal(gh.Export(), oh.export(with_vectors=False))
+
+
+def test_concurrent_callers_thread_safety(gpu):
+    """cgo calls arrive on arbitrary OS threads: hammer one HNSW handle and one FLAT handle from 8 threads at once and
+    require every answer to equal the single-threaded answer."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, d = 1500, 48
+    X, ids, oh = oracle_index(n, d, O.L2, seed=91)
+    gh = gpu.Hnsw(d, O.L2); gh.BulkLoad(oh.export(with_vectors=False), X)
+    gf = gpu.FlatSpace(d, O.L2); gf.ChangedVertex(ids, X)
+    Q = O.fill_normal(92, (64, d))
+    want_h = gh.Search(Q, 10, ef=40); want_f = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+
+    def work(t):
+        for it in range(6):
+            lo = (t * 8) % 64
+            a = gh.Search(Q[lo:lo + 8], 10, ef=40); b = gf.VertexSearch(Q[lo:lo + 8], 10, gpu.SELECT_NEAREST)
+            assert np.array_equal(a[0], want_h[0][lo:lo + 8]) and np.array_equal(a[1].view(np.uint32), want_h[1][lo:lo + 8].view(np.uint32))
+            assert np.array_equal(b[0], want_f[0][lo:lo + 8]) and np.array_equal(b[1].view(np.uint32), want_f[1][lo:lo + 8].view(np.uint32))
+        return True
+    with ThreadPoolExecutor(8) as ex:
+        assert all(ex.map(work, range(8)))
