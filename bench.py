@@ -62,9 +62,13 @@ def parse():
 def make_rows(torch, dev, c, dim, gen, args, basis):
     """one chunk of synthetic vectors in HBM"""
     if basis is None:
-        return torch.randn((c, dim), device=dev, dtype=torch.float32, generator=gen)
-    z = torch.randn((c, basis.shape[0]), device=dev, dtype=torch.float32, generator=gen)
-    return (z @ basis).contiguous()
+        x = torch.randn((c, dim), device=dev, dtype=torch.float32, generator=gen)
+    else:
+        z = torch.randn((c, basis.shape[0]), device=dev, dtype=torch.float32, generator=gen)
+        x = (z @ basis).contiguous()
+    # the library reads this buffer on ITS OWN stream: the producer (torch's stream) must be finished first
+    torch.cuda.synchronize()
+    return x
 
 
 def make_basis(torch, dev, dim, args):

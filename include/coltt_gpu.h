@@ -12,7 +12,9 @@
  *     Nothing aborts or throws across the boundary.
  *   - all entry points are thread-safe (cgo calls arrive on arbitrary OS threads).
  *   - "*_device" variants take pointers that already live in this GPU's HBM (hipMalloc'd or a
- *     torch.Tensor.data_ptr()); they exist so resident data never crosses PCIe.
+ *     torch.Tensor.data_ptr()); they exist so resident data never crosses PCIe.  The library works on its own
+ *     HIP stream: a device buffer handed in must be complete (its producer stream synchronised) before the call,
+ *     and results are complete when the call returns.
  */
 #ifndef COLTT_GPU_H
 #define COLTT_GPU_H

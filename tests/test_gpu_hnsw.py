@@ -102,7 +102,7 @@ def test_hnsw_gpu_build_sequential_equals_reference_insert(gpu, metric):
     X = O.fill_normal(61, (n, d)); lv = O.levels(62, n); ids = np.arange(n, dtype=np.uint64) + np.uint64(500)
     oh = O.Hnsw(d, metric); oh.insert_many(ids, X, lv)          # literal restatement (Go heaps)
     gh = gpu.Hnsw(d, metric)
-    xd = torch.from_numpy(X).cuda()
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
     gh.InsertBatchDevice(xd.data_ptr(), n, lv, batch=1, ids=ids)
     go = gh.Export(); oo = oh.export(with_vectors=False)
     assert np.array_equal(go["ids"], oo["ids"])
@@ -124,7 +124,7 @@ def test_hnsw_gpu_build_batched(gpu):
     sched = lambda i: max(1, min(256, i // 16))
     oh = O.Hnsw(d, O.L2, O.default_cfg(efConstruction=64)); oh.insert_batched(ids, X, lv, 0, schedule=sched)
     gh = gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(ef_construction=64))
-    xd = torch.from_numpy(X).cuda()
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
     i = 0
     while i < n:
         b = min(sched(i), n - i)
@@ -164,7 +164,7 @@ def test_hnsw_remove_parity(gpu):
         assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
     # inserts after removals keep matching
     Y = O.fill_normal(84, (50, d)); ly = O.levels(85, 50)
-    yd = torch.from_numpy(Y).cuda()
+    yd = torch.from_numpy(Y).cuda(); torch.cuda.synchronize()
     nid = np.arange(50, dtype=np.uint64) + np.uint64(10000)
     for i in range(50): assert oh.insert(nid[i], Y[i], ly[i]) == 0
     gh.InsertBatchDevice(yd.data_ptr(), 50, ly, batch=1, ids=nid)
