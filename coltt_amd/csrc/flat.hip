@@ -372,8 +372,8 @@ int launch_mfma_scan(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const
   const size_t lds = mfma_lds_bytes<BN>();
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-  kern<<<grid, 256, lds, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 512);
+  kern<<<grid, MF_NT, lds, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
                                       nearest, cand, cnt, cap);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;

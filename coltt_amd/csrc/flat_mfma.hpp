@@ -24,10 +24,15 @@ namespace dev {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MF_BM = 128;        // rows per workgroup tile
-constexpr int MF_BK = 64;         // halves per K step (128 B of every row per step)
-constexpr int MF_LD = MF_BK + 8;  // padded LDS row (144 B): conflict-free ds_read_b128 fragment reads
+#ifndef COLTT_MF_BK
+#define COLTT_MF_BK 32
+#endif
+constexpr int MF_BK = COLTT_MF_BK; // halves per K step; 32 (64 B of every row per step) keeps stages small => 2 workgroups per CU
+constexpr int MF_CPR = MF_BK / 8; // 16-byte chunks per row per K step
+constexpr int MF_LD = MF_BK + 8;  // padded LDS row (80 B = 5 slots, odd => conflict-free ds_read_b128 fragment reads)
 constexpr float MF_MARGIN = 6e-4f;
 
 template <int BN> constexpr size_t mfma_lds_bytes() { return (size_t)2 * (MF_BM + BN) * MF_LD * 2 + MF_BM * 4; }
@@ -40,107 +45,125 @@ __global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq
   q16[i] = q < nq ? (_Float16)q_eff[i] : (_Float16)0.f;
 }
 
+// 256 threads = 4 waves per workgroup, wave grid 2 x 2 over the 128 x BN tile; stages are small enough (61 KB of LDS at
+// BN = 256) for TWO workgroups per CU, so one group's global-load / barrier stalls are covered by the other's MFMAs.
+// Registers must stay <= 256 per lane and must not spill (a scratch reload is a VMEM op: it drains the in-order vmcnt queue).
+constexpr int MF_NT = 256;
 template <int BN>
-__global__ __launch_bounds__(256) void flat_mfma_cos_f16_kernel(
+__global__ __launch_bounds__(MF_NT, (MF_BK <= 32 ? 2 : 1)) void flat_mfma_cos_f16_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, uint64_t begin, uint64_t end,
     const _Float16* __restrict__ q16, const float* __restrict__ qnorms, int nq, int dim, const uint32_t* __restrict__ thr,
     int nearest, unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
-  constexpr int TN = BN / 64;  // 32-wide query tiles per wave (wave grid 2 x 2)
+  constexpr int WN = 2, WM = 2;
+  constexpr int TM = MF_BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NA = MF_BM * MF_CPR / MF_NT, NB = BN * MF_CPR / MF_NT;  // 16-byte chunks per thread per K step
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   _Float16* As = reinterpret_cast<_Float16*>(smem);                    // [2][MF_BM][MF_LD]
   _Float16* Bs = As + 2 * MF_BM * MF_LD;                               // [2][BN][MF_LD]
   float* tnorm = reinterpret_cast<float*>(Bs + 2 * BN * MF_LD);        // [MF_BM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
   const int nk = dim / MF_BK;
-  // per-lane query constants for its TN columns
-  float qn[TN]; uint32_t th[TN]; int qidx[TN];
+  // per-lane query constants for its TN columns: 1/||q||, the threshold as a float (+-inf = everything passes)
+  float iq[TN], tf[TN]; int qidx[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; tn++) {
-    qidx[tn] = wn * (BN / 2) + tn * 32 + (lane & 31);
-    qn[tn] = qidx[tn] < nq ? qnorms[qidx[tn]] : 1.f;
-    th[tn] = qidx[tn] < nq ? thr[qidx[tn]] : 0u;
+    qidx[tn] = wn * (BN / WN) + tn * 32 + (lane & 31);
+    const bool live = qidx[tn] < nq;
+    iq[tn] = live ? rsqrtf(qnorms[qidx[tn]]) : 0.f;
+    const uint32_t t = live ? thr[qidx[tn]] : (nearest ? 0u : 0xffffffffu);
+    if (nearest) tf[tn] = !live ? -1.f : (t == 0xffffffffu ? __builtin_inff() : key_score(t));
+    else tf[tn] = !live ? __builtin_inff() : (t == 0u ? -__builtin_inff() : key_score(t));
   }
   const uint64_t ntiles = (end - begin + MF_BM - 1) / MF_BM;
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t row0 = begin + tile * MF_BM;
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++)
+    for (int tm = 0; tm < TM; tm++)
 #pragma unroll
       for (int tn = 0; tn < TN; tn++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[tm][tn][r] = 0.f;
     __syncthreads();  // previous tile's epilogue is done with tnorm / LDS
-    if (tid < MF_BM) { uint64_t r = row0 + tid; tnorm[tid] = norms[r < end ? r : end - 1]; }
-    // ---- global -> registers -> LDS staging of one K step
-    uint4 ra[4], rb[BN / 32];
-    auto gload = [&](int ks) {
-      const int k0 = ks * MF_BK;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        int c = tid + 256 * i, r = c >> 3, c16 = c & 7;
-        uint64_t gr = row0 + r; if (gr >= end) gr = end - 1;
-        ra[i] = *reinterpret_cast<const uint4*>(rows + gr * stride + (size_t)(k0 + c16 * 8) * 2);
-      }
-#pragma unroll
-      for (int i = 0; i < BN / 32; i++) {
-        int c = tid + 256 * i, q = c >> 3, c16 = c & 7;
-        rb[i] = *reinterpret_cast<const uint4*>(q16 + (size_t)q * dim + k0 + c16 * 8);
-      }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        int c = tid + 256 * i, r = c >> 3, c16 = c & 7;
-        *reinterpret_cast<uint4*>(As + ((size_t)buf * MF_BM + r) * MF_LD + c16 * 8) = ra[i];
-      }
-#pragma unroll
-      for (int i = 0; i < BN / 32; i++) {
-        int c = tid + 256 * i, q = c >> 3, c16 = c & 7;
-        *reinterpret_cast<uint4*>(Bs + ((size_t)buf * BN + q) * MF_LD + c16 * 8) = rb[i];
-      }
-    };
-    gload(0);
-    lstore(0);
+    if (tid < MF_BM) { uint64_t r = row0 + tid; tnorm[tid] = rsqrtf(norms[r < end ? r : end - 1]); }  // 1/||row||; NaN rows never pass... see below
+    // ---- global -> registers -> LDS staging.  Rows (HBM, ~2 us under load) are requested TWO K steps ahead, queries
+    // (L2-resident) one step ahead: with one workgroup per CU, bytes in flight per CU are what buys HBM bandwidth.
+    // (ext_vector types and macros on purpose: HIP's uint4 struct / lambda captures put these arrays in scratch.)
+    u32x4 ra[NA], rb[NB];
+#define MF_GLOAD(KS)                                                                                         \
+    {                                                                                                        \
+      const int k0_ = (KS) * MF_BK;                                                                          \
+      _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                       \
+        int c = tid + MF_NT * i, r = c / MF_CPR, c16 = c % MF_CPR;                                           \
+        uint64_t gr = row0 + r; if (gr >= end) gr = end - 1;                                                 \
+        ra[i] = *reinterpret_cast<const u32x4*>(rows + gr * stride + (size_t)(k0_ + c16 * 8) * 2);           \
+      }                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                       \
+        int c = tid + MF_NT * i, q = c / MF_CPR, c16 = c % MF_CPR;                                           \
+        rb[i] = *reinterpret_cast<const u32x4*>(q16 + (size_t)q * dim + k0_ + c16 * 8);                      \
+      }                                                                                                      \
+    }
+#define MF_LSTORE(BUF)                                                                                       \
+    {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                       \
+        int c = tid + MF_NT * i, r = c / MF_CPR, c16 = c % MF_CPR;                                           \
+        *reinterpret_cast<u32x4*>(As + ((size_t)(BUF) * MF_BM + r) * MF_LD + c16 * 8) = ra[i];               \
+      }                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                       \
+        int c = tid + MF_NT * i, q = c / MF_CPR, c16 = c % MF_CPR;                                           \
+        *reinterpret_cast<u32x4*>(Bs + ((size_t)(BUF) * BN + q) * MF_LD + c16 * 8) = rb[i];                  \
+      }                                                                                                      \
+    }
+    MF_GLOAD(0);
+    MF_LSTORE(0);
     __syncthreads();
     for (int ks = 0; ks < nk; ks++) {
       const int buf = ks & 1;
-      if (ks + 1 < nk) gload(ks + 1);
+      if (ks + 1 < nk) MF_GLOAD(ks + 1);
       const _Float16* Ab = As + (size_t)buf * MF_BM * MF_LD;
       const _Float16* Bb = Bs + (size_t)buf * BN * MF_LD;
 #pragma unroll
       for (int kk = 0; kk < MF_BK / 16; kk++) {
         const int kofs = kk * 16 + (lane >> 5) * 8;
-        half8 a[2], b[TN];
+        half8 a[TM], b[TN];
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) a[tm] = *reinterpret_cast<const half8*>(Ab + (size_t)(wm * 64 + tm * 32 + (lane & 31)) * MF_LD + kofs);
+        for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const half8*>(Ab + (size_t)(wm * (MF_BM / WM) + tm * 32 + (lane & 31)) * MF_LD + kofs);
 #pragma unroll
-        for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const half8*>(Bb + (size_t)(wn * (BN / 2) + tn * 32 + (lane & 31)) * MF_LD + kofs);
+        for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const half8*>(Bb + (size_t)(wn * (BN / WN) + tn * 32 + (lane & 31)) * MF_LD + kofs);
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++)
+        for (int tm = 0; tm < TM; tm++)
 #pragma unroll
           for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
       }
-      if (ks + 1 < nk) lstore(buf ^ 1);
+      if (ks + 1 < nk) MF_LSTORE(buf ^ 1);
       __syncthreads();
     }
-    // ---- epilogue: approximate cosine distance, threshold filter, candidate emission
+#undef MF_GLOAD
+#undef MF_LSTORE
+    // ---- epilogue: s~ = |1 - dot * (1/||q||) * (1/||r||)|, threshold filter in the float domain (4 VALU per element),
+    // survivors (rare behind the threshold) appended to the candidate list.  `!(s > t)` also passes NaN scores, which the
+    // exact path orders last, so nothing is lost for zero-norm rows.
 #pragma unroll
-    for (int tm = 0; tm < 2; tm++)
+    for (int tm = 0; tm < TM; tm++) {
+      f32x4 ir[4];  // 1/||row|| of this lane's 16 rows: 4 runs of 4 consecutive rows
+#pragma unroll
+      for (int g = 0; g < 4; g++) ir[g] = *reinterpret_cast<const f32x4*>(tnorm + wm * (MF_BM / WM) + tm * 32 + 8 * g + 4 * (lane >> 5));
 #pragma unroll
       for (int tn = 0; tn < TN; tn++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int rl = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const uint64_t gr = row0 + rl;
-          float s = fabsf(1.0f - acc[tm][tn][r] * rsqrtf(qn[tn] * tnorm[rl]));
-          uint32_t sk = score_key(s);
-          bool pass = gr < end && qidx[tn] < nq && (nearest ? sk <= th[tn] : sk >= th[tn]);
+          float s = fabsf(1.0f - acc[tm][tn][r] * iq[tn] * ir[r >> 2][r & 3]);
+          const bool pass = nearest ? !(s > tf[tn]) : !(s < tf[tn]);
           if (pass) {
-            uint32_t idx = atomicAdd(&cnt[qidx[tn]], 1u);
-            if (idx < cap) cand[(size_t)qidx[tn] * cap + idx] = ((unsigned long long)sk << 32) | (uint32_t)gr;
+            const int rl = wm * (MF_BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const uint64_t gr = row0 + rl;
+            if (gr < end && qidx[tn] < nq) {
+              uint32_t idx = atomicAdd(&cnt[qidx[tn]], 1u);
+              if (idx < cap) cand[(size_t)qidx[tn] * cap + idx] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
+            }
           }
         }
+    }
   }
 }
 
