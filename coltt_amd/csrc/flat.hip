@@ -22,7 +22,7 @@ using namespace coltt::dev;
 
 namespace {
 
-constexpr int QB = 8;             // queries per row read in the exact scan
+constexpr int QB = 16;            // queries per row read in the exact scan (dim <= 1024; 4 above that: LDS query tile)
 constexpr uint32_t K_MAX = 2048;  // largest top-k served by flat_select's LDS rank sort
 
 // ---------------------------------------------------------------------------------------------------
@@ -31,7 +31,7 @@ constexpr uint32_t K_MAX = 2048;  // largest top-k served by flat_select's LDS r
 // all QB queries (queries broadcast from LDS).  Survivors of the per-query threshold are appended to a
 // candidate list as (score_key << 32 | slot).
 // ---------------------------------------------------------------------------------------------------
-template <int METRIC, int QUANT, bool GATHER>
+template <int METRIC, int QUANT, bool GATHER, int QB>
 __global__ __launch_bounds__(256) void flat_scan_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms,
     const uint32_t* __restrict__ gather, uint64_t begin, uint64_t end, const float* __restrict__ q_eff,
@@ -293,15 +293,25 @@ int prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_slots, 
   }
 }
 
+inline int scan_qb(const Flat* f) { return f->dim <= 1024 ? QB : 4; }
+
+template <int METRIC, int QUANT, bool GATHER, int QBT>
+void launch_scan_q(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+                   int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+  uint64_t groups = (end - begin + 31) / 32;
+  uint32_t grid = (uint32_t)std::min<uint64_t>((groups + 3) / 4, 256 * 8);
+  size_t lds = (size_t)QBT * f->dim * 4;
+  auto kern = flat_scan_kernel<METRIC, QUANT, GATHER, QBT>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<grid, 256, lds, f->stream>>>(
+      f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), gather, begin, end, q_eff, qn, nq_grp, (int)f->dim, thr,
+      nearest, cand, cnt, cap);
+}
 template <int METRIC, int QUANT, bool GATHER>
 void launch_scan(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
                  int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-  uint64_t groups = (end - begin + 31) / 32;
-  uint32_t grid = (uint32_t)std::min<uint64_t>((groups + 3) / 4, 256 * 8);
-  size_t lds = (size_t)QB * f->dim * 4;
-  flat_scan_kernel<METRIC, QUANT, GATHER><<<grid, 256, lds, f->stream>>>(
-      f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), gather, begin, end, q_eff, qn, nq_grp, (int)f->dim, thr,
-      nearest, cand, cnt, cap);
+  if (scan_qb(f) == QB) launch_scan_q<METRIC, QUANT, GATHER, QB>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
+  else launch_scan_q<METRIC, QUANT, GATHER, 4>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
 }
 template <bool GATHER>
 void scan_dispatch(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
@@ -365,18 +375,25 @@ int search_group_exact(Flat* f, size_t q0, int g, uint32_t k, int nearest, const
   return COLTT_OK;
 }
 
-template <int BN>
-int launch_mfma_scan(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                     unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-  auto kern = flat_mfma_cos_f16_kernel<BN>;
+template <int BN, bool AF32>
+int launch_mfma_scan_t(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
+                       unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+  auto kern = flat_mfma_cos_kernel<BN, AF32>;
   const size_t lds = mfma_lds_bytes<BN>();
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 512);
+  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
   kern<<<grid, MF_NT, lds, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
                                       nearest, cand, cnt, cap);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
+}
+
+template <int BN>
+int launch_mfma_scan(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
+                     unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
+  return launch_mfma_scan_t<BN, false>(f, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
 }
 
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
@@ -398,7 +415,7 @@ int search_group_mfma(Flat* f, size_t q0, int g, uint32_t k, int nearest, uint64
     if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
     else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
     else COLTT_TRY(launch_mfma_scan<256>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    flat_pick_kernel<<<g, 256, 0, f->stream>>>(cur, oth, cnt, thr, cap, k, nearest, MF_MARGIN, ovf);
+    flat_pick_kernel<<<g, 256, 0, f->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     std::swap(cur, oth);
     return COLTT_OK;
   };
@@ -430,9 +447,9 @@ int search_prepared(Flat* f, size_t nq, uint32_t k, int select, int mode, const 
   const int nearest = select == COLTT_SELECT_NEAREST;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
   const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && f->metric == COLTT_COSINE &&
-                    (f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
-  const size_t gq = mfma ? 256 : QB;
-  COLTT_TRY(f->w_cand.reserve((size_t)gq * cap * 8));
+                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
+  const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
+  COLTT_TRY(f->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
   if (mfma) { COLTT_TRY(f->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(f->w_q16.reserve((size_t)256 * f->dim * 2)); }
   COLTT_TRY(f->w_cnt.reserve(4096));
   COLTT_HIP(hipEventRecord(f->ev0, f->stream));
@@ -444,8 +461,8 @@ int search_prepared(Flat* f, size_t nq, uint32_t k, int select, int mode, const 
       f->mfma_groups++;
       if (!fb) continue;
       f->mfma_fallbacks++;
-      for (size_t s = 0; s < (size_t)g; s += QB)
-        COLTT_TRY(search_group_exact(f, q0 + s, (int)std::min<size_t>(QB, g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+      for (size_t s = 0; s < (size_t)g; s += scan_qb(f))
+        COLTT_TRY(search_group_exact(f, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     } else {
       COLTT_TRY(search_group_exact(f, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     }
@@ -500,7 +517,6 @@ int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out) 
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
-  if ((size_t)QB * dim * 4 > 64 * 1024) return fail(COLTT_E_UNSUPPORTED, "flat_create: dim %u too large for the LDS query tile", dim);
   COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
   COLTT_HIP(hipEventCreate(&f->ev0));
   COLTT_HIP(hipEventCreate(&f->ev1));

@@ -26,7 +26,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_BM = 128;        // rows per workgroup tile
+#ifndef COLTT_MF_BM
+#define COLTT_MF_BM 128
+#endif
+constexpr int MF_BM = COLTT_MF_BM; // rows per workgroup tile
 #ifndef COLTT_MF_BK
 #define COLTT_MF_BK 32
 #endif
@@ -34,10 +37,13 @@ constexpr int MF_BK = COLTT_MF_BK; // halves per K step; 32 (64 B of every row p
 constexpr int MF_CPR = MF_BK / 8; // 16-byte chunks per row per K step
 constexpr int MF_LD = MF_BK + 8;  // padded LDS row (80 B = 5 slots, odd => conflict-free ds_read_b128 fragment reads)
 constexpr float MF_MARGIN = 6e-4f;
+// f32 rows rounded to binary16 for candidate generation: |x~ - x| <= 2^-11 |x| per element of row AND query =>
+// |d dot| <= (2^-10 + 2^-22) sum|a_i b_i| <= 9.8e-4 for unit vectors, + accumulation 2.5e-4, + epilogue => d = 1.3e-3.
+constexpr float MF_MARGIN_F32 = 2.6e-3f;
 
 template <int BN> constexpr size_t mfma_lds_bytes() { return (size_t)2 * (MF_BM + BN) * MF_LD * 2 + MF_BM * 4; }
 
-// queries as f16 [BN][dim]; q_eff holds values that are exactly representable in binary16 (they went through Lower)
+// queries as f16 [BN][dim]: exact for the 2-byte stores (q_eff went through Lower), rounded to nearest for f32 stores
 __global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq, int bn, int dim, _Float16* __restrict__ q16) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)bn * dim) return;
@@ -49,8 +55,10 @@ __global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq
 // BN = 256) for TWO workgroups per CU, so one group's global-load / barrier stalls are covered by the other's MFMAs.
 // Registers must stay <= 256 per lane and must not spill (a scratch reload is a VMEM op: it drains the in-order vmcnt queue).
 constexpr int MF_NT = 256;
-template <int BN>
-__global__ __launch_bounds__(MF_NT, (MF_BK <= 32 ? 2 : 1)) void flat_mfma_cos_f16_kernel(
+// AF32: the stored rows are f32 (COLTT_Q_NONE); they are rounded to binary16 on their way into LDS (candidate generation
+// only — MF_MARGIN_F32 covers the rounding), so the same f16 matrix-core loop serves both row formats.
+template <int BN, bool AF32>
+__global__ __launch_bounds__(MF_NT, (MF_BM <= 64 ? 3 : (MF_BK <= 32 ? 2 : 1))) void flat_mfma_cos_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, uint64_t begin, uint64_t end,
     const _Float16* __restrict__ q16, const float* __restrict__ qnorms, int nq, int dim, const uint32_t* __restrict__ thr,
     int nearest, unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
@@ -89,14 +97,17 @@ __global__ __launch_bounds__(MF_NT, (MF_BK <= 32 ? 2 : 1)) void flat_mfma_cos_f1
     // ---- global -> registers -> LDS staging.  Rows (HBM, ~2 us under load) are requested TWO K steps ahead, queries
     // (L2-resident) one step ahead: with one workgroup per CU, bytes in flight per CU are what buys HBM bandwidth.
     // (ext_vector types and macros on purpose: HIP's uint4 struct / lambda captures put these arrays in scratch.)
-    u32x4 ra[NA], rb[NB];
+    u32x4 ra[NA], ra_hi[AF32 ? NA : 1], rb[NB];  // raw bits; f32 rows are converted at LDS-store time, not at load time
 #define MF_GLOAD(KS)                                                                                         \
     {                                                                                                        \
       const int k0_ = (KS) * MF_BK;                                                                          \
       _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                       \
         int c = tid + MF_NT * i, r = c / MF_CPR, c16 = c % MF_CPR;                                           \
         uint64_t gr = row0 + r; if (gr >= end) gr = end - 1;                                                 \
-        ra[i] = *reinterpret_cast<const u32x4*>(rows + gr * stride + (size_t)(k0_ + c16 * 8) * 2);           \
+        if constexpr (AF32) {                                                                                \
+          const uint8_t* p_ = rows + gr * stride + (size_t)(k0_ + c16 * 8) * 4;                              \
+          ra[i] = *reinterpret_cast<const u32x4*>(p_); ra_hi[i] = *reinterpret_cast<const u32x4*>(p_ + 16);  \
+        } else ra[i] = *reinterpret_cast<const u32x4*>(rows + gr * stride + (size_t)(k0_ + c16 * 8) * 2);    \
       }                                                                                                      \
       _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                       \
         int c = tid + MF_NT * i, q = c / MF_CPR, c16 = c % MF_CPR;                                           \
@@ -107,7 +118,14 @@ __global__ __launch_bounds__(MF_NT, (MF_BK <= 32 ? 2 : 1)) void flat_mfma_cos_f1
     {                                                                                                        \
       _Pragma("unroll") for (int i = 0; i < NA; i++) {                                                       \
         int c = tid + MF_NT * i, r = c / MF_CPR, c16 = c % MF_CPR;                                           \
-        *reinterpret_cast<u32x4*>(As + ((size_t)(BUF) * MF_BM + r) * MF_LD + c16 * 8) = ra[i];               \
+        u32x4 v_ = ra[i];                                                                                    \
+        if constexpr (AF32) {                                                                                \
+          f32x4 lo_ = __builtin_bit_cast(f32x4, ra[i]), hi_ = __builtin_bit_cast(f32x4, ra_hi[i]);           \
+          half8 h_ = {(_Float16)lo_.x, (_Float16)lo_.y, (_Float16)lo_.z, (_Float16)lo_.w,                     \
+                      (_Float16)hi_.x, (_Float16)hi_.y, (_Float16)hi_.z, (_Float16)hi_.w};                    \
+          v_ = __builtin_bit_cast(u32x4, h_);                                                                \
+        }                                                                                                    \
+        *reinterpret_cast<u32x4*>(As + ((size_t)(BUF) * MF_BM + r) * MF_LD + c16 * 8) = v_;                  \
       }                                                                                                      \
       _Pragma("unroll") for (int i = 0; i < NB; i++) {                                                       \
         int c = tid + MF_NT * i, q = c / MF_CPR, c16 = c % MF_CPR;                                           \

@@ -107,7 +107,7 @@ def test_flat_adversarial_order_overflow_path(gpu):
     assert_same_results(gi[0], gs[0], wi, ws)
 
 
-@pytest.mark.parametrize("quant", [O.Q_F16, O.Q_BF16])
+@pytest.mark.parametrize("quant", [O.Q_F16, O.Q_BF16, O.Q_NONE])
 def test_flat_mfma_mode_equals_exact_mode(gpu, quant):
     """COLTT_MODE_MFMA: matrix-core candidate generation + exact re-score returns the SAME ids, ranks and score bits as
     the exact-order scan (and hence as the oracle), for every batch size / k / direction."""
@@ -136,9 +136,22 @@ def test_flat_mfma_768_duplicates_and_fallbacks(gpu):
         ei, es, ec = gf.VertexSearch(Q, k, select, gpu.MODE_EXACT)
         mi, ms, mc = gf.VertexSearch(Q, k, select, gpu.MODE_MFMA)
         assert np.array_equal(ei, mi) and np.array_equal(bits(es), bits(ms)), (k, select)
-    # combinations the MFMA kernel does not cover (f32 rows, L2, dim % 64 != 0) are served by the exact path: same answer
-    for metric, quant, dd in ((O.L2, O.Q_F16, 128), (O.COSINE, O.Q_NONE, 128), (O.COSINE, O.Q_F16, 72)):
+    # combinations the MFMA kernel does not cover (f8 codes, L2, dim % 32 != 0) are served by the exact path: same answer
+    for metric, quant, dd in ((O.L2, O.Q_F16, 128), (O.COSINE, O.Q_F8, 128), (O.COSINE, O.Q_F16, 72)):
         Y = O.fill_normal(5, (700, dd)); g2 = gpu.FlatSpace(dd, metric, quant); g2.ChangedVertex(np.arange(700, dtype=np.uint64), Y)
         q = O.fill_normal(6, (5, dd))
         a = g2.VertexSearch(q, 7, 1, gpu.MODE_EXACT); b = g2.VertexSearch(q, 7, 1, gpu.MODE_MFMA)
         assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_flat_mfma_large_dims(gpu):
+    """dim = 1536 / 2048 through the MFMA path."""
+    for d in (1536, 2048):
+        n = 3000
+        X = O.fill_normal(29, (n, d)); ids = np.arange(n, dtype=np.uint64)
+        gf = gpu.FlatSpace(d, O.COSINE, O.Q_F16); gf.ChangedVertex(ids, X)
+        Q = O.fill_normal(30, (130, d))
+        for k, select in ((10, 1), (33, 0)):
+            ei, es, ec = gf.VertexSearch(Q, k, select, gpu.MODE_EXACT)
+            mi, ms, mc = gf.VertexSearch(Q, k, select, gpu.MODE_MFMA)
+            assert np.array_equal(ei, mi) and np.array_equal(bits(es), bits(ms)), (d, k, select)

@@ -49,7 +49,7 @@ def main():
     for n, dim, quant, batch in cases:
         e, ei, es = run(G, torch, n, dim, quant, batch, G.MODE_EXACT)
         print(json.dumps(e), flush=True)
-        if quant in (1, 3):
+        if quant in (0, 1, 3):
             m, mi, msc = run(G, torch, n, dim, quant, batch, G.MODE_MFMA)
             m["identical_to_exact_mode"] = bool(np.array_equal(ei, mi) and np.array_equal(es.view(np.uint32), msc.view(np.uint32)))
             print(json.dumps(m), flush=True)
