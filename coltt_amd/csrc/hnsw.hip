@@ -544,6 +544,68 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
   return COLTT_OK;
 }
 
+// Installs graph topology + id tables (everything of a bulk load except the vectors).
+int graph_install(Hnsw* x, uint64_t n, const uint64_t* ids, const int32_t* levels, const uint8_t* deleted, const int64_t* row_offsets,
+                  const int32_t* nbr, const float* nbr_dist, int32_t entry_slot) {
+  if (n >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw_bulk_load: more than 2^31-1 slots");
+  if (n && (entry_slot < -1 || entry_slot >= (int64_t)n)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: entry slot out of range");
+  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  uint64_t n_upper = 0;
+  for (uint64_t i = 0; i < n; i++) { if (levels[i] < 0) return fail(COLTT_E_INVALID, "hnsw_bulk_load: negative level"); n_upper += (uint64_t)levels[i]; }
+  x->n = 0; x->live = 0; x->cap = 0; x->ucap = 0; x->n_upper = 0;
+  x->dense = (ids == nullptr); x->dense_base = 0; x->id2slot.clear();
+  COLTT_TRY(x->reserve(n, n_upper));
+  std::vector<uint32_t> a0((size_t)n * W0, NBR_NONE), aU((size_t)n_upper * WU, NBR_NONE), uo(n, NBR_NONE);
+  std::vector<float> d0((size_t)n * W0, 0.f), dU((size_t)n_upper * WU, 0.f);
+  x->h_levels.assign(levels, levels + n);
+  x->h_del.assign((n + 31) / 32, 0u);
+  x->any_deleted = false;
+  uint64_t row = 0, up = 0;
+  std::vector<std::pair<uint32_t, float>> tmp;
+  for (uint64_t i = 0; i < n; i++) {
+    bool del = deleted && deleted[i];
+    if (del) { x->h_del[i >> 5] |= 1u << (i & 31); x->any_deleted = true; } else x->live++;
+    if (levels[i] > 0) { uo[i] = (uint32_t)up; }
+    for (int l = 0; l <= levels[i]; l++, row++) {
+      int64_t b = row_offsets[row], e = row_offsets[row + 1];
+      uint32_t W = l == 0 ? W0 : WU;
+      if (e - b > (int64_t)W) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d has %lld edges > width %u", (unsigned long long)i, l, (long long)(e - b), W);
+      tmp.clear();
+      for (int64_t j = b; j < e; j++) {
+        if (nbr[j] < 0 || (uint64_t)nbr[j] >= n) return fail(COLTT_E_INVALID, "hnsw_bulk_load: neighbour slot out of range");
+        tmp.push_back({(uint32_t)nbr[j], nbr_dist ? nbr_dist[j] : 0.f});
+      }
+      std::sort(tmp.begin(), tmp.end());
+      uint32_t* ar = l == 0 ? &a0[(size_t)i * W0] : &aU[(size_t)(up + l - 1) * WU];
+      float* dr = l == 0 ? &d0[(size_t)i * W0] : &dU[(size_t)(up + l - 1) * WU];
+      for (size_t j = 0; j < tmp.size(); j++) { ar[j] = tmp[j].first; dr[j] = tmp[j].second; }
+    }
+    up += (uint64_t)levels[i];
+  }
+  x->h_upper_off = uo;
+  if (!x->dense) {
+    x->h_ids.assign(ids, ids + n);
+    x->id2slot.reserve(n * 2);
+    for (uint64_t i = 0; i < n; i++) if (!(deleted && deleted[i])) x->id2slot[ids[i]] = (uint32_t)i;
+    COLTT_HIP(hipMemcpyAsync(x->ids.p, ids, n * 8, hipMemcpyHostToDevice, x->stream));
+  }
+  if (n) {
+    COLTT_HIP(hipMemcpyAsync(x->adj0.p, a0.data(), a0.size() * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->adj0_d.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->upper_off.p, uo.data(), n * 4, hipMemcpyHostToDevice, x->stream));
+    COLTT_HIP(hipMemcpyAsync(x->del_bits.p, x->h_del.data(), x->h_del.size() * 4, hipMemcpyHostToDevice, x->stream));
+    if (n_upper) {
+      COLTT_HIP(hipMemcpyAsync(x->adjU.p, aU.data(), aU.size() * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(x->adjU_d.p, dU.data(), dU.size() * 4, hipMemcpyHostToDevice, x->stream));
+    }
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  x->n = n; x->n_upper = n_upper;
+  x->entry = n ? entry_slot : -1;
+  x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
+  return COLTT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -603,59 +665,10 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_bulk_load: unknown handle");
   if (n && (!levels || !vectors || !row_offsets)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: NULL input");
-  if (n >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw_bulk_load: more than 2^31-1 slots");
-  if (n && (entry_slot < -1 || entry_slot >= (int64_t)n)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: entry slot out of range");
   std::lock_guard<std::mutex> g(x->mu);
   COLTT_TRY(ensure_device());
-  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
-  uint64_t n_upper = 0;
-  for (uint64_t i = 0; i < n; i++) { if (levels[i] < 0) return fail(COLTT_E_INVALID, "hnsw_bulk_load: negative level"); n_upper += (uint64_t)levels[i]; }
-  x->n = 0; x->live = 0; x->cap = 0; x->ucap = 0; x->n_upper = 0;
-  x->dense = (ids == nullptr); x->dense_base = 0; x->id2slot.clear();
-  COLTT_TRY(x->reserve(n, n_upper));
-  std::vector<uint32_t> a0((size_t)n * W0, NBR_NONE), aU((size_t)n_upper * WU, NBR_NONE), uo(n, NBR_NONE);
-  std::vector<float> d0((size_t)n * W0, 0.f), dU((size_t)n_upper * WU, 0.f);
-  x->h_levels.assign(levels, levels + n);
-  x->h_del.assign((n + 31) / 32, 0u);
-  x->any_deleted = false;
-  uint64_t row = 0, up = 0;
-  std::vector<std::pair<uint32_t, float>> tmp;
-  for (uint64_t i = 0; i < n; i++) {
-    bool del = deleted && deleted[i];
-    if (del) { x->h_del[i >> 5] |= 1u << (i & 31); x->any_deleted = true; } else x->live++;
-    if (levels[i] > 0) { uo[i] = (uint32_t)up; }
-    for (int l = 0; l <= levels[i]; l++, row++) {
-      int64_t b = row_offsets[row], e = row_offsets[row + 1];
-      uint32_t W = l == 0 ? W0 : WU;
-      if (e - b > (int64_t)W) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d has %lld edges > width %u", (unsigned long long)i, l, (long long)(e - b), W);
-      tmp.clear();
-      for (int64_t j = b; j < e; j++) {
-        if (nbr[j] < 0 || (uint64_t)nbr[j] >= n) return fail(COLTT_E_INVALID, "hnsw_bulk_load: neighbour slot out of range");
-        tmp.push_back({(uint32_t)nbr[j], nbr_dist ? nbr_dist[j] : 0.f});
-      }
-      std::sort(tmp.begin(), tmp.end());
-      uint32_t* ar = l == 0 ? &a0[(size_t)i * W0] : &aU[(size_t)(up + l - 1) * WU];
-      float* dr = l == 0 ? &d0[(size_t)i * W0] : &dU[(size_t)(up + l - 1) * WU];
-      for (size_t j = 0; j < tmp.size(); j++) { ar[j] = tmp[j].first; dr[j] = tmp[j].second; }
-    }
-    up += (uint64_t)levels[i];
-  }
-  x->h_upper_off = uo;
-  if (!x->dense) {
-    x->h_ids.assign(ids, ids + n);
-    x->id2slot.reserve(n * 2);
-    for (uint64_t i = 0; i < n; i++) if (!(deleted && deleted[i])) x->id2slot[ids[i]] = (uint32_t)i;
-    COLTT_HIP(hipMemcpyAsync(x->ids.p, ids, n * 8, hipMemcpyHostToDevice, x->stream));
-  }
+  COLTT_TRY(graph_install(x.get(), n, ids, levels, deleted, row_offsets, nbr, nbr_dist, entry_slot));
   if (n) {
-    COLTT_HIP(hipMemcpyAsync(x->adj0.p, a0.data(), a0.size() * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->adj0_d.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->upper_off.p, uo.data(), n * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->del_bits.p, x->h_del.data(), x->h_del.size() * 4, hipMemcpyHostToDevice, x->stream));
-    if (n_upper) {
-      COLTT_HIP(hipMemcpyAsync(x->adjU.p, aU.data(), aU.size() * 4, hipMemcpyHostToDevice, x->stream));
-      COLTT_HIP(hipMemcpyAsync(x->adjU_d.p, dU.data(), dU.size() * 4, hipMemcpyHostToDevice, x->stream));
-    }
     // vectors in chunks through a staging buffer: Normalize (cosine) + Lower, as Insert does (hnsw.go:105-107)
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)x->dim * 4));
     COLTT_TRY(x->w_raw.reserve(std::min<uint64_t>(chunk, n) * x->dim * 4));
@@ -666,10 +679,193 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
       COLTT_HIP(hipStreamSynchronize(x->stream));
     }
   }
-  COLTT_HIP(hipStreamSynchronize(x->stream));
-  x->n = n; x->n_upper = n_upper;
-  x->entry = n ? entry_slot : -1;
-  x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
+  return COLTT_OK;
+}
+
+// ---- Hnsw.Commit / Hnsw.Load (core/vectorindex/hnsw_commit.go:69-278) ------------------------------------------------
+namespace {
+struct BEW {
+  uint8_t* p; uint64_t cap, n = 0;
+  void put(const void* s, size_t k) { if (p && n + k <= cap) std::memcpy(p + n, s, k); n += k; }
+  void u8(uint8_t v) { put(&v, 1); }
+  void u16(uint16_t v) { uint8_t b[2] = {(uint8_t)(v >> 8), (uint8_t)v}; put(b, 2); }
+  void u32(uint32_t v) { uint8_t b[4]; for (int i = 0; i < 4; i++) b[i] = (uint8_t)(v >> (8 * (3 - i))); put(b, 4); }
+  void u64(uint64_t v) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * (7 - i))); put(b, 8); }
+  void f32(float f) { uint32_t u; std::memcpy(&u, &f, 4); u32(u); }
+};
+struct BER {
+  const uint8_t* p; uint64_t n, i = 0; bool ok = true;
+  bool need(uint64_t k) { if (i + k > n) { ok = false; return false; } return true; }
+  uint8_t u8() { if (!need(1)) return 0; return p[i++]; }
+  uint16_t u16() { if (!need(2)) return 0; uint16_t v = (uint16_t)((p[i] << 8) | p[i + 1]); i += 2; return v; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v = 0; for (int k = 0; k < 4; k++) v = (v << 8) | p[i + k]; i += 4; return v; }
+  uint64_t u64() { if (!need(8)) return 0; uint64_t v = 0; for (int k = 0; k < 8; k++) v = (v << 8) | p[i + k]; i += 8; return v; }
+  float f32() { uint32_t u = u32(); float f; std::memcpy(&f, &u, 4); return f; }
+};
+// big-endian f32 vectors at arbitrary byte offsets of the uploaded stream chunk -> f32 staging rows (Vector.Load, edge/constants.go:115-122)
+__global__ void be_rows_kernel(const uint8_t* __restrict__ chunk, const uint64_t* __restrict__ offs, uint64_t m, int dim, float* __restrict__ out) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * (uint64_t)dim) return;
+  uint64_t i = t / dim; int e = (int)(t - i * dim);
+  const uint8_t* s = chunk + offs[i] + (size_t)e * 4;
+  uint32_t u = ((uint32_t)s[0] << 24) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 8) | s[3];
+  out[t] = __uint_as_float(u);
+}
+}  // namespace
+
+int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t len, uint64_t* out_n, uint64_t* out_ids,
+                    uint64_t* out_meta_off, uint32_t* out_meta_len, uint64_t cap_n) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_load: unknown handle");
+  if (!buf && len) return fail(COLTT_E_INVALID, "hnsw_load: NULL buffer");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  BER r{buf, len};
+  if (header) {  // hnswConfig.load (hnsw_config.go:205-245), dim, distIdx (hnsw_commit.go:165-183)
+    coltt_hnsw_cfg c = x->cfg;
+    c.algo = (int32_t)r.u32(); c.level_multiplier = r.f32(); c.ef = (int32_t)r.u32(); c.ef_construction = (int32_t)r.u32();
+    c.m = (int32_t)r.u32(); c.m_max = (int32_t)r.u32(); c.m_max0 = (int32_t)r.u32();
+    uint32_t dim = r.u32(); uint8_t di = r.u8();
+    if (!r.ok) return fail(COLTT_E_INVALID, "hnsw_load: truncated header");
+    if (di != 1 && di != 2) return fail(COLTT_E_INVALID, "Invalid space type");  // InvalidSpaceTypeErr
+    if (dim != x->dim) return fail(COLTT_E_INVALID, "hnsw_load: stream dim %u != index dim %u", dim, x->dim);
+    if ((di == 1) != (x->metric == COLTT_COSINE)) return fail(COLTT_E_INVALID, "hnsw_load: stream distance differs from the index's");
+    if (c.m <= 0 || c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024 || c.ef <= 0 || c.ef_construction <= 0 || (c.algo != 0 && c.algo != 1))
+      return fail(COLTT_E_INVALID, "hnsw_load: invalid config in stream");
+    x->cfg = c;
+  }
+  std::vector<uint64_t> ids, voff, moff; std::vector<int32_t> levels; std::vector<uint32_t> mlen;
+  uint64_t entry_id = 0; bool empty = r.i >= len;
+  if (!empty) {
+    entry_id = r.u64();
+    for (int s = 0; s < 16 && r.ok; s++) {
+      uint32_t cnt = r.u32();
+      for (uint32_t i = 0; i < cnt && r.ok; i++) {
+        ids.push_back(r.u64()); levels.push_back((int32_t)r.u32());
+        voff.push_back(r.i); r.need((uint64_t)x->dim * 4); r.i += (uint64_t)x->dim * 4;
+        uint64_t m0 = r.i; uint16_t pairs = r.u16();
+        for (uint16_t p = 0; p < pairs && r.ok; p++) { uint8_t kl = r.u8(); r.need(kl); r.i += kl; uint16_t vl = r.u16(); r.need(vl); r.i += vl; }
+        moff.push_back(m0); mlen.push_back((uint32_t)(r.i - m0));
+        if (levels.back() < 0 || levels.back() > 60) return fail(COLTT_E_INVALID, "hnsw_load: bad level in stream");
+      }
+    }
+  }
+  if (!r.ok) return fail(COLTT_E_INVALID, "hnsw_load: truncated vertex section");
+  const uint64_t n = ids.size();
+  std::unordered_map<uint64_t, int32_t> slot; slot.reserve(n * 2);
+  for (uint64_t i = 0; i < n; i++) if (!slot.emplace(ids[i], (int32_t)i).second) return fail(COLTT_E_INVALID, "hnsw_load: duplicate id in stream");
+  int32_t entry = -1;
+  if (n) { auto it = slot.find(entry_id); if (it == slot.end()) return fail(COLTT_E_INVALID, "hnsw_load: entrypoint id not in stream"); entry = it->second; }
+  // edges -> per (slot, level) lists, then CSR in slot-major / level-minor order
+  std::vector<int64_t> row_of(n + 1, 0);
+  for (uint64_t i = 0; i < n; i++) row_of[i + 1] = row_of[i] + levels[i] + 1;
+  std::vector<std::vector<std::pair<int32_t, float>>> rows((size_t)row_of[n]);
+  for (uint64_t k = 0; k < n && r.ok; k++) {
+    uint64_t id = r.u64();
+    auto it = slot.find(id);
+    if (!r.ok || it == slot.end()) return fail(COLTT_E_INVALID, "hnsw_load: edge record for an unknown vertex");
+    int32_t s = it->second;
+    for (int l = levels[s]; l >= 0; l--) {
+      uint32_t c = r.u32();
+      auto& lst = rows[(size_t)row_of[s] + l];
+      for (uint32_t j = 0; j < c && r.ok; j++) {
+        uint64_t nid = r.u64(); float d = r.f32();
+        auto nit = slot.find(nid);
+        if (nit == slot.end()) return fail(COLTT_E_INVALID, "hnsw_load: edge to an unknown vertex");
+        lst.push_back({nit->second, d});
+      }
+    }
+  }
+  if (!r.ok) return fail(COLTT_E_INVALID, "hnsw_load: truncated edge section");
+  std::vector<int64_t> offs(rows.size() + 1, 0);
+  for (size_t i = 0; i < rows.size(); i++) offs[i + 1] = offs[i] + (int64_t)rows[i].size();
+  std::vector<int32_t> nbr((size_t)offs.back()); std::vector<float> nd((size_t)offs.back());
+  for (size_t i = 0; i < rows.size(); i++)
+    for (size_t j = 0; j < rows[i].size(); j++) { nbr[(size_t)offs[i] + j] = rows[i][j].first; nd[(size_t)offs[i] + j] = rows[i][j].second; }
+  COLTT_TRY(graph_install(x.get(), n, n ? ids.data() : nullptr, levels.data(), nullptr, offs.data(), nbr.data(), nd.data(), entry));
+  // vectors: upload the stream in chunks, byte-swap on the device; stored vectors are NOT re-normalised (hnsw_commit.go:217-220)
+  if (n) {
+    const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)x->dim * 4));
+    DevBuf d_chunk, d_offs;
+    for (uint64_t b = 0; b < n; b += rows_per) {
+      uint64_t m = std::min<uint64_t>(rows_per, n - b);
+      uint64_t lo = voff[b], hi = voff[b + m - 1] + (uint64_t)x->dim * 4;
+      std::vector<uint64_t> rel(m);
+      for (uint64_t i = 0; i < m; i++) rel[i] = voff[b + i] - lo;
+      COLTT_TRY(d_chunk.reserve(hi - lo)); COLTT_TRY(d_offs.reserve(m * 8)); COLTT_TRY(x->w_raw.reserve(m * x->dim * 4));
+      COLTT_HIP(hipMemcpyAsync(d_chunk.p, buf + lo, hi - lo, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(d_offs.p, rel.data(), m * 8, hipMemcpyHostToDevice, x->stream));
+      be_rows_kernel<<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)x->dim, x->w_raw.as<float>());
+      COLTT_TRY(prep_rows_any(x.get(), x->w_raw.as<float>(), m, b, false));
+      COLTT_HIP(hipStreamSynchronize(x->stream));
+    }
+  }
+  if (out_n) *out_n = n;
+  for (uint64_t i = 0; i < n && i < cap_n; i++) {
+    if (out_ids) out_ids[i] = ids[i];
+    if (out_meta_off) out_meta_off[i] = moff[i];
+    if (out_meta_len) out_meta_len[i] = mlen[i];
+  }
+  return COLTT_OK;
+}
+
+int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens, uint8_t* out,
+                      uint64_t cap, uint64_t* out_len) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_commit: unknown handle");
+  if (!out_len) return fail(COLTT_E_INVALID, "hnsw_commit: out_len is NULL");
+  if (x->quant != COLTT_Q_NONE) return fail(COLTT_E_UNSUPPORTED, "hnsw_commit: the reference stream stores f32 vectors; quantised indexes are not committable");
+  std::lock_guard<std::mutex> g(x->mu);
+  COLTT_TRY(ensure_device());
+  BEW w{out, out ? cap : 0};
+  if (header) {  // hnswConfig.save (hnsw_config.go:179-203) + dim + distIdx (hnsw_commit.go:70-80)
+    w.u32((uint32_t)x->cfg.algo); w.f32(x->cfg.level_multiplier); w.u32((uint32_t)x->cfg.ef); w.u32((uint32_t)x->cfg.ef_construction);
+    w.u32((uint32_t)x->cfg.m); w.u32((uint32_t)x->cfg.m_max); w.u32((uint32_t)x->cfg.m_max0);
+    w.u32(x->dim); w.u8(x->metric == COLTT_COSINE ? 1 : 2);
+  }
+  if (x->live == 0) { *out_len = w.n; return (out && w.n > cap) ? fail(COLTT_E_INVALID, "hnsw_commit: buffer too small") : COLTT_OK; }
+  if (x->entry < 0) return fail(COLTT_E_INVALID, "hnsw_commit: no entrypoint");  // NoEntrypointErr
+  const uint64_t n = x->n;
+  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  auto id_of = [&](uint64_t s) { return x->dense ? x->dense_base + s : x->h_ids[s]; };
+  auto dead = [&](uint64_t s) { return (x->h_del[s >> 5] >> (s & 31)) & 1u; };
+  std::vector<std::vector<uint32_t>> shards(16);
+  for (uint64_t s = 0; s < n; s++) if (!dead(s)) shards[shard_vertex(id_of(s), 16)].push_back((uint32_t)s);
+  w.u64(id_of((uint64_t)x->entry));
+  // section 1: vertices (rows fetched from HBM in blocks)
+  std::vector<float> rowbuf;
+  const uint64_t blk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)x->dim * 4));
+  std::vector<float> all;  // sized only when actually writing
+  if (out) { all.resize(n * (size_t)x->dim);
+    for (uint64_t b = 0; b < n; b += blk) { uint64_t m = std::min<uint64_t>(blk, n - b);
+      COLTT_HIP(hipMemcpy2D(all.data() + b * x->dim, (size_t)x->dim * 4, x->rows.as<uint8_t>() + b * x->stride, x->stride, (size_t)x->dim * 4, m, hipMemcpyDeviceToHost)); } }
+  for (auto& sh : shards) {
+    w.u32((uint32_t)sh.size());
+    for (uint32_t s : sh) {
+      w.u64(id_of(s)); w.u32((uint32_t)x->h_levels[s]);
+      if (out) for (uint32_t e = 0; e < x->dim; e++) w.f32(all[(size_t)s * x->dim + e]); else w.n += (uint64_t)x->dim * 4;
+      if (meta_blobs && meta_blobs[s] && meta_lens && meta_lens[s] >= 2) w.put(meta_blobs[s], meta_lens[s]); else w.u16(0);
+    }
+  }
+  // section 2: edges, highest level first, tombstoned neighbours skipped (hnsw_commit.go:133-157)
+  std::vector<uint32_t> a0((size_t)n * W0), aU((size_t)x->n_upper * WU); std::vector<float> d0(a0.size()), dU(aU.size());
+  if (n) { COLTT_HIP(hipMemcpy(a0.data(), x->adj0.p, a0.size() * 4, hipMemcpyDeviceToHost)); COLTT_HIP(hipMemcpy(d0.data(), x->adj0_d.p, d0.size() * 4, hipMemcpyDeviceToHost)); }
+  if (x->n_upper) { COLTT_HIP(hipMemcpy(aU.data(), x->adjU.p, aU.size() * 4, hipMemcpyDeviceToHost)); COLTT_HIP(hipMemcpy(dU.data(), x->adjU_d.p, dU.size() * 4, hipMemcpyDeviceToHost)); }
+  for (auto& sh : shards)
+    for (uint32_t s : sh) {
+      w.u64(id_of(s));
+      for (int l = x->h_levels[s]; l >= 0; l--) {
+        uint32_t W = l == 0 ? W0 : WU;
+        const uint32_t* row = l == 0 ? &a0[(size_t)s * W0] : &aU[((size_t)x->h_upper_off[s] + l - 1) * WU];
+        const float* dr = l == 0 ? &d0[(size_t)s * W0] : &dU[((size_t)x->h_upper_off[s] + l - 1) * WU];
+        uint32_t c = 0;
+        for (uint32_t j = 0; j < W && row[j] != NBR_NONE; j++) if (!dead(row[j])) c++;
+        w.u32(c);
+        for (uint32_t j = 0; j < W && row[j] != NBR_NONE; j++) { if (dead(row[j])) continue; w.u64(id_of(row[j])); w.f32(dr[j]); }
+      }
+    }
+  *out_len = w.n;
+  if (out && w.n > cap) return fail(COLTT_E_INVALID, "hnsw_commit: buffer of %llu bytes is too small for %llu", (unsigned long long)cap, (unsigned long long)w.n);
   return COLTT_OK;
 }
 

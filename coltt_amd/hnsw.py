@@ -108,6 +108,21 @@ class Hnsw:
                                           L.vp(nb), L.vp(nd), C.byref(ent)))
         return {"ids": ids, "levels": lv, "deleted": dl, "row_offsets": off, "nbr": nb, "nbr_dist": nd, "entry": ent.value}
 
+    # -- Hnsw.Commit / Hnsw.Load (core/vectorindex/hnsw_commit.go:69-278)
+    def Commit(self, header=True):
+        n = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, None, C.c_uint64(0), C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, L.vp(buf), C.c_uint64(n.value), C.byref(n)))
+        return buf.tobytes()
+
+    def Load(self, data, header=True):
+        b = np.frombuffer(data, np.uint8)
+        n = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_load(self.h, int(header), L.vp(b), C.c_uint64(len(b)), C.byref(n), None, None, None, C.c_uint64(0)))
+        L.check(L.lib().coltt_hnsw_get_cfg(self.h, C.byref(self.cfg)))
+        return n.value
+
     def ExportRaw(self):
         """adjacency in the HBM layout: adj0 [n, mMax0], upper_off [n], adjU [n_upper, mMax] (0xffffffff padded)."""
         ns, nu, ent, el = C.c_uint64(0), C.c_uint64(0), C.c_int32(0), C.c_int32(0)

@@ -153,6 +153,20 @@ int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq
 int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uint64_t* n_edges, uint64_t* ids,
                       int32_t* levels, uint8_t* deleted, int64_t* row_offsets, int32_t* nbr, float* nbr_dist,
                       int32_t* entry_slot);
+/* Hnsw.Commit(w, header) (core/vectorindex/hnsw_commit.go:69-162): the reference's big-endian stream — [config
+ * (hnsw_config.go:179-203), u32 dim, u8 distIdx], u64 entrypoint id, 16 FNV shards of {u64 id, i32 level, dim x f32,
+ * metadata}, then per vertex {u64 id, per level (top down) u32 n, n x (u64 neighbour id, f32 distance)}; removed
+ * vertices and edges to them are skipped.  meta_blobs[slot]/meta_lens[slot] = the vertex's Metadata already in stream
+ * encoding (metadata.go:31-74: u16 pairs, {u8 keylen, key, u16 vallen, msgpack}); NULL => empty maps.
+ * out == NULL => only *out_len is computed. */
+int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens,
+                      uint8_t* out, uint64_t cap, uint64_t* out_len);
+/* Hnsw.Load(r, header) (hnsw_commit.go:164-278) straight into the HBM layout: vectors are byte-swapped on the device
+ * and NOT re-normalised (as in the reference).  Slots follow stream order.  out_ids / out_meta_off / out_meta_len
+ * (capacity cap_n, may be NULL) receive each vertex's id and the position of its metadata blob inside buf, so the
+ * caller can decode the msgpack values itself. */
+int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t len, uint64_t* out_n, uint64_t* out_ids,
+                    uint64_t* out_meta_off, uint32_t* out_meta_len, uint64_t cap_n);
 /* the adjacency exactly as it lives in HBM: adj0 [n][m_max0], upper_off [n], adjU [n_upper][m_max],
  * padded with 0xffffffff.  NULL arrays => sizes only. */
 int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper_rows, int32_t* entry_slot,

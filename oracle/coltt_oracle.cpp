@@ -872,6 +872,111 @@ static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int3
   return n;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Hnsw.Commit / Hnsw.Load (core/vectorindex/hnsw_commit.go:69-278): big-endian stream
+//   [header: config (hnsw_config.go:179-203: u32 algo, f32 levelMult, i32 ef, efC, m, mMax, mMax0), u32 dim, u8 distIdx (1 cosine, 2 l2)]
+//   u64 entrypoint id | 16 shards x { u32 count, count x { u64 id, i32 level, dim x f32, metadata } }
+//   then per vertex { u64 id, for l = level..0 { u32 n, n x { u64 neighbour id, f32 distance } } }   (deleted neighbours skipped)
+// Metadata (metadata.go:31-105) = u16 pairs, each { u8 keylen, key, u16 vallen, msgpack value } — kept as an opaque blob here.
+// Go iterates maps in random order; canonical order here = shard by shard (FNV ShardVertex(id,16)), ascending slot inside.
+// ------------------------------------------------------------------------------------------------
+struct BEWriter {
+  std::vector<uint8_t>& b;
+  void u8(uint8_t v) { b.push_back(v); }
+  void u16(uint16_t v) { b.push_back(v >> 8); b.push_back(v & 0xff); }
+  void u32(uint32_t v) { for (int i = 3; i >= 0; i--) b.push_back((v >> (8 * i)) & 0xff); }
+  void u64(uint64_t v) { for (int i = 7; i >= 0; i--) b.push_back((v >> (8 * i)) & 0xff); }
+  void f32(float f) { u32(f2u(f)); }
+};
+struct BEReader {
+  const uint8_t* p; size_t n, i = 0; bool ok = true;
+  bool need(size_t k) { if (i + k > n) { ok = false; return false; } return true; }
+  uint8_t u8() { if (!need(1)) return 0; return p[i++]; }
+  uint16_t u16() { if (!need(2)) return 0; uint16_t v = (uint16_t)((p[i] << 8) | p[i + 1]); i += 2; return v; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v = 0; for (int k = 0; k < 4; k++) v = (v << 8) | p[i + k]; i += 4; return v; }
+  uint64_t u64() { if (!need(8)) return 0; uint64_t v = 0; for (int k = 0; k < 8; k++) v = (v << 8) | p[i + k]; i += 8; return v; }
+  float f32() { return u2f(u32()); }
+};
+static void hnsw_commit(Hnsw* h, bool header, std::vector<uint8_t>& out) {
+  BEWriter w{out};
+  if (header) {
+    w.u32((uint32_t)h->cfg.algo); w.f32(h->cfg.levelMultiplier); w.u32((uint32_t)h->cfg.ef); w.u32((uint32_t)h->cfg.efConstruction);
+    w.u32((uint32_t)h->cfg.m); w.u32((uint32_t)h->cfg.mMax); w.u32((uint32_t)h->cfg.mMax0);
+    w.u32(h->dim); w.u8(h->metric == METRIC_COS ? 1 : 2);
+  }
+  if (h->len == 0) return;
+  w.u64(h->v[h->entry].id);
+  std::vector<std::vector<int32_t>> shards(16);
+  for (size_t i = 0; i < h->v.size(); i++) if (!h->v[i].deleted) shards[shard_vertex(h->v[i].id, 16)].push_back((int32_t)i);
+  for (auto& sh : shards) {
+    w.u32((uint32_t)sh.size());
+    for (int32_t vi : sh) {
+      const Vertex& v = h->v[vi];
+      w.u64(v.id); w.u32((uint32_t)(int32_t)v.level);
+      for (uint32_t e = 0; e < h->dim; e++) w.f32(v.vec[e]);
+      w.u16(0);  // empty Metadata map
+    }
+  }
+  for (auto& sh : shards)
+    for (int32_t vi : sh) {
+      const Vertex& v = h->v[vi];
+      w.u64(v.id);
+      for (int l = v.level; l >= 0; l--) {
+        uint32_t c = 0;
+        for (const Edge& e : v.edges[l]) if (!h->v[e.to].deleted) c++;
+        w.u32(c);
+        for (const Edge& e : v.edges[l]) { if (h->v[e.to].deleted) continue; w.u64(h->v[e.to].id); w.f32(e.d); }
+      }
+    }
+}
+static int hnsw_load(Hnsw* h, bool header, const uint8_t* buf, size_t len) {
+  BEReader r{buf, len};
+  if (header) {
+    h->cfg.algo = (int32_t)r.u32(); h->cfg.levelMultiplier = r.f32(); h->cfg.ef = (int32_t)r.u32(); h->cfg.efConstruction = (int32_t)r.u32();
+    h->cfg.m = (int32_t)r.u32(); h->cfg.mMax = (int32_t)r.u32(); h->cfg.mMax0 = (int32_t)r.u32();
+    h->dim = r.u32(); uint8_t di = r.u8();
+    if (di != 1 && di != 2) return -1;  // InvalidSpaceTypeErr
+    h->metric = di == 1 ? METRIC_COS : METRIC_L2;
+  }
+  h->v.clear(); h->by_id.clear(); h->len = 0; h->entry = -1;
+  if (r.i >= len) return r.ok ? 0 : -1;
+  uint64_t entry_id = r.u64();
+  for (int s = 0; s < 16; s++) {
+    uint32_t cnt = r.u32();
+    for (uint32_t i = 0; i < cnt && r.ok; i++) {
+      Vertex v; v.id = r.u64(); v.level = (int32_t)r.u32(); v.deleted = false;
+      v.own.resize(h->dim);
+      for (uint32_t e = 0; e < h->dim; e++) v.own[e] = r.f32();  // stored vectors are NOT re-normalised by Load
+      uint16_t pairs = r.u16();
+      for (uint16_t p = 0; p < pairs && r.ok; p++) { uint8_t kl = r.u8(); r.need(kl); r.i += kl; uint16_t vl = r.u16(); r.need(vl); r.i += vl; }
+      v.edges.resize(v.level + 1);
+      h->by_id[v.id] = (int32_t)h->v.size();
+      h->v.push_back(std::move(v)); h->v.back().vec = h->v.back().own.data(); h->len++;
+    }
+  }
+  if (!r.ok) return -1;
+  auto it = h->by_id.find(entry_id);
+  h->entry = it == h->by_id.end() ? -1 : it->second;
+  for (size_t n = 0; n < h->v.size() && r.ok; n++) {
+    uint64_t id = r.u64();
+    auto vit = h->by_id.find(id);
+    if (vit == h->by_id.end()) return -1;
+    Vertex& v = h->v[vit->second];
+    for (int l = v.level; l >= 0; l--) {
+      uint32_t c = r.u32();
+      for (uint32_t j = 0; j < c && r.ok; j++) {
+        uint64_t nid = r.u64(); float d = r.f32();
+        auto nit = h->by_id.find(nid);
+        if (nit == h->by_id.end()) return -1;
+        edge_set(v.edges[l], nit->second, d);
+      }
+    }
+  }
+  for (auto& v : h->v) v.vec = v.own.data();
+  return r.ok ? 0 : -1;
+}
+
 static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -1071,6 +1176,15 @@ int orc_csr_search(const void* rows, int quant, const uint32_t* adj0, const uint
     out_counts[i] = csr_search(g, queries + i * dim, k, ef, out_slots + i * k, out_scores + i * k, stats3);
   return 0;
 }
+
+
+// returns the stream length; writes it when out != null and cap suffices
+int64_t orc_hnsw_commit(void* h, int header, uint8_t* out, uint64_t cap) {
+  std::vector<uint8_t> b; hnsw_commit((Hnsw*)h, header != 0, b);
+  if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
+  return (int64_t)b.size();
+}
+int orc_hnsw_load(void* h, int header, const uint8_t* buf, uint64_t len) { return hnsw_load((Hnsw*)h, header != 0, buf, len); }
 
 uint64_t orc_hnsw_graph_hash(void* h) {
   Hnsw* x = (Hnsw*)h; uint64_t hs = 14695981039346656037ull;

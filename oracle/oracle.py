@@ -309,6 +309,21 @@ class Hnsw:
             return ids[:n].copy(), sc[:n].copy(), {"n_dist": st[0], "n_exp": st[1], "n_hops": st[2]}
         return ids[:n].copy(), sc[:n].copy()
 
+    def commit(self, header=True):
+        """Hnsw.Commit (hnsw_commit.go:69-162) -> bytes"""
+        lib().orc_hnsw_commit.restype = C.c_int64
+        n = lib().orc_hnsw_commit(self.h, int(header), None, C.c_uint64(0))
+        buf = np.empty(n, np.uint8)
+        lib().orc_hnsw_commit(self.h, int(header), _p(buf), C.c_uint64(n))
+        return buf.tobytes()
+
+    def load_stream(self, data, header=True):
+        """Hnsw.Load (hnsw_commit.go:164-278)"""
+        b = np.frombuffer(data, np.uint8)
+        rc = lib().orc_hnsw_load(self.h, int(header), _p(b), C.c_uint64(len(b)))
+        lib().orc_hnsw_get_cfg(self.h, C.byref(self.cfg))
+        return rc
+
     def graph_hash(self):
         return int(lib().orc_hnsw_graph_hash(self.h))
 

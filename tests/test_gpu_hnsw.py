@@ -191,3 +191,43 @@ def test_concurrent_callers_thread_safety(gpu):
         return True
     with ThreadPoolExecutor(8) as ex:
         assert all(ex.map(work, range(8)))
+
+
+def test_hnsw_commit_load_streams(gpu):
+    """Hnsw.Commit / Hnsw.Load (hnsw_commit.go:69-278): the reference's own Commit->Load invariant (hnsw_commit_test.go:127-181:
+    structure, vectors and edge distances survive the round trip), here ACROSS implementations: oracle stream -> GPU index,
+    GPU stream -> oracle index, with searches bit-identical on both sides."""
+    import torch
+    n, d = 900, 40
+    X = O.fill_normal(101, (n, d)); lv = O.levels(102, n); ids = np.arange(n, dtype=np.uint64) * np.uint64(11) + np.uint64(5)
+    oh = O.Hnsw(d, O.COSINE, O.default_cfg(ef=33)); oh.insert_many(ids, X, lv)
+    rng = np.random.default_rng(7)
+    for i in rng.choice(n, 150, replace=False): oh.remove(ids[i])      # 20 % removals, as the reference test does
+    stream = oh.commit(header=True)
+    gh = gpu.Hnsw(d, O.COSINE)
+    assert gh.Load(stream, header=True) == len(oh) == n - 150
+    assert gh.cfg.ef == 33 and gh.Len() == n - 150
+    Q = O.fill_normal(103, (25, d))
+    gi, gs, gc = gh.Search(Q, 10, ef=60)
+    o2 = O.Hnsw(d, O.COSINE); assert o2.load_stream(stream) == 0          # same slot order as the GPU (stream order)
+    for qi in range(25):
+        wi, ws = o2.search(Q[qi], 10, mode=1, ef=60)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
+    # GPU -> stream -> oracle, and the stream is a fixed point of Commit(Load(.))
+    s2 = gh.Commit(header=True)
+    o3 = O.Hnsw(d, O.L2); assert o3.load_stream(s2) == 0
+    assert o3.graph_hash() == o2.graph_hash()
+    assert o2.commit(header=True) == s2
+    # a GPU-built index commits to a stream the oracle loads into the same graph
+    g2 = gpu.Hnsw(d, O.L2); xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    g2.InsertBatchDevice(xd.data_ptr(), n, lv, batch=1, ids=ids)
+    o4 = O.Hnsw(d, O.L2); o4.insert_many(ids, X, lv)
+    o5 = O.Hnsw(d, O.L2); assert o5.load_stream(g2.Commit()) == 0
+    o6 = O.Hnsw(d, O.L2); assert o6.load_stream(o4.commit()) == 0
+    assert o5.graph_hash() == o6.graph_hash()
+    # malformed input is an error, not a crash
+    with pytest.raises(gpu.ColttError):
+        gh.Load(stream[:len(stream) // 2])
+    with pytest.raises(gpu.ColttError):
+        gpu.Hnsw(d + 8, O.COSINE).Load(stream)
+    e = gpu.Hnsw(d, O.COSINE); assert e.Load(e.Commit()) == 0             # empty index round trip
