@@ -234,6 +234,37 @@ __global__ void init_group_kernel(uint32_t* cnt, uint32_t* thr, uint32_t* overfl
   if (q == 0) *overflow = 0;
 }
 
+
+// stored codes of the edge .vertex stream (big-endian f32 / u16, raw u8) at arbitrary byte offsets -> rows
+template <int QUANT>
+__global__ void be_codes_kernel(const uint8_t* __restrict__ chunk, const uint64_t* __restrict__ offs, uint64_t m, int dim,
+                                uint8_t* __restrict__ rows, size_t stride, uint64_t slot_base) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * (uint64_t)dim) return;
+  uint64_t i = t / dim; int e = (int)(t - i * dim);
+  constexpr int EB = QUANT == Q_NONE ? 4 : (QUANT == Q_F8 ? 1 : 2);
+  const uint8_t* s = chunk + offs[i] + (size_t)e * EB;
+  uint8_t* d = rows + (slot_base + i) * stride + (size_t)e * EB;
+  if (EB == 4) { d[0] = s[3]; d[1] = s[2]; d[2] = s[1]; d[3] = s[0]; }
+  else if (EB == 2) { d[0] = s[1]; d[1] = s[0]; }
+  else d[0] = s[0];
+  if (e == 0) for (size_t b = (size_t)dim * EB; b < stride; b++) rows[(slot_base + i) * stride + b] = 0;
+}
+struct FBER {
+  const uint8_t* p; uint64_t n, i = 0; bool ok = true;
+  bool need(uint64_t k) { if (i + k > n) { ok = false; return false; } return true; }
+  uint8_t u8() { if (!need(1)) return 0; return p[i++]; }
+  uint16_t u16() { if (!need(2)) return 0; uint16_t v = (uint16_t)((p[i] << 8) | p[i + 1]); i += 2; return v; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v = 0; for (int k = 0; k < 4; k++) v = (v << 8) | p[i + k]; i += 4; return v; }
+  uint64_t u64() { if (!need(8)) return 0; uint64_t v = 0; for (int k = 0; k < 8; k++) v = (v << 8) | p[i + k]; i += 8; return v; }
+};
+struct FBEW {
+  uint8_t* p; uint64_t cap, n = 0;
+  void put(const void* s, size_t k) { if (p && n + k <= cap) std::memcpy(p + n, s, k); n += k; }
+  void u32(uint32_t v) { uint8_t b[4]; for (int i = 0; i < 4; i++) b[i] = (uint8_t)(v >> (8 * (3 - i))); put(b, 4); }
+  void u64(uint64_t v) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * (7 - i))); put(b, 8); }
+};
+
 // ---------------------------------------------------------------------------------------------------
 struct Flat : Object {
   uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
@@ -718,6 +749,114 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
   if (!slots.empty()) COLTT_HIP(hipMemcpyAsync(f->w_gather.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, f->stream));
   return flat_search_common(f.get(), queries, false, nq, k, select, COLTT_MODE_EXACT, f->w_gather.as<uint32_t>(), slots.size(),
                             out_ids, out_scores, out_counts, false);
+}
+
+
+/* LoadVertex (edge/none_vectorstore.go:425-516 and the f16/f8/bf16 twins) */
+int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, uint64_t* out_n, uint64_t* out_ids,
+                           uint64_t* out_meta_off, uint32_t* out_meta_len, uint64_t cap_n) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_load_vertex: unknown handle");
+  if (!buf && len) return fail(COLTT_E_INVALID, "flat_load_vertex: NULL buffer");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  FBER r{buf, len};
+  const size_t eb = quant_bytes(f->quant);
+  std::vector<uint64_t> ids, voff, moff; std::vector<uint32_t> mlen;
+  for (int s = 0; s < 16 && r.ok; s++) {
+    uint64_t cnt = r.u64();
+    for (uint64_t i = 0; i < cnt && r.ok; i++) {
+      ids.push_back(r.u64());
+      uint32_t vl = r.u32();
+      if (r.ok && vl != f->dim) return fail(COLTT_E_INVALID, "Dim Length UnmatchdError: expect dimension: [%u], but got [%u]", f->dim, vl);
+      voff.push_back(r.i); r.need((uint64_t)vl * eb); r.i += (uint64_t)vl * eb;
+      uint64_t m0 = r.i; uint32_t mc = r.u32();
+      for (uint32_t m = 0; m < mc && r.ok; m++) {
+        uint16_t kl = r.u16(); r.need(kl); r.i += kl; uint8_t tag = r.u8();
+        if (tag == 0 || tag == 2) { r.need(8); r.i += 8; } else if (tag == 1) { uint16_t sl = r.u16(); r.need(sl); r.i += sl; }
+        else if (tag == 3) { r.need(1); r.i += 1; } else return fail(COLTT_E_INVALID, "unsupported metadata type tag: %d", (int)tag);
+      }
+      moff.push_back(m0); mlen.push_back((uint32_t)(r.i - m0));
+    }
+  }
+  if (!r.ok) return fail(COLTT_E_INVALID, "flat_load_vertex: truncated stream");
+  const uint64_t n = ids.size();
+  // replace the store's content (LoadVertex swaps the shard maps in, none_vectorstore.go:510-515)
+  f->n = 0; f->id2slot.clear(); f->h_ids.clear(); f->dense = false;
+  f->id2slot.reserve(n * 2);
+  for (uint64_t i = 0; i < n; i++) if (!f->id2slot.emplace(ids[i], (uint32_t)i).second) return fail(COLTT_E_INVALID, "flat_load_vertex: duplicate key in stream");
+  f->h_ids = ids;
+  COLTT_TRY(f->reserve(std::max<uint64_t>(n, 1)));
+  COLTT_TRY(f->ids.reserve(std::max<uint64_t>(f->cap, 1024) * 8, false, f->stream));
+  if (n) {
+    COLTT_HIP(hipMemcpyAsync(f->ids.p, ids.data(), n * 8, hipMemcpyHostToDevice, f->stream));
+    const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)f->dim * eb));
+    DevBuf d_chunk, d_offs;
+    for (uint64_t b = 0; b < n; b += rows_per) {
+      uint64_t m = std::min<uint64_t>(rows_per, n - b);
+      uint64_t lo = voff[b], hi = voff[b + m - 1] + (uint64_t)f->dim * eb;
+      std::vector<uint64_t> rel(m);
+      for (uint64_t i = 0; i < m; i++) rel[i] = voff[b + i] - lo;
+      COLTT_TRY(d_chunk.reserve(hi - lo)); COLTT_TRY(d_offs.reserve(m * 8));
+      COLTT_HIP(hipMemcpyAsync(d_chunk.p, buf + lo, hi - lo, hipMemcpyHostToDevice, f->stream));
+      COLTT_HIP(hipMemcpyAsync(d_offs.p, rel.data(), m * 8, hipMemcpyHostToDevice, f->stream));
+      uint32_t grid = ceil_div(m * f->dim, 256);
+      uint8_t* R = f->rows.as<uint8_t>();
+      if (f->quant == COLTT_Q_NONE) { be_codes_kernel<Q_NONE><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
+        row_norms_kernel<Q_NONE><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
+      else if (f->quant == COLTT_Q_F8) { be_codes_kernel<Q_F8><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
+        row_norms_kernel<Q_F8><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
+      else { be_codes_kernel<Q_F16><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
+        row_norms_kernel<Q_F16><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
+      COLTT_HIP(hipGetLastError());
+      COLTT_HIP(hipStreamSynchronize(f->stream));
+    }
+  }
+  f->n = n;
+  if (out_n) *out_n = n;
+  for (uint64_t i = 0; i < n && i < cap_n; i++) {
+    if (out_ids) out_ids[i] = ids[i];
+    if (out_meta_off) out_meta_off[i] = moff[i];
+    if (out_meta_len) out_meta_len[i] = mlen[i];
+  }
+  return COLTT_OK;
+}
+
+/* SaveVertex (edge/none_vectorstore.go:308-423 and twins).  meta_blobs[slot] = {u32 metaCount, typed pairs} or NULL. */
+int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uint8_t* const* meta_blobs, const uint32_t* meta_lens,
+                           uint64_t n_meta, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_save_vertex: unknown handle");
+  if (!out_len) return fail(COLTT_E_INVALID, "flat_save_vertex: out_len is NULL");
+  std::lock_guard<std::mutex> g(f->mu);
+  COLTT_TRY(ensure_device());
+  const size_t eb = quant_bytes(f->quant);
+  std::unordered_map<uint64_t, uint64_t> meta_of;
+  for (uint64_t i = 0; i < n_meta; i++) if (meta_ids && meta_blobs && meta_blobs[i] && meta_lens[i] >= 4) meta_of[meta_ids[i]] = i;
+  auto id_of = [&](uint64_t s) { return f->dense ? f->dense_base + s : f->h_ids[s]; };
+  // canonical order: shard 0..15 (FNV ShardVertex), ascending id inside (Go iterates its maps in random order)
+  std::vector<std::vector<std::pair<uint64_t, uint32_t>>> shards(16);
+  for (uint64_t s = 0; s < f->n; s++) shards[shard_vertex(id_of(s), 16)].push_back({id_of(s), (uint32_t)s});
+  for (auto& sh : shards) std::sort(sh.begin(), sh.end());
+  std::vector<uint8_t> all;
+  if (out && f->n) { all.resize(f->n * (size_t)f->dim * eb);
+    COLTT_HIP(hipMemcpy2D(all.data(), (size_t)f->dim * eb, f->rows.p, f->stride, (size_t)f->dim * eb, f->n, hipMemcpyDeviceToHost)); }
+  FBEW w{out, out ? cap : 0};
+  for (auto& sh : shards) {
+    w.u64(sh.size());
+    for (auto& e : sh) {
+      w.u64(e.first); w.u32(f->dim);
+      if (out) {
+        const uint8_t* p = all.data() + (size_t)e.second * f->dim * eb;
+        for (uint32_t k = 0; k < f->dim; k++) { uint8_t b[4]; for (size_t j = 0; j < eb; j++) b[j] = p[k * eb + (eb - 1 - j)]; w.put(b, eb); }
+      } else w.n += (uint64_t)f->dim * eb;
+      auto it = meta_of.find(e.first);
+      if (it != meta_of.end()) w.put(meta_blobs[it->second], meta_lens[it->second]); else w.u32(0);
+    }
+  }
+  *out_len = w.n;
+  if (out && w.n > cap) return fail(COLTT_E_INVALID, "flat_save_vertex: buffer too small");
+  return COLTT_OK;
 }
 
 int coltt_last_kernel_ms_flat(coltt_handle_t h, float* out_ms) {

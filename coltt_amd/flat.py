@@ -92,6 +92,20 @@ class FlatSpace:
                                               C.c_size_t(len(cand)), L.vp(ids), L.vp(sc), L.vp(cnt)))
         return ids, sc, cnt
 
+    # -- SaveVertex / LoadVertex (edge/none_vectorstore.go:308-516)
+    def SaveVertex(self):
+        n = C.c_uint64(0)
+        L.check(L.lib().coltt_flat_save_vertex(self.h, None, None, None, C.c_uint64(0), None, C.c_uint64(0), C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        L.check(L.lib().coltt_flat_save_vertex(self.h, None, None, None, C.c_uint64(0), L.vp(buf), C.c_uint64(n.value), C.byref(n)))
+        return buf.tobytes()
+
+    def LoadVertex(self, data):
+        b = np.frombuffer(data, np.uint8)
+        n = C.c_uint64(0)
+        L.check(L.lib().coltt_flat_load_vertex(self.h, L.vp(b), C.c_uint64(len(b)), C.byref(n), None, None, None, C.c_uint64(0)))
+        return n.value
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

@@ -101,6 +101,16 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
                           const uint64_t* cand_ids, size_t n_cand,
                           uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
 
+/* SaveVertex / LoadVertex (edge/none_vectorstore.go:308-516; f16_vectorstore.go:317-532 and the f8/bf16 twins): 16 shards
+ * x {u64 count, count x {u64 key, u32 vecLen, vecLen x big-endian STORED code (f32 | u16 | u8), u32 metaCount, typed
+ * pairs}}.  Vector codes go straight into the HBM rows (byte-swapped on the device, no re-normalisation); metadata is
+ * opaque to the library: load reports each vertex's blob position in buf, save re-emits the blobs the caller passes
+ * (meta_ids[i] -> meta_blobs[i], each starting with its u32 metaCount; others are written as empty maps). */
+int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, uint64_t* out_n, uint64_t* out_ids,
+                           uint64_t* out_meta_off, uint32_t* out_meta_len, uint64_t cap_n);
+int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uint8_t* const* meta_blobs,
+                           const uint32_t* meta_lens, uint64_t n_meta, uint8_t* out, uint64_t cap, uint64_t* out_len);
+
 /* ---- core HNSW: replaces *vectorindex.Hnsw (core/vectorindex/hnsw.go:43-54) --------------------- */
 typedef struct coltt_hnsw_cfg {       /* hnswConfig defaults: hnsw_config.go:135-162 */
   int32_t m;                          /* 16 */

@@ -977,6 +977,55 @@ static int hnsw_load(Hnsw* h, bool header, const uint8_t* buf, size_t len) {
   return r.ok ? 0 : -1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// edge SaveVertex / LoadVertex (edge/none_vectorstore.go:308-516; f16_vectorstore.go:317-532; f8/bf16 twins):
+//   16 shards x { u64 count, count x { u64 key, u32 vecLen, vecLen x elem (BE f32 | u16 | u8 = the STORED codes),
+//                                      u32 metaCount, metaCount x { u16 keylen, key, u8 tag, value } } }
+//   tag 0 int64 BE, 1 {u16 len, bytes}, 2 float64 BE, 3 u8 bool.  Metadata is carried as an opaque blob here.
+// Canonical order: shard 0..15, ascending id inside (std::map order).
+// ------------------------------------------------------------------------------------------------
+static void flat_save(const Flat* f, std::vector<uint8_t>& out) {
+  BEWriter w{out};
+  for (int s = 0; s < 16; s++) {
+    w.u64(f->shards[s].size());
+    for (auto& kv : f->shards[s]) {
+      w.u64(kv.first); w.u32(f->dim);
+      const uint8_t* p = kv.second.data();
+      for (uint32_t e = 0; e < f->dim; e++) {
+        if (f->quant == Q_NONE) { uint32_t u; std::memcpy(&u, p + 4 * e, 4); w.u32(u); }
+        else if (f->quant == Q_F8) w.u8(p[e]);
+        else { uint16_t u; std::memcpy(&u, p + 2 * e, 2); w.u16(u); }
+      }
+      w.u32(0);  // empty metadata map
+    }
+  }
+}
+static int flat_load(Flat* f, const uint8_t* buf, size_t len) {
+  BEReader r{buf, len};
+  for (auto& s : f->shards) s.clear();
+  for (int s = 0; s < 16; s++) {
+    uint64_t cnt = r.u64();
+    for (uint64_t i = 0; i < cnt && r.ok; i++) {
+      uint64_t key = r.u64(); uint32_t vl = r.u32();
+      if (vl != f->dim) return -1;
+      std::vector<uint8_t> codes((size_t)f->dim * quant_bytes(f->quant));
+      for (uint32_t e = 0; e < vl; e++) {
+        if (f->quant == Q_NONE) { uint32_t u = r.u32(); std::memcpy(codes.data() + 4 * e, &u, 4); }
+        else if (f->quant == Q_F8) codes[e] = r.u8();
+        else { uint16_t u = r.u16(); std::memcpy(codes.data() + 2 * e, &u, 2); }
+      }
+      uint32_t mc = r.u32();
+      for (uint32_t m = 0; m < mc && r.ok; m++) {
+        uint16_t kl = r.u16(); r.need(kl); r.i += kl; uint8_t tag = r.u8();
+        if (tag == 0 || tag == 2) { r.need(8); r.i += 8; } else if (tag == 1) { uint16_t sl = r.u16(); r.need(sl); r.i += sl; } else if (tag == 3) { r.need(1); r.i += 1; } else return -1;
+      }
+      f->shards[s][key] = std::move(codes);  // LoadVertex keeps the shard of the stream, not a re-hash (none_vectorstore.go:505-513)
+    }
+  }
+  return r.ok ? 0 : -1;
+}
+
 static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -1090,6 +1139,14 @@ int orc_flat_search(void* h, const float* query, int topK, int nearest, int mode
                     size_t n_cand, int use_cand, uint64_t* out_ids, float* out_scores) {
   return flat_search((Flat*)h, query, topK, nearest, mode, use_cand != 0, cand, n_cand, out_ids, out_scores);
 }
+
+
+int64_t orc_flat_save(void* h, uint8_t* out, uint64_t cap) {
+  std::vector<uint8_t> b; flat_save((Flat*)h, b);
+  if (out && cap >= b.size()) std::memcpy(out, b.data(), b.size());
+  return (int64_t)b.size();
+}
+int orc_flat_load(void* h, const uint8_t* buf, uint64_t len) { return flat_load((Flat*)h, buf, len); }
 
 // ---- HNSW ----
 void* orc_hnsw_create(uint32_t dim, int metric, int order, const HnswCfg* cfg) {

@@ -237,6 +237,18 @@ class Flat:
         o = np.empty(self.dim, QUANT_DTYPE[self.quant])
         return o if lib().orc_flat_get(self.h, C.c_uint64(int(id_)), _p(o)) == 0 else None
 
+    def save_vertex(self):
+        """SaveVertex (edge/none_vectorstore.go:308-423) -> bytes"""
+        lib().orc_flat_save.restype = C.c_int64
+        n = lib().orc_flat_save(self.h, None, C.c_uint64(0))
+        buf = np.empty(n, np.uint8); lib().orc_flat_save(self.h, _p(buf), C.c_uint64(n))
+        return buf.tobytes()
+
+    def load_vertex(self, data):
+        """LoadVertex (edge/none_vectorstore.go:425-516)"""
+        b = np.frombuffer(data, np.uint8)
+        return lib().orc_flat_load(self.h, _p(b), C.c_uint64(len(b)))
+
     def search(self, query, k, nearest=False, mode=2, cand=None):
         """mode 0 literal (highCpu=false), 1 literal (highCpu=true), 2 canonical (score,id) order."""
         q = _f32(query)

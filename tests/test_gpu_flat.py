@@ -155,3 +155,27 @@ def test_flat_mfma_large_dims(gpu):
             ei, es, ec = gf.VertexSearch(Q, k, select, gpu.MODE_EXACT)
             mi, ms, mc = gf.VertexSearch(Q, k, select, gpu.MODE_MFMA)
             assert np.array_equal(ei, mi) and np.array_equal(bits(es), bits(ms)), (d, k, select)
+
+
+@pytest.mark.parametrize("quant", [O.Q_NONE, O.Q_F16, O.Q_F8, O.Q_BF16])
+def test_flat_save_load_vertex_streams(gpu, quant):
+    """SaveVertex / LoadVertex: the GPU store writes the byte-identical stream the oracle writes (canonical shard/id order),
+    and loads the oracle's stream into a store that answers identically."""
+    n, d = 700, 24
+    X = O.fill_normal(41, (n, d)); ids = (np.arange(n, dtype=np.uint64) * np.uint64(977) + np.uint64(13)) % np.uint64(1 << 30)
+    of = O.Flat(d, O.COSINE, quant); of.upsert(ids, X)
+    gf = gpu.FlatSpace(d, O.COSINE, quant); gf.ChangedVertex(ids, X)
+    stream = of.save_vertex()
+    assert gf.SaveVertex() == stream
+    g2 = gpu.FlatSpace(d, O.COSINE, quant)
+    assert g2.LoadVertex(stream) == n and g2.LoadSize() == n
+    assert g2.SaveVertex() == stream
+    Q = O.fill_normal(42, (9, d))
+    a = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST); b = g2.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    o2 = O.Flat(d, O.COSINE, quant); assert o2.load_vertex(stream) == 0
+    wi, ws = o2.search(Q[0], 10, nearest=True, mode=2)
+    assert_same_results(b[0][0], b[1][0], wi, ws)
+    with pytest.raises(gpu.ColttError):
+        g2.LoadVertex(stream[:-3])
+    assert gpu.FlatSpace(d, O.COSINE, quant).LoadVertex(gpu.FlatSpace(d, O.COSINE, quant).SaveVertex()) == 0
