@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--vectors", dest="n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--queries", type=int, default=10_000, help="queries per step (per rank)")
     ap.add_argument("--k", type=int, default=10)
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--seed", type=int, default=0xC0177)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device exist only to smoke-test the N>1 plumbing on a 1-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (plumbing test only)")
     ap.add_argument("--dataset", default="normal",
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R = x = A z, z ~ N(0, I_R) "
                          "(structured data with intrinsic dimension R, where recall is meaningful)")
@@ -115,10 +117,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
     import coltt_amd as G
     L = G.lib()
     assert L.coltt_init(local) == 0, L.coltt_last_error()
@@ -145,7 +153,7 @@ def main():
         st = h.SearchDevice(q.data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
         if shard:
             gid = out_ids * world + rank  # shard-local id -> collection id (ids with id % world == rank live here)
-            gi, gs, gc = D.allgather_topk(gid, out_sc, out_cnt)      # ONE RCCL all-gather per tensor over xGMI
+            gi, gs, gc = D.allgather_topk(gid.to(cdev), out_sc.to(cdev), out_cnt.to(cdev))  # ONE RCCL all-gather per tensor over xGMI
             if rank == 0:                                             # host-side final merge (north star)
                 merged.append(D.merge_topk(gi.cpu().numpy().astype(np.uint64), gs.cpu().numpy(), gc.cpu().numpy(), k, True))
         return st
@@ -169,7 +177,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_q = args.steps * nq * (1 if shard else world)

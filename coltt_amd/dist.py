@@ -32,17 +32,35 @@ def shard_mask(ids, rank, world, how="fnv"):
 
 def merge_topk(ids, scores, counts, k, nearest=True):
     """k-way merge of per-shard results.  ids/scores: [world, nq, k]; counts: [world, nq].  Canonical (score, id) order;
-    nearest=False keeps the K LARGEST (the reference FLAT direction), output ascending either way."""
-    ids = np.asarray(ids); scores = np.asarray(scores); counts = np.asarray(counts)
+    nearest=False keeps the K LARGEST (the reference FLAT direction), output ascending either way.  Vectorised over queries."""
+    ids = np.asarray(ids).astype(np.uint64); scores = np.asarray(scores, dtype=np.float32); counts = np.asarray(counts)
     world, nq, kk = ids.shape
-    out_i = np.zeros((nq, k), np.uint64); out_s = np.zeros((nq, k), np.float32); out_c = np.zeros(nq, np.uint32)
-    for q in range(nq):
-        ci = np.concatenate([ids[r, q, :counts[r, q]] for r in range(world)]).astype(np.uint64)
-        cs = np.concatenate([scores[r, q, :counts[r, q]] for r in range(world)]).astype(np.float32)
-        order = np.lexsort((ci, cs))            # ascending by (score, id)
-        sel = order[:k] if nearest else order[max(0, len(order) - k):]
-        n = len(sel)
-        out_i[q, :n] = ci[sel]; out_s[q, :n] = cs[sel]; out_c[q] = n
+    ci = np.transpose(ids, (1, 0, 2)).reshape(nq, world * kk)
+    cs = np.transpose(scores, (1, 0, 2)).reshape(nq, world * kk).astype(np.float64)
+    valid = (np.arange(kk)[None, None, :] < counts[:, :, None])
+    valid = np.transpose(valid, (1, 0, 2)).reshape(nq, world * kk)
+    # invalid slots sort to the far end of whichever side is NOT selected
+    cs = np.where(valid, cs, np.inf if nearest else -np.inf)
+    order = np.lexsort((ci, cs), axis=1)            # ascending by (score, id) per row
+    n_valid = valid.sum(axis=1)
+    out_c = np.minimum(n_valid, k).astype(np.uint32)
+    if nearest:
+        sel = order[:, :k]
+    else:
+        sel = order[:, max(0, world * kk - k):]
+    out_i = np.take_along_axis(ci, sel, 1); out_s = np.take_along_axis(cs, sel, 1).astype(np.float32)
+    if sel.shape[1] < k:
+        pad = k - sel.shape[1]
+        out_i = np.pad(out_i, ((0, 0), (0, pad))); out_s = np.pad(out_s, ((0, 0), (0, pad)))
+    if not nearest:  # rows with fewer than k valid entries: shift the valid tail to the front
+        short = np.nonzero(n_valid < k)[0]
+        for q in short:
+            c = int(n_valid[q]); w = out_i.shape[1]
+            vi = out_i[q, w - c:].copy() if c else out_i[q, :0]; vs = out_s[q, w - c:].copy() if c else out_s[q, :0]
+            out_i[q, :] = 0; out_s[q, :] = 0; out_i[q, :c] = vi; out_s[q, :c] = vs
+    else:
+        mask = np.arange(out_i.shape[1])[None, :] >= out_c[:, None]
+        out_i[mask] = 0; out_s[mask] = 0
     return out_i, out_s, out_c
 
 
