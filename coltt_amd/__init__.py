@@ -10,4 +10,5 @@ from ._lib import (COSINE, EUCLIDEAN, Q_NONE, Q_F16, Q_F8, Q_BF16, SELECT_REFERE
                    MODE_EXACT, MODE_MFMA, ColttError, lib, lib_path, declared_symbols)
 from .flat import FlatSpace  # noqa: F401
 from .hnsw import Hnsw, HnswCfg  # noqa: F401
+from .cflat import MultiVectorSpace  # noqa: F401
 from . import kernels  # noqa: F401

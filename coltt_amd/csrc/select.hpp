@@ -1,0 +1,133 @@
+// select.hpp — top-k selection shared by the FLAT and CFLAT stores.
+#pragma once
+#include "exact.hpp"
+
+namespace coltt {
+namespace dev {
+
+constexpr uint32_t K_MAX = 2048;  // largest top-k served by flat_select's LDS rank sort
+
+// ---------------------------------------------------------------------------------------------------
+// Selection: the bounded queue + ToSlice of edge.PriorityQueue (edge/priority_queue.go:39-69) in closed
+// form.  REFERENCE keeps the K LARGEST (score,id) keys, NEAREST the K smallest; output ascending.
+// One block per query: radix-select on the score key (4 x 8 bits), a second radix-select on the id among
+// boundary ties only when they do not all fit, then an LDS rank sort of the <= K survivors.
+// ---------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ uint64_t slot_id(const uint64_t* ids, uint64_t dense_base, uint32_t slot) {
+  return ids ? ids[slot] : dense_base + slot;
+}
+
+static __global__ __launch_bounds__(256) void flat_select_kernel(
+    unsigned long long* __restrict__ cand_all, uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all,
+    uint32_t cap, uint32_t k, int nearest, const uint64_t* __restrict__ ids, uint64_t dense_base,
+    uint32_t* __restrict__ overflow, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+    uint32_t* __restrict__ out_counts) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sel_key[K_MAX];
+  __shared__ uint32_t sel_slot[K_MAX];
+  __shared__ uint64_t sel_id[K_MAX];
+  __shared__ uint32_t s_digit, s_need, s_nsel;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  unsigned long long* cand = cand_all + (size_t)q * cap;
+  uint32_t c = cnt_all[q];
+  if (c > cap) { if (tid == 0) atomicOr(overflow, 1u); c = cap; }
+  const uint32_t kk = k < c ? k : c;
+  if (kk == 0) {
+    if (tid == 0) { out_counts[q] = 0; cnt_all[q] = 0; thr_all[q] = nearest ? 0xffffffffu : 0u; }
+    return;
+  }
+  const uint32_t flip = nearest ? 0u : 0xffffffffu;  // key' = key ^ flip : we want the kk smallest key'
+  // ---- pass 1: radix-select the kk-th smallest key'
+  uint32_t prefix = 0, mask = 0, need = kk;
+  for (int pass = 3; pass >= 0; pass--) {
+    const int shift = pass * 8;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < c; i += 256) {
+      uint32_t kp = (uint32_t)(cand[i] >> 32) ^ flip;
+      if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cum = 0, b = 0;
+      for (; b < 256; b++) { if (cum + hist[b] >= need) break; cum += hist[b]; }
+      s_digit = b; s_need = need - cum;
+    }
+    __syncthreads();
+    prefix |= s_digit << shift; mask |= 255u << shift; need = s_need;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;            // boundary key'
+  const uint32_t ties = hist[s_digit];  // elements with key' == T (last pass histogram)
+  // ---- boundary ties that do not all fit: radix-select on id' among them
+  const uint64_t idflip = nearest ? 0ull : ~0ull;
+  uint64_t idT = ~0ull;  // take ties with id' <= idT
+  if (ties > need) {
+    uint64_t ipre = 0, imask = 0; uint32_t ineed = need;
+    for (int pass = 7; pass >= 0; pass--) {
+      const int shift = pass * 8;
+      __syncthreads();
+      hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < c; i += 256) {
+        unsigned long long e = cand[i];
+        if (((uint32_t)(e >> 32) ^ flip) != T) continue;
+        uint64_t ip = slot_id(ids, dense_base, (uint32_t)e) ^ idflip;
+        if ((ip & imask) == ipre) atomicAdd(&hist[(ip >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0, b = 0;
+        for (; b < 256; b++) { if (cum + hist[b] >= ineed) break; cum += hist[b]; }
+        s_digit = b; s_need = ineed - cum;
+      }
+      __syncthreads();
+      ipre |= (uint64_t)s_digit << shift; imask |= 255ull << shift; ineed = s_need;
+    }
+    idT = ipre;
+  }
+  // ---- gather the survivors
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < c; i += 256) {
+    unsigned long long e = cand[i];
+    uint32_t kp = (uint32_t)(e >> 32) ^ flip;
+    if (kp > T) continue;
+    uint64_t ip = slot_id(ids, dense_base, (uint32_t)e) ^ idflip;
+    if (kp == T && ip > idT) continue;
+    uint32_t j = atomicAdd(&s_nsel, 1u);
+    if (j < K_MAX) { sel_key[j] = kp; sel_slot[j] = (uint32_t)e; sel_id[j] = ip; }
+  }
+  __syncthreads();
+  const uint32_t ns = s_nsel < kk ? s_nsel : kk;  // == kk by construction
+  // ---- rank sort by (key', id'); emit ascending by (score, id)
+  for (uint32_t i = tid; i < ns; i += 256) {
+    uint32_t ki = sel_key[i]; uint64_t ii = sel_id[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < ns; j++) {
+      uint32_t kj = sel_key[j]; uint64_t ij = sel_id[j];
+      rank += (kj < ki) || (kj == ki && ij < ii);
+    }
+    uint32_t pos = nearest ? rank : (ns - 1 - rank);
+    uint32_t key = ki ^ flip;
+    out_ids[(size_t)q * k + pos] = ii ^ idflip;
+    out_scores[(size_t)q * k + pos] = key_score(key);
+    cand[pos] = ((unsigned long long)key << 32) | sel_slot[i];
+  }
+  if (tid == 0) {
+    out_counts[q] = ns; cnt_all[q] = ns;
+    thr_all[q] = (ns == k) ? (T ^ flip) : (nearest ? 0xffffffffu : 0u);
+  }
+}
+
+// group state: cnt[256] | thr[256] | overflow
+static __global__ void init_group_kernel(uint32_t* cnt, uint32_t* thr, uint32_t* overflow, int nearest) {
+  int q = threadIdx.x;
+  if (q < 256) { cnt[q] = 0; thr[q] = nearest ? 0xffffffffu : 0u; }
+  if (q == 0) *overflow = 0;
+}
+
+
+
+}  // namespace dev
+}  // namespace coltt

@@ -111,6 +111,18 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
 int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uint8_t* const* meta_blobs,
                            const uint32_t* meta_lens, uint64_t n_meta, uint8_t* out, uint64_t cap, uint64_t* out_len);
 
+/* ---- experimental CFLAT: multi-vector weighted FLAT scan (experimental/multi_vector_vertex.go:60-137) -------------
+ * A vertex carries n_fields f32 vectors ([n][n_fields][dim] on upload; every field is normalised for cosine, :65-67).
+ * MultiVertexSearch: score = sum over included fields of scoreHelper(Distance(node[f], q[f])) * (float32(ratio[f])/100)
+ * (:113-119); the K LARGEST scores are kept and returned DESCENDING by (score, id) (multi_priority_queue.go:46-77). */
+int coltt_cflat_create(uint32_t dim, int metric, uint32_t n_fields, coltt_handle_t* out);
+int coltt_cflat_destroy(coltt_handle_t h);
+int coltt_cflat_len(coltt_handle_t h, uint64_t* out);
+int coltt_cflat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n);
+int coltt_cflat_remove(coltt_handle_t h, const uint64_t* ids, size_t n);
+int coltt_cflat_search(coltt_handle_t h, const float* queries, const uint32_t* ratios, const uint8_t* include, size_t nq,
+                       uint32_t k, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+
 /* ---- core HNSW: replaces *vectorindex.Hnsw (core/vectorindex/hnsw.go:43-54) --------------------- */
 typedef struct coltt_hnsw_cfg {       /* hnswConfig defaults: hnsw_config.go:135-162 */
   int32_t m;                          /* 16 */

@@ -1026,6 +1026,45 @@ static int flat_load(Flat* f, const uint8_t* buf, size_t len) {
   return r.ok ? 0 : -1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// experimental CFLAT: multi-vector weighted FLAT scan (experimental/multi_vector_vertex.go:60-137)
+// ------------------------------------------------------------------------------------------------
+struct CFlat {
+  uint32_t dim, nf; int metric, order;
+  std::map<uint64_t, std::vector<float>> v;  // id -> nf * dim floats (normalised per field for cosine)
+};
+// scoreHelper (experimental, same as edge/edge_helper.go:143-148): cosine ((2-d)/2)*100 ; l2 float32(max(0, float64(100-d)))
+static inline float score_helper(float d, int metric) {
+  if (metric == METRIC_COS) return ((2.0f - d) / 2.0f) * 100.0f;
+  return (float)std::fmax(0.0, (double)(100.0f - d));
+}
+// MultiVertexSearch (multi_vector_vertex.go:85-137): score = sum over included fields of scoreHelper(Distance(node, q)) *
+// (float32(ratio)/100); the queue keeps the K LARGEST scores (min-heap + pop-min — correct for a similarity) and ToSlice
+// sorts DESCENDING (experimental/multi_priority_queue.go:54-77).  Canonical tie order: (score, id) descending.
+static int cflat_search(const CFlat* c, const float* q /*nf*dim*/, const uint32_t* ratio, const uint8_t* include, int topK,
+                        uint64_t* out_ids, float* out_scores) {
+  std::vector<float> qn((size_t)c->nf * c->dim);
+  for (uint32_t f = 0; f < c->nf; f++) {
+    if (include[f] && c->metric == METRIC_COS) normalize(q + (size_t)f * c->dim, qn.data() + (size_t)f * c->dim, c->dim);
+    else std::memcpy(qn.data() + (size_t)f * c->dim, q + (size_t)f * c->dim, c->dim * 4);
+  }
+  std::vector<Scored> all;
+  for (auto& kv : c->v) {
+    float score = 0.f;
+    for (uint32_t f = 0; f < c->nf; f++) {
+      if (!include[f]) continue;
+      float sim = dist(c->metric, c->order, kv.second.data() + (size_t)f * c->dim, qn.data() + (size_t)f * c->dim, c->dim);
+      score += score_helper(sim, c->metric) * ((float)ratio[f] / 100.0f);
+    }
+    all.push_back({score, kv.first});
+  }
+  std::sort(all.begin(), all.end(), scored_less);
+  size_t n = all.size(), k = std::min((size_t)std::max(topK, 0), n);
+  for (size_t i = 0; i < k; i++) { out_ids[i] = all[n - 1 - i].tie; out_scores[i] = all[n - 1 - i].score; }
+  return (int)k;
+}
+
 static inline uint64_t fnv_mix(uint64_t h, const void* p, size_t n) {
   const uint8_t* b = (const uint8_t*)p;
   for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
@@ -1147,6 +1186,27 @@ int64_t orc_flat_save(void* h, uint8_t* out, uint64_t cap) {
   return (int64_t)b.size();
 }
 int orc_flat_load(void* h, const uint8_t* buf, uint64_t len) { return flat_load((Flat*)h, buf, len); }
+
+
+void* orc_cflat_create(uint32_t dim, int metric, uint32_t nf, int order) { CFlat* c = new CFlat(); c->dim = dim; c->nf = nf; c->metric = metric; c->order = order; return c; }
+void orc_cflat_destroy(void* h) { delete (CFlat*)h; }
+// ChangedVertex (multi_vector_vertex.go:60-75): every field is normalised for cosine
+int orc_cflat_upsert(void* h, const uint64_t* ids, const float* vecs, size_t n) {
+  CFlat* c = (CFlat*)h; size_t per = (size_t)c->nf * c->dim;
+  for (size_t i = 0; i < n; i++) {
+    std::vector<float> row(per);
+    for (uint32_t f = 0; f < c->nf; f++) {
+      const float* src = vecs + i * per + (size_t)f * c->dim;
+      if (c->metric == METRIC_COS) normalize(src, row.data() + (size_t)f * c->dim, c->dim); else std::memcpy(row.data() + (size_t)f * c->dim, src, c->dim * 4);
+    }
+    c->v[ids[i]] = std::move(row);
+  }
+  return 0;
+}
+int orc_cflat_remove(void* h, const uint64_t* ids, size_t n) { CFlat* c = (CFlat*)h; for (size_t i = 0; i < n; i++) c->v.erase(ids[i]); return 0; }
+int orc_cflat_search(void* h, const float* q, const uint32_t* ratio, const uint8_t* include, int topK, uint64_t* out_ids, float* out_scores) {
+  return cflat_search((CFlat*)h, q, ratio, include, topK, out_ids, out_scores);
+}
 
 // ---- HNSW ----
 void* orc_hnsw_create(uint32_t dim, int metric, int order, const HnswCfg* cfg) {

@@ -261,6 +261,32 @@ class Flat:
         return ids[:n].copy(), sc[:n].copy()
 
 
+class CFlat:
+    """experimental multiVectorVertex restated (experimental/multi_vector_vertex.go:60-137)."""
+
+    def __init__(self, dim, n_fields, metric=COSINE, order=ORDER_AVX):
+        self.dim, self.nf = dim, n_fields
+        lib().orc_cflat_create.restype = _vp
+        self.h = _vp(lib().orc_cflat_create(dim, metric, n_fields, order))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_cflat_destroy(self.h); self.h = None
+
+    def upsert(self, ids, vecs):
+        ids = np.ascontiguousarray(ids, np.uint64); vecs = _f32(vecs).reshape(len(ids), self.nf, self.dim)
+        lib().orc_cflat_upsert(self.h, _p(ids), _p(vecs), C.c_size_t(len(ids)))
+
+    def remove(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint64); lib().orc_cflat_remove(self.h, _p(ids), C.c_size_t(len(ids)))
+
+    def search(self, q, ratios, include, k):
+        q = _f32(q).reshape(self.nf, self.dim); r = np.ascontiguousarray(ratios, np.uint32); inc = np.ascontiguousarray(include, np.uint8)
+        ids = np.empty(max(k, 1), np.uint64); sc = np.empty(max(k, 1), np.float32)
+        n = lib().orc_cflat_search(self.h, _p(q), _p(r), _p(inc), int(k), _p(ids), _p(sc))
+        return ids[:n].copy(), sc[:n].copy()
+
+
 # ------------------------------------------------------------------ HNSW
 class Hnsw:
     """core/vectorindex.Hnsw restated (core/vectorindex/hnsw.go)."""
