@@ -320,7 +320,11 @@ SearchGeom search_geom(const Hnsw* x, uint32_t ef) {
   s.ef_pad = (ef + 63) & ~63u;
   // visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
   s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
-  s.lds = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8 + (size_t)s.hcap * 4;
+  auto total = [&]() { return (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8 + (size_t)s.hcap * 4; };
+  // large ef x dim: shrink the visited set until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps
+  // results exact; it needs 0.75 * hcap > ef + 64)
+  while (total() > 160 * 1024 && s.hcap > 4096 && (s.hcap / 2) * 3 / 4 > ef + 64) s.hcap /= 2;
+  s.lds = total();
   return s;
 }
 

@@ -231,3 +231,38 @@ def test_hnsw_commit_load_streams(gpu):
     with pytest.raises(gpu.ColttError):
         gpu.Hnsw(d + 8, O.COSINE).Load(stream)
     e = gpu.Hnsw(d, O.COSINE); assert e.Load(e.Commit()) == 0             # empty index round trip
+
+
+def test_hnsw_ragged_dim_large_ef_and_k_above_ef(gpu):
+    """dim not a multiple of 8 (scalar tail of the AVX kernels), ef = 1024 (largest LDS geometry), k > cfg.ef (ef = max(ef, k))."""
+    n, d = 2500, 20
+    X, ids, oh = oracle_index(n, d, O.COSINE, seed=111)
+    gh = gpu.Hnsw(d, O.COSINE); gh.BulkLoad(oh.export(with_vectors=False), X)
+    Q = O.fill_normal(112, (12, d))
+    for k, ef in ((10, 1024), (300, 20), (5, 7)):
+        gi, gs, gc, st = gh.Search(Q, k, ef=ef, with_stats=True)
+        assert st["n_visit_resets"] == 0
+        for qi in range(len(Q)):
+            wi, ws = oh.search(Q[qi], k, mode=1, ef=ef)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} k{k} ef{ef}")
+
+
+def test_hnsw_visited_set_reset_keeps_results_exact(gpu):
+    """ef = 3000 on a small dense graph: the bounded visited set (16384 slots here) is reset-and-reseeded; results stay exact."""
+    n, d = 60000, 8
+    X = O.fill_normal(121, (n, d)); lv = O.levels(122, n); ids = np.arange(n, dtype=np.uint64)
+    import torch
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    gh = gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(ef_construction=40))
+    i = 0
+    while i < n:
+        b = max(1, min(2048, i // 16)); b = min(b, n - i)
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i); i += b
+    g = gh.Export(); g["vectors"] = X
+    oh = O.Hnsw(d, O.L2, O.default_cfg(efConstruction=40)); oh.load(g)
+    Q = O.fill_normal(123, (6, d))
+    gi, gs, gc, st = gh.Search(Q, 10, ef=3000, with_stats=True)
+    for qi in range(len(Q)):
+        wi, ws = oh.search(Q[qi], 10, mode=1, ef=3000)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
+    assert st["n_visit_resets"] > 0, st
