@@ -203,7 +203,7 @@ int coltt_cflat_search(coltt_handle_t h, const float* queries, const uint32_t* r
   for (size_t qi = 0; qi < nq; qi++) {
     COLTT_HIP(hipMemcpyAsync(c->w_raw.p, queries + qi * per, per * 4, hipMemcpyHostToDevice, c->stream));
     // included fields are normalised for cosine (multi_vector_vertex.go:96-100); excluded ones are never read
-    prep_queries_kernel<Q_NONE><<<1, 64, 0, c->stream>>>(c->w_raw.as<float>(), c->nf, (int)c->dim, c->metric == COLTT_COSINE, c->w_q.as<float>());
+    launch_prep_queries<Q_NONE>(c->stream, c->w_raw.as<float>(), c->nf, (int)c->dim, c->metric == COLTT_COSINE, c->w_q.as<float>());
     query_norms_kernel<<<1, 64, 0, c->stream>>>(c->w_q.as<float>(), c->nf, (int)c->dim, c->w_qn.as<float>());
     init_group_kernel<<<1, 256, 0, c->stream>>>(cnt, thr, ovf, 0);
     auto scan = [&](uint64_t b, uint64_t e) {

@@ -51,6 +51,85 @@ __global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq
   q16[i] = q < nq ? (_Float16)q_eff[i] : (_Float16)0.f;
 }
 
+// ---- epilogue shared by both GEMM kernels -----------------------------------------------------------------------------
+// A lane holds, per 32x32 block, the dots of ONE query against 16 rows.  Testing every element costs ~6 VALU + a branch each,
+// and with two workgroups per CU little of that hides behind another wave's MFMAs.  So the block is filtered first: t_r = dot_r / ||row_r|| (= cos * ||q||), one max (or min/max) over the 16
+// values, ONE compare against a per-query bound that is the exact test loosened by MF_BLOCK_SLACK; only blocks that may
+// hold a survivor — rare once the threshold has tightened — run the exact per-element test.  Blocks containing a row whose
+// norm is zero / inf / NaN always take the element path (`bad`), so NaN scores still reach the exact re-score.
+constexpr float MF_BLOCK_SLACK = 1e-5f;
+
+struct QCol {            // per-lane constants of one query column
+  float iq, tf;          // 1/||q||, threshold on s~ (+-inf = everything / nothing passes)
+  float lo, hi;          // block bounds on t = cos*||q||: nearest: hit iff max t >= lo;  farthest: hit iff min t <= lo or max t >= hi
+  int qidx;
+};
+
+__device__ __forceinline__ QCol mf_query_col(int qidx, int nq, const float* __restrict__ qnorms, const uint32_t* __restrict__ thr, int nearest) {
+  QCol c; c.qidx = qidx;
+  const bool live = qidx < nq;
+  const float nrm = live ? qnorms[qidx] : 1.f;
+  c.iq = live ? rsqrtf(nrm) : 0.f;
+  const float len = sqrtf(nrm);            // ||q||; NaN / 0 / inf propagate into lo/hi and make every block take the element path
+  const uint32_t t = live ? thr[qidx] : (nearest ? 0u : 0xffffffffu);
+  if (nearest) {
+    c.tf = !live ? -1.f : (t == 0xffffffffu ? __builtin_inff() : key_score(t));
+    c.lo = !live ? __builtin_inff() : (1.0f - c.tf - MF_BLOCK_SLACK) * len;
+    c.hi = __builtin_inff();
+  } else {
+    c.tf = !live ? __builtin_inff() : (t == 0u ? -__builtin_inff() : key_score(t));
+    c.lo = !live ? -__builtin_inff() : (1.0f - c.tf + MF_BLOCK_SLACK) * len;
+    c.hi = !live ? __builtin_inff() : (1.0f + c.tf - MF_BLOCK_SLACK) * len;
+  }
+  return c;
+}
+
+// ir[g][j] = 1/||row|| of local row 8*g + j (+ 4 for the upper half-wave); rbase = global index of the lane's local row 0;
+// ep = this lane's private 16-float LDS slot.  The element path is a ROLLED loop over values parked in LDS: unrolled it is
+// ~500 instructions per block, 16 blocks per tile — the epilogue then no longer fits the instruction cache and every tile
+// pays the misses even though the path is almost never taken.
+__device__ __forceinline__ void mf_emit_block(const f32x16& acc, const f32x4 (&ir)[4], bool bad, const QCol& qc, int nearest, int nq,
+                                              uint64_t rbase, uint64_t end, unsigned long long* __restrict__ cand,
+                                              uint32_t* __restrict__ cnt, uint32_t cap, float* ep) {
+  float t[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = acc[r] * ir[r >> 2][r & 3];
+  float mx = t[0], mn = t[0];
+#pragma unroll
+  for (int r = 1; r < 16; r++) mx = __builtin_fmaxf(mx, t[r]);
+  bool hit;
+  if (nearest) hit = !(mx < qc.lo);
+  else {
+#pragma unroll
+    for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
+    hit = !(mn > qc.lo) || !(mx < qc.hi);
+  }
+  if (!(hit || bad)) return;
+#pragma unroll
+  for (int g = 0; g < 4; g++) reinterpret_cast<f32x4*>(ep)[g] = f32x4{t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+#pragma unroll 1
+  for (int r = 0; r < 16; r++) {
+    float s = fabsf(1.0f - reinterpret_cast<volatile float*>(ep)[r] * qc.iq);
+    const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
+    if (pass) {
+      const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
+      if (gr < end && qc.qidx < nq) {
+        uint32_t idx = atomicAdd(&cnt[qc.qidx], 1u);
+        if (idx < cap) cand[(size_t)qc.qidx * cap + idx] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool mf_bad_norms(const f32x4 (&ir)[4]) {
+  bool bad = false;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) bad |= !(ir[g][j] > 0.f && ir[g][j] < __builtin_inff());
+  return bad;
+}
+
 // 256 threads = 4 waves per workgroup, wave grid 2 x 2 over the 128 x BN tile; stages are small enough (61 KB of LDS at
 // BN = 256) for TWO workgroups per CU, so one group's global-load / barrier stalls are covered by the other's MFMAs.
 // Registers must stay <= 256 per lane and must not spill (a scratch reload is a VMEM op: it drains the in-order vmcnt queue).
@@ -72,16 +151,9 @@ __global__ __launch_bounds__(MF_NT, (MF_BM <= 64 ? 3 : (MF_BK <= 32 ? 2 : 1))) v
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
   const int nk = dim / MF_BK;
   // per-lane query constants for its TN columns: 1/||q||, the threshold as a float (+-inf = everything passes)
-  float iq[TN], tf[TN]; int qidx[TN];
+  QCol qc[TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; tn++) {
-    qidx[tn] = wn * (BN / WN) + tn * 32 + (lane & 31);
-    const bool live = qidx[tn] < nq;
-    iq[tn] = live ? rsqrtf(qnorms[qidx[tn]]) : 0.f;
-    const uint32_t t = live ? thr[qidx[tn]] : (nearest ? 0u : 0xffffffffu);
-    if (nearest) tf[tn] = !live ? -1.f : (t == 0xffffffffu ? __builtin_inff() : key_score(t));
-    else tf[tn] = !live ? __builtin_inff() : (t == 0u ? -__builtin_inff() : key_score(t));
-  }
+  for (int tn = 0; tn < TN; tn++) qc[tn] = mf_query_col(wn * (BN / WN) + tn * 32 + (lane & 31), nq, qnorms, thr, nearest);
   const uint64_t ntiles = (end - begin + MF_BM - 1) / MF_BM;
   for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint64_t row0 = begin + tile * MF_BM;
@@ -158,29 +230,17 @@ __global__ __launch_bounds__(MF_NT, (MF_BM <= 64 ? 3 : (MF_BK <= 32 ? 2 : 1))) v
     }
 #undef MF_GLOAD
 #undef MF_LSTORE
-    // ---- epilogue: s~ = |1 - dot * (1/||q||) * (1/||r||)|, threshold filter in the float domain (4 VALU per element),
-    // survivors (rare behind the threshold) appended to the candidate list.  `!(s > t)` also passes NaN scores, which the
-    // exact path orders last, so nothing is lost for zero-norm rows.
+    // ---- epilogue: block filter, then (rarely) the per-element test s~ = |1 - dot * (1/||q||) * (1/||r||)| — see mf_emit_block
 #pragma unroll
     for (int tm = 0; tm < TM; tm++) {
       f32x4 ir[4];  // 1/||row|| of this lane's 16 rows: 4 runs of 4 consecutive rows
 #pragma unroll
       for (int g = 0; g < 4; g++) ir[g] = *reinterpret_cast<const f32x4*>(tnorm + wm * (MF_BM / WM) + tm * 32 + 8 * g + 4 * (lane >> 5));
+      const bool bad = mf_bad_norms(ir);
+      const uint64_t rbase = row0 + wm * (MF_BM / WM) + tm * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int tn = 0; tn < TN; tn++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float s = fabsf(1.0f - acc[tm][tn][r] * iq[tn] * ir[r >> 2][r & 3]);
-          const bool pass = nearest ? !(s > tf[tn]) : !(s < tf[tn]);
-          if (pass) {
-            const int rl = wm * (MF_BM / WM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const uint64_t gr = row0 + rl;
-            if (gr < end && qidx[tn] < nq) {
-              uint32_t idx = atomicAdd(&cnt[qidx[tn]], 1u);
-              if (idx < cap) cand[(size_t)qidx[tn] * cap + idx] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
-            }
-          }
-        }
+        mf_emit_block(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, end, cand, cnt, cap, reinterpret_cast<float*>(smem) + tid * 16);
     }
   }
 }
@@ -190,7 +250,7 @@ __global__ __launch_bounds__(MF_NT, (MF_BM <= 64 ? 3 : (MF_BK <= 32 ? 2 : 1))) v
 __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long* __restrict__ src_all, unsigned long long* __restrict__ dst_all,
                                                        uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all, uint32_t cap,
                                                        uint32_t k, int nearest, float margin, uint32_t* __restrict__ overflow) {
-  __shared__ uint32_t hist[256];
+  __shared__ uint32_t hist[256], wsum[4];
   __shared__ uint32_t s_digit, s_need, s_n;
   const int q = blockIdx.x, tid = threadIdx.x;
   const unsigned long long* src = src_all + (size_t)q * cap;
@@ -210,10 +270,18 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
         if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        uint32_t cum = 0, b = 0;
-        for (; b < 256; b++) { if (cum + hist[b] >= need) break; cum += hist[b]; }
-        s_digit = b; s_need = need - cum;
+      {  // the digit whose bucket holds the need-th key: inclusive prefix sum of the 256 buckets (a serial walk by one
+         // thread is 256 dependent LDS reads = ~10 us per pass, 40 us per pick: more than the later segments' scans)
+        const uint32_t h = hist[tid];
+        uint32_t inc = h;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if ((tid & 63) >= d) inc += o; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+        inc += base;
+        if (inc >= need && inc - h < need) { s_digit = tid; s_need = need - (inc - h); }  // exactly one thread (need >= 1, total >= need)
       }
       __syncthreads();
       prefix |= s_digit << shift; mask |= 255u << shift; need = s_need;

@@ -301,11 +301,10 @@ int prep_queries_any(Hnsw* x, const float* d_qraw, size_t nq) {
   COLTT_TRY(x->w_qeff.reserve(nq * x->dim * 4));
   COLTT_TRY(x->w_qn.reserve(nq * 4));
   int norm = x->metric == COLTT_COSINE;
-  uint32_t g = ceil_div(nq, 64);
   float* qe = x->w_qeff.as<float>();
-  if (x->quant == COLTT_Q_NONE) prep_queries_kernel<Q_NONE><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
-  else if (x->quant == COLTT_Q_F8) prep_queries_kernel<Q_F8><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
-  else prep_queries_kernel<Q_F16><<<g, 64, 0, x->stream>>>(d_qraw, nq, (int)x->dim, norm, qe);
+  if (x->quant == COLTT_Q_NONE) launch_prep_queries<Q_NONE>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
+  else if (x->quant == COLTT_Q_F8) launch_prep_queries<Q_F8>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
+  else launch_prep_queries<Q_F16>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
   query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, x->stream>>>(qe, nq, (int)x->dim, x->w_qn.as<float>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;

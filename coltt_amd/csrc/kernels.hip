@@ -202,7 +202,7 @@ int coltt_normalize(const float* in, size_t n, uint32_t dim, float* out) {
   Stage st; float *di, *dout;
   COLTT_TRY(st.alloc((void**)&di, n * dim * 4)); COLTT_TRY(st.alloc((void**)&dout, n * dim * 4));
   COLTT_HIP(hipMemcpy(di, in, n * dim * 4, hipMemcpyHostToDevice));
-  prep_queries_kernel<Q_NONE><<<ceil_div(n, 64), 64>>>(di, n, (int)dim, 1, dout);
+  launch_prep_queries<Q_NONE>(nullptr, di, n, (int)dim, 1, dout);
   COLTT_HIP(hipGetLastError());
   COLTT_HIP(hipMemcpy(out, dout, n * dim * 4, hipMemcpyDeviceToHost));
   return COLTT_OK;
