@@ -204,6 +204,17 @@ def main():
                 recall = exact_recall(G, torch, dev, h, args, seed, n_local, dim, q, rq, k, ids_h)
         except Exception as e:  # recall is reported, never allowed to kill the bench line
             recall = f"failed: {e}"
+        # ---- throughput along the same ef curve (one full step of nq queries per ef, kernel time): with recall_vs_ef this
+        # gives "queries/s at recall@10 = r" points, the form BASELINE.json's metric is quoted in
+        qps_vs_ef = None
+        if not shard:
+            qps_vs_ef = {}
+            for ef in [args.ef] + [int(e) for e in args.ef_curve.split(",") if e]:
+                try:
+                    h.SearchDevice(queries[0].data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=ef)
+                    qps_vs_ef[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
+                except Exception as e:
+                    qps_vs_ef[str(ef)] = f"failed: {e}"
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -220,6 +231,7 @@ def main():
                        "n": n_total, "dim": dim, "queries_per_step": nq, "ef": args.ef, "build_batch": args.build_batch},
             "recall_at_10": recall[str(args.ef)] if isinstance(recall, dict) else recall,
             "recall_vs_ef": recall if isinstance(recall, dict) else None,
+            "qps_vs_ef": qps_vs_ef,
             "recall_note": ("iid random-normal 768-d has no neighbourhood structure (all cosine distances are 1 +- 0.04): any HNSW "
                             "that visits ~4e3 of 1e7 points finds ~0.1 % of the exact top-10; GPU answers equal the CPU oracle's on "
                             "the same graph (cpu_baseline.gpu_equals_oracle_on_sample). See --dataset lowrank:R and DESIGN.md §6."

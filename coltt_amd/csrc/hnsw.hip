@@ -23,13 +23,14 @@ using namespace coltt::dev;
 namespace {
 
 // Hnsw.Search (hnsw.go:243-278) for a batch: one wave per query, queries pulled from a global counter.
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, bool VISG>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                         const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                         uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
                                                         uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
                                                         float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                        unsigned long long* __restrict__ stats) {
+                                                        unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
+                                                        size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
+  w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
+  if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
   for (;;) {
     // dynamic work fetch.  Branch-free on purpose: with `if (lane == 0) t = atomicAdd(..)` hipcc threads the
     // loop-invariant divergent branch through the back edge, lanes 1..63 re-enter the loop without lane 0 and the
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     w.n_dist += 1;
     uint32_t len; int buf;
-    search_level<METRIC, QUANT>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
+    search_level<METRIC, QUANT, VISG>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
     // selectNeighbors + pop into result[n-1..0] (:261-277) == the k smallest, ascending
     uint32_t n = len < k ? len : k;
     const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
       atomicAdd(&stats[1], (unsigned long long)w.n_exp);
       atomicAdd(&stats[2], (unsigned long long)w.n_hops);
       atomicAdd(&stats[3], (unsigned long long)w.n_resets);
+      if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
     }
   }
+  if constexpr (VISG) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 
@@ -90,13 +95,14 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 // ---------------------------------------------------------------------------------------------------
 struct BuildReq { uint32_t rid, from; float d; uint32_t next; };
 
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, bool VISG>
 __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int32_t entry, int32_t entry_level, uint32_t base,
                                                               uint32_t count, const int32_t* __restrict__ levels, uint32_t M,
                                                               uint32_t efc, uint32_t ef_pad, uint32_t hcap, uint64_t cap_slots,
                                                               uint32_t* __restrict__ counter, uint32_t* __restrict__ req_count,
                                                               BuildReq* __restrict__ req, uint32_t* __restrict__ head,
-                                                              unsigned long long* __restrict__ stats) {
+                                                              unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
+                                                              size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
@@ -105,6 +111,8 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
+  w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
+  if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
   for (;;) {
     const uint32_t bt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free, see hnsw_search_kernel
     const uint32_t bi = (uint32_t)__shfl((int)bt, 0, 64);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
     for (int l = entry_level < lv ? entry_level : lv; l >= 0; l--) {
       uint32_t len; int buf;
       w.n_dist += 1;
-      search_level<METRIC, QUANT>(g, w, cur, curd, efc, l, lane, len, buf);
+      search_level<METRIC, QUANT, VISG>(g, w, cur, curd, efc, l, lane, len, buf);
       const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
       const uint32_t m = len < M ? len : M;
       // the m nearest, re-ordered by slot (canonical row order)
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
     }
   }
+  if constexpr (VISG) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 // Phase B: apply the queued links to the neighbours' rows (hnsw.go:151-158: neighbor.addEdge + pruneNeighbors when
@@ -239,6 +248,7 @@ struct Hnsw : Object {
   hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
   DevBuf w_raw, w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc;
   DevBuf b_head, b_req, b_levels; uint64_t head_cap = 0;  // builder scratch
+  DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;  // HBM visited set (hnsw_dev.hpp, VISG)
   coltt_hnsw_stats build_stats{};
   ~Hnsw() override {
     if (ev0) (void)hipEventDestroy(ev0);
@@ -312,30 +322,69 @@ int prep_queries_any(Hnsw* x, const float* d_qraw, size_t nq) {
 
 uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; };
-SearchGeom search_geom(const Hnsw* x, uint32_t ef) {
+struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; };
+
+#ifndef COLTT_VISG_MIN_EF
+#define COLTT_VISG_MIN_EF 128
+#endif
+constexpr uint32_t VIS_MAX_REGIONS = 2048;  // 8 waves on each of 256 CUs
+
+// (Re)allocate the HBM visited set for the current slot capacity: one byte per slot and workgroup, zeroed, epochs reset.
+// Sized against a quarter of the device memory; if that buys fewer than one region per CU the LDS hash is used instead.
+int ensure_visg(Hnsw* x) {
+  const uint64_t stride = (std::max<uint64_t>(x->cap, 1) + 1023) & ~1023ull;
+  if (x->vis_stride == stride) return COLTT_OK;
+  if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
+  size_t free_b = 0, total_b = 0;
+  COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
+  const uint64_t budget = std::min<uint64_t>(total_b / 4, free_b / 2);
+  const uint64_t regions = std::min<uint64_t>(VIS_MAX_REGIONS, budget / stride);
+  x->vis_stride = stride;
+  x->vis_regions = 0;
+  if (regions < 256) return COLTT_OK;
+  COLTT_TRY(x->w_visg.reserve(regions * stride));
+  COLTT_TRY(x->w_vepoch.reserve(VIS_MAX_REGIONS * 4));
+  COLTT_HIP(hipMemsetAsync(x->w_visg.p, 0, regions * stride, x->stream));
+  COLTT_HIP(hipMemsetAsync(x->w_vepoch.p, 0, VIS_MAX_REGIONS * 4, x->stream));
+  x->vis_regions = (uint32_t)regions;
+  return COLTT_OK;
+}
+
+// COLTT_VISG=0 / 1 forces the LDS hash / the HBM byte map (measurement and test knob, read at every call); default: the
+// byte map above ef 128.  Measured on 10 M x 768 f16 (lowrank:32), queries/s LDS hash -> byte map: ef 128 728 k -> 724 k,
+// ef 256 246 k -> 404 k, ef 512 62 k -> 212 k, ef 1024 25 k -> 105 k; build (efConstruction 200) 36 s -> 22 s.
+int visg_policy() {
+  const char* e = getenv("COLTT_VISG");
+  return e && *e ? atoi(e) : -1;
+}
+
+SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   SearchGeom s;
   s.ef = ef;
   s.ef_pad = (ef + 63) & ~63u;
-  // visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
+  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8;
+  // LDS visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
   s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
-  auto total = [&]() { return (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8 + (size_t)s.hcap * 4; };
-  // large ef x dim: shrink the visited set until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps
-  // results exact; it needs 0.75 * hcap > ef + 64)
-  while (total() > 160 * 1024 && s.hcap > 4096 && (s.hcap / 2) * 3 / 4 > ef + 64) s.hcap /= 2;
-  s.lds = total();
+  // large ef x dim: shrink it until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps results exact;
+  // it needs 0.75 * hcap > ef + 64)
+  while (fixed + (size_t)s.hcap * 4 > 160 * 1024 && s.hcap > 4096 && (s.hcap / 2) * 3 / 4 > ef + 64) s.hcap /= 2;
+  const int pol = visg_policy();
+  s.visg = x->vis_regions > 0 && (pol < 0 ? ef > COLTT_VISG_MIN_EF : pol != 0);
+  if (s.visg) { s.hcap = 64; s.lds = fixed; s.max_grid = x->vis_regions; }
+  else { s.lds = fixed + (size_t)s.hcap * 4; s.max_grid = 0xffffffffu; }
   return s;
 }
 
 template <int METRIC, int QUANT>
 int launch_search(Hnsw* x, const SearchGeom& sg, uint32_t nq, uint32_t k, uint32_t* counter, uint64_t* oi, float* os,
                   uint32_t* oc, unsigned long long* stats) {
-  auto kern = hnsw_search_kernel<METRIC, QUANT>;
+  auto kern = sg.visg ? hnsw_search_kernel<METRIC, QUANT, true> : hnsw_search_kernel<METRIC, QUANT, false>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
-  uint32_t grid = std::min<uint32_t>(nq, 256u * per_cu);
+  uint32_t grid = std::min<uint32_t>({nq, 256u * per_cu, sg.max_grid});
   kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, x->w_qeff.as<float>(), x->w_qn.as<float>(), nq,
-                                        k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
+                                        k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, x->w_visg.as<uint8_t>(),
+                                        (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -360,6 +409,7 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
   }
   uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
   if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: ef=%u > 4096", ef);
+  COLTT_TRY(ensure_visg(x));
   SearchGeom sg = search_geom(x, ef);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
   const float* d_q = queries;
@@ -434,12 +484,13 @@ int hnsw_undense(Hnsw* x) {
 template <int METRIC, int QUANT>
 int launch_build(Hnsw* x, const SearchGeom& sg, uint32_t base, uint32_t count, const int32_t* d_levels, uint32_t* counter,
                  uint32_t* req_count, BuildReq* req, uint32_t* head, unsigned long long* stats) {
-  auto kern = hnsw_build_search_kernel<METRIC, QUANT>;
+  auto kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true> : hnsw_build_search_kernel<METRIC, QUANT, false>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
-  uint32_t grid = std::min<uint32_t>(count, 256u * per_cu);
+  uint32_t grid = std::min<uint32_t>({count, 256u * per_cu, sg.max_grid});
   kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, base, count, d_levels, (uint32_t)x->cfg.m,
-                                        sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats);
+                                        sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats,
+                                        x->w_visg.as<uint8_t>(), (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -464,8 +515,6 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     }
   }
   const uint32_t efc = (uint32_t)x->cfg.ef_construction;
-  SearchGeom sg = search_geom(x, efc);
-  if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", sg.lds);
   COLTT_TRY(x->w_misc.reserve(64));
   uint32_t* counter = x->w_misc.as<uint32_t>();
   uint32_t* req_count = counter + 1;
@@ -479,6 +528,9 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     for (uint32_t j = 0; j < b; j++) up += first ? 0 : (uint64_t)levels[i + j];
     const uint64_t base = x->n;
     COLTT_TRY(x->reserve(base + b, x->n_upper + up));
+    COLTT_TRY(ensure_visg(x));  // the slot capacity may just have grown
+    const SearchGeom sg = search_geom(x, efc);
+    if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", sg.lds);
     // host mirrors + per-slot tables
     std::vector<uint32_t> uo(b);
     std::vector<int32_t> lv(b);

@@ -3,7 +3,11 @@
 // One wave64 owns one query (or one vertex being inserted).  State in LDS, per wave:
 //   qs   [dim] f32         the query as the distance kernel sees it (normalised / decoded)
 //   res  [2][ef_pad] u64   result set, sorted ascending, double-buffered; entry = d_bits<<32 | slot<<1 | expanded
-//   vis  [hcap] u32        open-addressed visited set (slots), linear probing, EMPTY = 0xffffffff
+//   vis  [hcap] u32        open-addressed visited set (slots), linear probing, EMPTY = 0xffffffff   (VISG = false)
+// or, VISG = true, the visited set lives in HBM: one byte per slot in a region private to the workgroup, holding the epoch of
+// the last traversal that visited the slot (no clearing between traversals; wiped when the 8-bit epoch wraps).  That costs one
+// dependent global access per neighbour chunk and ~2 cache lines per visit, but frees 32-128 KB of LDS per wave: 8 waves per
+// CU instead of 4 (ef 128), 2 (ef 256, efConstruction 200) or 1 (ef >= 512).
 //
 // Algorithm = the canonical closed form of Hnsw.searchLevel (core/vectorindex/hnsw.go:345-389) worked out in
 // SURVEY.md §3.2 and restated on the CPU by oracle/coltt_oracle.cpp:search_level_canon:
@@ -20,6 +24,7 @@
 namespace coltt {
 namespace dev {
 
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 constexpr uint32_t VIS_EMPTY = 0xffffffffu;
 constexpr uint32_t NBR_NONE = 0xffffffffu;
 
@@ -39,6 +44,7 @@ struct WaveCtx {
   float qnorm;
   // counters (wave-uniform)
   uint32_t n_dist, n_exp, n_hops, n_resets;
+  uint8_t* visg; size_t vis_bytes; uint32_t epoch;  // VISG: this workgroup's byte-per-slot region, its size, current epoch
   uint32_t err;  // watchdog: 1 visited-set probe overflow, 2 expansion budget, 3 greedy hop budget (every loop is bounded)
 };
 
@@ -151,15 +157,24 @@ __device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* 
 
 // searchLevel (hnsw.go:345-389).  On return w.res[buf][0..len) holds the result set ascending by (d, slot).
 // The wave must be the only one in its workgroup (uses __syncthreads as a wave-level LDS fence).
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, bool VISG>
 __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
                                              int level, int lane_in, uint32_t& out_len, int& out_buf) {
   int lane = lane_in;
-  vis_clear(w, lane);
+  if constexpr (VISG) {
+    if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
+      for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
+      __threadfence();
+      w.epoch = 1;
+    }
+  } else vis_clear(w, lane);
   int buf = 0;
   if (lane == 0) w.res0[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
   __syncthreads();
-  if (lane == 0) vis_insert(w.vis, w.hcap_mask, ep);
+  if (lane == 0) {
+    if constexpr (VISG) __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else vis_insert(w.vis, w.hcap_mask, ep);
+  }
   uint32_t len = 1, vis_count = 1;
   bool had_reset = false;
   __syncthreads();
@@ -185,10 +200,12 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     const uint32_t cslot = (uint32_t)ce >> 1;
     uint32_t free_slots = ef - len;  // len <= ef
     w.n_exp++;
-    if (vis_count + 64 > (w.hcap >> 2) * 3) {  // bounded visited set: forget everything but the result set
-      __syncthreads();
-      vis_reset(w, res, len, lane);
-      vis_count = len; had_reset = true; w.n_resets++;
+    if constexpr (!VISG) {
+      if (vis_count + 64 > (w.hcap >> 2) * 3) {  // bounded visited set: forget everything but the result set
+        __syncthreads();
+        vis_reset(w, res, len, lane);
+        vis_count = len; had_reset = true; w.n_resets++;
+      }
     }
     __syncthreads();
     uint32_t width;
@@ -199,7 +216,16 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       int fresh_i = 0;
-      if (valid && half == 0) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+      if (valid && half == 0) {
+        if constexpr (VISG) {
+          // No two lanes hold the same slot (a row lists a neighbour once), so load + store is a race-free test-and-set.
+          // Agent-scope atomics: served by L2, never by a stale L1 line; the store is complete (vmcnt) before the next
+          // chunk's loads are issued because the distance loads issued after it are waited for first.
+          const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
+          if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+      }
       fresh_i = __shfl(fresh_i, lane & ~1, 64);
       bool fresh = fresh_i != 0;
       if (had_reset) {

@@ -247,8 +247,10 @@ def test_hnsw_ragged_dim_large_ef_and_k_above_ef(gpu):
             assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} k{k} ef{ef}")
 
 
-def test_hnsw_visited_set_reset_keeps_results_exact(gpu):
-    """ef = 3000 on a small dense graph: the bounded visited set (16384 slots here) is reset-and-reseeded; results stay exact."""
+def test_hnsw_visited_set_reset_keeps_results_exact(gpu, monkeypatch):
+    """ef = 3000 on a small dense graph with the LDS visited set forced (COLTT_VISG=0; above ef 128 the default is the HBM byte
+    map): the bounded hash (16384 slots here) is reset-and-reseeded; results stay exact."""
+    monkeypatch.setenv("COLTT_VISG", "0")
     n, d = 60000, 8
     X = O.fill_normal(121, (n, d)); lv = O.levels(122, n); ids = np.arange(n, dtype=np.uint64)
     import torch
@@ -266,3 +268,31 @@ def test_hnsw_visited_set_reset_keeps_results_exact(gpu):
         wi, ws = oh.search(Q[qi], 10, mode=1, ef=3000)
         assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
     assert st["n_visit_resets"] > 0, st
+
+
+def test_hnsw_hbm_visited_set_epoch_wrap(gpu, monkeypatch):
+    """HBM byte-per-slot visited set forced at small ef (COLTT_VISG=1): the batched builder's graph, the answers and the
+    traversal counters equal the oracle's, and keep doing so after a workgroup's 8-bit epoch has wrapped (> 255 traversals by
+    the same workgroup => its region is wiped)."""
+    import torch
+    monkeypatch.setenv("COLTT_VISG", "1")
+    n, d = 3000, 24
+    X = O.fill_normal(131, (n, d)); lv = O.levels(132, n); ids = np.arange(n, dtype=np.uint64)
+    sched = lambda i: max(1, min(8, i // 16))       # few workgroups, many traversals each: epochs wrap during the build
+    oh = O.Hnsw(d, O.COSINE, O.default_cfg(efConstruction=32)); oh.insert_batched(ids, X, lv, 0, schedule=sched)
+    gh = gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(ef_construction=32))
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    i = 0
+    while i < n:
+        b = min(sched(i), n - i)
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i)
+        i += b
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
+    Q = O.fill_normal(133, (2, d))
+    for rep in range(300):                          # 2 workgroups x 300 launches on top of the build's epochs
+        gi, gs, gc, st = gh.Search(Q, 10, ef=40, with_stats=True)
+        if rep % 50 == 0 or rep == 299:
+            for qi in range(len(Q)):
+                wi, ws = oh.search(Q[qi], 10, mode=1, ef=40)
+                assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"rep{rep} q{qi}")
+            assert st["n_visit_resets"] == 0
