@@ -187,42 +187,86 @@ __device__ __forceinline__ float pair_sqnorm_f32(const float* __restrict__ v, in
   return pair_sqnorm<Q_NONE>(reinterpret_cast<const uint8_t*>(v), dim, half);
 }
 
-// Distance(query, row) for the pair-owned row; q = f32 query in LDS.  Valid in both lanes of the pair.
-// Row loads are software-pipelined in bursts of U steps: the next U raw chunks are requested back to back while the
-// previous U are decoded and consumed (U..2U loads per lane in flight).  The traversal kernels run 4 waves per CU, so
-// bytes in flight per wave are what buys HBM bandwidth (Little's law); U is tuned per element size.
+// 2-byte codes, wide loads.  With 8 B per lane a wave-wide load touches 32 rows x 16 B: the same number of vector-memory
+// instructions (and cache-line lookups) as f32 rows for half the bytes, and the quantised walk ran at 0.52 of HBM peak where
+// the f32 walk reaches 0.70.  Here a lane loads 16 B — the WHOLE 8-element group 2s + half — and the pair swaps the halves
+// that belong to the other lane's residue chains through DPP (quad_perm [1,0,3,2]), so every chain still adds group 2s, then
+// group 2s+1: same values, same order, half the load instructions.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+}
+typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2e __attribute__((ext_vector_type(2)));
+template <int METRIC>
+__device__ __forceinline__ void h2_consume(f32x4& acc, u32x4e raw, const float* __restrict__ q, int s, int half) {
+  const uint32_t k0 = half ? raw.z : raw.x, k1 = half ? raw.w : raw.y;   // my chains' part of the group I loaded
+  const uint32_t g0 = half ? raw.x : raw.z, g1 = half ? raw.y : raw.w;   // my partner's chains' part
+  const uint32_t r0 = dpp_swap1(g0), r1 = dpp_swap1(g1);
+  const u32x2e a = {half ? r0 : k0, half ? r1 : k1};                     // group 2s
+  const u32x2e b = {half ? k0 : r0, half ? k1 : r1};                     // group 2s + 1
+  const f32x4 ra = __builtin_convertvector(__builtin_bit_cast(f16x4, a), f32x4);
+  const f32x4 rb = __builtin_convertvector(__builtin_bit_cast(f16x4, b), f32x4);
+  const f32x4 qa = *reinterpret_cast<const f32x4*>(q + 16 * s + 4 * half);
+  const f32x4 qb = *reinterpret_cast<const f32x4*>(q + 16 * s + 8 + 4 * half);
+  if constexpr (METRIC == M_COS) { f32x4 p = qa * ra; acc = acc + p; p = qb * rb; acc = acc + p; }
+  else { f32x4 d = qa - ra; f32x4 p = d * d; acc = acc + p; d = qb - rb; p = d * d; acc = acc + p; }
+}
+// Software pipeline of a row walk: `n` steps in bursts of U — the next burst is requested back to back while the previous
+// one is decoded and consumed (U..2U loads per lane in flight; bytes in flight per wave are what buys HBM bandwidth).  The
+// remainder (n % U steps; the whole row when n < U, e.g. dim 128) goes four predicated steps at a time (a full predicated
+// burst doubled the kernels' register count).
+// Written as a macro over LOAD(step) / CONSUME(raw, step): lambdas and helper templates around the staging arrays cost 10 %
+// (extra registers, lost overlap) in hipcc 7.2.
+#define COLTT_BURST_WALK(U_, RAW_T, N_, LOAD, CONSUME)                                              \
+  {                                                                                                 \
+    const int n_ = (N_), nb_ = n_ / (U_);                                                           \
+    RAW_T cur_[U_], nxt_[U_];                                                                       \
+    if (nb_ > 0) {                                                                                  \
+      _Pragma("unroll") for (int u = 0; u < (U_); u++) cur_[u] = LOAD(u);                           \
+    }                                                                                               \
+    for (int b_ = 0; b_ < nb_; b_++) {                                                              \
+      if (b_ + 1 < nb_) {                                                                           \
+        _Pragma("unroll") for (int u = 0; u < (U_); u++) nxt_[u] = LOAD((b_ + 1) * (U_) + u);       \
+      }                                                                                             \
+      _Pragma("unroll") for (int u = 0; u < (U_); u++) { CONSUME(cur_[u], b_ * (U_) + u); }         \
+      _Pragma("unroll") for (int u = 0; u < (U_); u++) cur_[u] = nxt_[u];                           \
+    }                                                                                               \
+    for (int t_ = nb_ * (U_); t_ < n_; t_ += 4) {  /* remainder: 4 steps in flight at a time */   \
+      RAW_T r_[4];                                                                                  \
+      _Pragma("unroll") for (int u = 0; u < 4; u++) if (t_ + u < n_) r_[u] = LOAD(t_ + u);          \
+      _Pragma("unroll") for (int u = 0; u < 4; u++) if (t_ + u < n_) { CONSUME(r_[u], t_ + u); }    \
+    }                                                                                               \
+  }
+
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void narrow_consume(f32x4& acc, typename Raw4<QUANT>::type raw, const float* __restrict__ q, int t, int half) {
+  f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * t + 4 * half);
+  f32x4 r = decode4<QUANT>(raw);
+  if constexpr (METRIC == M_COS) { f32x4 p = qq * r; acc = acc + p; }
+  else { f32x4 d = qq - r; f32x4 p = d * d; acc = acc + p; }
+}
+
+// Distance(query, row) for the pair-owned row; q = f32 query in LDS (or global).  Valid in both lanes of the pair.
 template <int METRIC, int QUANT, int U = 8>
 __device__ __forceinline__ float pair_distance(const uint8_t* __restrict__ row, const float* __restrict__ q, int dim,
                                                float qnorm, float rnorm, int half) {
   typedef typename Raw4<QUANT>::type raw_t;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int n8 = dim >> 3;
-  const int nb = n8 / U;
-  raw_t cur[U], nxt[U];
-  if (nb > 0) {
-#pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = load_raw4<QUANT>(row, 8 * u + 4 * half);
-  }
-  for (int b = 0; b < nb; b++) {
-    if (b + 1 < nb) {
-#pragma unroll
-      for (int u = 0; u < U; u++) nxt[u] = load_raw4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * (b * U + u) + 4 * half);
-      f32x4 r = decode4<QUANT>(cur[u]);
-      if constexpr (METRIC == M_COS) { f32x4 p = qq * r; acc = acc + p; }
-      else { f32x4 d = qq - r; f32x4 p = d * d; acc = acc + p; }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) cur[u] = nxt[u];
-  }
-  for (int t = nb * U; t < n8; t++) {
-    f32x4 r = decode4<QUANT>(load_raw4<QUANT>(row, 8 * t + 4 * half));
-    f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * t + 4 * half);
-    if constexpr (METRIC == M_COS) { f32x4 p = qq * r; acc = acc + p; }
-    else { f32x4 d = qq - r; f32x4 p = d * d; acc = acc + p; }
+  if constexpr ((QUANT == Q_F16 || QUANT == Q_BF16) && U >= 2) {
+    // wide walk over pairs of groups (every store keeps rows 16-byte aligned: row strides are rounded up to 16 B)
+#define COLTT_LD_(S) (*reinterpret_cast<const u32x4e*>(row + (size_t)(16 * (S) + 8 * half) * 2))
+#define COLTT_CS_(RAW, S) h2_consume<METRIC>(acc, RAW, q, S, half)
+    COLTT_BURST_WALK(U / 2, u32x4e, n8 >> 1, COLTT_LD_, COLTT_CS_)
+#undef COLTT_LD_
+#undef COLTT_CS_
+    if (n8 & 1) narrow_consume<METRIC, QUANT>(acc, load_raw4<QUANT>(row, 8 * (n8 - 1) + 4 * half), q, n8 - 1, half);  // odd group count
+  } else {
+#define COLTT_LD_(T) load_raw4<QUANT>(row, 8 * (T) + 4 * half)
+#define COLTT_CS_(RAW, T) narrow_consume<METRIC, QUANT>(acc, RAW, q, T, half)
+    COLTT_BURST_WALK(U, raw_t, n8, COLTT_LD_, COLTT_CS_)
+#undef COLTT_LD_
+#undef COLTT_CS_
   }
   float s = pair_hsum(acc, half);
   for (int e = n8 * 8; e < dim; e++) {  // scalar tail (avx.cpp:28-31,68-72)

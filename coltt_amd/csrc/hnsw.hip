@@ -31,6 +31,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
                                                         float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
                                                         unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
                                                         size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+  constexpr int PROF = VISG ? PROF_SEARCH_HBM : PROF_SEARCH_LDS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     __syncthreads();
     // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253)
     uint32_t cur = (uint32_t)entry;
-    float curd = eval_pair<METRIC, QUANT>(g, w, cur, lane & 1);
+    float curd = eval_pair<METRIC, QUANT, PROF>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
-    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT>(g, w, cur, curd, l, lane);  // :254-256
+    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF>(g, w, cur, curd, l, lane);  // :254-256
     // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     w.n_dist += 1;
     uint32_t len; int buf;
-    search_level<METRIC, QUANT, VISG>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
+    search_level<METRIC, QUANT, VISG, PROF>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
     // selectNeighbors + pop into result[n-1..0] (:261-277) == the k smallest, ascending
     uint32_t n = len < k ? len : k;
     const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
@@ -128,14 +129,14 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
     w.qnorm = METRIC == M_COS ? g.norms[vi] : 0.f;
     __syncthreads();
     uint32_t cur = (uint32_t)entry;
-    float curd = eval_pair<METRIC, QUANT>(g, w, cur, lane & 1);
+    float curd = eval_pair<METRIC, QUANT, PROF_BUILD>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
-    for (int l = entry_level; l > lv; l--) greedy_level<METRIC, QUANT>(g, w, cur, curd, l, lane);
+    for (int l = entry_level; l > lv; l--) greedy_level<METRIC, QUANT, PROF_BUILD>(g, w, cur, curd, l, lane);
     for (int l = entry_level < lv ? entry_level : lv; l >= 0; l--) {
       uint32_t len; int buf;
       w.n_dist += 1;
-      search_level<METRIC, QUANT, VISG>(g, w, cur, curd, efc, l, lane, len, buf);
+      search_level<METRIC, QUANT, VISG, PROF_BUILD>(g, w, cur, curd, efc, l, lane, len, buf);
       const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
       const uint32_t m = len < M ? len : M;
       // the m nearest, re-ordered by slot (canonical row order)

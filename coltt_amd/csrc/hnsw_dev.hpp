@@ -98,23 +98,27 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
   for (uint32_t i = lane; i < w.hcap; i += 64) w.vis[i] = VIS_EMPTY;
 }
 
-#ifndef COLTT_U_F32
-#define COLTT_U_F32 16
-#endif
-#ifndef COLTT_U_Q
-#define COLTT_U_Q 24
-#endif
-template <int METRIC, int QUANT>
+// Burst depth of the row loads (exact.hpp: pair_distance), per kernel profile.  What buys HBM bandwidth here is bytes in
+// flight per CU = waves x bursts, and registers decide both: the LDS-visited search kernel runs 1 wave per SIMD anyway (LDS
+// bound), so its 2-byte path keeps a WHOLE 768-dim row in flight (U = 48: 2 x 24 x 16 B per lane, ~350 registers with AGPR
+// spills, 13.15 -> 11.88 ms per 10 k queries at 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under
+// 256.  Measured on MI355X, 2 M x 768, ef 128 unless noted: f32 U = 16 19.76 ms, 24 19.64, 32 21.58; f32 ef 256 (HBM visited)
+// U = 16 160 k q/s, 24 197 k; f16 U = 24 13.15 ms, 32 12.53, 48 11.88; f16 ef 256 (HBM visited) U = 24 421 k q/s, 48 364 k.
+enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2 };
+template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst_depth() {
+  if (QUANT == Q_NONE) return PROFILE == PROF_SEARCH_HBM ? 24 : 16;
+  return PROFILE == PROF_SEARCH_LDS ? 48 : 24;
+}
+template <int METRIC, int QUANT, int PROFILE>
 __device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
   float rn = 0.f;
   if constexpr (METRIC == M_COS) rn = g.norms[slot];
-  // burst depth, tuned on MI355X at 2M x 768 (f32: U=8 5.5, 12 6.06, 16 6.15 TB/s; f16: U=16 3.9, 24 4.8, 32 4.6 TB/s)
-  constexpr int U = QUANT == Q_NONE ? COLTT_U_F32 : COLTT_U_Q;
+  constexpr int U = burst_depth<QUANT, PROFILE>();
   return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
 // greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, int PROFILE>
 __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level,
                                              int lane_in) {
   for (uint32_t hops = 0;; hops++) {
@@ -130,7 +134,7 @@ __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uin
       uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       float d = 0.f;
-      if (valid) d = eval_pair<METRIC, QUANT>(g, w, nb, half);
+      if (valid) d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
       w.n_dist += __popcll(__ballot(valid && half == 0));
       unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;
       unsigned long long km = wave_min_u64(key);
@@ -157,7 +161,7 @@ __device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* 
 
 // searchLevel (hnsw.go:345-389).  On return w.res[buf][0..len) holds the result set ascending by (d, slot).
 // The wave must be the only one in its workgroup (uses __syncthreads as a wave-level LDS fence).
-template <int METRIC, int QUANT, bool VISG>
+template <int METRIC, int QUANT, bool VISG, int PROFILE>
 __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
                                              int level, int lane_in, uint32_t& out_len, int& out_buf) {
   int lane = lane_in;
@@ -177,6 +181,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
   }
   uint32_t len = 1, vis_count = 1;
   bool had_reset = false;
+  uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE;
   __syncthreads();
   for (uint32_t iters = 0;; iters++) {
     if (iters > (1u << 22)) { w.err |= 2u; break; }
@@ -184,13 +189,18 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     const int half = lane & 1, p = lane >> 1;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
-    // ---- pop: the smallest unexpanded member
-    int ci = -1;
+    // ---- pop: the smallest unexpanded member (cj = the one after it: the likely next pop, see the adjacency prefetch)
+    int ci = -1, cj = -1;
     for (uint32_t base = 0; base < len; base += 64) {
       uint32_t i = base + lane;
       bool un = i < len && !(res[i] & 1ull);
       unsigned long long m = __ballot(un);
-      if (m) { ci = (int)base + __builtin_ctzll(m); break; }
+      if (m) {
+        ci = (int)base + __builtin_ctzll(m);
+        m &= m - 1;
+        if (m) cj = (int)base + __builtin_ctzll(m);
+        break;
+      }
     }
     if (ci < 0) break;
     unsigned long long ce = res[ci];
@@ -210,10 +220,22 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     __syncthreads();
     uint32_t width;
     const uint32_t* row = adj_row(g, cslot, level, width);
+    // Adjacency prefetch (level 0): the row of the runner-up candidate is requested now and is in registers when it is
+    // popped next — unless a closer vertex is admitted in between, in which case the row is simply loaded as usual.  Takes
+    // one dependent HBM round trip out of most expansions; the rows are frozen during a search, so nothing changes.
+    const bool use_pre = level == 0 && pre_slot == cslot;
+    const uint32_t pre_now = pre_nb;
+    if (level == 0) {
+      pre_slot = NBR_NONE;
+      if (cj >= 0) {
+        pre_slot = (uint32_t)res[cj] >> 1;
+        pre_nb = (uint32_t)p < g.mMax0 ? g.adj0[(size_t)pre_slot * g.mMax0 + p] : NBR_NONE;
+      }
+    }
     for (uint32_t c0 = 0; c0 < width; c0 += 32) {
       res = w.res0 + (size_t)buf * w.ef_pad;
       uint32_t idx = c0 + p;
-      uint32_t nb = idx < width ? row[idx] : NBR_NONE;
+      uint32_t nb = idx < width ? ((use_pre && c0 == 0) ? pre_now : row[idx]) : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       int fresh_i = 0;
       if (valid && half == 0) {
@@ -247,7 +269,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       if (nfresh == 0) continue;
       vis_count += nfresh; w.n_dist += nfresh;
       float d = 0.f;
-      if (fresh) d = eval_pair<METRIC, QUANT>(g, w, nb, half);
+      if (fresh) d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
       uint32_t rank = __popcll(E & lt_mask);
       bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
       free_slots = free_slots > nfresh ? free_slots - nfresh : 0;
