@@ -376,12 +376,21 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   return s;
 }
 
+// Resident waves per CU.  2-byte rows want all 8 (two per SIMD); f32 rows are faster with 4: eight 3-KB-per-row streams per
+// CU measured slower both in search (ef 256: 160 k vs 197 k q/s) and in the 10 M build (61 s vs 50 s).  COLTT_WAVES_PER_CU
+// overrides (measurement knob).
+size_t waves_per_cu_cap(int quant) {
+  const char* e = getenv("COLTT_WAVES_PER_CU");
+  if (e && *e) return (size_t)std::max(1, std::min(8, atoi(e)));
+  return quant == Q_NONE ? 4 : 8;
+}
+
 template <int METRIC, int QUANT>
 int launch_search(Hnsw* x, const SearchGeom& sg, uint32_t nq, uint32_t k, uint32_t* counter, uint64_t* oi, float* os,
                   uint32_t* oc, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_search_kernel<METRIC, QUANT, true> : hnsw_search_kernel<METRIC, QUANT, false>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / sg.lds));
   uint32_t grid = std::min<uint32_t>({nq, 256u * per_cu, sg.max_grid});
   kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, x->w_qeff.as<float>(), x->w_qn.as<float>(), nq,
                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, x->w_visg.as<uint8_t>(),
@@ -487,7 +496,7 @@ int launch_build(Hnsw* x, const SearchGeom& sg, uint32_t base, uint32_t count, c
                  uint32_t* req_count, BuildReq* req, uint32_t* head, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true> : hnsw_build_search_kernel<METRIC, QUANT, false>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / sg.lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / sg.lds));
   uint32_t grid = std::min<uint32_t>({count, 256u * per_cu, sg.max_grid});
   kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, base, count, d_levels, (uint32_t)x->cfg.m,
                                         sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats,
