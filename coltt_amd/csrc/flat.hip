@@ -188,8 +188,8 @@ struct Flat : Object {
 template <int QUANT>
 int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_slots, uint64_t slot_base) {
   if (n == 0) return COLTT_OK;
-  prep_rows_kernel<QUANT><<<ceil_div(n, 128), 128, 0, f->stream>>>(d_raw, n, (int)f->dim, f->metric == COLTT_COSINE,
-                                                                    d_slots, slot_base, f->rows.as<uint8_t>(), f->stride);
+  dev::launch_prep_rows<QUANT>(f->stream, d_raw, n, (int)f->dim, f->metric == COLTT_COSINE, d_slots, slot_base,
+                               f->rows.as<uint8_t>(), f->stride);
   row_norms_kernel<QUANT><<<ceil_div(n * 2, 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, d_slots,
                                                                        slot_base, n, (int)f->dim, f->norms.as<float>());
   COLTT_HIP(hipGetLastError());

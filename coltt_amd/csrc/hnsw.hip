@@ -297,7 +297,7 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
   float* N = x->norms.as<float>();
 #define COLTT_PREP(Q)                                                                                                  \
   do {                                                                                                                 \
-    prep_rows_kernel<Q><<<ceil_div(n, 128), 128, 0, x->stream>>>(d_raw, n, (int)x->dim, nrm, nullptr, slot_base, R, x->stride); \
+    launch_prep_rows<Q>(x->stream, d_raw, n, (int)x->dim, nrm, nullptr, slot_base, R, x->stride);                     \
     row_norms_kernel<Q><<<ceil_div(n * 2, 256), 256, 0, x->stream>>>(R, x->stride, nullptr, slot_base, n, (int)x->dim, N);     \
   } while (0)
   if (x->quant == COLTT_Q_NONE) COLTT_PREP(Q_NONE);
@@ -713,6 +713,16 @@ int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out) {
   auto x = lookup<Hnsw>(h);
   if (!x || !out) return fail(COLTT_E_NOT_FOUND, "hnsw_get_cfg: unknown handle");
   *out = x->cfg;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_random_level(coltt_handle_t h, float u, int32_t* out_level) {
+  auto x = lookup<Hnsw>(h);
+  if (!x || !out_level) return fail(COLTT_E_NOT_FOUND, "hnsw_random_level: unknown handle");
+  if (!(u > 0.f && u < 1.f)) return fail(COLTT_E_INVALID, "hnsw_random_level: u must be in (0,1)");
+  const float lg = (float)std::log((double)u);       // gomath.Log
+  const float v = -lg * x->cfg.level_multiplier;      // RandomExponential (f32 multiply)
+  *out_level = (int32_t)std::floor((double)v);        // gomath.Floor
   return COLTT_OK;
 }
 

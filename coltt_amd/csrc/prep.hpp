@@ -1,6 +1,7 @@
 // prep.hpp — ingest-side kernels shared by the FLAT store and the HNSW index: Normalize + Lower of stored
 // vectors, AVX-order row norms, and the query-side Normalize / Lower / decode.
 #pragma once
+#include <algorithm>
 #include "exact.hpp"
 
 namespace coltt {
@@ -8,32 +9,72 @@ namespace dev {
 
 // ---------------------------------------------------------------------------------------------------
 // Normalize (edge/vectorstore.go:173-189) + Quantization.Lower (edge/f16_quantization.go:47-53 ...).
-// One thread per vector: the reference's norm is ONE sequential f32 chain (norm += v[i]*v[i]).
+// One wave per vector.  The reference's norm is ONE sequential f32 chain (norm += v[i]*v[i]), so one lane walks it — over an
+// LDS copy fetched with coalesced loads — and the element-wise half (divide, encode, store) runs on all 64 lanes.  (One
+// thread per vector, each striding through its own row, ingested at 0.2 TB/s.)
 // ---------------------------------------------------------------------------------------------------
+constexpr int PQ_CHUNK = 4096;
+// norm += v[0]^2, += v[1]^2, ... strictly in order (mul, then add: no FMA), reading LDS 16 values at a time so the chain
+// pays the LDS latency once per 16 elements instead of once per element.
+__device__ __forceinline__ float seq_sqsum(float norm, const float* v, int m) {
+  int e = 0;
+  for (; e + 16 <= m; e += 16) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(v + e), b = *reinterpret_cast<const f32x4*>(v + e + 4);
+    f32x4 c = *reinterpret_cast<const f32x4*>(v + e + 8), d = *reinterpret_cast<const f32x4*>(v + e + 12);
+    f32x4 pa = a * a, pb = b * b, pc = c * c, pd = d * d;
+    norm += pa.x; norm += pa.y; norm += pa.z; norm += pa.w;
+    norm += pb.x; norm += pb.y; norm += pb.z; norm += pb.w;
+    norm += pc.x; norm += pc.y; norm += pc.z; norm += pc.w;
+    norm += pd.x; norm += pd.y; norm += pd.z; norm += pd.w;
+  }
+  for (; e < m; e++) { float x = v[e]; norm += x * x; }
+  return norm;
+}
 template <int QUANT>
-__global__ void prep_rows_kernel(const float* __restrict__ raw, uint64_t n, int dim, int normalize,
-                                 const uint32_t* __restrict__ slots, uint64_t slot_base, uint8_t* __restrict__ rows,
-                                 size_t stride) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(64) void prep_rows_kernel(const float* __restrict__ raw, uint64_t n, int dim, int normalize,
+                                                       const uint32_t* __restrict__ slots, uint64_t slot_base,
+                                                       uint8_t* __restrict__ rows, size_t stride) {
+  __shared__ __attribute__((aligned(16))) float buf[PQ_CHUNK];
+  __shared__ float s_norm;
+  const uint64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
   const float* v = raw + i * (uint64_t)dim;
-  uint64_t slot = slots ? slots[i] : slot_base + i;
+  const uint64_t slot = slots ? slots[i] : slot_base + i;
   uint8_t* out = rows + slot * stride;
   float norm = 0.f;
   bool zero = false;
   if (normalize) {
-    for (int e = 0; e < dim; e++) { float x = v[e]; norm += x * x; }
+    for (int c0 = 0; c0 < dim; c0 += PQ_CHUNK) {
+      const int m = min(PQ_CHUNK, dim - c0);
+      for (int e = lane; e < m; e += 64) buf[e] = v[c0 + e];
+      __syncthreads();
+      if (lane == 0) norm = seq_sqsum(norm, buf, m);
+      __syncthreads();
+    }
+    if (lane == 0) s_norm = norm;
+    __syncthreads();
+    norm = s_norm;
     zero = (norm == 0.f);
     norm = go_sqrt(norm);
   }
-  for (int e = 0; e < dim; e++) {
+  for (int e = lane; e < dim; e += 64) {
     float x = v[e];
     if (normalize) x = zero ? 0.f : div_rn(x, norm);
     if constexpr (QUANT == Q_NONE) reinterpret_cast<float*>(out)[e] = x;
     else if constexpr (QUANT == Q_F8) out[e] = (uint8_t)f32bits_to_f8bits(__float_as_uint(x));
     else reinterpret_cast<unsigned short*>(out)[e] = (unsigned short)f32bits_to_f16bits(__float_as_uint(x));
   }
-  for (size_t b = (size_t)dim * elem_bytes<QUANT>(); b < stride; b++) out[b] = 0;
+  for (size_t bb = (size_t)dim * elem_bytes<QUANT>() + lane; bb < stride; bb += 64) out[bb] = 0;
+}
+template <int QUANT>
+inline void launch_prep_rows(hipStream_t st, const float* raw, uint64_t n, int dim, int normalize, const uint32_t* slots,
+                             uint64_t slot_base, uint8_t* rows, size_t stride) {
+  const uint64_t step = 1ull << 24;  // grid x 64 threads must stay below 2^32
+  for (uint64_t o = 0; o < n; o += step) {
+    const uint64_t m = std::min<uint64_t>(step, n - o);
+    prep_rows_kernel<QUANT><<<(unsigned)m, 64, 0, st>>>(raw + o * (uint64_t)dim, m, dim, normalize, slots ? slots + o : nullptr,
+                                                       slot_base + o, rows, stride);
+  }
 }
 
 // ||row||^2 in AVX order, one lane pair per row.
@@ -54,11 +95,10 @@ __global__ void row_norms_kernel(const uint8_t* __restrict__ rows, size_t stride
 // one lane walks it — but over an LDS copy the whole wave fetched with coalesced loads, and the element-wise half
 // (divide, Lower, decode) runs on all 64 lanes.  (One THREAD per query, each striding through its own row, cost 330 us for
 // 256 x 768 queries: 5 % of a batched FLAT search.)
-constexpr int PQ_CHUNK = 4096;
 template <int QUANT>
 __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ raw, uint64_t nq, int dim, int normalize,
                                                           float* __restrict__ q_eff) {
-  __shared__ float buf[PQ_CHUNK];
+  __shared__ __attribute__((aligned(16))) float buf[PQ_CHUNK];
   __shared__ float s_norm;
   const uint64_t i = blockIdx.x;
   const int lane = threadIdx.x;
@@ -71,7 +111,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
       const int n = min(PQ_CHUNK, dim - c0);
       for (int e = lane; e < n; e += 64) buf[e] = v[c0 + e];
       __syncthreads();
-      if (lane == 0) for (int e = 0; e < n; e++) { float x = buf[e]; norm += x * x; }
+      if (lane == 0) norm = seq_sqsum(norm, buf, n);
       __syncthreads();
     }
     if (lane == 0) s_norm = norm;

@@ -53,6 +53,12 @@ class Hnsw:
     def Dim(self):
         return self.dim
 
+    def RandomLevel(self, u):
+        """Hnsw.RandomLevel() (hnsw.go:280-282) for a uniform draw u in (0,1) supplied by the caller."""
+        lv = C.c_int32(0)
+        L.check(L.lib().coltt_hnsw_random_level(self.h, C.c_float(u), C.byref(lv)))
+        return lv.value
+
     # -- Hnsw.Load-shaped bulk import (graph dict in the oracle's export layout; raw vectors in slot order)
     def BulkLoad(self, g, raw_vectors):
         v = np.ascontiguousarray(raw_vectors, np.float32)

@@ -14,6 +14,7 @@ package colttgpu
 import "C"
 
 import (
+	"math/rand"
 	"context"
 	"errors"
 	"fmt"
@@ -112,6 +113,18 @@ func (x *Hnsw) Search(_ context.Context, query []float32, k uint) (SearchResult,
 }
 
 func (x *Hnsw) Len() int { var n C.uint64_t; C.coltt_hnsw_len(x.h, &n); return int(n) }
+
+// RandomLevel mirrors (*vectorindex.Hnsw).RandomLevel (hnsw.go:280-282): the uniform draw stays on the Go side
+// (math/rand, as in the reference), the library applies gomath.Floor(-gomath.Log(u) * levelMultiplier).
+func (x *Hnsw) RandomLevel() int {
+	u := rand.Float32()
+	for u <= 0 { // the reference would produce Floor(+Inf); redraw instead
+		u = rand.Float32()
+	}
+	var lv C.int32_t
+	C.coltt_hnsw_random_level(x.h, C.float(u), &lv)
+	return int(lv)
+}
 func (x *Hnsw) Dim() uint32 { return uint32(x.dim) }
 func (x *Hnsw) Close()    { C.coltt_hnsw_destroy(x.h) }
 

@@ -149,6 +149,11 @@ typedef struct coltt_hnsw_stats {     /* per search call, summed over the batch 
 int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out);
 int coltt_hnsw_destroy(coltt_handle_t h);
 int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out);
+/* Hnsw.RandomLevel() (hnsw.go:280-282) for a caller-supplied uniform draw u in (0,1) — the value the shim's
+ * rand.Float32() returned (gomath/rand.go:42-44: -Log(u) * levelMultiplier; math.go:52-62: float32 log, Floor through
+ * float64).  The reference draws from the auto-seeded global math/rand, so the draw itself stays on the Go side.
+ * u <= 0 (the reference's +Inf -> undefined int) or u >= 1 is COLTT_E_INVALID. */
+int coltt_hnsw_random_level(coltt_handle_t h, float u, int32_t* out_level);
 /* Load a graph built elsewhere (the oracle, Hnsw.Load's stream, another shard): slot-major arrays.
  * vectors are raw (Normalize/Lower are applied here for cosine/quant, as Insert does, hnsw.go:105-107).
  * rows = sum(level+1); row r of slot s, level l holds nbr[row_offsets[r] .. row_offsets[r+1]).  */

@@ -100,6 +100,8 @@ class Hnsw {
     return r;
   }
   int Len() const { uint64_t n = 0; check(coltt_hnsw_len(h_, &n)); return (int)n; }
+  // RandomLevel() (hnsw.go:280-282) for the caller's uniform draw u in (0,1)
+  int RandomLevel(float u) const { int32_t lv = 0; check(coltt_hnsw_random_level(h_, u, &lv)); return lv; }
   uint32_t Dim() const { return dim_; }
   coltt_hnsw_cfg Config() const { coltt_hnsw_cfg c; check(coltt_hnsw_get_cfg(h_, &c)); return c; }
   coltt_handle_t handle() const { return h_; }

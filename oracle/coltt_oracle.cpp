@@ -1148,12 +1148,16 @@ void orc_fill_normal(uint64_t seed, uint64_t first, float* out, size_t n) {
 // HNSW level draw: floor(-ln(U) * mult) (hnsw.go:280-282; gomath/rand.go:42-44; math.go:52-54,60-62)
 // with U = (24 random bits + 1) / 2^24 in (0,1] from the counter stream (the reference uses the
 // auto-seeded global math/rand, so no sequence is reproducible there).
-int orc_level(uint64_t seed, uint64_t i, float mult) {
-  uint64_t r = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
-  float u = (float)((r >> 40) + 1) * (1.0f / 16777216.0f);
+// Hnsw.RandomLevel for a given uniform draw u (the value rand.Float32() returned): gomath.Floor(-gomath.Log(u) * mult)
+int orc_level_from_u(float u, float mult) {
   float lg = (float)std::log((double)u);
   float x = -lg * mult;
   return (int)std::floor((double)x);
+}
+int orc_level(uint64_t seed, uint64_t i, float mult) {
+  uint64_t r = splitmix64(seed ^ (i * 0x9E3779B97F4A7C15ull));
+  float u = (float)((r >> 40) + 1) * (1.0f / 16777216.0f);
+  return orc_level_from_u(u, mult);
 }
 
 // ---- FLAT ----

@@ -70,6 +70,7 @@ def lib():
         L.orc_hnsw_export.restype = C.c_int64
         L.orc_hnsw_graph_hash.restype = C.c_uint64
         L.orc_level.argtypes = [C.c_uint64, C.c_uint64, C.c_float]
+        L.orc_level_from_u.argtypes = [C.c_float, C.c_float]
         L.orc_fill_normal.argtypes = [C.c_uint64, C.c_uint64, _vp, C.c_size_t]
         _lib = L
     return _lib
@@ -202,6 +203,11 @@ def fill_normal(seed, shape, first=0):
 
 def level(seed, i, mult):
     return int(lib().orc_level(int(seed), int(i), C.c_float(mult)))
+
+
+def level_from_u(u, mult):
+    """Hnsw.RandomLevel (hnsw.go:280-282) for the uniform draw u that rand.Float32() returned."""
+    return int(lib().orc_level_from_u(C.c_float(u), C.c_float(mult)))
 
 
 def levels(seed, n, m=16):

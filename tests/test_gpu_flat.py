@@ -179,3 +179,17 @@ def test_flat_save_load_vertex_streams(gpu, quant):
     with pytest.raises(gpu.ColttError):
         g2.LoadVertex(stream[:-3])
     assert gpu.FlatSpace(d, O.COSINE, quant).LoadVertex(gpu.FlatSpace(d, O.COSINE, quant).SaveVertex()) == 0
+
+
+def test_flat_config0_full_size_single_queries(gpu):
+    """BASELINE.json configs[0] at full size — 100 000 x 128 f32 cosine, single-query searches, k = 10 — GPU (exact-order
+    mode and matrix-core mode) vs the oracle's canonical scan, both select directions; the CPU side finishes in seconds."""
+    n, d = 100_000, 128
+    X, ids, of, gf = build_pair(gpu, n, d, O.COSINE, O.Q_NONE, seed=41)
+    Q = O.fill_normal(42, (6, d))
+    for qi in range(len(Q)):
+        for select in (gpu.SELECT_REFERENCE, gpu.SELECT_NEAREST):
+            wi, ws = of.search(Q[qi], 10, nearest=bool(select), mode=2)
+            for mode in (gpu.MODE_EXACT, gpu.MODE_MFMA):
+                gi, gs, gc = gf.VertexSearch(Q[qi:qi + 1], 10, select, mode=mode)
+                assert_same_results(gi[0, :gc[0]], gs[0, :gc[0]], wi, ws, f"q{qi} sel{select} mode{mode}")

@@ -69,11 +69,13 @@ def test_hnsw_empty_and_tiny(gpu):
         assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
 
 
-@pytest.mark.parametrize("quant", [O.Q_F16, O.Q_F8])
-def test_hnsw_quantised_rows(gpu, quant):
+@pytest.mark.parametrize("quant,d", [(O.Q_F16, 64), (O.Q_F8, 64), (O.Q_F16, 24), (O.Q_F16, 77), (O.Q_F16, 784), (O.Q_F8, 77)])
+def test_hnsw_quantised_rows(gpu, quant, d):
     """2-/1-byte stored codes (BASELINE configs[4]): distances as the edge quantised stores compute them —
-    decode(query') vs decode(row).  Oracle: an f32 index over the decoded vectors gives the same arithmetic."""
-    n, d = 800, 64
+    decode(query') vs decode(row).  Oracle: an f32 index over the decoded vectors gives the same arithmetic.
+    Dims cover the wide 16-byte walk of 2-byte rows: even / odd 8-element group counts (64 / 24), odd + scalar tail (77),
+    full bursts + remainder (784 = 49 group pairs)."""
+    n = 800
     X = O.fill_normal(3, (n, d)); lv = O.levels(4, n); ids = np.arange(n, dtype=np.uint64)
     Xs = O.f16_decode(O.lower(quant, X)) if quant != O.Q_F8 else O.f8_decode(O.lower(quant, X))
     oh = O.Hnsw(d, O.L2); oh.insert_many(ids, Xs, lv)
@@ -296,3 +298,19 @@ def test_hnsw_hbm_visited_set_epoch_wrap(gpu, monkeypatch):
                 wi, ws = oh.search(Q[qi], 10, mode=1, ef=40)
                 assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"rep{rep} q{qi}")
             assert st["n_visit_resets"] == 0
+
+
+def test_hnsw_random_level_matches_reference_formula(gpu):
+    """coltt_hnsw_random_level == gomath.Floor(-gomath.Log(u) * levelMultiplier) (hnsw.go:280-282) for given draws."""
+    gh = gpu.Hnsw(8, O.L2)
+    mult = gh.cfg.level_multiplier
+    rng = np.random.default_rng(7)
+    us = np.concatenate([rng.random(2000, dtype=np.float32), np.float32([1e-30, 1e-7, 0.0624, 0.0625, 0.0626, 0.25, 0.999999])])
+    for u in us:
+        if not (0.0 < u < 1.0):
+            continue
+        assert gh.RandomLevel(float(u)) == O.level_from_u(float(u), mult), u
+    for bad in (0.0, 1.0, -0.5, float("nan")):
+        with pytest.raises(gpu.ColttError) as e:
+            gh.RandomLevel(bad)
+        assert e.value.code == -1
