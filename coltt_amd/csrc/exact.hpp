@@ -199,11 +199,13 @@ typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2e __attribute__((ext_vector_type(2)));
 template <int METRIC>
 __device__ __forceinline__ void h2_consume(f32x4& acc, u32x4e raw, const float* __restrict__ q, int s, int half) {
-  const uint32_t k0 = half ? raw.z : raw.x, k1 = half ? raw.w : raw.y;   // my chains' part of the group I loaded
-  const uint32_t g0 = half ? raw.x : raw.z, g1 = half ? raw.y : raw.w;   // my partner's chains' part
-  const uint32_t r0 = dpp_swap1(g0), r1 = dpp_swap1(g1);
-  const u32x2e a = {half ? r0 : k0, half ? r1 : k1};                     // group 2s
-  const u32x2e b = {half ? k0 : r0, half ? k1 : r1};                     // group 2s + 1
+  // a = my residues of group 2s, b = my residues of group 2s + 1: the half I loaded myself or my partner's.  The swaps are
+  // computed unconditionally, by all lanes: a DPP read under a partial EXEC mask would see its partner disabled.
+  // (v_fma_mix_f32 — q * f16 + (-0.0), no separate convert — is bit-identical and 4 VALU shorter per step, but measured
+  // 3 % slower: it is not packed and not full rate.)
+  const uint32_t sx = dpp_swap1(raw.x), sy = dpp_swap1(raw.y), sz = dpp_swap1(raw.z), sw = dpp_swap1(raw.w);
+  const u32x2e a = {half ? sz : raw.x, half ? sw : raw.y};
+  const u32x2e b = {half ? raw.z : sx, half ? raw.w : sy};
   const f32x4 ra = __builtin_convertvector(__builtin_bit_cast(f16x4, a), f32x4);
   const f32x4 rb = __builtin_convertvector(__builtin_bit_cast(f16x4, b), f32x4);
   const f32x4 qa = *reinterpret_cast<const f32x4*>(q + 16 * s + 4 * half);
@@ -211,6 +213,7 @@ __device__ __forceinline__ void h2_consume(f32x4& acc, u32x4e raw, const float* 
   if constexpr (METRIC == M_COS) { f32x4 p = qa * ra; acc = acc + p; p = qb * rb; acc = acc + p; }
   else { f32x4 d = qa - ra; f32x4 p = d * d; acc = acc + p; d = qb - rb; p = d * d; acc = acc + p; }
 }
+
 // Software pipeline of a row walk: `n` steps in bursts of U — the next burst is requested back to back while the previous
 // one is decoded and consumed (U..2U loads per lane in flight; bytes in flight per wave are what buys HBM bandwidth).  The
 // remainder (n % U steps; the whole row when n < U, e.g. dim 128) goes four predicated steps at a time (a full predicated
