@@ -157,7 +157,10 @@ __device__ __forceinline__ float cos_epilogue_native(float dot, float na, float 
   return fabsf(1.0f - div_rn(dot, den));
 }
 
-__device__ __forceinline__ float xor1(float v) { return __shfl_xor(v, 1, 64); }
+// partner lane's value (lane ^ 1) through DPP quad_perm [1,0,3,2]: a VALU move, not a trip through the LDS crossbar
+__device__ __forceinline__ float xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
 
 // hadd,hadd,lane0+lane4 (avx.cpp:4-8) for an accumulator split over a lane pair: each half first forms
 // (r0+r1)+(r2+r3) of its own four residues, then low half + high half.  Result valid in BOTH lanes.

@@ -50,16 +50,21 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
     if (qi >= nq) break;
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
-    __syncthreads();
+#ifdef COLTT_PHASE_TIMING
+    for (int i_ = 0; i_ < 8; i_++) w.pt[i_] = 0;
+    w.t_last = __builtin_amdgcn_s_memtime();
+#endif
+    wave_sync();
     for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
     w.qnorm = qnorms[qi];
-    __syncthreads();
+    wave_sync();
     // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253)
     uint32_t cur = (uint32_t)entry;
     float curd = eval_pair<METRIC, QUANT, PROF>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
     for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF>(g, w, cur, curd, l, lane);  // :254-256
+    COLTT_PT(w, 5)  // query load + entry distance + upper levels
     // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     w.n_dist += 1;
     uint32_t len; int buf;
@@ -80,6 +85,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
       atomicAdd(&stats[2], (unsigned long long)w.n_hops);
       atomicAdd(&stats[3], (unsigned long long)w.n_resets);
       if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
+#ifdef COLTT_PHASE_TIMING
+      COLTT_PT(w, 6)  // result write-out
+      for (int i_ = 0; i_ < 8; i_++) atomicAdd(&stats[8 + i_], w.pt[i_]);
+#endif
     }
   }
   if constexpr (VISG) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
@@ -121,13 +130,13 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
     const uint32_t vi = base + bi;
     const int lv = levels[bi];
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
-    __syncthreads();
+    wave_sync();
     {  // the query is the vertex's own stored row, decoded to f32
       const uint8_t* row = g.rows + (size_t)vi * g.stride;
       for (int e = lane; e < g.dim; e += 64) w.qs[e] = load1<QUANT>(row, e);
     }
     w.qnorm = METRIC == M_COS ? g.norms[vi] : 0.f;
-    __syncthreads();
+    wave_sync();
     uint32_t cur = (uint32_t)entry;
     float curd = eval_pair<METRIC, QUANT, PROF_BUILD>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       // next level starts from the nearest result (hnsw.go:145 `entrypoint = neighbor`, last popped = nearest)
       unsigned long long e0 = res[0];
       cur = (uint32_t)e0 >> 1; curd = __uint_as_float((uint32_t)(e0 >> 32));
-      __syncthreads();
+      wave_sync();
     }
     if (lane == 0) {
       atomicAdd(&stats[0], (unsigned long long)w.n_dist);
@@ -429,10 +438,10 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
     d_q = x->w_qraw.as<float>();
   }
   COLTT_TRY(prep_queries_any(x, d_q, nq));
-  COLTT_TRY(x->w_misc.reserve(64));
+  COLTT_TRY(x->w_misc.reserve(256));
   uint32_t* counter = x->w_misc.as<uint32_t>();
   unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
-  COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 64, x->stream));
+  COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 256, x->stream));
   COLTT_HIP(hipEventRecord(x->ev0, x->stream));
   int rc;
 #define COLTT_LS(M, Q) rc = launch_search<M, Q>(x, sg, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats)
@@ -452,7 +461,20 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
     COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
   }
   COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, x->stream));
+#ifdef COLTT_PHASE_TIMING
+  unsigned long long h_pt[8] = {0};
+  COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, x->stream));
+#endif
   COLTT_HIP(hipStreamSynchronize(x->stream));
+#ifdef COLTT_PHASE_TIMING
+  {
+    static const char* nm[8] = {"pop", "adjacency", "visited", "rows+dist", "merge", "prologue(upper levels)", "writeout", "-"};
+    double tot = 0; for (int i = 0; i < 7; i++) tot += (double)h_pt[i];
+    fprintf(stderr, "[phase] nq=%zu ef=%u visg=%d:", nq, sg.ef, (int)sg.visg);
+    for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_pt[i] / tot);
+    fprintf(stderr, "  | ticks/query %.0f\n", tot / (double)nq);
+  }
+#endif
   (void)hipEventElapsedTime(&x->last_ms, x->ev0, x->ev1);
   if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_search: traversal watchdog tripped (code %llu)", h_stats[4]);
   if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }

@@ -45,6 +45,9 @@ struct WaveCtx {
   // counters (wave-uniform)
   uint32_t n_dist, n_exp, n_hops, n_resets;
   uint8_t* visg; size_t vis_bytes; uint32_t epoch;  // VISG: this workgroup's byte-per-slot region, its size, current epoch
+#ifdef COLTT_PHASE_TIMING
+  unsigned long long pt[8], t_last;  // shader-clock ticks per traversal phase (diagnostic build only)
+#endif
   uint32_t err;  // watchdog: 1 visited-set probe overflow, 2 expansion budget, 3 greedy hop budget (every loop is bounded)
 };
 
@@ -52,6 +55,20 @@ struct WaveCtx {
 // back edge, which splits the wave around convergent operations (ballot / shuffle / readlane) — observed as an
 // endless loop in the work-fetch of the search kernel.  Re-reading the lane id through an opaque asm at the top of
 // every traversal loop iteration makes the predicates non-invariant and keeps the wave converged.
+#ifdef COLTT_PHASE_TIMING
+#define COLTT_PT(W, K) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); (W).pt[K] += t_ - (W).t_last; (W).t_last = t_; }
+#else
+#define COLTT_PT(W, K)
+#endif
+// Cross-lane LDS hand-off inside ONE wave (the traversal kernels run single-wave workgroups).  LDS operations of a wave
+// execute in order, so a later read by one lane sees an earlier write by another without any hardware wait; what is needed is
+// only that the compiler keeps the order.  __syncthreads() would also drain vmcnt — i.e. wait for every global load in
+// flight, which is exactly what the adjacency prefetch must not do.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int j) {
@@ -154,13 +171,13 @@ __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uin
 // Rebuild the visited set from the current result set (bounded-memory fallback; see search_level).
 __device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* res, uint32_t len, int lane) {
   vis_clear(w, lane);
-  __syncthreads();
+  wave_sync();
   for (uint32_t i = lane; i < len; i += 64) vis_insert(w.vis, w.hcap_mask, (uint32_t)res[i] >> 1);
-  __syncthreads();
+  wave_sync();
 }
 
 // searchLevel (hnsw.go:345-389).  On return w.res[buf][0..len) holds the result set ascending by (d, slot).
-// The wave must be the only one in its workgroup (uses __syncthreads as a wave-level LDS fence).
+// The wave must be the only one in its workgroup (wave_sync is a wave-level LDS fence).
 template <int METRIC, int QUANT, bool VISG, int PROFILE>
 __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
                                              int level, int lane_in, uint32_t& out_len, int& out_buf) {
@@ -174,7 +191,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
   } else vis_clear(w, lane);
   int buf = 0;
   if (lane == 0) w.res0[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {
     if constexpr (VISG) __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else vis_insert(w.vis, w.hcap_mask, ep);
@@ -182,14 +199,14 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
   uint32_t len = 1, vis_count = 1;
   bool had_reset = false;
   uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE;
-  __syncthreads();
+  wave_sync();
   for (uint32_t iters = 0;; iters++) {
     if (iters > (1u << 22)) { w.err |= 2u; break; }
     lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
-    // ---- pop: the smallest unexpanded member (cj = the one after it: the likely next pop, see the adjacency prefetch)
+    // ---- pop: the smallest unexpanded member (cj = the unexpanded member after it, see the adjacency prefetch)
     int ci = -1, cj = -1;
     for (uint32_t base = 0; base < len; base += 64) {
       uint32_t i = base + lane;
@@ -203,40 +220,50 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       }
     }
     if (ci < 0) break;
+    COLTT_PT(w, 0)  // pop scan
     unsigned long long ce = res[ci];
+    const unsigned long long runner_key = cj >= 0 ? (res[cj] & ~1ull) : ~0ull;
     float lower_bound = __uint_as_float((uint32_t)(res[len - 1] >> 32));
-    __syncthreads();
+    wave_sync();
     if (lane == 0) res[ci] = ce | 1ull;
     const uint32_t cslot = (uint32_t)ce >> 1;
     uint32_t free_slots = ef - len;  // len <= ef
     w.n_exp++;
     if constexpr (!VISG) {
       if (vis_count + 64 > (w.hcap >> 2) * 3) {  // bounded visited set: forget everything but the result set
-        __syncthreads();
+        wave_sync();
         vis_reset(w, res, len, lane);
         vis_count = len; had_reset = true; w.n_resets++;
       }
     }
-    __syncthreads();
+    wave_sync();
     uint32_t width;
     const uint32_t* row = adj_row(g, cslot, level, width);
-    // Adjacency prefetch (level 0): the row of the runner-up candidate is requested now and is in registers when it is
-    // popped next — unless a closer vertex is admitted in between, in which case the row is simply loaded as usual.  Takes
-    // one dependent HBM round trip out of most expansions; the rows are frozen during a search, so nothing changes.
+    // Adjacency prefetch (level 0).  The NEXT pop is known as soon as this expansion's distances are: it is the smaller of
+    // the runner-up (the unexpanded member after the one popped now) and the best vertex admitted now.  Its adjacency row
+    // is requested right then and flies during the merge and the next pop scan, which takes the dependent HBM round trip
+    // (8 % / 12 % of the walk for f32 / f16 rows) out of the chain.  Rows are frozen during a search: nothing else changes.
     const bool use_pre = level == 0 && pre_slot == cslot;
     const uint32_t pre_now = pre_nb;
-    if (level == 0) {
-      pre_slot = NBR_NONE;
-      if (cj >= 0) {
-        pre_slot = (uint32_t)res[cj] >> 1;
-        pre_nb = (uint32_t)p < g.mMax0 ? g.adj0[(size_t)pre_slot * g.mMax0 + p] : NBR_NONE;
-      }
+    pre_slot = NBR_NONE;
+    unsigned long long best_new = ~0ull;
+#define COLTT_PREFETCH_NEXT()                                                                        \
+    if (level == 0) {                                                                                \
+      const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
+      if (nk_ != ~0ull) {                                                                            \
+        pre_slot = (uint32_t)nk_ >> 1;                                                               \
+        pre_nb = (uint32_t)p < g.mMax0 ? g.adj0[(size_t)pre_slot * g.mMax0 + p] : NBR_NONE;          \
+      }                                                                                              \
     }
     for (uint32_t c0 = 0; c0 < width; c0 += 32) {
       res = w.res0 + (size_t)buf * w.ef_pad;
       uint32_t idx = c0 + p;
       uint32_t nb = idx < width ? ((use_pre && c0 == 0) ? pre_now : row[idx]) : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+#ifdef COLTT_PHASE_TIMING
+      if (__ballot(valid) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the adjacency values to have arrived
+#endif
+      COLTT_PT(w, 1)  // adjacency row
       int fresh_i = 0;
       if (valid && half == 0) {
         if constexpr (VISG) {
@@ -248,7 +275,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
           if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
       }
-      fresh_i = __shfl(fresh_i, lane & ~1, 64);
+      fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);  // even lane's verdict to its pair: quad_perm [0,0,2,2]
       bool fresh = fresh_i != 0;
       if (had_reset) {
         // a forgotten vertex that is still in the result set must not be admitted twice
@@ -266,19 +293,40 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       }
       unsigned long long E = __ballot(fresh && half == 0);
       uint32_t nfresh = __popcll(E);
-      if (nfresh == 0) continue;
+      COLTT_PT(w, 2)  // visited test-and-set
+      const bool last_chunk = c0 + 32 >= width;
+      if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT() } continue; }
       vis_count += nfresh; w.n_dist += nfresh;
       float d = 0.f;
       if (fresh) d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
       uint32_t rank = __popcll(E & lt_mask);
       bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
+#ifdef COLTT_PHASE_TIMING
+      if (__ballot(adm) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the distances
+#endif
+      COLTT_PT(w, 3)  // row reads + distances
       free_slots = free_slots > nfresh ? free_slots - nfresh : 0;
       unsigned long long A = __ballot(adm);
       uint32_t m = __popcll(A);
+      unsigned long long mykey = adm ? (((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)nb << 1)) : ~0ull;
+      uint32_t myrank = 0;  // rank of my key among the admitted ones (readlane broadcasts: no LDS round trips)
+      {
+        unsigned long long am = A;
+        while (am) {
+          int j = __builtin_ctzll(am); am &= am - 1;
+          unsigned long long kj = readlane_u64(mykey, j);
+          myrank += (kj < mykey) ? 1u : 0u;
+        }
+      }
+      if (m) {  // the smallest admitted key is the one of rank 0
+        const unsigned long long z = __ballot(adm && myrank == 0);
+        const unsigned long long mn = readlane_u64(mykey, __builtin_ctzll(z));
+        best_new = mn < best_new ? mn : best_new;
+      }
+      if (last_chunk) { COLTT_PREFETCH_NEXT() }
       if (m == 0) continue;
       // ---- merge the m admitted (d, slot) into the sorted result set, keep the ef smallest
       unsigned long long* dst = w.res0 + (size_t)(buf ^ 1) * w.ef_pad;
-      unsigned long long mykey = adm ? (((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)nb << 1)) : ~0ull;
       uint32_t mypos = 0;
       if (adm) {  // lower_bound over the sorted result set
         uint32_t lo = 0, hi = len;
@@ -299,21 +347,16 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
         if (i < len && np < ef) dst[np] = e;
       }
       {
-        unsigned long long am = A;
-        uint32_t myrank = 0;
-        while (am) {
-          int j = __builtin_ctzll(am); am &= am - 1;
-          unsigned long long kj = readlane_u64(mykey, j);
-          myrank += (kj < mykey) ? 1u : 0u;
-        }
         uint32_t np = mypos + myrank;
         if (adm && np < ef) dst[np] = mykey;
       }
       len = len + m < ef ? len + m : ef;
       buf ^= 1;
-      __syncthreads();
+      wave_sync();
+      COLTT_PT(w, 4)  // merge
     }
   }
+#undef COLTT_PREFETCH_NEXT
   out_len = len;
   out_buf = buf;
 }
