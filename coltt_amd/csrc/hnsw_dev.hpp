@@ -242,13 +242,21 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     // Adjacency prefetch (level 0).  The NEXT pop is known as soon as this expansion's distances are: it is the smaller of
     // the runner-up (the unexpanded member after the one popped now) and the best vertex admitted now.  Its adjacency row
     // is requested right then and flies during the merge and the next pop scan, which takes the dependent HBM round trip
-    // (8 % / 12 % of the walk for f32 / f16 rows) out of the chain.  Rows are frozen during a search: nothing else changes.
+    // (12 % of the walk for f16 rows) out of the chain.  Rows are frozen during a search: nothing else changes.
     const bool use_pre = level == 0 && pre_slot == cslot;
     const uint32_t pre_now = pre_nb;
     pre_slot = NBR_NONE;
     unsigned long long best_new = ~0ull;
+    // Enabled for 2-/1-byte rows only: with f32 rows it measured SLOWER at 10 M x 768 on one box (search 22.4 -> 23.1 ms per
+    // 10 k queries, build 39.8 -> 47.8 s; neutral at 2 M) — the walk is then at the memory system's limit and the early
+    // request only reorders traffic.  -DCOLTT_NO_ADJ_PREFETCH turns it off everywhere.
+#ifdef COLTT_NO_ADJ_PREFETCH
+#define COLTT_PREFETCH_LEVEL(L) false
+#else
+#define COLTT_PREFETCH_LEVEL(L) (QUANT != Q_NONE && (L) == 0)
+#endif
 #define COLTT_PREFETCH_NEXT()                                                                        \
-    if (level == 0) {                                                                                \
+    if (COLTT_PREFETCH_LEVEL(level)) {                                                               \
       const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
       if (nk_ != ~0ull) {                                                                            \
         pre_slot = (uint32_t)nk_ >> 1;                                                               \
