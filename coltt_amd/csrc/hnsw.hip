@@ -368,6 +368,12 @@ int visg_policy() {
   return e && *e ? atoi(e) : -1;
 }
 
+// does this ef want the HBM visited set (policy only; whether the workspace could be had is vis_regions > 0)
+bool wants_visg(uint32_t ef) {
+  const int pol = visg_policy();
+  return pol < 0 ? ef > COLTT_VISG_MIN_EF : pol != 0;
+}
+
 SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   SearchGeom s;
   s.ef = ef;
@@ -378,8 +384,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   // large ef x dim: shrink it until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps results exact;
   // it needs 0.75 * hcap > ef + 64)
   while (fixed + (size_t)s.hcap * 4 > 160 * 1024 && s.hcap > 4096 && (s.hcap / 2) * 3 / 4 > ef + 64) s.hcap /= 2;
-  const int pol = visg_policy();
-  s.visg = x->vis_regions > 0 && (pol < 0 ? ef > COLTT_VISG_MIN_EF : pol != 0);
+  s.visg = wants_visg(ef) && x->vis_stride != 0 && x->vis_regions > 0;
   if (s.visg) { s.hcap = 64; s.lds = fixed; s.max_grid = x->vis_regions; }
   else { s.lds = fixed + (size_t)s.hcap * 4; s.max_grid = 0xffffffffu; }
   return s;
@@ -428,7 +433,7 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
   }
   uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
   if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: ef=%u > 4096", ef);
-  COLTT_TRY(ensure_visg(x));
+  if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
   SearchGeom sg = search_geom(x, ef);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
   const float* d_q = queries;
@@ -560,7 +565,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     for (uint32_t j = 0; j < b; j++) up += first ? 0 : (uint64_t)levels[i + j];
     const uint64_t base = x->n;
     COLTT_TRY(x->reserve(base + b, x->n_upper + up));
-    COLTT_TRY(ensure_visg(x));  // the slot capacity may just have grown
+    if (wants_visg(efc)) COLTT_TRY(ensure_visg(x));  // (re)sized here: the slot capacity may just have grown
     const SearchGeom sg = search_geom(x, efc);
     if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", sg.lds);
     // host mirrors + per-slot tables
