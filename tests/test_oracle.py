@@ -179,3 +179,126 @@ def test_golden_flat_and_hnsw():
     rng = np.random.default_rng(40 + d)
     for i in rng.choice(n, 200, replace=False): x.remove(ids[i])
     assert x.graph_hash() == int(h["1000x128_cos_graph_hash_removed"][0])
+
+
+# ------------------------------------------------------------------ invariants the reference's own tests assert
+def test_hnsw_commit_load_round_trip_structural_equality():
+    """hnsw_commit_test.go:32-102 — Commit -> Load gives a structurally equal index (config, vertices, edges, entrypoint):
+    restated on the oracle's big-endian stream (hnsw_commit.go:69-278), with removals in the graph, and the loaded index
+    answers searches identically."""
+    n, d = 600, 20
+    X = O.fill_normal(21, (n, d)); lv = O.levels(22, n); ids = np.arange(n, dtype=np.uint64) * np.uint64(5) + np.uint64(9)
+    for metric in (O.COSINE, O.L2):
+        a = O.Hnsw(d, metric, O.default_cfg(efConstruction=48, ef=30)); a.insert_many(ids, X, lv)
+        for r in (ids[7], ids[100], ids[599]):
+            assert a.remove(int(r)) == 0
+        for header in (True, False):
+            blob = a.commit(header=header)
+            b = O.Hnsw(d, metric, O.default_cfg(efConstruction=48, ef=30))
+            assert b.load_stream(blob, header=header) == 0
+            assert len(b) == len(a) == n - 3
+            ga, gb = a.export(), b.export()
+            # tombstoned vertices are not written (hnsw_commit.go skips deleted), and Load appends in stream (shard) order:
+            # compare the live vertices per id, not per slot
+            la, lb = ga["deleted"] == 0, gb["deleted"] == 0
+            assert lb.all()
+            ia, ib = np.argsort(ga["ids"][la]), np.argsort(gb["ids"])
+            assert np.array_equal(ga["ids"][la][ia], gb["ids"][ib]) and np.array_equal(ga["levels"][la][ia], gb["levels"][ib])
+            assert np.array_equal(bits(ga["vectors"][la][ia]), bits(gb["vectors"][ib]))
+            assert ga["ids"][a.entry] == gb["ids"][b.entry]
+            c = O.Hnsw(d, metric); assert c.load_stream(b.commit(header=True), header=True) == 0   # Commit(Load(.)) is a fixed point
+            assert c.graph_hash() == b.graph_hash() and c.commit(header=header) == b.commit(header=header)
+            for q in O.fill_normal(23, (12, d)):
+                ra, rb = a.search(q, 8, mode=1), b.search(q, 8, mode=1)
+                assert np.array_equal(ra[0], rb[0]) and np.array_equal(bits(ra[1]), bits(rb[1]))
+
+
+@pytest.mark.parametrize("quant", [O.Q_NONE, O.Q_F16, O.Q_F8, O.Q_BF16])
+def test_flat_vertex_stream_round_trip(quant):
+    """SaveVertex -> LoadVertex (none_vectorstore.go:308-516, f16_vectorstore.go:317-532): same ids, same stored bits, same answers."""
+    n, d = 300, 36
+    X = O.fill_normal(31, (n, d)); ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919) + np.uint64(13)) % np.uint64(1 << 33)
+    a = O.Flat(d, O.COSINE, quant); a.upsert(ids, X); a.remove(ids[5:9])
+    blob = a.save_vertex()
+    b = O.Flat(d, O.COSINE, quant); b.load_vertex(blob)
+    assert len(b) == len(a) == n - 4
+    for i in (0, 4, 9, n - 1):
+        assert np.array_equal(a.get(ids[i]).view(np.uint8), b.get(ids[i]).view(np.uint8))
+    for q in O.fill_normal(32, (6, d)):
+        for nearest in (False, True):
+            ra, rb = a.search(q, 10, nearest=nearest, mode=2), b.search(q, 10, nearest=nearest, mode=2)
+            assert np.array_equal(ra[0], rb[0]) and np.array_equal(bits(ra[1]), bits(rb[1]))
+    assert b.save_vertex() == blob
+
+
+def test_random_level_formula():
+    """Hnsw.RandomLevel = gomath.Floor(-gomath.Log(u) * levelMultiplier) (hnsw.go:280-282, gomath/math.go:52-62): float32 log
+    (through float64), float32 multiply, floor through float64 — against an independent numpy restatement."""
+    mult = np.float32(1.0) / np.float32(np.log(np.float64(np.float32(16))))
+    rng = np.random.default_rng(3)
+    us = np.concatenate([rng.random(5000, dtype=np.float32), np.float32([1e-38, 1e-20, 0.0625, 0.5, 0.99999994])])
+    us = us[(us > 0) & (us < 1)]
+    for u in us:
+        want = int(np.floor(np.float64(np.float32(-np.float32(np.log(np.float64(u)))) * mult)))
+        assert O.level_from_u(float(u), float(mult)) == want, u
+    lv = O.levels(7, 200000)   # the counter-stream draw used by tests/bench: geometric-like, P(level >= 1) = 1/16
+    assert lv.min() == 0 and 0.055 < (lv >= 1).mean() < 0.07 and lv.max() < 12
+
+
+def test_cflat_weighted_multi_vector_score():
+    """experimental MultiVertexSearch (multi_vector_vertex.go:85-137): score = sum over included fields of
+    scoreHelper(distance) * ratio / 100, scoreHelper(cos) = ((2 - d) / 2) * 100 (experimental_helper.go:134-139), accumulated
+    in field order in f32; the K LARGEST scores are kept, descending."""
+    n, d, nf = 200, 16, 3
+    X = O.fill_normal(51, (n, nf, d)); ids = np.arange(n, dtype=np.uint64) + np.uint64(1000)
+    c = O.CFlat(d, nf, O.COSINE); c.upsert(ids, X)
+    q = O.fill_normal(52, (nf, d)); ratios = np.array([50, 30, 20], np.uint32); include = np.array([1, 0, 1], np.uint8)
+    got_i, got_s = c.search(q, ratios, include, 7)
+    qn = O.normalize(q)
+    sc = np.zeros(n, np.float32)
+    for f in range(nf):
+        if not include[f]:
+            continue
+        rows = O.normalize(X[:, f, :])
+        dist = O.dist_rows(O.COSINE, qn[f], rows)
+        term = ((np.float32(2) - dist) / np.float32(2)) * np.float32(100)
+        sc = (sc + term * (np.float32(ratios[f]) / np.float32(100))).astype(np.float32)
+    order = np.lexsort((ids, -sc.astype(np.float64)))[:7]
+    assert np.array_equal(np.sort(got_s)[::-1], got_s)
+    assert np.array_equal(bits(got_s), bits(sc[order]))
+    assert set(got_i.tolist()) == set(ids[order].tolist())
+    c.remove(ids[order[:2]])
+    i2, s2 = c.search(q, ratios, include, 7)
+    assert not (set(i2.tolist()) & set(ids[order[:2]].tolist()))
+
+
+def test_hnsw_remove_semantics():
+    """Hnsw.Remove (hnsw.go:191-241): the vertex disappears from answers and from its neighbours' rows; removing twice is
+    ItemNotFoundError; Len counts live vertices; searching after removing every answer still returns k live ids."""
+    n, d = 400, 12
+    X = O.fill_normal(61, (n, d)); lv = O.levels(62, n); ids = np.arange(n, dtype=np.uint64)
+    h = O.Hnsw(d, O.L2); h.insert_many(ids, X, lv)
+    q = O.fill_normal(63, d)
+    i0, s0 = h.search(q, 5, mode=1, ef=40)
+    removed = []
+    for v in (int(x) for x in i0[:3]):
+        if h.remove(v) == 0:           # (removing the entrypoint's last neighbour can be refused; not the case here)
+            removed.append(v)
+            assert h.remove(v) == -3   # ItemNotFoundError the second time
+    assert len(removed) == 3
+    assert len(h) == n - len(removed)
+    i1, s1 = h.search(q, 5, mode=1, ef=40)
+    assert len(i1) == 5 and not (set(i1.tolist()) & set(removed))
+    g = h.export()
+    assert int(g["deleted"].sum()) == len(removed)
+    # Remove unlinks the vertex from the rows of ITS OWN neighbours (hnsw.go:234-236); vertices that merely pointed at it keep
+    # the stale edge, which searchLevel skips through the tombstone (hnsw_vertex.go:70-76).
+    first_row = np.concatenate([[0], np.cumsum(g["levels"].astype(np.int64) + 1)])
+    def row(slot, level):
+        r = first_row[slot] + level
+        return g["nbr"][g["row_offsets"][r]:g["row_offsets"][r + 1]]
+    for v in np.nonzero(g["deleted"])[0]:
+        for level in range(int(g["levels"][v]) + 1):
+            for u in row(v, level):
+                if u >= 0 and not g["deleted"][u] and int(g["levels"][u]) >= level:
+                    assert v not in row(int(u), level).tolist(), (v, u, level)
