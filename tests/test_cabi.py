@@ -47,3 +47,56 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "libcoltt_oracle" not in src \
                     and "orc_" not in src, f
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/coltt_gpu.h compiles as C99 with nothing but <stdint.h>/<stddef.h>, a C program calling through it links
+    against libcoltt_gpu.so and runs (argument validation and error strings need no device) — what a cgo binding sees."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "c_consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "coltt_gpu.h"
+int main(void) {
+  coltt_handle_t h = 0;
+  int rc = coltt_flat_create(0, COLTT_COSINE, COLTT_Q_NONE, &h);            /* dim 0 -> COLTT_E_INVALID, no device needed */
+  if (rc != COLTT_E_INVALID) { printf("rc=%d\n", rc); return 1; }
+  if (!coltt_last_error() || !strlen(coltt_last_error())) return 2;
+  if (coltt_hnsw_destroy(424242) != COLTT_E_NOT_FOUND) return 3;
+  coltt_hnsw_cfg cfg; memset(&cfg, 0, sizeof cfg);
+  if (sizeof(cfg) != 9 * 4) return 4;                                      /* the layout the Go shim mirrors */
+  printf("%s\n", coltt_version());
+  return 0;
+}
+''')
+    exe = tmp_path / "c_consumer"
+    libdir = os.path.dirname(coltt_amd.lib_path())
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lcoltt_gpu", f"-Wl,-rpath,{libdir}"])
+    env = dict(os.environ)
+    try:  # the library needs the HIP runtime torch ships (or /opt/rocm's) at load time
+        import torch
+        env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    except Exception:
+        env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "gfx950" in out.stdout
+
+
+def test_cpp_mirror_header_compiles():
+    """include/coltt_gpu.hpp (the header-only C++ mirror of the reference's Go interfaces) is valid C++17."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    subprocess.check_call([gxx, "-std=c++17", "-Wall", "-fsyntax-only", "-x", "c++", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "include", "coltt_gpu.hpp")])
