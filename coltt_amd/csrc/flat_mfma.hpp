@@ -4,7 +4,7 @@
 // queries turns the scan into a [rows x D] x [D x B] GEMM.  MFMA accumulates in a different order than the reference's AVX
 // kernel, so its scores are NOT the reference's bits.  They are used only to pick candidates:
 //
-//   1. flat_mfma_cos_f16_kernel : s~ = |1 - dot/sqrt(nq*nr)| for every (row, query) of a 128-row tile with
+//   1. flat_mfma_cos_kernel     : s~ = |1 - dot/sqrt(nq*nr)| for every (row, query) of a 128-row tile with
 //      v_mfma_f32_32x32x16_f16 (f16 x f16 products are exact in f32; only the summation order differs), fused
 //      threshold filter, survivors appended to the per-query candidate list — the score matrix is never materialised;
 //   2. flat_pick_kernel        : k-th best s~ per query, keep everything within MARGIN of it, publish the bound as the

@@ -69,6 +69,19 @@ class VecSpace {
     for (uint32_t i = 0; i < n; i++) r[i] = {ids[i], sc[i]};
     return r;
   }
+  // SaveVertex / LoadVertex (none_vectorstore.go:308-516 and twins): the `.vertex` byte stream, metadata written as empty maps
+  std::vector<uint8_t> SaveVertex() const {
+    uint64_t n = 0;
+    check(coltt_flat_save_vertex(h_, nullptr, nullptr, nullptr, 0, nullptr, 0, &n));
+    std::vector<uint8_t> out(n);
+    check(coltt_flat_save_vertex(h_, nullptr, nullptr, nullptr, 0, out.data(), out.size(), &n));
+    return out;
+  }
+  uint64_t LoadVertex(const std::vector<uint8_t>& data) {
+    uint64_t n = 0;
+    check(coltt_flat_load_vertex(h_, data.data(), data.size(), &n, nullptr, nullptr, nullptr, 0));
+    return n;
+  }
   int Quantization() const { return quant_; }
   int Distance() const { return distance_; }
   uint32_t Dim() const { return dim_; }
@@ -100,6 +113,19 @@ class Hnsw {
     return r;
   }
   int Len() const { uint64_t n = 0; check(coltt_hnsw_len(h_, &n)); return (int)n; }
+  // Commit(w, header) / Load(r, header) (hnsw_commit.go:69-278): the reference's big-endian stream (metadata: empty maps)
+  std::vector<uint8_t> Commit(bool header = true) const {
+    uint64_t n = 0;
+    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, nullptr, 0, &n));
+    std::vector<uint8_t> out(n);
+    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, out.data(), out.size(), &n));
+    return out;
+  }
+  uint64_t Load(const std::vector<uint8_t>& data, bool header = true) {
+    uint64_t n = 0;
+    check(coltt_hnsw_load(h_, header, data.data(), data.size(), &n, nullptr, nullptr, nullptr, 0));
+    return n;
+  }
   // RandomLevel() (hnsw.go:280-282) for the caller's uniform draw u in (0,1)
   int RandomLevel(float u) const { int32_t lv = 0; check(coltt_hnsw_random_level(h_, u, &lv)); return lv; }
   uint32_t Dim() const { return dim_; }

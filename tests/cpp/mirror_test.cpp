@@ -1,0 +1,92 @@
+// C++ host-side mirror (include/coltt_gpu.hpp) exercised the way the reference's own Go tests exercise *vectorindex.Hnsw and
+// the edge vector store — the Go toolchain is absent, so this is the compiled-language consumer of the C-ABI:
+//   * TestHnswCommitLoad-style round trip (core/vectorindex/hnsw_commit_test.go:32-102, 127-181): insert, remove ~20 %,
+//     Commit, Load into a fresh index, Len and every search result equal;
+//   * ItemAlreadyExistsError / ItemNotFoundError (hnsw.go:38-41), empty index => empty result (hnsw.go:249-251);
+//   * edge VertexSearch keeps the K farthest ascending (edge/priority_queue.go:39-69), dimension-mismatch error text
+//     (none_vectorstore.go:86-88), SaveVertex -> LoadVertex round trip.
+// Prints one line per check; the pytest wrapper (tests/test_gpu_cpp_mirror.py) also compares the printed search results with
+// the Python binding's on the same data.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "coltt_gpu.hpp"
+
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+static std::vector<float> vec(std::mt19937& g, int d) {
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> v(d);
+  for (auto& x : v) x = nd(g);
+  return v;
+}
+
+int main() {
+  if (coltt_init(0) != COLTT_OK) { std::printf("no device: %s\n", coltt_last_error()); return 77; }
+  const int d = 32, n = 500;
+  std::mt19937 g(12345);
+  std::uniform_real_distribution<float> U(1e-6f, 0.999999f);
+  // ---- *vectorindex.Hnsw
+  coltt::Hnsw a(d, COLTT_COSINE);
+  EXPECT(a.Search(vec(g, d), 5).empty());                      // empty index => empty result, not an error
+  std::vector<std::vector<float>> X;
+  for (int i = 0; i < n; i++) { X.push_back(vec(g, d)); a.Insert(1000 + i, X.back(), a.RandomLevel(U(g))); }
+  EXPECT(a.Len() == n);
+  try { a.Insert(1000, X[0], 0); EXPECT(false); } catch (const coltt::ItemAlreadyExistsError&) {}
+  try { a.Remove(999999); EXPECT(false); } catch (const coltt::ItemNotFoundError&) {}
+  int removed = 0;
+  for (int i = 0; i < n; i += 5) { a.Remove(1000 + i); removed++; }
+  EXPECT(a.Len() == n - removed);
+  std::vector<uint8_t> blob = a.Commit(true);
+  {
+    coltt::Hnsw wrong(d, COLTT_EUCLIDEAN);                     // a stream written with another distance is refused, not misread
+    try { wrong.Load(blob, true); EXPECT(false); } catch (const coltt::Error& e) { EXPECT(e.code == COLTT_E_INVALID); }
+  }
+  coltt::Hnsw b(d, COLTT_COSINE);
+  EXPECT(b.Load(blob, true) == (uint64_t)(n - removed));
+  EXPECT(b.Len() == a.Len());
+  EXPECT(b.Commit(true).size() == blob.size());
+  coltt::Hnsw c(d, COLTT_COSINE);                             // Commit(Load(.)) is a fixed point: c == b slot for slot
+  EXPECT(c.Load(b.Commit(true), true) == (uint64_t)(n - removed));
+  std::mt19937 gq(777);
+  for (int q = 0; q < 20; q++) {
+    auto qv = vec(gq, d);
+    auto ra = a.Search(qv, 10), rb = b.Search(qv, 10), rc = c.Search(qv, 10);
+    EXPECT(ra.size() == 10 && rb.size() == 10 && rc.size() == 10);
+    int common = 0;
+    for (size_t i = 0; i < rb.size() && i < rc.size(); i++) {
+      EXPECT(rb[i].Id == rc[i].Id);
+      EXPECT(std::memcmp(&rb[i].Score, &rc[i].Score, 4) == 0);
+      EXPECT((rb[i].Id - 1000) % 5 != 0);                      // removed vertices never come back
+      if (i) EXPECT(rb[i - 1].Score <= rb[i].Score);           // ascending by distance (hnsw.go:261-277)
+      for (auto& x : ra) common += x.Id == rb[i].Id;
+    }
+    // a (insertion slot order, tombstones) and b (stream slot order) walk their neighbours in different canonical orders —
+    // as two runs of the reference do with Go's random map order — so they agree on the neighbourhood, not on every bit
+    EXPECT(common >= 7);
+    if (q < 3) { std::printf("hnsw q%d:", q); for (auto& r : rb) std::printf(" %llu/%08x", (unsigned long long)r.Id, *(const unsigned*)&r.Score); std::printf("\n"); }
+  }
+  // ---- edge.vectorspace
+  coltt::VecSpace s(d, COLTT_COSINE, COLTT_Q_F16);
+  for (int i = 0; i < n; i++) s.ChangedVertex(50 + i, X[i]);
+  EXPECT(s.LoadSize() == n);
+  try { s.ChangedVertex(1, std::vector<float>(d + 1)); EXPECT(false); }
+  catch (const coltt::Error& e) { EXPECT(std::strstr(e.what(), "expect dimension: [32], but got [33]") != nullptr); }
+  auto far = s.VertexSearch(X[3], 10);                         // the reference's queue keeps the K FARTHEST, ascending
+  auto near = s.VertexSearch(X[3], 10, false, COLTT_SELECT_NEAREST);
+  EXPECT(far.size() == 10 && near.size() == 10);
+  EXPECT(near[0].Id == 53);
+  for (size_t i = 1; i < far.size(); i++) EXPECT(far[i - 1].Score <= far[i].Score);
+  EXPECT(near.back().Score <= far.front().Score);
+  coltt::VecSpace t(d, COLTT_COSINE, COLTT_Q_F16);
+  EXPECT(t.LoadVertex(s.SaveVertex()) == (uint64_t)n);
+  auto near2 = t.VertexSearch(X[3], 10, false, COLTT_SELECT_NEAREST);
+  for (size_t i = 0; i < near.size(); i++) EXPECT(near[i].Id == near2[i].Id && std::memcmp(&near[i].Score, &near2[i].Score, 4) == 0);
+  auto filt = s.FilterableVertexSearch({51, 53, 60, 61}, X[3], 3, COLTT_SELECT_NEAREST);
+  EXPECT(filt.size() == 3 && filt[0].Id == 53);
+  std::printf(fails ? "FAILED %d checks\n" : "mirror ok\n", fails);
+  return fails ? 1 : 0;
+}
