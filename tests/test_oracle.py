@@ -302,3 +302,59 @@ def test_hnsw_remove_semantics():
             for u in row(v, level):
                 if u >= 0 and not g["deleted"][u] and int(g["levels"][u]) >= level:
                     assert v not in row(int(u), level).tolist(), (v, u, level)
+
+
+def _csr_from_export(g, w0, wu):
+    """export() dict -> the padded arrays the GPU keeps in HBM (adj0 [n][w0], upper_off [n], adjU [rows][wu])."""
+    n = len(g["levels"])
+    first_row = np.concatenate([[0], np.cumsum(g["levels"].astype(np.int64) + 1)])
+    adj0 = np.full((n, w0), 0xFFFFFFFF, np.uint32)
+    upper_off = np.full(n, 0xFFFFFFFF, np.uint32)
+    n_upper = int(g["levels"].sum())
+    adjU = np.full((max(n_upper, 1), wu), 0xFFFFFFFF, np.uint32)
+    u = 0
+    for s in range(n):
+        for l in range(int(g["levels"][s]) + 1):
+            r = first_row[s] + l
+            row = g["nbr"][g["row_offsets"][r]:g["row_offsets"][r + 1]].astype(np.uint32)
+            if l == 0:
+                adj0[s, :len(row)] = row
+            else:
+                if l == 1:
+                    upper_off[s] = u
+                adjU[u, :len(row)] = row
+                u += 1
+    return adj0, upper_off, adjU
+
+
+@pytest.mark.parametrize("metric,quant", [(O.COSINE, O.Q_NONE), (O.L2, O.Q_NONE), (O.L2, O.Q_F16)])
+def test_csr_search_equals_canonical_search(metric, quant):
+    """bench.py's cpu_baseline leg walks the arrays copied out of HBM with orc_csr_search; here the same function over arrays
+    rebuilt from the oracle's own export equals Hnsw.search (canonical form): slots, score bits and the traversal counters."""
+    n, d, k, ef = 1200, 24, 10, 48
+    X = O.fill_normal(71, (n, d)); lv = O.levels(72, n); ids = np.arange(n, dtype=np.uint64)
+    Xs = O.f16_decode(O.lower(quant, X)) if quant == O.Q_F16 else X       # what a quantised index stores, decoded
+    h = O.Hnsw(d, metric); h.insert_many(ids, Xs, lv)
+    for v in (3, 77, 500):
+        assert h.remove(v) == 0
+    g = h.export()
+    adj0, upper_off, adjU = _csr_from_export(g, 32, 16)
+    del_bits = np.zeros((n + 31) // 32, np.uint32)
+    for s in np.nonzero(g["deleted"])[0]:
+        del_bits[s >> 5] |= np.uint32(1) << np.uint32(s & 31)
+    rows = np.ascontiguousarray(O.lower(quant, X)) if quant == O.Q_F16 else np.ascontiguousarray(g["vectors"], np.float32)
+    Q = O.fill_normal(73, (30, d))
+    sl = np.empty((len(Q), k), np.int32); sc = np.empty((len(Q), k), np.float32); cn = np.empty(len(Q), np.int32); st = (C.c_uint64 * 3)()
+    L = O.lib()
+    L.orc_csr_search(rows.ctypes.data_as(C.c_void_p), int(quant), adj0.ctypes.data_as(C.c_void_p), upper_off.ctypes.data_as(C.c_void_p),
+                     adjU.ctypes.data_as(C.c_void_p), del_bits.ctypes.data_as(C.c_void_p), C.c_uint32(32), C.c_uint32(16), C.c_uint32(d),
+                     int(metric), 0, C.c_int32(h.entry), C.c_int32(int(g["levels"][h.entry])), Q.ctypes.data_as(C.c_void_p),
+                     C.c_size_t(len(Q)), k, ef, sl.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p), st)
+    tot = np.zeros(3, np.int64)
+    Qs = O.f16_decode(O.lower(quant, Q)) if quant == O.Q_F16 else Q       # the quantised stores lower the query too
+    for qi in range(len(Q)):
+        wi, ws, wst = h.search(Qs[qi], k, mode=1, ef=ef, with_stats=True)
+        assert cn[qi] == len(wi)
+        assert np.array_equal(g["ids"][sl[qi, :cn[qi]]], wi) and np.array_equal(bits(sc[qi, :cn[qi]]), bits(ws)), qi
+        tot += np.array([wst["n_dist"], wst["n_exp"], wst["n_hops"]], np.int64)
+    assert [int(st[0]), int(st[1]), int(st[2])] == tot.tolist()
