@@ -14,10 +14,10 @@ package colttgpu
 import "C"
 
 import (
-	"math/rand"
 	"context"
 	"errors"
 	"fmt"
+	"math/rand"
 	"sync"
 	"unsafe"
 )
