@@ -8,7 +8,7 @@
 // §8c), the Go toolchain is absent, so the Go path cannot be run here.  What IS pinned:
 //   * the distance kernels (orc_l2 / orc_cosine, order=avx|sse) are checked bit-for-bit against the
 //     reference's own pkg/distance/simd/cpp/{avx,sse}.cpp compiled from where they lie
-//     (oracle/_ref/libcoltt_ref_simd.so, recipe oracle/Makefile) — tests/test_oracle_ref.py;
+//     (oracle/_ref/libcoltt_ref_simd.so, recipe oracle/Makefile) — tests/test_oracle.py::test_distance_orders_equal_reference_sources;
 //   * the codecs are checked against IEEE binary16 (numpy float16) over all 65 536 codes / random f32;
 //   * FNV-1a against Python's own restatement of hash/fnv.
 // Everything above that (heaps, FLAT scan, HNSW) is a line-by-line restatement with the reference
