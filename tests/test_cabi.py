@@ -100,3 +100,33 @@ def test_cpp_mirror_header_compiles():
         pytest.skip("no g++")
     subprocess.check_call([gxx, "-std=c++17", "-Wall", "-fsyntax-only", "-x", "c++", "-I", os.path.join(root, "include"),
                            os.path.join(root, "include", "coltt_gpu.hpp")])
+
+
+def test_pmc_traffic_tool_on_a_synthetic_counter_csv(tmp_path):
+    """tools/pmc_traffic.py (rocprofv3 --pmc FETCH_SIZE CSV -> profiles/pmc_traffic.json record): calibration on the
+    flat_scan_kernel launches, x2 correction, per-launch traffic and the key bench.py looks up."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import pmc_traffic as T
+    n, dim, nq = 1_000_000, 768, 10_000
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    def add(did, grid, name, val):
+        for part in range(2):   # a counter may arrive split over dimensions: rows of one dispatch are summed
+            rows.append(f"{did},{did},1,1,1,1,{grid},7,\"{name}\",64,0,0,64,0,32,FETCH_SIZE,{val / 2},0,1")
+    true_bytes_per_launch = 12_000_000_000
+    for d in range(3):
+        add(10 + d, 65536, "void (anonymous namespace)::hnsw_search_kernel<0, 0, false>(coltt::dev::GraphView, int)", true_bytes_per_launch / 2 / 1024)
+    add(20, 64000, "void (anonymous namespace)::hnsw_search_kernel<0, 0, false>(coltt::dev::GraphView, int)", 1.0)  # recall sample: ignored
+    add(30, 131072, "void (anonymous namespace)::flat_scan_kernel<0, 0, false, 16>(unsigned char const*)", 65536 * 3072 / 2 / 1024)
+    add(31, 524288, "void (anonymous namespace)::flat_scan_kernel<0, 0, false, 16>(unsigned char const*)", (n - 65536) * 3072 / 2 / 1024)
+    p = tmp_path / "p_counter_collection.csv"; p.write_text("\n".join(rows) + "\n")
+    bj = tmp_path / "bench.json"
+    bj.write_text(json.dumps({"dtype": "f32", "dataset": "normal", "per_query": {"bytes": 1_150_000.0},
+                              "config": {"workload": "core/vectorindex HNSW M=16 efSearch=128 x", "n": n, "dim": dim, "queries_per_step": nq, "ef": 128}}))
+    out = tmp_path / "pmc_traffic.json"
+    T.main([str(p), "--bench-json", str(bj), "--out", str(out)])
+    rec = json.load(open(out))[f"hnsw n={n} dim={dim} quant=0 ef=128 m=16 queries={nq} dataset=normal"]
+    assert abs(rec["hbm_bytes_per_launch"] - true_bytes_per_launch) / true_bytes_per_launch < 1e-9
+    assert abs(rec["traffic_over_algorithmic"] - true_bytes_per_launch / (1_150_000.0 * nq)) < 1e-9

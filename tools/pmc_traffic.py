@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""HBM traffic of hnsw_search_kernel from a rocprofv3 PMC pass -> profiles/pmc_traffic.json (what bench.py reports as
+roofline.traffic).  Procedure (MI355X_MICROARCH.md, HBM / rocprofv3 section: counters in their OWN pass, no trace domains):
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "hnsw_search_kernel|flat_scan_kernel" -f csv -d /tmp/pmc -o p -- \\
+        python $REPO/bench.py --no-cpu-baseline
+    python $REPO/tools/pmc_traffic.py /tmp/pmc/p_counter_collection.csv --bench-json <the JSON line bench.py printed>
+
+FETCH_SIZE is reported in KiB; on gfx950 it counts this library's 16 B/lane row streams at half their size, so the factor is
+CALIBRATED in the same pass on flat_scan_kernel, whose byte count is known exactly (rows x stride per launch; bench.py's recall
+leg runs it over the same index): factor = known bytes / reported bytes, expected 2.0 +- 1 %.  The search kernel's launches are
+picked by grid size (one 64-thread workgroup per resident wave, 10 000-query launches use the full persistent grid)."""
+import argparse
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_counter(path, counter="FETCH_SIZE"):
+    """-> {kernel short name: [(grid_size, value), ...]} summed over the counter's dimensions per dispatch"""
+    per_dispatch = collections.OrderedDict()
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            key = (r["Dispatch_Id"], r["Kernel_Name"], int(r["Grid_Size"]))
+            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])
+    out = collections.defaultdict(list)
+    for (_, name, grid), v in per_dispatch.items():
+        short = "hnsw_search_kernel" if "hnsw_search_kernel" in name else ("flat_scan_kernel" if "flat_scan_kernel" in name else name[:40])
+        out[short].append((grid, v))
+    return out
+
+
+def calibrate(flat_launches, rows, stride):
+    """flat_scan_kernel launches of the recall leg: a small unfiltered first segment + the remainder, together `rows` rows.
+    Returns known_bytes / reported_bytes over the launches of the LARGEST grid (the remainder: least edge effects)."""
+    if not flat_launches:
+        return None, None
+    big = max(g for g, _ in flat_launches)
+    vals = [v for g, v in flat_launches if g == big]
+    small = [v for g, v in flat_launches if g != big]
+    # rows covered by the big launches = rows - rows of the first segment; first segment = 65536 rows (flat.hip: min(cap, ...))
+    first_rows = 65536 if small else 0
+    known_kib = (rows - first_rows) * stride / 1024.0
+    mean = sum(vals) / len(vals)
+    return known_kib / mean, {"launches": len(vals), "FETCH_SIZE_KiB_mean": mean, "known_KiB": known_kib}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv")
+    ap.add_argument("--bench-json", required=True, help="file holding the JSON line bench.py printed in the same run")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    a = ap.parse_args(argv)
+    b = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
+    cfg = b["config"]
+    n, dim, nq, ef = cfg["n"], cfg["dim"], cfg["queries_per_step"], cfg["ef"]
+    quant = 0 if b["dtype"] == "f32" else 1
+    m = int(cfg["workload"].split("M=")[1].split()[0])
+    stride = ((dim * (4 if quant == 0 else 2) + 15) // 16) * 16
+    c = read_counter(a.csv)
+    hs = c.get("hnsw_search_kernel", [])
+    if not hs:
+        sys.exit("no hnsw_search_kernel dispatches with FETCH_SIZE in " + a.csv)
+    full = max(g for g, _ in hs)
+    vals = [v for g, v in hs if g == full]
+    factor, cal = calibrate(c.get("flat_scan_kernel", []), n, stride)
+    if factor is None or not (1.9 < factor < 2.1):
+        print(f"warning: calibration factor {factor} outside 2.0 +- 5 % — using it anyway; check the flat_scan launches", file=sys.stderr)
+    factor = factor or 2.0
+    mean_kib = sum(vals) / len(vals)
+    traffic = mean_kib * 1024.0 * factor
+    algorithmic = b["per_query"]["bytes"] * nq
+    key = f"hnsw n={n} dim={dim} quant={quant} ef={ef} m={m} queries={nq} dataset={b.get('dataset', 'normal')}"
+    rec = {"hbm_bytes_per_launch": traffic, f"FETCH_SIZE_KiB_mean_of_{len(vals)}_launches": mean_kib,
+           "correction": f"x{factor:.4f}: gfx950 FETCH_SIZE under-counts 16 B/lane streams; calibrated in this pass on flat_scan_kernel ({cal})",
+           "algorithmic_bytes_per_launch": algorithmic, "traffic_over_algorithmic": traffic / algorithmic, "source": os.path.basename(a.csv)}
+    table = {}
+    if os.path.exists(a.out):
+        try:
+            table = json.load(open(a.out))
+        except Exception:
+            table = {}
+    table[key] = rec
+    json.dump(table, open(a.out, "w"), indent=1)
+    print(key, "->", json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
