@@ -358,3 +358,30 @@ def test_csr_search_equals_canonical_search(metric, quant):
         assert np.array_equal(g["ids"][sl[qi, :cn[qi]]], wi) and np.array_equal(bits(sc[qi, :cn[qi]]), bits(ws)), qi
         tot += np.array([wst["n_dist"], wst["n_exp"], wst["n_hops"]], np.int64)
     assert [int(st[0]), int(st[1]), int(st[2])] == tot.tolist()
+
+
+def test_canonical_form_equals_literal_go_heaps_on_random_configurations():
+    """The foundation of every HNSW parity claim: the closed form the GPU runs (sorted result set, ascending-slot neighbour
+    order, stale lowerBound, first ef-len0 admitted unconditionally) is the SAME function as the literal restatement with Go's
+    container/heap and per-candidate lowerBound sampling (hnsw.go:345-389) — checked over random sizes, dims, M, ef, k,
+    metrics, algorithms and removals: graph hash of the builds, answers, score bits and the n_dist/n_exp/n_hops counters."""
+    rng = np.random.default_rng(20250328)
+    for trial in range(120):
+        n = int(rng.integers(30, 420)); d = int(rng.integers(2, 48)); m = int(rng.choice([4, 6, 8, 16]))
+        metric = int(rng.integers(0, 2)); efc = int(rng.integers(max(m, 8), 96)); algo = int(rng.integers(0, 2))
+        X = O.fill_normal(1000 + trial, (n, d))
+        mult = np.float32(1.0) / np.float32(np.log(np.float64(np.float32(m))))
+        lv = np.array([O.level(2000 + trial, i, float(mult)) for i in range(n)], np.int32)
+        ids = rng.permutation(n).astype(np.uint64) * np.uint64(17) + np.uint64(3)
+        cfg = dict(m=m, efConstruction=efc, algo=algo)
+        a = O.Hnsw(d, metric, O.default_cfg(**cfg)); a.insert_many(ids, X, lv)                          # literal
+        b = O.Hnsw(d, metric, O.default_cfg(**cfg), canonical_build=True); b.insert_many(ids, X, lv)    # closed form
+        assert a.graph_hash() == b.graph_hash(), (trial, n, d, m, metric, efc, algo)
+        for v in rng.choice(ids, size=int(rng.integers(0, max(1, n // 6))), replace=False):
+            ra, rb = a.remove(int(v)), b.remove(int(v))
+            assert ra == rb
+        assert a.graph_hash() == b.graph_hash(), ("after removals", trial)
+        for q in O.fill_normal(3000 + trial, (6, d)):
+            k = int(rng.integers(1, 25)); ef = int(rng.integers(1, 90))
+            r0 = a.search(q, k, mode=0, ef=ef, with_stats=True); r1 = a.search(q, k, mode=1, ef=ef, with_stats=True)
+            assert np.array_equal(r0[0], r1[0]) and np.array_equal(bits(r0[1]), bits(r1[1])) and r0[2] == r1[2], (trial, k, ef)
