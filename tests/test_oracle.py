@@ -385,3 +385,24 @@ def test_canonical_form_equals_literal_go_heaps_on_random_configurations():
             k = int(rng.integers(1, 25)); ef = int(rng.integers(1, 90))
             r0 = a.search(q, k, mode=0, ef=ef, with_stats=True); r1 = a.search(q, k, mode=1, ef=ef, with_stats=True)
             assert np.array_equal(r0[0], r1[0]) and np.array_equal(bits(r0[1]), bits(r1[1])) and r0[2] == r1[2], (trial, k, ef)
+
+
+def test_flat_canonical_equals_literal_queue_on_random_configurations():
+    """FLAT: the canonical select the GPU implements (mode 2) == the literal edge.PriorityQueue run (mode 0: per-shard Go map
+    walk + container/heap pop-min; mode 1: the 16-goroutine highCpu split with local queues merged) over random sizes, dims,
+    k, metrics and the four quantisations — ids, order and score bits."""
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        n = int(rng.integers(1, 700)); d = int(rng.integers(1, 72)); k = int(rng.integers(1, 48))
+        metric = int(rng.integers(0, 2)); quant = int(rng.integers(0, 4))
+        X = O.fill_normal(5000 + trial, (n, d)); ids = rng.permutation(4 * n)[:n].astype(np.uint64) + np.uint64(1)
+        f = O.Flat(d, metric, quant); f.upsert(ids, X)
+        if n > 4:
+            f.remove(ids[: n // 5])
+        for q in O.fill_normal(6000 + trial, (3, d)):
+            ref = f.search(q, k, nearest=False, mode=2)
+            for mode in (0, 1):
+                got = f.search(q, k, nearest=False, mode=mode)
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), (trial, n, d, k, metric, quant, mode)
+            near = f.search(q, k, nearest=True, mode=2)
+            assert len(near[0]) == min(k, len(f)) and np.all(np.diff(near[1]) >= 0)
