@@ -105,6 +105,7 @@ int coltt_cflat_create(uint32_t dim, int metric, uint32_t n_fields, coltt_handle
   auto c = std::make_shared<CFlat>();
   c->dim = dim; c->nf = n_fields; c->metric = metric; c->stride = ((size_t)dim * 4 + 15) & ~(size_t)15;
   COLTT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->device = default_device();
   *out = Registry::get().add(c);
   return COLTT_OK;
 }
@@ -117,7 +118,7 @@ int coltt_cflat_destroy(coltt_handle_t h) {
 int coltt_cflat_len(coltt_handle_t h, uint64_t* out) {
   auto c = lookup<CFlat>(h);
   if (!c || !out) return fail(COLTT_E_NOT_FOUND, "cflat_len: unknown handle");
-  std::lock_guard<std::mutex> g(c->mu);
+  WriteLock g(c->rw);
   *out = c->n;
   return COLTT_OK;
 }
@@ -128,8 +129,8 @@ int coltt_cflat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs,
   if (!c) return fail(COLTT_E_NOT_FOUND, "cflat_upsert: unknown handle");
   if (n == 0) return COLTT_OK;
   if (!ids || !vecs) return fail(COLTT_E_INVALID, "cflat_upsert: NULL input");
-  std::lock_guard<std::mutex> g(c->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(c->rw);
+  COLTT_TRY(use_device(c->device));
   for (size_t i = 0; i < n; i++) {  // one vertex at a time keeps "last write wins" trivially right; this path is not hot
     uint32_t slot;
     auto it = c->id2slot.find(ids[i]);
@@ -154,8 +155,8 @@ int coltt_cflat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
   auto c = lookup<CFlat>(h);
   if (!c) return fail(COLTT_E_NOT_FOUND, "cflat_remove: unknown handle");
   if (n && !ids) return fail(COLTT_E_INVALID, "cflat_remove: NULL ids");
-  std::lock_guard<std::mutex> g(c->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(c->rw);
+  COLTT_TRY(use_device(c->device));
   for (size_t i = 0; i < n; i++) {
     auto it = c->id2slot.find(ids[i]);
     if (it == c->id2slot.end()) continue;
@@ -185,8 +186,8 @@ int coltt_cflat_search(coltt_handle_t h, const float* queries, const uint32_t* r
   if (nq == 0) return COLTT_OK;
   if (!queries || !ratios || !include || !out_ids || !out_scores || !out_counts) return fail(COLTT_E_INVALID, "cflat_search: NULL buffer");
   if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "cflat_search: k=%u outside [1,%u]", k, K_MAX);
-  std::lock_guard<std::mutex> g(c->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(c->rw);
+  COLTT_TRY(use_device(c->device));
   const size_t per = (size_t)c->nf * c->dim;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
   COLTT_TRY(c->w_raw.reserve(per * 4)); COLTT_TRY(c->w_q.reserve(per * 4)); COLTT_TRY(c->w_qn.reserve(c->nf * 4 + 256));

@@ -31,7 +31,7 @@ bool Registry::erase(coltt_handle_t h) {
     keep = it->second;
     map_.erase(it);
   }
-  std::lock_guard<std::mutex> g2(keep->mu);  // wait for an in-flight call
+  WriteLock g2(keep->rw);  // wait for in-flight calls (searches hold it shared)
   return true;
 }
 
@@ -54,7 +54,17 @@ int ensure_device() {
   return COLTT_OK;
 }
 
-hipStream_t main_stream() { return nullptr; }  // per-object streams are created by the objects themselves
+int default_device() { std::lock_guard<std::mutex> g(g_dev_mu); return g_device < 0 ? 0 : g_device; }
+
+int use_device(int device) {
+  COLTT_HIP(hipSetDevice(device));
+  return COLTT_OK;
+}
+
+size_t max_search_ctx() {
+  static const size_t v = [] { const char* e = getenv("COLTT_MAX_SEARCH_CTX"); long n = e && *e ? atol(e) : 32; return (size_t)(n < 1 ? 1 : (n > 256 ? 256 : n)); }();
+  return v;
+}
 
 }  // namespace coltt
 

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -57,8 +59,12 @@ struct DevBuf {
     void* np = nullptr;
     COLTT_HIP(hipMalloc(&np, ncap));
     if (keep && p && cap) {
-      COLTT_HIP(hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s));
-      COLTT_HIP(hipStreamSynchronize(s));
+      hipError_t e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {  // the old buffer stays valid; do not leak the new one
+        (void)hipFree(np);
+        return ::coltt::fail(COLTT_E_DEVICE, "DevBuf::reserve copy: %s", hipGetErrorString(e));
+      }
     }
     if (p) (void)hipFree(p);
     p = np;
@@ -68,9 +74,46 @@ struct DevBuf {
   template <class T> T* as() const { return (T*)p; }
 };
 
+// Locking discipline = the reference's (RWMutex per shard / per vertex level: edge/none_vectorstore.go:40, core/vectorindex/hnsw.go:51,
+// hnsw_vertex.go:39): searches hold the object's lock SHARED and run concurrently, each on its own stream with its own
+// workspaces (CtxPool below); Insert / Remove / Load / upsert hold it EXCLUSIVE.  Mutations complete (stream synchronised)
+// before they release the lock, so a search that starts afterwards sees them — the device mirror never needs an epoch.
 struct Object {
-  std::mutex mu;  // one call at a time per object (the Go side micro-batches; SURVEY.md §8b threading)
+  std::shared_mutex rw;
+  int device = 0;  // the HIP device this object's memory lives on; every entry point selects it for the calling thread
   virtual ~Object() {}
+};
+typedef std::shared_lock<std::shared_mutex> ReadLock;
+typedef std::unique_lock<std::shared_mutex> WriteLock;
+
+// Pool of per-call search contexts (stream + events + workspaces).  C needs `int init()`.  At most max_ctx contexts exist;
+// further callers wait for one to come back (COLTT_MAX_SEARCH_CTX, default 32).
+size_t max_search_ctx();
+template <class C> class CtxPool {
+ public:
+  C* acquire() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      if (!idle_.empty()) { C* c = idle_.back(); idle_.pop_back(); return c; }
+      if (all_.size() < max_search_ctx()) {
+        auto c = std::make_unique<C>();
+        if (c->init() != COLTT_OK) return nullptr;  // message already in g_last_error
+        C* p = c.get(); all_.push_back(std::move(c)); return p;
+      }
+      cv_.wait(lk);
+    }
+  }
+  void release(C* c) { { std::lock_guard<std::mutex> lk(mu_); idle_.push_back(c); } cv_.notify_one(); }
+  size_t created() { std::lock_guard<std::mutex> lk(mu_); return all_.size(); }
+ private:
+  std::mutex mu_; std::condition_variable cv_;
+  std::vector<std::unique_ptr<C>> all_; std::vector<C*> idle_;
+};
+template <class C> struct CtxLease {
+  CtxPool<C>& pool; C* c;
+  explicit CtxLease(CtxPool<C>& p) : pool(p), c(p.acquire()) {}
+  ~CtxLease() { if (c) pool.release(c); }
+  CtxLease(const CtxLease&) = delete; CtxLease& operator=(const CtxLease&) = delete;
 };
 
 class Registry {
@@ -90,10 +133,22 @@ template <class T> std::shared_ptr<T> lookup(coltt_handle_t h) {
   return std::dynamic_pointer_cast<T>(Registry::get().find(h));
 }
 
-int ensure_device();
-hipStream_t main_stream();
+int ensure_device();          // selects the process default device (coltt_init) for the calling thread
+int default_device();         // that device's index (after ensure_device succeeded)
+int use_device(int device);   // selects an object's device for the calling thread
 
 inline size_t quant_bytes(int q) { return q == COLTT_Q_NONE ? 4 : (q == COLTT_Q_F8 ? 1 : 2); }
+
+// Quantisation dispatch.  The reference's "BF16" is IEEE binary16 (pkg/compresshelper/bf16.go:233-317 is float16.go:237-321
+// with the names changed), so COLTT_Q_BF16 deliberately shares the Q_F16 device code; anything else is an error, never a
+// silent fall-through (edge/vectorstore.go:79 "not support quantization type").
+#define COLTT_DISPATCH_QUANT(q, F)                                                                  \
+  switch (q) {                                                                                      \
+    case COLTT_Q_NONE: F(::coltt::dev::Q_NONE); break;                                              \
+    case COLTT_Q_F8: F(::coltt::dev::Q_F8); break;                                                  \
+    case COLTT_Q_F16: case COLTT_Q_BF16: F(::coltt::dev::Q_F16); break;                             \
+    default: return ::coltt::fail(COLTT_E_UNSUPPORTED, "not support quantization type %d", (int)(q)); \
+  }
 inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 }  // namespace coltt

@@ -11,6 +11,7 @@
 // tile of QB queries per row read, threshold-filtered candidate emission), flat_select (radix-select +
 // rank-sort of the candidates by the canonical (score, id) order).
 #include <algorithm>
+#include <atomic>
 
 #include "common.hpp"
 #include "exact.hpp"
@@ -37,8 +38,13 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
     const uint32_t* __restrict__ gather, uint64_t begin, uint64_t end, const float* __restrict__ q_eff,
     const float* __restrict__ qnorms, int nq_grp, int dim, const uint32_t* __restrict__ thr, int nearest,
     unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) float qs[];  // [QB][dim]
-  for (int i = threadIdx.x; i < QB * dim; i += blockDim.x) qs[i] = (i / dim) < nq_grp ? q_eff[i] : 0.f;
+  // [QB][dimp]: the query rows are read with ds_read_b128, so each starts on a 16-byte boundary (dim % 4 != 0 is legal)
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  const int dimp = (dim + 3) & ~3;
+  for (int i = threadIdx.x; i < QB * dimp; i += blockDim.x) {
+    const int q = i / dimp, e = i - q * dimp;
+    qs[i] = (q < nq_grp && e < dim) ? q_eff[(size_t)q * dim + e] : 0.f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane & 1, p = lane >> 1;
   float qn[QB];
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
         const f32x4 rc = decode4<QUANT>(cur[u]);
 #pragma unroll
         for (int q = 0; q < QB; q++) {
-          f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dim);
+          f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
           if constexpr (METRIC == M_COS) { f32x4 pr = qq * rc; acc[q] = acc[q] + pr; }
           else { f32x4 d = qq - rc; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
         }
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
       const float* qp = qs + 8 * t + 4 * half;
 #pragma unroll
       for (int q = 0; q < QB; q++) {
-        f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dim);
+        f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
         if constexpr (METRIC == M_COS) { f32x4 pr = qq * r; acc[q] = acc[q] + pr; }
         else { f32x4 d = qq - r; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
       }
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
       float s = pair_hsum(acc[q], half);
       for (int e = n8 * 8; e < dim; e++) {
         float r = load1<QUANT>(row, e);
-        if constexpr (METRIC == M_COS) s += qs[q * dim + e] * r;
-        else { float d = qs[q * dim + e] - r; s += d * d; }
+        if constexpr (METRIC == M_COS) s += qs[q * dimp + e] * r;
+        else { float d = qs[q * dimp + e] - r; s += d * d; }
       }
       float score;
       if constexpr (METRIC == M_COS) score = cos_epilogue(s, qn[q], rn);
@@ -145,6 +151,24 @@ struct FBEW {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// Per-call search context (stream, events, workspaces): searches hold the store's lock shared and run concurrently.
+struct FCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBuf w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  int init() {  // the caller has selected the store's device
+    COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    COLTT_HIP(hipEventCreate(&ev0));
+    COLTT_HIP(hipEventCreate(&ev1));
+    return COLTT_OK;
+  }
+  ~FCtx() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
 struct Flat : Object {
   uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
   uint64_t n = 0, cap = 0;
@@ -152,14 +176,13 @@ struct Flat : Object {
   bool dense = true; uint64_t dense_base = 0;     // id = dense_base + slot, no map
   std::unordered_map<uint64_t, uint32_t> id2slot;  // !dense
   std::vector<uint64_t> h_ids;                     // !dense : slot -> id (host mirror)
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
-  // workspaces
-  DevBuf w_raw, w_slots, w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
-  uint64_t mfma_groups = 0, mfma_fallbacks = 0;  // statistics: groups served by the MFMA path / sent back to the exact path
+  hipStream_t stream = nullptr;      // mutations (exclusive lock); searches use their context's stream
+  std::atomic<float> last_ms{0.f};   // kernel time of the most recently finished search call
+  CtxPool<FCtx> pool;
+  DevBuf w_raw, w_slots;             // ingest staging
+  std::atomic<uint64_t> mfma_groups{0}, mfma_fallbacks{0};  // groups served by the MFMA path / sent back to the exact path
   ~Flat() override {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipSetDevice(device);
     if (stream) (void)hipStreamDestroy(stream);
   }
   int reserve(uint64_t rows_needed) {
@@ -196,135 +219,130 @@ int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_
   return COLTT_OK;
 }
 int prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_slots, uint64_t slot_base) {
-  switch (f->quant) {
-    case COLTT_Q_NONE: return launch_prep_rows<Q_NONE>(f, d_raw, n, d_slots, slot_base);
-    case COLTT_Q_F8: return launch_prep_rows<Q_F8>(f, d_raw, n, d_slots, slot_base);
-    default: return launch_prep_rows<Q_F16>(f, d_raw, n, d_slots, slot_base);
-  }
+#define COLTT_PR(Q) return launch_prep_rows<Q>(f, d_raw, n, d_slots, slot_base)
+  COLTT_DISPATCH_QUANT(f->quant, COLTT_PR)
+#undef COLTT_PR
+  return COLTT_OK;
 }
 
 inline int scan_qb(const Flat* f) { return f->dim <= 1024 ? QB : 4; }
 
 template <int METRIC, int QUANT, bool GATHER, int QBT>
-void launch_scan_q(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+void launch_scan_q(Flat* f, FCtx* c, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
                    int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
   uint64_t groups = (end - begin + 31) / 32;
   uint32_t grid = (uint32_t)std::min<uint64_t>((groups + 3) / 4, 256 * 8);
-  size_t lds = (size_t)QBT * f->dim * 4;
+  size_t lds = (size_t)QBT * ((f->dim + 3) & ~3u) * 4;
   auto kern = flat_scan_kernel<METRIC, QUANT, GATHER, QBT>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<grid, 256, lds, f->stream>>>(
+  kern<<<grid, 256, lds, c->stream>>>(
       f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), gather, begin, end, q_eff, qn, nq_grp, (int)f->dim, thr,
       nearest, cand, cnt, cap);
 }
 template <int METRIC, int QUANT, bool GATHER>
-void launch_scan(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+void launch_scan(Flat* f, FCtx* c, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
                  int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-  if (scan_qb(f) == QB) launch_scan_q<METRIC, QUANT, GATHER, QB>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
-  else launch_scan_q<METRIC, QUANT, GATHER, 4>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
+  if (scan_qb(f) == QB) launch_scan_q<METRIC, QUANT, GATHER, QB>(f, c, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
+  else launch_scan_q<METRIC, QUANT, GATHER, 4>(f, c, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap);
 }
 template <bool GATHER>
-void scan_dispatch(Flat* f, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
+int scan_dispatch(Flat* f, FCtx* c, const uint32_t* gather, uint64_t begin, uint64_t end, const float* q_eff, const float* qn,
                    int nq_grp, const uint32_t* thr, int nearest, unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-#define COLTT_SCAN(M, Q) launch_scan<M, Q, GATHER>(f, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap)
-  if (f->metric == COLTT_COSINE) {
-    if (f->quant == COLTT_Q_NONE) COLTT_SCAN(M_COS, Q_NONE);
-    else if (f->quant == COLTT_Q_F8) COLTT_SCAN(M_COS, Q_F8);
-    else COLTT_SCAN(M_COS, Q_F16);
-  } else {
-    if (f->quant == COLTT_Q_NONE) COLTT_SCAN(M_L2, Q_NONE);
-    else if (f->quant == COLTT_Q_F8) COLTT_SCAN(M_L2, Q_F8);
-    else COLTT_SCAN(M_L2, Q_F16);
-  }
+#define COLTT_SCAN_ARGS f, c, gather, begin, end, q_eff, qn, nq_grp, thr, nearest, cand, cnt, cap
+#define COLTT_SCAN(Q) do { if (f->metric == COLTT_COSINE) launch_scan<M_COS, Q, GATHER>(COLTT_SCAN_ARGS); else launch_scan<M_L2, Q, GATHER>(COLTT_SCAN_ARGS); } while (0)
+  COLTT_DISPATCH_QUANT(f->quant, COLTT_SCAN)
 #undef COLTT_SCAN
+#undef COLTT_SCAN_ARGS
+  return COLTT_OK;
 }
 
-int prep_queries(Flat* f, const float* d_qraw, size_t nq) {
-  COLTT_TRY(f->w_qeff.reserve(nq * f->dim * 4));
-  COLTT_TRY(f->w_qn.reserve(nq * 4));
+int prep_queries(Flat* f, FCtx* c, const float* d_qraw, size_t nq) {
+  COLTT_TRY(c->w_qeff.reserve(nq * f->dim * 4));
+  COLTT_TRY(c->w_qn.reserve(nq * 4));
   int norm = f->metric == COLTT_COSINE;
-  if (f->quant == COLTT_Q_NONE) launch_prep_queries<Q_NONE>(f->stream, d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
-  else if (f->quant == COLTT_Q_F8) launch_prep_queries<Q_F8>(f->stream, d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
-  else launch_prep_queries<Q_F16>(f->stream, d_qraw, nq, (int)f->dim, norm, f->w_qeff.as<float>());
-  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, f->stream>>>(f->w_qeff.as<float>(), nq, (int)f->dim, f->w_qn.as<float>());
+#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)f->dim, norm, c->w_qeff.as<float>())
+  COLTT_DISPATCH_QUANT(f->quant, COLTT_PQ)
+#undef COLTT_PQ
+  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, c->stream>>>(c->w_qeff.as<float>(), nq, (int)f->dim, c->w_qn.as<float>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
 // One group of <= QB prepared queries [q0, q0+g) over positions [0, total) (rows, or entries of the gather list), exact order.
-int search_group_exact(Flat* f, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total,
+int search_group_exact(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total,
                        uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt, uint32_t cap) {
-  uint32_t* cnt = f->w_cnt.as<uint32_t>();
+  uint32_t* cnt = c->w_cnt.as<uint32_t>();
   uint32_t* thr = cnt + 256;
   uint32_t* ovf = cnt + 512;
-  unsigned long long* cand = f->w_cand.as<unsigned long long>();
+  unsigned long long* cand = c->w_cand.as<unsigned long long>();
   const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
-  const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
-  const float* qn = f->w_qn.as<float>() + q0;
+  const float* qe = c->w_qeff.as<float>() + q0 * f->dim;
+  const float* qn = c->w_qn.as<float>() + q0;
   uint64_t* oi = d_out_ids + q0 * k; float* os = d_out_sc + q0 * k; uint32_t* oc = d_out_cnt + q0;
-  auto scan = [&](uint64_t b, uint64_t e) {
-    if (d_gather) scan_dispatch<true>(f, d_gather, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
-    else scan_dispatch<false>(f, nullptr, b, e, qe, qn, g, thr, nearest, cand, cnt, cap);
-    flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc);
+  auto scan = [&](uint64_t b, uint64_t e) -> int {
+    if (d_gather) COLTT_TRY(scan_dispatch<true>(f, c, d_gather, b, e, qe, qn, g, thr, nearest, cand, cnt, cap));
+    else COLTT_TRY(scan_dispatch<false>(f, c, nullptr, b, e, qe, qn, g, thr, nearest, cand, cnt, cap));
+    flat_select_kernel<<<g, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc);
+    return COLTT_OK;
   };
-  init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
-  if (total == 0) { flat_select_kernel<<<g, 256, 0, f->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc); return COLTT_OK; }
+  init_group_kernel<<<1, 256, 0, c->stream>>>(cnt, thr, ovf, nearest);
+  if (total == 0) { flat_select_kernel<<<g, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, oi, os, oc); return COLTT_OK; }
   // optimistic: first segment (everything passes, <= cap candidates), then the rest behind the threshold
   uint64_t s0 = std::min<uint64_t>(total, cap);
-  scan(0, s0);
-  if (s0 < total) scan(s0, total);
+  COLTT_TRY(scan(0, s0));
+  if (s0 < total) COLTT_TRY(scan(s0, total));
   uint32_t h_ovf = 0;
-  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
-  COLTT_HIP(hipStreamSynchronize(f->stream));
+  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
+  COLTT_HIP(hipStreamSynchronize(c->stream));
   if (h_ovf) {  // adversarial order: redo with segments that cannot overflow (list holds <= k + segment)
-    init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
+    init_group_kernel<<<1, 256, 0, c->stream>>>(cnt, thr, ovf, nearest);
     uint64_t seg = cap - std::min<uint32_t>(k, cap / 2);
-    for (uint64_t b = 0; b < total; b += seg) scan(b, std::min<uint64_t>(total, b + seg));
+    for (uint64_t b = 0; b < total; b += seg) COLTT_TRY(scan(b, std::min<uint64_t>(total, b + seg)));
   }
   return COLTT_OK;
 }
 
 template <int BN, bool AF32>
-int launch_mfma_scan_t(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
+int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                        unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
   auto kern = flat_mfma_cos_kernel<BN, AF32>;
   const size_t lds = mfma_lds_bytes<BN>();
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
   uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
-  kern<<<grid, MF_NT, lds, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+  kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
                                       nearest, cand, cnt, cap);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
 template <int BN>
-int launch_mfma_scan(Flat* f, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
+int launch_mfma_scan(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                      unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
-  return launch_mfma_scan_t<BN, false>(f, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
+  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
+  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
 }
 
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
-int search_group_mfma(Flat* f, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
+int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
                       uint32_t* d_out_cnt, uint32_t cap, bool* used_fallback) {
-  uint32_t* cnt = f->w_cnt.as<uint32_t>();
+  uint32_t* cnt = c->w_cnt.as<uint32_t>();
   uint32_t* thr = cnt + 256;
   uint32_t* ovf = cnt + 512;
-  unsigned long long* cur = f->w_cand.as<unsigned long long>();
-  unsigned long long* oth = f->w_cand2.as<unsigned long long>();
+  unsigned long long* cur = c->w_cand.as<unsigned long long>();
+  unsigned long long* oth = c->w_cand2.as<unsigned long long>();
   const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
-  const float* qe = f->w_qeff.as<float>() + q0 * f->dim;
-  const float* qn = f->w_qn.as<float>() + q0;
-  _Float16* q16 = f->w_q16.as<_Float16>();
+  const float* qe = c->w_qeff.as<float>() + q0 * f->dim;
+  const float* qn = c->w_qn.as<float>() + q0;
+  _Float16* q16 = c->w_q16.as<_Float16>();
   const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
-  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, f->stream>>>(qe, g, BN, (int)f->dim, q16);
-  init_group_kernel<<<1, 256, 0, f->stream>>>(cnt, thr, ovf, nearest);
+  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, q16);
+  init_group_kernel<<<1, 256, 0, c->stream>>>(cnt, thr, ovf, nearest);
   auto scan = [&](uint64_t b, uint64_t e) -> int {
-    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    else COLTT_TRY(launch_mfma_scan<256>(f, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    flat_pick_kernel<<<g, 256, 0, f->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
+    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     std::swap(cur, oth);
     return COLTT_OK;
   };
@@ -337,54 +355,54 @@ int search_group_mfma(Flat* f, size_t q0, int g, uint32_t k, int nearest, uint64
   for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * 8)) COLTT_TRY(scan(b, e));
   struct { uint32_t cnt[256]; } hc;
   uint32_t h_ovf = 0;
-  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, f->stream));
-  COLTT_HIP(hipMemcpyAsync(hc.cnt, cnt, 256 * 4, hipMemcpyDeviceToHost, f->stream));
-  COLTT_HIP(hipStreamSynchronize(f->stream));
+  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
+  COLTT_HIP(hipMemcpyAsync(hc.cnt, cnt, 256 * 4, hipMemcpyDeviceToHost, c->stream));
+  COLTT_HIP(hipStreamSynchronize(c->stream));
   if (h_ovf) { *used_fallback = true; return COLTT_OK; }  // candidate list overflowed: caller re-runs the group in exact mode
   uint32_t maxc = 0;
   for (int i = 0; i < g; i++) maxc = std::max(maxc, hc.cnt[i]);
   if (maxc) {
     dim3 grid(ceil_div(maxc, 32), g);
-    if (f->quant == COLTT_Q_NONE) flat_rescore_kernel<Q_NONE><<<grid, 64, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
-    else flat_rescore_kernel<Q_F16><<<grid, 64, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
+    if (f->quant == COLTT_Q_NONE) flat_rescore_kernel<Q_NONE><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
+    else flat_rescore_kernel<Q_F16><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
   }
-  flat_select_kernel<<<g, 256, 0, f->stream>>>(cur, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, d_out_ids + q0 * k, d_out_sc + q0 * k, d_out_cnt + q0);
+  flat_select_kernel<<<g, 256, 0, c->stream>>>(cur, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, d_out_ids + q0 * k, d_out_sc + q0 * k, d_out_cnt + q0);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
 // Search nq prepared queries over positions [0, total) (rows, or entries of the gather list).
-int search_prepared(Flat* f, size_t nq, uint32_t k, int select, int mode, const uint32_t* d_gather, uint64_t total,
+int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mode, const uint32_t* d_gather, uint64_t total,
                     uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt) {
   const int nearest = select == COLTT_SELECT_NEAREST;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
   const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && f->metric == COLTT_COSINE &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
-  COLTT_TRY(f->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
-  if (mfma) { COLTT_TRY(f->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(f->w_q16.reserve((size_t)256 * f->dim * 2)); }
-  COLTT_TRY(f->w_cnt.reserve(4096));
-  COLTT_HIP(hipEventRecord(f->ev0, f->stream));
+  COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
+  if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * f->dim * 2)); }
+  COLTT_TRY(c->w_cnt.reserve(4096));
+  COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   for (size_t q0 = 0; q0 < nq; q0 += gq) {
     int g = (int)std::min<size_t>(gq, nq - q0);
     if (mfma) {
       bool fb = false;
-      COLTT_TRY(search_group_mfma(f, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, &fb));
-      f->mfma_groups++;
+      COLTT_TRY(search_group_mfma(f, c, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, &fb));
+      f->mfma_groups.fetch_add(1);
       if (!fb) continue;
-      f->mfma_fallbacks++;
+      f->mfma_fallbacks.fetch_add(1);
       for (size_t s = 0; s < (size_t)g; s += scan_qb(f))
-        COLTT_TRY(search_group_exact(f, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+        COLTT_TRY(search_group_exact(f, c, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     } else {
-      COLTT_TRY(search_group_exact(f, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+      COLTT_TRY(search_group_exact(f, c, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     }
   }
-  COLTT_HIP(hipEventRecord(f->ev1, f->stream));
+  COLTT_HIP(hipEventRecord(c->ev1, c->stream));
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
-int flat_search_common(Flat* f, const float* queries, bool q_on_device, size_t nq, uint32_t k, int select, int mode,
+int flat_search_common(Flat* f, FCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, int select, int mode,
                        const uint32_t* d_gather, uint64_t total, uint64_t* out_ids, float* out_scores,
                        uint32_t* out_counts, bool out_on_device) {
   if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "flat search: k=%u outside [1,%u]", k, K_MAX);
@@ -393,27 +411,52 @@ int flat_search_common(Flat* f, const float* queries, bool q_on_device, size_t n
   if (nq == 0) return COLTT_OK;
   const float* d_q = queries;
   if (!q_on_device) {
-    COLTT_TRY(f->w_qraw.reserve(nq * f->dim * 4));
-    COLTT_HIP(hipMemcpyAsync(f->w_qraw.p, queries, nq * f->dim * 4, hipMemcpyHostToDevice, f->stream));
-    d_q = f->w_qraw.as<float>();
+    COLTT_TRY(c->w_qraw.reserve(nq * f->dim * 4));
+    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, queries, nq * f->dim * 4, hipMemcpyHostToDevice, c->stream));
+    d_q = c->w_qraw.as<float>();
   }
-  COLTT_TRY(prep_queries(f, d_q, nq));
+  COLTT_TRY(prep_queries(f, c, d_q, nq));
   uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
   if (!out_on_device) {
-    COLTT_TRY(f->w_out_ids.reserve(nq * k * 8));
-    COLTT_TRY(f->w_out_sc.reserve(nq * k * 4));
-    COLTT_TRY(f->w_out_cnt.reserve(nq * 4));
-    d_oi = f->w_out_ids.as<uint64_t>(); d_os = f->w_out_sc.as<float>(); d_oc = f->w_out_cnt.as<uint32_t>();
+    COLTT_TRY(c->w_out_ids.reserve(nq * k * 8));
+    COLTT_TRY(c->w_out_sc.reserve(nq * k * 4));
+    COLTT_TRY(c->w_out_cnt.reserve(nq * 4));
+    d_oi = c->w_out_ids.as<uint64_t>(); d_os = c->w_out_sc.as<float>(); d_oc = c->w_out_cnt.as<uint32_t>();
   }
-  COLTT_TRY(search_prepared(f, nq, k, select, mode, d_gather, total, d_oi, d_os, d_oc));
+  COLTT_TRY(search_prepared(f, c, nq, k, select, mode, d_gather, total, d_oi, d_os, d_oc));
   if (!out_on_device) {
-    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, f->stream));
-    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, f->stream));
-    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, f->stream));
+    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
   }
-  COLTT_HIP(hipStreamSynchronize(f->stream));
-  (void)hipEventElapsedTime(&f->last_ms, f->ev0, f->ev1);
+  COLTT_HIP(hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  f->last_ms.store(ms);
   return COLTT_OK;
+}
+
+// Slot plan of an upsert, computed WITHOUT touching the store: an existing id keeps its slot, new ids get n, n+1, ...
+// (a repeated new id gets one slot).  The store's maps, id table and row count change only in commit_upsert, after the
+// device work has succeeded — a failed upsert (NOMEM on growth, device error) leaves the store exactly as it was.
+struct UpsertPlan { std::vector<uint32_t> slots; std::vector<uint64_t> new_ids; uint64_t nn = 0; };
+int plan_upsert(const Flat* f, const uint64_t* ids, uint64_t first_id, size_t n, UpsertPlan& p) {
+  p.slots.resize(n); p.nn = f->n;
+  std::unordered_map<uint64_t, uint32_t> fresh;
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t id = ids ? ids[i] : first_id + i;
+    auto it = f->id2slot.find(id);
+    if (it != f->id2slot.end()) { p.slots[i] = it->second; continue; }
+    auto r = fresh.emplace(id, (uint32_t)p.nn);
+    if (r.second) { p.new_ids.push_back(id); p.nn++; }
+    p.slots[i] = r.first->second;
+  }
+  if (p.nn > 0xffffffffull) return fail(COLTT_E_UNSUPPORTED, "flat upsert: more than 2^32-1 rows in one store");
+  return COLTT_OK;
+}
+void commit_upsert(Flat* f, const UpsertPlan& p) {
+  for (size_t j = 0; j < p.new_ids.size(); j++) { f->id2slot[p.new_ids[j]] = (uint32_t)(f->n + j); f->h_ids.push_back(p.new_ids[j]); }
+  f->n = p.nn;
 }
 
 }  // namespace
@@ -429,9 +472,8 @@ int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out) 
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
+  f->device = default_device();
   COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
-  COLTT_HIP(hipEventCreate(&f->ev0));
-  COLTT_HIP(hipEventCreate(&f->ev1));
   *out = Registry::get().add(f);
   return COLTT_OK;
 }
@@ -444,8 +486,8 @@ int coltt_flat_destroy(coltt_handle_t h) {
 int coltt_flat_reserve(coltt_handle_t h, uint64_t n_rows) {
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_reserve: unknown handle");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   return f->reserve(n_rows);
 }
 
@@ -454,49 +496,32 @@ int coltt_flat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, 
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_upsert: unknown handle");
   if (n == 0) return COLTT_OK;
   if (!ids || !vecs) return fail(COLTT_E_INVALID, "flat_upsert: NULL input");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   COLTT_TRY(f->undense());
-  // slot assignment: existing id -> overwrite in place; a repeated id inside the batch -> last one wins
-  std::vector<uint32_t> slots(n);
-  uint64_t nn = f->n;
-  for (size_t i = 0; i < n; i++) {
-    auto it = f->id2slot.find(ids[i]);
-    if (it != f->id2slot.end()) slots[i] = it->second;
-    else { slots[i] = (uint32_t)nn; f->id2slot[ids[i]] = (uint32_t)nn; nn++; }
-  }
-  COLTT_TRY(f->reserve(nn));
-  f->h_ids.resize(nn);
-  for (size_t i = 0; i < n; i++) f->h_ids[slots[i]] = ids[i];
-  // last-wins for duplicates inside the batch: keep only the last occurrence of each slot
+  UpsertPlan pl;
+  COLTT_TRY(plan_upsert(f.get(), ids, 0, n, pl));
+  COLTT_TRY(f->reserve(pl.nn));
+  // a repeated id inside the batch: last one wins — upload only the winning rows
+  const float* src = vecs; const uint32_t* sl = pl.slots.data(); size_t m = n;
+  std::vector<uint32_t> s2; std::vector<float> v2;
   {
     std::unordered_map<uint32_t, size_t> last;
-    for (size_t i = 0; i < n; i++) last[slots[i]] = i;
+    for (size_t i = 0; i < n; i++) last[pl.slots[i]] = i;
     if (last.size() != n) {
-      // process duplicates serially by uploading only the winning rows
-      std::vector<uint32_t> s2; std::vector<float> v2;
       s2.reserve(last.size()); v2.reserve(last.size() * f->dim);
-      for (size_t i = 0; i < n; i++) if (last[slots[i]] == i) { s2.push_back(slots[i]); v2.insert(v2.end(), vecs + i * f->dim, vecs + (i + 1) * f->dim); }
-      size_t m = s2.size();
-      COLTT_TRY(f->w_raw.reserve(m * f->dim * 4));
-      COLTT_TRY(f->w_slots.reserve(m * 4));
-      COLTT_HIP(hipMemcpyAsync(f->w_raw.p, v2.data(), m * f->dim * 4, hipMemcpyHostToDevice, f->stream));
-      COLTT_HIP(hipMemcpyAsync(f->w_slots.p, s2.data(), m * 4, hipMemcpyHostToDevice, f->stream));
-      COLTT_TRY(prep_rows(f.get(), f->w_raw.as<float>(), m, f->w_slots.as<uint32_t>(), 0));
-      COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
-      COLTT_HIP(hipStreamSynchronize(f->stream));
-      f->n = nn;
-      return COLTT_OK;
+      for (size_t i = 0; i < n; i++) if (last[pl.slots[i]] == i) { s2.push_back(pl.slots[i]); v2.insert(v2.end(), vecs + i * f->dim, vecs + (i + 1) * f->dim); }
+      src = v2.data(); sl = s2.data(); m = s2.size();
     }
   }
-  COLTT_TRY(f->w_raw.reserve(n * f->dim * 4));
-  COLTT_TRY(f->w_slots.reserve(n * 4));
-  COLTT_HIP(hipMemcpyAsync(f->w_raw.p, vecs, n * f->dim * 4, hipMemcpyHostToDevice, f->stream));
-  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, f->stream));
-  COLTT_TRY(prep_rows(f.get(), f->w_raw.as<float>(), n, f->w_slots.as<uint32_t>(), 0));
-  COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
+  COLTT_TRY(f->w_raw.reserve(m * f->dim * 4));
+  COLTT_TRY(f->w_slots.reserve(m * 4));
+  COLTT_HIP(hipMemcpyAsync(f->w_raw.p, src, m * f->dim * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, sl, m * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_TRY(prep_rows(f.get(), f->w_raw.as<float>(), m, f->w_slots.as<uint32_t>(), 0));
+  if (!pl.new_ids.empty()) COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>() + f->n, pl.new_ids.data(), pl.new_ids.size() * 8, hipMemcpyHostToDevice, f->stream));
   COLTT_HIP(hipStreamSynchronize(f->stream));
-  f->n = nn;
+  commit_upsert(f.get(), pl);
   return COLTT_OK;
 }
 
@@ -505,34 +530,27 @@ int coltt_flat_upsert_device(coltt_handle_t h, const uint64_t* ids, uint64_t fir
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_upsert_device: unknown handle");
   if (n == 0) return COLTT_OK;
   if (!d_vecs) return fail(COLTT_E_INVALID, "flat_upsert_device: NULL vectors");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   if (!ids && f->dense && (f->n == 0 || first_id == f->dense_base + f->n)) {  // append-only dense fast path
-    if (f->n == 0) f->dense_base = first_id;
+    if (f->n + n > 0xffffffffull) return fail(COLTT_E_UNSUPPORTED, "flat upsert: more than 2^32-1 rows in one store");
     COLTT_TRY(f->reserve(f->n + n));
     COLTT_TRY(prep_rows(f.get(), d_vecs, n, nullptr, f->n));
     COLTT_HIP(hipStreamSynchronize(f->stream));
+    if (f->n == 0) f->dense_base = first_id;
     f->n += n;
     return COLTT_OK;
   }
   COLTT_TRY(f->undense());
-  std::vector<uint32_t> slots(n);
-  uint64_t nn = f->n;
-  for (size_t i = 0; i < n; i++) {
-    uint64_t id = ids ? ids[i] : first_id + i;
-    auto it = f->id2slot.find(id);
-    if (it != f->id2slot.end()) slots[i] = it->second;
-    else { slots[i] = (uint32_t)nn; f->id2slot[id] = (uint32_t)nn; nn++; }
-  }
-  COLTT_TRY(f->reserve(nn));
-  f->h_ids.resize(nn);
-  for (size_t i = 0; i < n; i++) f->h_ids[slots[i]] = ids ? ids[i] : first_id + i;
+  UpsertPlan pl;
+  COLTT_TRY(plan_upsert(f.get(), ids, first_id, n, pl));
+  COLTT_TRY(f->reserve(pl.nn));
   COLTT_TRY(f->w_slots.reserve(n * 4));
-  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, slots.data(), n * 4, hipMemcpyHostToDevice, f->stream));
+  COLTT_HIP(hipMemcpyAsync(f->w_slots.p, pl.slots.data(), n * 4, hipMemcpyHostToDevice, f->stream));
   COLTT_TRY(prep_rows(f.get(), d_vecs, n, f->w_slots.as<uint32_t>(), 0));
-  COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), nn * 8, hipMemcpyHostToDevice, f->stream));
+  if (!pl.new_ids.empty()) COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>() + f->n, pl.new_ids.data(), pl.new_ids.size() * 8, hipMemcpyHostToDevice, f->stream));
   COLTT_HIP(hipStreamSynchronize(f->stream));
-  f->n = nn;
+  commit_upsert(f.get(), pl);
   return COLTT_OK;
 }
 
@@ -541,8 +559,8 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_remove: unknown handle");
   if (n == 0) return COLTT_OK;
   if (!ids) return fail(COLTT_E_INVALID, "flat_remove: NULL ids");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   COLTT_TRY(f->undense());
   for (size_t i = 0; i < n; i++) {
     auto it = f->id2slot.find(ids[i]);
@@ -557,11 +575,11 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
       uint64_t moved = f->h_ids[last];
       f->h_ids[s] = moved;
       f->id2slot[moved] = s;
+      COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>() + s, f->ids.as<uint64_t>() + last, 8, hipMemcpyDeviceToDevice, f->stream));
     }
     f->h_ids.pop_back();
     f->n--;
   }
-  if (f->n) COLTT_HIP(hipMemcpyAsync(f->ids.as<uint64_t>(), f->h_ids.data(), f->n * 8, hipMemcpyHostToDevice, f->stream));
   COLTT_HIP(hipStreamSynchronize(f->stream));
   return COLTT_OK;
 }
@@ -569,7 +587,7 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
 int coltt_flat_len(coltt_handle_t h, uint64_t* out) {
   auto f = lookup<Flat>(h);
   if (!f || !out) return fail(COLTT_E_NOT_FOUND, "flat_len: unknown handle");
-  std::lock_guard<std::mutex> g(f->mu);
+  ReadLock g(f->rw);
   *out = f->n;
   return COLTT_OK;
 }
@@ -577,8 +595,8 @@ int coltt_flat_len(coltt_handle_t h, uint64_t* out) {
 int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row) {
   auto f = lookup<Flat>(h);
   if (!f || !out_row) return fail(COLTT_E_NOT_FOUND, "flat_get: unknown handle");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   uint64_t slot;
   if (f->dense) { if (id < f->dense_base || id >= f->dense_base + f->n) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = id - f->dense_base; }
   else { auto it = f->id2slot.find(id); if (it == f->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = it->second; }
@@ -591,9 +609,11 @@ int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search: NULL buffer");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
-  return flat_search_common(f.get(), queries, false, nq, k, select, mode, nullptr, f->n, out_ids, out_scores, out_counts, false);
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
+  CtxLease<FCtx> ctx(f->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return flat_search_common(f.get(), ctx.c, queries, false, nq, k, select, mode, nullptr, f->n, out_ids, out_scores, out_counts, false);
 }
 
 int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, int select, int mode,
@@ -601,9 +621,11 @@ int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_device: unknown handle");
   if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "flat_search_device: NULL buffer");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
-  return flat_search_common(f.get(), d_queries, true, nq, k, select, mode, nullptr, f->n, d_out_ids, d_out_scores, d_out_counts, true);
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
+  CtxLease<FCtx> ctx(f->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return flat_search_common(f.get(), ctx.c, d_queries, true, nq, k, select, mode, nullptr, f->n, d_out_ids, d_out_scores, d_out_counts, true);
 }
 
 int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,
@@ -613,8 +635,8 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_ids: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search_ids: NULL buffer");
   if (n_cand && !cand_ids) return fail(COLTT_E_INVALID, "flat_search_ids: NULL candidates");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   // id -> slot; ids that are not stored are skipped (none_vectorstore.go:201 `if node, ok := ...; ok`);
   // a repeated candidate id is scored once (roaring64 ToArray yields a set, pkg/inverted/search.go:113-119)
   std::vector<uint32_t> slots;
@@ -626,9 +648,11 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
   }
   std::sort(slots.begin(), slots.end());
   slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
-  COLTT_TRY(f->w_gather.reserve(std::max<size_t>(slots.size(), 1) * 4));
-  if (!slots.empty()) COLTT_HIP(hipMemcpyAsync(f->w_gather.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, f->stream));
-  return flat_search_common(f.get(), queries, false, nq, k, select, COLTT_MODE_EXACT, f->w_gather.as<uint32_t>(), slots.size(),
+  CtxLease<FCtx> ctx(f->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  COLTT_TRY(ctx.c->w_gather.reserve(std::max<size_t>(slots.size(), 1) * 4));
+  if (!slots.empty()) COLTT_HIP(hipMemcpyAsync(ctx.c->w_gather.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, ctx.c->stream));
+  return flat_search_common(f.get(), ctx.c, queries, false, nq, k, select, COLTT_MODE_EXACT, ctx.c->w_gather.as<uint32_t>(), slots.size(),
                             out_ids, out_scores, out_counts, false);
 }
 
@@ -639,8 +663,8 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_load_vertex: unknown handle");
   if (!buf && len) return fail(COLTT_E_INVALID, "flat_load_vertex: NULL buffer");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   FBER r{buf, len};
   const size_t eb = quant_bytes(f->quant);
   std::vector<uint64_t> ids, voff, moff; std::vector<uint32_t> mlen;
@@ -662,14 +686,16 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
   }
   if (!r.ok) return fail(COLTT_E_INVALID, "flat_load_vertex: truncated stream");
   const uint64_t n = ids.size();
-  // replace the store's content (LoadVertex swaps the shard maps in, none_vectorstore.go:510-515)
-  f->n = 0; f->id2slot.clear(); f->h_ids.clear(); f->dense = false;
-  f->id2slot.reserve(n * 2);
-  for (uint64_t i = 0; i < n; i++) if (!f->id2slot.emplace(ids[i], (uint32_t)i).second) return fail(COLTT_E_INVALID, "flat_load_vertex: duplicate key in stream");
-  f->h_ids = ids;
+  if (n > 0xffffffffull) return fail(COLTT_E_UNSUPPORTED, "flat_load_vertex: more than 2^32-1 rows");
+  // the whole stream is parsed and validated before the store is touched; a device failure while the rows are being
+  // replaced leaves an EMPTY store (LoadVertex swaps complete shard maps in, none_vectorstore.go:510-515)
+  std::unordered_map<uint64_t, uint32_t> new_map;
+  new_map.reserve(n * 2);
+  for (uint64_t i = 0; i < n; i++) if (!new_map.emplace(ids[i], (uint32_t)i).second) return fail(COLTT_E_INVALID, "flat_load_vertex: duplicate key in stream");
   COLTT_TRY(f->reserve(std::max<uint64_t>(n, 1)));
   COLTT_TRY(f->ids.reserve(std::max<uint64_t>(f->cap, 1024) * 8, false, f->stream));
-  if (n) {
+  f->n = 0; f->id2slot.clear(); f->h_ids.clear(); f->dense = false;
+  auto upload = [&]() -> int {
     COLTT_HIP(hipMemcpyAsync(f->ids.p, ids.data(), n * 8, hipMemcpyHostToDevice, f->stream));
     const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)f->dim * eb));
     DevBuf d_chunk, d_offs;
@@ -683,16 +709,18 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
       COLTT_HIP(hipMemcpyAsync(d_offs.p, rel.data(), m * 8, hipMemcpyHostToDevice, f->stream));
       uint32_t grid = ceil_div(m * f->dim, 256);
       uint8_t* R = f->rows.as<uint8_t>();
-      if (f->quant == COLTT_Q_NONE) { be_codes_kernel<Q_NONE><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
-        row_norms_kernel<Q_NONE><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
-      else if (f->quant == COLTT_Q_F8) { be_codes_kernel<Q_F8><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
-        row_norms_kernel<Q_F8><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
-      else { be_codes_kernel<Q_F16><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b);
-        row_norms_kernel<Q_F16><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); }
+#define COLTT_BE(Q) do { be_codes_kernel<Q><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b); \
+        row_norms_kernel<Q><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); } while (0)
+      COLTT_DISPATCH_QUANT(f->quant, COLTT_BE)
+#undef COLTT_BE
       COLTT_HIP(hipGetLastError());
       COLTT_HIP(hipStreamSynchronize(f->stream));
     }
-  }
+    return COLTT_OK;
+  };
+  if (n) COLTT_TRY(upload());
+  f->id2slot = std::move(new_map);
+  f->h_ids = ids;
   f->n = n;
   if (out_n) *out_n = n;
   for (uint64_t i = 0; i < n && i < cap_n; i++) {
@@ -709,8 +737,8 @@ int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uin
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_save_vertex: unknown handle");
   if (!out_len) return fail(COLTT_E_INVALID, "flat_save_vertex: out_len is NULL");
-  std::lock_guard<std::mutex> g(f->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
   const size_t eb = quant_bytes(f->quant);
   std::unordered_map<uint64_t, uint64_t> meta_of;
   for (uint64_t i = 0; i < n_meta; i++) if (meta_ids && meta_blobs && meta_blobs[i] && meta_lens[i] >= 4) meta_of[meta_ids[i]] = i;
@@ -743,7 +771,7 @@ int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uin
 int coltt_last_kernel_ms_flat(coltt_handle_t h, float* out_ms) {
   auto f = lookup<Flat>(h);
   if (!f || !out_ms) return fail(COLTT_E_NOT_FOUND, "last_kernel_ms: unknown handle");
-  *out_ms = f->last_ms;
+  *out_ms = f->last_ms.load();
   return COLTT_OK;
 }
 

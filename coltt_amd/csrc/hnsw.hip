@@ -10,6 +10,7 @@
 //   adjU      [ucap][mMax] u32  levels >= 1                                                (+ adjU_d)
 //   del_bits  [cap/32] u32      tombstones (hnswVertex.deleted)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "common.hpp"
@@ -241,6 +242,24 @@ __global__ void add_base_kernel(uint64_t* ids, size_t n, uint64_t base) {
   if (i < n) ids[i] += base;
 }
 
+// Per-call search context: searches hold the index lock shared and run concurrently, each on its own stream and workspaces.
+struct HCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBuf w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc;
+  int init() {  // the caller has selected the index's device
+    COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    COLTT_HIP(hipEventCreate(&ev0));
+    COLTT_HIP(hipEventCreate(&ev1));
+    return COLTT_OK;
+  }
+  ~HCtx() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
 struct Hnsw : Object {
   uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
   coltt_hnsw_cfg cfg{};
@@ -254,15 +273,18 @@ struct Hnsw : Object {
   std::vector<int32_t> h_levels;     // per slot
   std::vector<uint32_t> h_upper_off; // per slot
   std::vector<uint32_t> h_del;       // bitmap mirror
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr; float last_ms = 0.f;
-  DevBuf w_raw, w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc;
+  hipStream_t stream = nullptr;        // mutations (exclusive lock); searches use their context's stream
+  std::atomic<float> last_ms{0.f};     // kernel time of the most recently finished search call
+  CtxPool<HCtx> pool;
+  DevBuf w_raw, w_misc;
   DevBuf b_head, b_req, b_levels; uint64_t head_cap = 0;  // builder scratch
-  DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;  // HBM visited set (hnsw_dev.hpp, VISG)
+  // HBM visited set (hnsw_dev.hpp, VISG): vis_regions regions of vis_stride bytes; concurrent searches lease disjoint
+  // contiguous runs of regions (vis_busy), the builder (exclusive lock) uses all of them.
+  DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;
+  std::mutex vis_mu; std::condition_variable vis_cv; std::vector<uint8_t> vis_busy;
   coltt_hnsw_stats build_stats{};
   ~Hnsw() override {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipSetDevice(device);
     if (stream) (void)hipStreamDestroy(stream);
   }
   GraphView view() const {
@@ -309,23 +331,21 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
     launch_prep_rows<Q>(x->stream, d_raw, n, (int)x->dim, nrm, nullptr, slot_base, R, x->stride);                     \
     row_norms_kernel<Q><<<ceil_div(n * 2, 256), 256, 0, x->stream>>>(R, x->stride, nullptr, slot_base, n, (int)x->dim, N);     \
   } while (0)
-  if (x->quant == COLTT_Q_NONE) COLTT_PREP(Q_NONE);
-  else if (x->quant == COLTT_Q_F8) COLTT_PREP(Q_F8);
-  else COLTT_PREP(Q_F16);
+  COLTT_DISPATCH_QUANT(x->quant, COLTT_PREP)
 #undef COLTT_PREP
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
-int prep_queries_any(Hnsw* x, const float* d_qraw, size_t nq) {
-  COLTT_TRY(x->w_qeff.reserve(nq * x->dim * 4));
-  COLTT_TRY(x->w_qn.reserve(nq * 4));
+int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
+  COLTT_TRY(c->w_qeff.reserve(nq * x->dim * 4));
+  COLTT_TRY(c->w_qn.reserve(nq * 4));
   int norm = x->metric == COLTT_COSINE;
-  float* qe = x->w_qeff.as<float>();
-  if (x->quant == COLTT_Q_NONE) launch_prep_queries<Q_NONE>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
-  else if (x->quant == COLTT_Q_F8) launch_prep_queries<Q_F8>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
-  else launch_prep_queries<Q_F16>(x->stream, d_qraw, nq, (int)x->dim, norm, qe);
-  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, x->stream>>>(qe, nq, (int)x->dim, x->w_qn.as<float>());
+  float* qe = c->w_qeff.as<float>();
+#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)x->dim, norm, qe)
+  COLTT_DISPATCH_QUANT(x->quant, COLTT_PQ)
+#undef COLTT_PQ
+  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, c->stream>>>(qe, nq, (int)x->dim, c->w_qn.as<float>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -342,6 +362,9 @@ constexpr uint32_t VIS_MAX_REGIONS = 2048;  // 8 waves on each of 256 CUs
 // (Re)allocate the HBM visited set for the current slot capacity: one byte per slot and workgroup, zeroed, epochs reset.
 // Sized against a quarter of the device memory; if that buys fewer than one region per CU the LDS hash is used instead.
 int ensure_visg(Hnsw* x) {
+  // Callers hold the index lock (shared or exclusive).  The slot capacity only changes under the exclusive lock, and every
+  // search that wants the byte map passes through here first, so a re-allocation can never race a traversal that uses it.
+  std::lock_guard<std::mutex> vg(x->vis_mu);
   const uint64_t stride = (std::max<uint64_t>(x->cap, 1) + 1023) & ~1023ull;
   if (x->vis_stride == stride) return COLTT_OK;
   if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
@@ -351,13 +374,55 @@ int ensure_visg(Hnsw* x) {
   const uint64_t regions = std::min<uint64_t>(VIS_MAX_REGIONS, budget / stride);
   x->vis_stride = stride;
   x->vis_regions = 0;
-  if (regions < 256) return COLTT_OK;
+  x->vis_busy.clear();
+  if (regions < 256) {
+    fprintf(stderr, "[coltt_gpu] hnsw: HBM visited workspace would get only %llu regions of %llu B (budget %llu B) — using the LDS hash "
+                    "visited set for ef > %d as well\n", (unsigned long long)regions, (unsigned long long)stride, (unsigned long long)budget, COLTT_VISG_MIN_EF);
+    return COLTT_OK;
+  }
+  if (regions < VIS_MAX_REGIONS)
+    fprintf(stderr, "[coltt_gpu] hnsw: HBM visited workspace capped at %llu of %u regions (%llu B each, budget %llu B): fewer resident "
+                    "traversals per launch\n", (unsigned long long)regions, VIS_MAX_REGIONS, (unsigned long long)stride, (unsigned long long)budget);
   COLTT_TRY(x->w_visg.reserve(regions * stride));
   COLTT_TRY(x->w_vepoch.reserve(VIS_MAX_REGIONS * 4));
   COLTT_HIP(hipMemsetAsync(x->w_visg.p, 0, regions * stride, x->stream));
   COLTT_HIP(hipMemsetAsync(x->w_vepoch.p, 0, VIS_MAX_REGIONS * 4, x->stream));
+  COLTT_HIP(hipStreamSynchronize(x->stream));  // searches run on other streams
   x->vis_regions = (uint32_t)regions;
+  x->vis_busy.assign(regions, 0);
   return COLTT_OK;
+}
+
+// Lease a contiguous run of visited-set regions for one search launch: `want` if a free run that long exists, else the
+// longest free run; blocks while every region is out.  Released by the RegionLease destructor.
+struct RegionLease {
+  Hnsw* x = nullptr; uint32_t base = 0, count = 0;
+  ~RegionLease() {
+    if (!x || !count) return;
+    { std::lock_guard<std::mutex> g(x->vis_mu); for (uint32_t i = 0; i < count; i++) x->vis_busy[base + i] = 0; }
+    x->vis_cv.notify_all();
+  }
+};
+void acquire_regions(Hnsw* x, uint32_t want, RegionLease& out) {
+  std::unique_lock<std::mutex> lk(x->vis_mu);
+  const uint32_t R = (uint32_t)x->vis_busy.size();
+  if (want > R) want = R;
+  for (;;) {
+    uint32_t best_b = 0, best_l = 0;
+    for (uint32_t i = 0; i < R;) {
+      if (x->vis_busy[i]) { i++; continue; }
+      uint32_t j = i; while (j < R && !x->vis_busy[j] && j - i < want) j++;
+      if (j - i > best_l) { best_l = j - i; best_b = i; }
+      if (best_l == want) break;
+      i = j;
+    }
+    if (best_l > 0) {
+      for (uint32_t i = 0; i < best_l; i++) x->vis_busy[best_b + i] = 1;
+      out.x = x; out.base = best_b; out.count = best_l;
+      return;
+    }
+    x->vis_cv.wait(lk);
+  }
 }
 
 // COLTT_VISG=0 / 1 forces the LDS hash / the HBM byte map (measurement and test knob, read at every call); default: the
@@ -399,36 +464,39 @@ size_t waves_per_cu_cap(int quant) {
   return quant == Q_NONE ? 4 : 8;
 }
 
+uint32_t resident_waves(const SearchGeom& sg, int quant) {
+  return 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(quant), (160 * 1024) / sg.lds));
+}
+
 template <int METRIC, int QUANT>
-int launch_search(Hnsw* x, const SearchGeom& sg, uint32_t nq, uint32_t k, uint32_t* counter, uint64_t* oi, float* os,
-                  uint32_t* oc, unsigned long long* stats) {
+int launch_search(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
+                  uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_search_kernel<METRIC, QUANT, true> : hnsw_search_kernel<METRIC, QUANT, false>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / sg.lds));
-  uint32_t grid = std::min<uint32_t>({nq, 256u * per_cu, sg.max_grid});
-  kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, x->w_qeff.as<float>(), x->w_qn.as<float>(), nq,
-                                        k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, x->w_visg.as<uint8_t>(),
-                                        (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>());
+  kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
+                                        k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats,
+                                        x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
+                                        x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
-int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
+int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
                   uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats) {
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (nq == 0) return COLTT_OK;
   if (k == 0) return fail(COLTT_E_INVALID, "hnsw_search: k must be >= 1");
   uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
   if (!on_device) {
-    COLTT_TRY(x->w_out_ids.reserve(nq * k * 8));
-    COLTT_TRY(x->w_out_sc.reserve(nq * k * 4));
-    COLTT_TRY(x->w_out_cnt.reserve(nq * 4));
-    d_oi = x->w_out_ids.as<uint64_t>(); d_os = x->w_out_sc.as<float>(); d_oc = x->w_out_cnt.as<uint32_t>();
+    COLTT_TRY(c->w_out_ids.reserve(nq * k * 8));
+    COLTT_TRY(c->w_out_sc.reserve(nq * k * 4));
+    COLTT_TRY(c->w_out_cnt.reserve(nq * 4));
+    d_oi = c->w_out_ids.as<uint64_t>(); d_os = c->w_out_sc.as<float>(); d_oc = c->w_out_cnt.as<uint32_t>();
   }
   if (x->entry < 0) {  // empty index => empty result, not an error (hnsw.go:249-251)
-    COLTT_HIP(hipMemsetAsync(d_oc, 0, nq * 4, x->stream));
-    if (!on_device) COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
-    COLTT_HIP(hipStreamSynchronize(x->stream));
+    COLTT_HIP(hipMemsetAsync(d_oc, 0, nq * 4, c->stream));
+    if (!on_device) COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipStreamSynchronize(c->stream));
     return COLTT_OK;
   }
   uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
@@ -436,41 +504,42 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
   if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
   SearchGeom sg = search_geom(x, ef);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
+  uint32_t grid = std::min<uint32_t>((uint32_t)std::min<size_t>(nq, 0xffffffffu), resident_waves(sg, x->quant));
+  RegionLease lease;
+  if (sg.visg) { acquire_regions(x, grid, lease); grid = lease.count; }
   const float* d_q = queries;
   if (!on_device) {
-    COLTT_TRY(x->w_qraw.reserve(nq * x->dim * 4));
-    COLTT_HIP(hipMemcpyAsync(x->w_qraw.p, queries, nq * x->dim * 4, hipMemcpyHostToDevice, x->stream));
-    d_q = x->w_qraw.as<float>();
+    COLTT_TRY(c->w_qraw.reserve(nq * x->dim * 4));
+    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, queries, nq * x->dim * 4, hipMemcpyHostToDevice, c->stream));
+    d_q = c->w_qraw.as<float>();
   }
-  COLTT_TRY(prep_queries_any(x, d_q, nq));
-  COLTT_TRY(x->w_misc.reserve(256));
-  uint32_t* counter = x->w_misc.as<uint32_t>();
-  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
-  COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 256, x->stream));
-  COLTT_HIP(hipEventRecord(x->ev0, x->stream));
+  COLTT_TRY(prep_queries_any(x, c, d_q, nq));
+  COLTT_TRY(c->w_misc.reserve(256));
+  uint32_t* counter = c->w_misc.as<uint32_t>();
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->w_misc.as<uint8_t>() + 16);
+  COLTT_HIP(hipMemsetAsync(c->w_misc.p, 0, 256, c->stream));
+  COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
-#define COLTT_LS(M, Q) rc = launch_search<M, Q>(x, sg, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats)
-  if (x->metric == COLTT_COSINE) {
-    if (x->quant == COLTT_Q_NONE) COLTT_LS(M_COS, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LS(M_COS, Q_F8); else COLTT_LS(M_COS, Q_F16);
-  } else {
-    if (x->quant == COLTT_Q_NONE) COLTT_LS(M_L2, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LS(M_L2, Q_F8); else COLTT_LS(M_L2, Q_F16);
-  }
+#define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
+#define COLTT_LS(Q) rc = x->metric == COLTT_COSINE ? launch_search<M_COS, Q>(COLTT_LS_ARGS) : launch_search<M_L2, Q>(COLTT_LS_ARGS)
+  COLTT_DISPATCH_QUANT(x->quant, COLTT_LS)
 #undef COLTT_LS
+#undef COLTT_LS_ARGS
   COLTT_TRY(rc);
-  COLTT_HIP(hipEventRecord(x->ev1, x->stream));
-  if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, x->stream>>>(d_oi, nq * k, x->dense_base);
+  COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+  if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, c->stream>>>(d_oi, nq * k, x->dense_base);
   unsigned long long h_stats[5] = {0, 0, 0, 0, 0};
   if (!on_device) {
-    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, x->stream));
-    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, x->stream));
-    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, x->stream));
+    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
   }
-  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, x->stream));
+  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
 #ifdef COLTT_PHASE_TIMING
   unsigned long long h_pt[8] = {0};
-  COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, x->stream));
+  COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, c->stream));
 #endif
-  COLTT_HIP(hipStreamSynchronize(x->stream));
+  COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
 #ifdef COLTT_PHASE_TIMING
   {
     static const char* nm[8] = {"pop", "adjacency", "visited", "rows+dist", "merge", "prologue(upper levels)", "writeout", "-"};
@@ -480,7 +549,9 @@ int search_common(Hnsw* x, const float* queries, bool on_device, size_t nq, uint
     fprintf(stderr, "  | ticks/query %.0f\n", tot / (double)nq);
   }
 #endif
-  (void)hipEventElapsedTime(&x->last_ms, x->ev0, x->ev1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  x->last_ms.store(ms);
   if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_search: traversal watchdog tripped (code %llu)", h_stats[4]);
   if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }
   return COLTT_OK;
@@ -558,9 +629,10 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
   unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
   size_t i = 0;
   while (i < n) {
-    const bool first = x->entry < 0 && x->live == 0 && x->n == 0;
+    // nil entrypoint (empty index, or Remove left no successor: hnsw.go:197-217 may CAS the entrypoint to nil): the vertex is
+    // stored at level 0 and becomes the entrypoint, nothing is linked (hnsw.go:108-116)
+    const bool first = x->entry < 0;
     uint32_t b = first ? 1u : (uint32_t)std::min<size_t>(batch, n - i);
-    if (!first && x->entry < 0) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: index lost its entrypoint (all entry neighbours removed)");
     uint64_t up = 0;
     for (uint32_t j = 0; j < b; j++) up += first ? 0 : (uint64_t)levels[i + j];
     const uint64_t base = x->n;
@@ -568,21 +640,28 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     if (wants_visg(efc)) COLTT_TRY(ensure_visg(x));  // (re)sized here: the slot capacity may just have grown
     const SearchGeom sg = search_geom(x, efc);
     if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", sg.lds);
-    // host mirrors + per-slot tables
+    // per-slot tables of the batch.  Host mirrors (h_levels, h_upper_off, h_ids, id2slot, h_del) are committed only after
+    // the device work of the batch has succeeded: a failed batch leaves the index exactly as it was (slots >= n unreferenced).
     std::vector<uint32_t> uo(b);
     std::vector<int32_t> lv(b);
+    std::vector<uint64_t> nid(x->dense ? 0 : b);
     uint64_t u = x->n_upper;
     for (uint32_t j = 0; j < b; j++) {
-      lv[j] = first ? 0 : levels[i + j];  // first vertex is forced to level 0 (hnsw.go:108-110)
+      lv[j] = first ? 0 : levels[i + j];
       uo[j] = lv[j] > 0 ? (uint32_t)u : NBR_NONE;
       u += (uint64_t)lv[j];
-      x->h_levels.push_back(lv[j]);
-      x->h_upper_off.push_back(uo[j]);
-      if (!x->dense) { uint64_t id = ids ? ids[i + j] : first_id + i + j; x->h_ids.push_back(id); x->id2slot[id] = (uint32_t)(base + j); }
+      if (!x->dense) nid[j] = ids ? ids[i + j] : first_id + i + j;
     }
-    x->h_del.resize((base + b + 31) / 32, 0u);
+    auto commit_host = [&]() {
+      for (uint32_t j = 0; j < b; j++) {
+        x->h_levels.push_back(lv[j]);
+        x->h_upper_off.push_back(uo[j]);
+        if (!x->dense) { x->h_ids.push_back(nid[j]); x->id2slot[nid[j]] = (uint32_t)(base + j); }
+      }
+      x->h_del.resize((base + b + 31) / 32, 0u);
+    };
     COLTT_HIP(hipMemcpyAsync(x->upper_off.as<uint32_t>() + base, uo.data(), (size_t)b * 4, hipMemcpyHostToDevice, x->stream));
-    if (!x->dense) COLTT_HIP(hipMemcpyAsync(x->ids.as<uint64_t>() + base, x->h_ids.data() + base, (size_t)b * 8, hipMemcpyHostToDevice, x->stream));
+    if (!x->dense) COLTT_HIP(hipMemcpyAsync(x->ids.as<uint64_t>() + base, nid.data(), (size_t)b * 8, hipMemcpyHostToDevice, x->stream));
     COLTT_HIP(hipMemsetAsync(x->adj0.as<uint32_t>() + base * x->cfg.m_max0, 0xff, (size_t)b * x->cfg.m_max0 * 4, x->stream));
     COLTT_HIP(hipMemsetAsync(x->adj0_d.as<float>() + base * x->cfg.m_max0, 0, (size_t)b * x->cfg.m_max0 * 4, x->stream));
     if (up) {
@@ -592,6 +671,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     COLTT_TRY(prep_rows_any(x, d_vecs + i * x->dim, b, base, x->metric == COLTT_COSINE));
     if (first) {
       COLTT_HIP(hipStreamSynchronize(x->stream));
+      commit_host();
       x->entry = (int32_t)base; x->entry_level = 0;
       x->n += 1; x->live += 1; i += 1;
       continue;
@@ -610,23 +690,25 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     COLTT_HIP(hipMemcpyAsync(x->b_levels.p, lv.data(), (size_t)b * 4, hipMemcpyHostToDevice, x->stream));
     COLTT_HIP(hipMemsetAsync(x->w_misc.p, 0, 64, x->stream));
     int rc;
-#define COLTT_LB(M, Q) rc = launch_build<M, Q>(x, sg, (uint32_t)base, b, x->b_levels.as<int32_t>(), counter, req_count, \
-                                               x->b_req.as<BuildReq>(), x->b_head.as<uint32_t>(), d_stats)
-    if (x->metric == COLTT_COSINE) {
-      if (x->quant == COLTT_Q_NONE) COLTT_LB(M_COS, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LB(M_COS, Q_F8); else COLTT_LB(M_COS, Q_F16);
-    } else {
-      if (x->quant == COLTT_Q_NONE) COLTT_LB(M_L2, Q_NONE); else if (x->quant == COLTT_Q_F8) COLTT_LB(M_L2, Q_F8); else COLTT_LB(M_L2, Q_F16);
-    }
+#define COLTT_LB_ARGS x, sg, (uint32_t)base, b, x->b_levels.as<int32_t>(), counter, req_count, x->b_req.as<BuildReq>(), x->b_head.as<uint32_t>(), d_stats
+#define COLTT_LB(Q) rc = x->metric == COLTT_COSINE ? launch_build<M_COS, Q>(COLTT_LB_ARGS) : launch_build<M_L2, Q>(COLTT_LB_ARGS)
+    COLTT_DISPATCH_QUANT(x->quant, COLTT_LB)
 #undef COLTT_LB
+#undef COLTT_LB_ARGS
     COLTT_TRY(rc);
     struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[5]; } hm;
     COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
     COLTT_HIP(hipStreamSynchronize(x->stream));
-    if (hm.st[4]) return fail(COLTT_E_DEVICE, "hnsw insert: traversal watchdog tripped (code %llu)", hm.st[4]);
+    if (hm.st[4]) {  // phase A queued link requests on head[] before tripping: drop them so the next batch starts clean
+      fill_u32_kernel<<<ceil_div(x->head_cap, 256), 256, 0, x->stream>>>(x->b_head.as<uint32_t>(), x->head_cap, NBR_NONE);
+      (void)hipStreamSynchronize(x->stream);
+      return fail(COLTT_E_DEVICE, "hnsw insert: traversal watchdog tripped (code %llu)", hm.st[4]);
+    }
     if (hm.n_req) {
       hnsw_link_kernel<<<ceil_div(hm.n_req, 64), 64, 0, x->stream>>>(x->view(), x->cap, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>());
       COLTT_HIP(hipGetLastError());
     }
+    commit_host();
     x->build_stats.n_dist += hm.st[0]; x->build_stats.n_exp += hm.st[1]; x->build_stats.n_hops += hm.st[2]; x->build_stats.n_visit_resets += hm.st[3];
     for (uint32_t j = 0; j < b; j++)  // entrypoint CAS in insertion order (hnsw.go:161-164)
       if (lv[j] > x->entry_level) { x->entry = (int32_t)(base + j); x->entry_level = lv[j]; }
@@ -636,35 +718,44 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
   return COLTT_OK;
 }
 
-// Installs graph topology + id tables (everything of a bulk load except the vectors).
-int graph_install(Hnsw* x, uint64_t n, const uint64_t* ids, const int32_t* levels, const uint8_t* deleted, const int64_t* row_offsets,
-                  const int32_t* nbr, const float* nbr_dist, int32_t entry_slot) {
+// A failed (re)load must not leave a half-installed index behind: fall back to the empty index (memory-safe, searchable).
+void make_empty(Hnsw* x) {
+  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false;
+  x->h_levels.clear(); x->h_upper_off.clear(); x->h_del.clear(); x->h_ids.clear(); x->id2slot.clear();
+  x->dense = true; x->dense_base = 0;
+}
+
+// Installs graph topology + id tables (everything of a bulk load except the vectors) under configuration `c`.
+// Transactional: the stream is validated and laid out on the host FIRST; the object (cfg included) is only touched once
+// nothing but a device failure can go wrong, and a device failure leaves an EMPTY index, never a half-installed one.
+int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* ids, const int32_t* levels, const uint8_t* deleted,
+                  const int64_t* row_offsets, const int32_t* nbr, const float* nbr_dist, int32_t entry_slot) {
   if (n >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw_bulk_load: more than 2^31-1 slots");
   if (n && (entry_slot < -1 || entry_slot >= (int64_t)n)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: entry slot out of range");
-  const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  const uint32_t W0 = (uint32_t)c.m_max0, WU = (uint32_t)c.m_max;
   uint64_t n_upper = 0;
-  for (uint64_t i = 0; i < n; i++) { if (levels[i] < 0) return fail(COLTT_E_INVALID, "hnsw_bulk_load: negative level"); n_upper += (uint64_t)levels[i]; }
-  x->n = 0; x->live = 0; x->cap = 0; x->ucap = 0; x->n_upper = 0;
-  x->dense = (ids == nullptr); x->dense_base = 0; x->id2slot.clear();
-  COLTT_TRY(x->reserve(n, n_upper));
+  for (uint64_t i = 0; i < n; i++) {
+    if (levels[i] < 0 || levels[i] > 60) return fail(COLTT_E_INVALID, "hnsw_bulk_load: level %d out of range", levels[i]);
+    n_upper += (uint64_t)levels[i];
+  }
   std::vector<uint32_t> a0((size_t)n * W0, NBR_NONE), aU((size_t)n_upper * WU, NBR_NONE), uo(n, NBR_NONE);
   std::vector<float> d0((size_t)n * W0, 0.f), dU((size_t)n_upper * WU, 0.f);
-  x->h_levels.assign(levels, levels + n);
-  x->h_del.assign((n + 31) / 32, 0u);
-  x->any_deleted = false;
+  std::vector<uint32_t> h_del((n + 31) / 32, 0u);
+  bool any_deleted = false; uint64_t live = 0;
   uint64_t row = 0, up = 0;
   std::vector<std::pair<uint32_t, float>> tmp;
   for (uint64_t i = 0; i < n; i++) {
     bool del = deleted && deleted[i];
-    if (del) { x->h_del[i >> 5] |= 1u << (i & 31); x->any_deleted = true; } else x->live++;
+    if (del) { h_del[i >> 5] |= 1u << (i & 31); any_deleted = true; } else live++;
     if (levels[i] > 0) { uo[i] = (uint32_t)up; }
     for (int l = 0; l <= levels[i]; l++, row++) {
       int64_t b = row_offsets[row], e = row_offsets[row + 1];
       uint32_t W = l == 0 ? W0 : WU;
-      if (e - b > (int64_t)W) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d has %lld edges > width %u", (unsigned long long)i, l, (long long)(e - b), W);
+      if (e < b || e - b > (int64_t)W) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d has %lld edges > width %u", (unsigned long long)i, l, (long long)(e - b), W);
       tmp.clear();
       for (int64_t j = b; j < e; j++) {
         if (nbr[j] < 0 || (uint64_t)nbr[j] >= n) return fail(COLTT_E_INVALID, "hnsw_bulk_load: neighbour slot out of range");
+        if (levels[nbr[j]] < l) return fail(COLTT_E_INVALID, "hnsw_bulk_load: slot %llu level %d lists a neighbour of lower level", (unsigned long long)i, l);
         tmp.push_back({(uint32_t)nbr[j], nbr_dist ? nbr_dist[j] : 0.f});
       }
       std::sort(tmp.begin(), tmp.end());
@@ -674,24 +765,43 @@ int graph_install(Hnsw* x, uint64_t n, const uint64_t* ids, const int32_t* level
     }
     up += (uint64_t)levels[i];
   }
-  x->h_upper_off = uo;
-  if (!x->dense) {
-    x->h_ids.assign(ids, ids + n);
-    x->id2slot.reserve(n * 2);
-    for (uint64_t i = 0; i < n; i++) if (!(deleted && deleted[i])) x->id2slot[ids[i]] = (uint32_t)i;
-    COLTT_HIP(hipMemcpyAsync(x->ids.p, ids, n * 8, hipMemcpyHostToDevice, x->stream));
+  std::unordered_map<uint64_t, uint32_t> id2slot;
+  if (ids) {
+    id2slot.reserve(n * 2);
+    for (uint64_t i = 0; i < n; i++)
+      if (!(deleted && deleted[i]) && !id2slot.emplace(ids[i], (uint32_t)i).second) return fail(COLTT_E_INVALID, "hnsw_bulk_load: duplicate id");
   }
-  if (n) {
-    COLTT_HIP(hipMemcpyAsync(x->adj0.p, a0.data(), a0.size() * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->adj0_d.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->upper_off.p, uo.data(), n * 4, hipMemcpyHostToDevice, x->stream));
-    COLTT_HIP(hipMemcpyAsync(x->del_bits.p, x->h_del.data(), x->h_del.size() * 4, hipMemcpyHostToDevice, x->stream));
-    if (n_upper) {
-      COLTT_HIP(hipMemcpyAsync(x->adjU.p, aU.data(), aU.size() * 4, hipMemcpyHostToDevice, x->stream));
-      COLTT_HIP(hipMemcpyAsync(x->adjU_d.p, dU.data(), dU.size() * 4, hipMemcpyHostToDevice, x->stream));
+  // ---- from here on the object changes.  Buffers only grow; capacities are re-derived under the new row widths.
+  const coltt_hnsw_cfg old_cfg = x->cfg;
+  const uint64_t old_cap = x->cap, old_ucap = x->ucap;
+  const bool old_dense = x->dense;
+  x->cfg = c; x->cap = 0; x->ucap = 0; x->dense = (ids == nullptr);
+  x->vis_stride = 0;  // the HBM visited workspace is sized by the slot capacity: re-made lazily
+  int rc = x->reserve(n, n_upper);
+  if (rc != COLTT_OK) { x->cfg = old_cfg; x->cap = old_cap; x->ucap = old_ucap; x->dense = old_dense; return rc; }  // nothing was written
+  auto upload = [&]() -> int {
+    if (!x->dense) COLTT_HIP(hipMemcpyAsync(x->ids.p, ids, n * 8, hipMemcpyHostToDevice, x->stream));
+    if (n) {
+      COLTT_HIP(hipMemcpyAsync(x->adj0.p, a0.data(), a0.size() * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(x->adj0_d.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(x->upper_off.p, uo.data(), n * 4, hipMemcpyHostToDevice, x->stream));
+      COLTT_HIP(hipMemcpyAsync(x->del_bits.p, h_del.data(), h_del.size() * 4, hipMemcpyHostToDevice, x->stream));
+      if (n_upper) {
+        COLTT_HIP(hipMemcpyAsync(x->adjU.p, aU.data(), aU.size() * 4, hipMemcpyHostToDevice, x->stream));
+        COLTT_HIP(hipMemcpyAsync(x->adjU_d.p, dU.data(), dU.size() * 4, hipMemcpyHostToDevice, x->stream));
+      }
     }
-  }
-  COLTT_HIP(hipStreamSynchronize(x->stream));
+    COLTT_HIP(hipStreamSynchronize(x->stream));
+    return COLTT_OK;
+  };
+  rc = upload();
+  x->id2slot.clear(); x->h_ids.clear(); x->dense_base = 0;
+  if (rc != COLTT_OK) { make_empty(x); return rc; }  // device failure mid-install: leave an empty (safe) index
+  x->h_levels.assign(levels, levels + n);
+  x->h_upper_off = std::move(uo);
+  x->h_del = std::move(h_del);
+  x->any_deleted = any_deleted; x->live = live;
+  if (!x->dense) { x->h_ids.assign(ids, ids + n); x->id2slot = std::move(id2slot); }
   x->n = n; x->n_upper = n_upper;
   x->entry = n ? entry_slot : -1;
   x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
@@ -724,9 +834,8 @@ int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg*
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
+  x->device = default_device();
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
-  COLTT_HIP(hipEventCreate(&x->ev0));
-  COLTT_HIP(hipEventCreate(&x->ev1));
   *out = Registry::get().add(x);
   return COLTT_OK;
 }
@@ -739,6 +848,7 @@ int coltt_hnsw_destroy(coltt_handle_t h) {
 int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out) {
   auto x = lookup<Hnsw>(h);
   if (!x || !out) return fail(COLTT_E_NOT_FOUND, "hnsw_get_cfg: unknown handle");
+  ReadLock g(x->rw);
   *out = x->cfg;
   return COLTT_OK;
 }
@@ -746,6 +856,7 @@ int coltt_hnsw_get_cfg(coltt_handle_t h, coltt_hnsw_cfg* out) {
 int coltt_hnsw_random_level(coltt_handle_t h, float u, int32_t* out_level) {
   auto x = lookup<Hnsw>(h);
   if (!x || !out_level) return fail(COLTT_E_NOT_FOUND, "hnsw_random_level: unknown handle");
+  ReadLock g(x->rw);
   if (!(u > 0.f && u < 1.f)) return fail(COLTT_E_INVALID, "hnsw_random_level: u must be in (0,1)");
   const float lg = (float)std::log((double)u);       // gomath.Log
   const float v = -lg * x->cfg.level_multiplier;      // RandomExponential (f32 multiply)
@@ -756,7 +867,7 @@ int coltt_hnsw_random_level(coltt_handle_t h, float u, int32_t* out_level) {
 int coltt_hnsw_len(coltt_handle_t h, uint64_t* out) {
   auto x = lookup<Hnsw>(h);
   if (!x || !out) return fail(COLTT_E_NOT_FOUND, "hnsw_len: unknown handle");
-  std::lock_guard<std::mutex> g(x->mu);
+  ReadLock g(x->rw);
   *out = x->live;
   return COLTT_OK;
 }
@@ -767,10 +878,10 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_bulk_load: unknown handle");
   if (n && (!levels || !vectors || !row_offsets)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: NULL input");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
-  COLTT_TRY(graph_install(x.get(), n, ids, levels, deleted, row_offsets, nbr, nbr_dist, entry_slot));
-  if (n) {
+  WriteLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
+  COLTT_TRY(graph_install(x.get(), x->cfg, n, ids, levels, deleted, row_offsets, nbr, nbr_dist, entry_slot));
+  auto upload_vectors = [&]() -> int {
     // vectors in chunks through a staging buffer: Normalize (cosine) + Lower, as Insert does (hnsw.go:105-107)
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / ((uint64_t)x->dim * 4));
     COLTT_TRY(x->w_raw.reserve(std::min<uint64_t>(chunk, n) * x->dim * 4));
@@ -780,7 +891,9 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
       COLTT_TRY(prep_rows_any(x.get(), x->w_raw.as<float>(), m, b, x->metric == COLTT_COSINE));
       COLTT_HIP(hipStreamSynchronize(x->stream));
     }
-  }
+    return COLTT_OK;
+  };
+  if (n) { int rc = upload_vectors(); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   return COLTT_OK;
 }
 
@@ -820,11 +933,11 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_load: unknown handle");
   if (!buf && len) return fail(COLTT_E_INVALID, "hnsw_load: NULL buffer");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   BER r{buf, len};
+  coltt_hnsw_cfg c = x->cfg;  // committed by graph_install only after the whole stream has been parsed and validated
   if (header) {  // hnswConfig.load (hnsw_config.go:205-245), dim, distIdx (hnsw_commit.go:165-183)
-    coltt_hnsw_cfg c = x->cfg;
     c.algo = (int32_t)r.u32(); c.level_multiplier = r.f32(); c.ef = (int32_t)r.u32(); c.ef_construction = (int32_t)r.u32();
     c.m = (int32_t)r.u32(); c.m_max = (int32_t)r.u32(); c.m_max0 = (int32_t)r.u32();
     uint32_t dim = r.u32(); uint8_t di = r.u8();
@@ -834,7 +947,6 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
     if ((di == 1) != (x->metric == COLTT_COSINE)) return fail(COLTT_E_INVALID, "hnsw_load: stream distance differs from the index's");
     if (c.m <= 0 || c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024 || c.ef <= 0 || c.ef_construction <= 0 || (c.algo != 0 && c.algo != 1))
       return fail(COLTT_E_INVALID, "hnsw_load: invalid config in stream");
-    x->cfg = c;
   }
   std::vector<uint64_t> ids, voff, moff; std::vector<int32_t> levels; std::vector<uint32_t> mlen;
   uint64_t entry_id = 0; bool empty = r.i >= len;
@@ -884,9 +996,9 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
   std::vector<int32_t> nbr((size_t)offs.back()); std::vector<float> nd((size_t)offs.back());
   for (size_t i = 0; i < rows.size(); i++)
     for (size_t j = 0; j < rows[i].size(); j++) { nbr[(size_t)offs[i] + j] = rows[i][j].first; nd[(size_t)offs[i] + j] = rows[i][j].second; }
-  COLTT_TRY(graph_install(x.get(), n, n ? ids.data() : nullptr, levels.data(), nullptr, offs.data(), nbr.data(), nd.data(), entry));
+  COLTT_TRY(graph_install(x.get(), c, n, n ? ids.data() : nullptr, levels.data(), nullptr, offs.data(), nbr.data(), nd.data(), entry));
   // vectors: upload the stream in chunks, byte-swap on the device; stored vectors are NOT re-normalised (hnsw_commit.go:217-220)
-  if (n) {
+  auto upload_vectors = [&]() -> int {
     const uint64_t rows_per = std::max<uint64_t>(1, (128ull << 20) / ((uint64_t)x->dim * 4));
     DevBuf d_chunk, d_offs;
     for (uint64_t b = 0; b < n; b += rows_per) {
@@ -901,7 +1013,9 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
       COLTT_TRY(prep_rows_any(x.get(), x->w_raw.as<float>(), m, b, false));
       COLTT_HIP(hipStreamSynchronize(x->stream));
     }
-  }
+    return COLTT_OK;
+  };
+  if (n) { int rc = upload_vectors(); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   if (out_n) *out_n = n;
   for (uint64_t i = 0; i < n && i < cap_n; i++) {
     if (out_ids) out_ids[i] = ids[i];
@@ -917,8 +1031,8 @@ int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_b
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_commit: unknown handle");
   if (!out_len) return fail(COLTT_E_INVALID, "hnsw_commit: out_len is NULL");
   if (x->quant != COLTT_Q_NONE) return fail(COLTT_E_UNSUPPORTED, "hnsw_commit: the reference stream stores f32 vectors; quantised indexes are not committable");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   BEW w{out, out ? cap : 0};
   if (header) {  // hnswConfig.save (hnsw_config.go:179-203) + dim + distIdx (hnsw_commit.go:70-80)
     w.u32((uint32_t)x->cfg.algo); w.f32(x->cfg.level_multiplier); w.u32((uint32_t)x->cfg.ef); w.u32((uint32_t)x->cfg.ef_construction);
@@ -976,9 +1090,11 @@ int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "hnsw_search: NULL buffer");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
-  return search_common(x.get(), queries, false, nq, k, ef_override, out_ids, out_scores, out_counts, stats);
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
+  CtxLease<HCtx> ctx(x->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return search_common(x.get(), ctx.c, queries, false, nq, k, ef_override, out_ids, out_scores, out_counts, stats);
 }
 
 int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
@@ -986,9 +1102,11 @@ int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search_device: unknown handle");
   if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "hnsw_search_device: NULL buffer");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
-  return search_common(x.get(), d_queries, true, nq, k, ef_override, d_out_ids, d_out_scores, d_out_counts, stats);
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
+  CtxLease<HCtx> ctx(x->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return search_common(x.get(), ctx.c, d_queries, true, nq, k, ef_override, d_out_ids, d_out_scores, d_out_counts, stats);
 }
 
 
@@ -996,8 +1114,8 @@ int coltt_hnsw_insert(coltt_handle_t h, uint64_t id, const float* vec, int32_t l
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert: unknown handle");
   if (!vec) return fail(COLTT_E_INVALID, "hnsw_insert: NULL vector");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   COLTT_TRY(x->w_raw.reserve((size_t)x->dim * 4));
   COLTT_HIP(hipMemcpyAsync(x->w_raw.p, vec, (size_t)x->dim * 4, hipMemcpyHostToDevice, x->stream));
   return insert_core(x.get(), &id, 0, x->w_raw.as<float>(), &level, 1, 1);
@@ -1008,16 +1126,16 @@ int coltt_hnsw_insert_batch_device(coltt_handle_t h, const uint64_t* ids, uint64
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert_batch_device: unknown handle");
   if (n && (!d_vecs || !levels)) return fail(COLTT_E_INVALID, "hnsw_insert_batch_device: NULL input");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   return insert_core(x.get(), ids, first_id, d_vecs, levels, n, batch);
 }
 
 int coltt_hnsw_remove(coltt_handle_t h, uint64_t id) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_remove: unknown handle");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  WriteLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   uint32_t vi;
   if (x->dense) {
     if (id < x->dense_base || id >= x->dense_base + x->n) return fail(COLTT_E_NOT_FOUND, "Item not found");
@@ -1080,8 +1198,8 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
                       int32_t* entry_slot) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export: unknown handle");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   const uint64_t n = x->n;
   const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
   std::vector<uint32_t> a0((size_t)n * W0), aU((size_t)x->n_upper * WU);
@@ -1123,8 +1241,8 @@ int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper
                           int32_t* entry_level, uint32_t* adj0, uint32_t* upper_off, uint32_t* adjU) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export_raw: unknown handle");
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
   if (n_slots) *n_slots = x->n;
   if (n_upper_rows) *n_upper_rows = x->n_upper;
   if (entry_slot) *entry_slot = x->entry;
@@ -1139,9 +1257,9 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_fetch_rows: unknown handle");
   if (n == 0) return COLTT_OK;
+  ReadLock g(x->rw);
   if (!out_rows || first_slot + n > x->n) return fail(COLTT_E_INVALID, "hnsw_fetch_rows: range outside [0,%llu)", (unsigned long long)x->n);
-  std::lock_guard<std::mutex> g(x->mu);
-  COLTT_TRY(ensure_device());
+  COLTT_TRY(use_device(x->device));
   const size_t rb = (size_t)x->dim * quant_bytes(x->quant);
   COLTT_HIP(hipMemcpy2D(out_rows, rb, x->rows.as<uint8_t>() + first_slot * x->stride, x->stride, rb, n, hipMemcpyDeviceToHost));
   return COLTT_OK;
@@ -1149,7 +1267,7 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
 
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms) {
   if (!out_ms) return fail(COLTT_E_INVALID, "last_kernel_ms: NULL out");
-  if (auto x = lookup<Hnsw>(h)) { *out_ms = x->last_ms; return COLTT_OK; }
+  if (auto x = lookup<Hnsw>(h)) { *out_ms = x->last_ms.load(); return COLTT_OK; }
   extern int coltt_last_kernel_ms_flat(coltt_handle_t, float*);
   return coltt_last_kernel_ms_flat(h, out_ms);
 }

@@ -20,12 +20,22 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include <atomic>
+#include <chrono>
+#include <queue>
+#include <thread>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #if defined(__clang__) || defined(__GNUC__)
 typedef float v8f __attribute__((vector_size(32)));
@@ -1315,6 +1325,182 @@ uint64_t orc_hnsw_graph_hash(void* h) {
     for (auto& es : v.edges) { int32_t c = (int32_t)es.size(); hs = fnv_mix(hs, &c, 4); for (auto& e : es) { hs = fnv_mix(hs, &e.to, 4); hs = fnv_mix(hs, &e.d, 4); } }
   }
   return hs;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// cpu_baseline drivers (bench.py only).  The reference serves one query per goroutine on the Go scheduler's threads
+// (core/core.go:633-667, edge/edge.go:610-690) and `highCpu` splits ONE edge query over 16 goroutines
+// (edge/none_vectorstore.go:148-178).  Here: native threads pinned one per allowed CPU, the corpus in a buffer whose pages
+// are interleaved over the NUMA nodes (mbind, then a parallel first touch by the pinned threads), so the all-cores number
+// is not an artefact of every page sitting on the node of one copy thread.
+// ================================================================================================
+static std::vector<int> allowed_cpus() {
+  cpu_set_t set; CPU_ZERO(&set);
+  std::vector<int> r;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &set)) r.push_back(c);
+  if (r.empty()) { unsigned n = std::thread::hardware_concurrency(); for (unsigned c = 0; c < (n ? n : 1); c++) r.push_back((int)c); }
+  return r;
+}
+static void pin_self(const std::vector<int>& cpus, int t) {
+  cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[(size_t)t % cpus.size()], &set);
+  (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+}
+template <class F> static double run_threads(int n_threads, int pin, F&& body) {
+  const std::vector<int> cpus = allowed_cpus();
+  std::atomic<int> ready{0}; std::atomic<bool> go{false};
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++)
+    th.emplace_back([&, t]() {
+      if (pin) pin_self(cpus, t);
+      ready.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      body(t);
+    });
+  while (ready.load() < n_threads) std::this_thread::yield();
+  auto t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
+  for (auto& x : th) x.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+extern "C" {
+
+int orc_cpu_count(void) { return (int)allowed_cpus().size(); }
+int orc_numa_nodes(void) {  // highest online node + 1 (from sysfs; 1 when unknown)
+  FILE* f = fopen("/sys/devices/system/node/online", "r");
+  if (!f) return 1;
+  char buf[256] = {0}; size_t k = fread(buf, 1, sizeof(buf) - 1, f); fclose(f); (void)k;
+  int hi = 0; for (char* p = buf; *p; p++) if (*p >= '0' && *p <= '9') { int v = (int)strtol(p, &p, 10); if (v > hi) hi = v; if (!*p) break; }
+  return hi + 1;
+}
+// Page-interleaved anonymous mapping.  flags out: bit0 = mbind(MPOL_INTERLEAVE) accepted, bit1 = transparent huge pages advised.
+void* orc_numa_alloc(size_t bytes, int n_threads, int* out_flags) {
+  if (bytes == 0) bytes = 1;
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return nullptr;
+  int flags = 0;
+  const int nodes = orc_numa_nodes();
+  if (nodes > 1 && nodes <= 64) {
+    unsigned long mask = nodes >= 64 ? ~0ul : ((1ul << nodes) - 1);
+    if (syscall(SYS_mbind, p, bytes, 3 /*MPOL_INTERLEAVE*/, &mask, (unsigned long)nodes + 1, 0ul) == 0) flags |= 1;
+  }
+  if (madvise(p, bytes, MADV_HUGEPAGE) == 0) flags |= 2;
+  // parallel first touch in 2 MiB blocks, block b by thread b % T (threads pinned round-robin over the allowed CPUs)
+  const size_t blk = 2u << 20, nblk = (bytes + blk - 1) / blk;
+  if (n_threads < 1) n_threads = 1;
+  run_threads(n_threads, 1, [&](int t) {
+    for (size_t b = (size_t)t; b < nblk; b += (size_t)n_threads) {
+      uint8_t* q = (uint8_t*)p + b * blk; size_t len = std::min(blk, bytes - b * blk);
+      for (size_t o = 0; o < len; o += 4096) q[o] = 0;
+    }
+  });
+  if (out_flags) *out_flags = flags;
+  return p;
+}
+void orc_numa_free(void* p, size_t bytes) { if (p) munmap(p, bytes ? bytes : 1); }
+
+// Hnsw.Search for nq queries on n_threads native threads (one query per thread at a time, work pulled from a shared counter).
+// Returns the wall time of the parallel region through *wall_s.  stats3 is summed over all queries.
+int orc_csr_search_mt(const void* rows, int quant, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* adjU,
+                      const uint32_t* del_bits, uint32_t w0, uint32_t wu, uint32_t dim, int metric, int order, int32_t entry,
+                      int32_t entry_level, const float* queries, size_t nq, int k, int ef, int32_t* out_slots, float* out_scores,
+                      int32_t* out_counts, uint64_t* stats3, int n_threads, int pin, double* wall_s) {
+  CsrGraph g{(const uint8_t*)rows, adj0, upper_off, adjU, del_bits, w0, wu, dim, metric, order, entry, entry_level, quant};
+  if (n_threads < 1) n_threads = 1;
+  std::atomic<size_t> next{0};
+  std::vector<uint64_t> st((size_t)n_threads * 3, 0);
+  double w = run_threads(n_threads, pin, [&](int t) {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= nq) break;
+      out_counts[i] = csr_search(g, queries + i * dim, k, ef, out_slots + i * k, out_scores + i * k, &st[(size_t)t * 3]);
+    }
+  });
+  if (stats3) for (int t = 0; t < n_threads; t++) for (int j = 0; j < 3; j++) stats3[j] += st[(size_t)t * 3 + j];
+  if (wall_s) *wall_s = w;
+  return 0;
+}
+
+// VertexSearch over CONTIGUOUS stored rows ("contiguous" variant of BASELINE.md §2; the reference walks 16 Go maps of
+// heap-scattered vectors, edge/none_vectorstore.go:136-147).  Per (query, row): Quantization.Similarity exactly as the
+// reference — shape 0 decodes BOTH operands per pair (f16_quantization.go:35-45: the value receiver defeats its buffer cache),
+// shape 1 decodes the query once — then the bounded queue.  The queue keeps the K extreme (score, slot) pairs in the
+// canonical order the GPU uses, so a sample can be compared bit-for-bit.
+//   split == 1  : one query per thread (concurrent RPC handlers), queries pulled from a shared counter;
+//   split == S>1: `highCpu` — every query is scanned by S threads over S contiguous row ranges with local queues, merged
+//                 by thread 0 (none_vectorstore.go:148-178); n_threads must equal S.
+struct TopK {
+  int k; bool nearest; std::vector<Scored> h;  // heap with the WORST kept element on top
+  bool worse(const Scored& a, const Scored& b) const { return nearest ? scored_less(b, a) : scored_less(a, b); }  // a worse than b
+  void add(const Scored& x) {
+    auto cmp = [&](const Scored& a, const Scored& b) { return worse(b, a); };  // max-heap on "worse"
+    if ((int)h.size() < k) { h.push_back(x); std::push_heap(h.begin(), h.end(), cmp); return; }
+    if (k == 0 || !worse(h.front(), x)) return;
+    std::pop_heap(h.begin(), h.end(), cmp); h.back() = x; std::push_heap(h.begin(), h.end(), cmp);
+  }
+};
+int orc_flat_scan_mt(const void* rows_v, int quant, uint64_t n, uint32_t dim, int metric, int order, const float* queries, size_t nq,
+                     int k, int nearest, int shape, int split, int n_threads, int pin, uint64_t* out_slots, float* out_scores,
+                     int32_t* out_counts, double* wall_s) {
+  const uint8_t* rows = (const uint8_t*)rows_v;
+  const size_t rb = (size_t)dim * quant_bytes(quant);
+  if (n_threads < 1) n_threads = 1;
+  if (split < 1) split = 1;
+  if (split > 1 && n_threads != split) return -1;
+  // per-query prepared operands: Normalize (cosine), Lower (f16_vectorstore.go:136)
+  std::vector<float> qn((size_t)nq * dim); std::vector<uint8_t> qlow((size_t)nq * rb);
+  for (size_t i = 0; i < nq; i++) {
+    if (metric == METRIC_COS) normalize(queries + i * dim, &qn[i * dim], dim); else std::memcpy(&qn[i * dim], queries + i * dim, (size_t)dim * 4);
+    lower(quant, &qn[i * dim], dim, &qlow[i * rb]);
+    if (quant != Q_NONE) raise(quant, &qlow[i * rb], dim, &qn[i * dim]);  // the decoded query (shape 1 uses it directly)
+  }
+  auto scan = [&](size_t qi, uint64_t lo, uint64_t hi, TopK& tk, float* bx, float* by) {
+    const float* qd = &qn[qi * dim]; const uint8_t* ql = &qlow[qi * rb];
+    for (uint64_t r = lo; r < hi; r++) {
+      const uint8_t* row = rows + r * rb; float sc;
+      if (quant == Q_NONE) sc = dist(metric, order, qd, (const float*)row, dim);
+      else if (shape == 0) { raise(quant, ql, dim, bx); raise(quant, row, dim, by); sc = dist(metric, order, bx, by, dim); }
+      else { raise(quant, row, dim, by); sc = dist(metric, order, qd, by, dim); }
+      tk.add({sc, r});
+    }
+  };
+  auto emit = [&](size_t qi, TopK& tk) {
+    std::sort(tk.h.begin(), tk.h.end(), scored_less);
+    out_counts[qi] = (int32_t)tk.h.size();
+    for (size_t j = 0; j < tk.h.size(); j++) { out_slots[qi * k + j] = tk.h[j].tie; out_scores[qi * k + j] = tk.h[j].score; }
+  };
+  double w;
+  if (split == 1) {
+    std::atomic<size_t> next{0};
+    w = run_threads(n_threads, pin, [&](int) {
+      std::vector<float> bx(dim), by(dim);
+      for (;;) {
+        size_t qi = next.fetch_add(1);
+        if (qi >= nq) break;
+        TopK tk{k, nearest != 0, {}};
+        scan(qi, 0, n, tk, bx.data(), by.data());
+        emit(qi, tk);
+      }
+    });
+  } else {
+    std::vector<TopK> local((size_t)split, TopK{k, nearest != 0, {}});
+    pthread_barrier_t bar; pthread_barrier_init(&bar, nullptr, (unsigned)split);
+    w = run_threads(split, pin, [&](int t) {
+      std::vector<float> bx(dim), by(dim);
+      for (size_t qi = 0; qi < nq; qi++) {
+        local[(size_t)t].h.clear();
+        scan(qi, n * (uint64_t)t / (uint64_t)split, n * (uint64_t)(t + 1) / (uint64_t)split, local[(size_t)t], bx.data(), by.data());
+        pthread_barrier_wait(&bar);
+        if (t == 0) { TopK g{k, nearest != 0, {}}; for (auto& l : local) for (auto& e : l.h) g.add(e); emit(qi, g); }
+        pthread_barrier_wait(&bar);
+      }
+    });
+    pthread_barrier_destroy(&bar);
+  }
+  if (wall_s) *wall_s = w;
+  return 0;
 }
 
 }  // extern "C"

@@ -396,3 +396,67 @@ class Hnsw:
             self._keep = (vec,)
         lib().orc_hnsw_import(self.h, C.c_int64(len(ids)), _p(ids), _p(lv), _p(dl) if dl is not None else None, _p(vec),
                               _p(off), _p(nb), _p(nd) if nd is not None else None, int(g["entry"]), int(view))
+
+
+# ------------------------------------------------------------------ cpu_baseline drivers (bench.py, tests)
+def cpu_count():
+    return int(lib().orc_cpu_count())
+
+
+class NumaArray:
+    """numpy view of a page-interleaved anonymous mapping (orc_numa_alloc): mbind(MPOL_INTERLEAVE) when the kernel accepts
+    it, transparent huge pages advised, first touch by `threads` pinned threads.  .flags: bit0 mbind ok, bit1 THP advised."""
+
+    def __init__(self, shape, dtype, threads=None):
+        L = lib()
+        L.orc_numa_alloc.restype = _vp
+        L.orc_numa_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_int)]
+        L.orc_numa_free.argtypes = [_vp, C.c_size_t]
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        fl = C.c_int(0)
+        self.ptr = L.orc_numa_alloc(C.c_size_t(self.nbytes), int(threads or cpu_count()), C.byref(fl))
+        if not self.ptr:
+            raise MemoryError(f"orc_numa_alloc({self.nbytes}) failed")
+        self.flags = fl.value
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.a = None
+            lib().orc_numa_free(_vp(self.ptr), C.c_size_t(self.nbytes))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def csr_search(rows, quant, adj0, upper_off, adjU, dim, metric, entry, entry_level, queries, k, ef, del_bits=None,
+               threads=1, pin=True, order=ORDER_AVX):
+    """canonical Hnsw.Search over the GPU's HBM-layout arrays (orc_csr_search_mt).  Returns slots, scores, counts,
+    {n_dist, n_exp, n_hops}, wall seconds of the parallel region."""
+    q = _f32(queries).reshape(-1, dim); nq = len(q)
+    sl = np.empty((nq, k), np.int32); sc = np.empty((nq, k), np.float32); cn = np.empty(nq, np.int32)
+    st = (C.c_uint64 * 3)(); wall = C.c_double(0)
+    adj0 = np.ascontiguousarray(adj0, np.uint32); adjU = np.ascontiguousarray(adjU, np.uint32)
+    lib().orc_csr_search_mt(_p(rows), int(quant), _p(adj0), _p(np.ascontiguousarray(upper_off, np.uint32)), _p(adjU),
+                            _p(del_bits) if del_bits is not None else None, C.c_uint32(adj0.shape[1]), C.c_uint32(adjU.shape[1]),
+                            C.c_uint32(dim), int(metric), int(order), C.c_int32(int(entry)), C.c_int32(int(entry_level)), _p(q),
+                            C.c_size_t(nq), int(k), int(ef), _p(sl), _p(sc), _p(cn), st, int(threads), int(bool(pin)), C.byref(wall))
+    return sl, sc, cn, {"n_dist": st[0], "n_exp": st[1], "n_hops": st[2]}, wall.value
+
+
+def flat_scan(rows, quant, dim, metric, queries, k, nearest=True, shape=0, split=1, threads=1, pin=True, order=ORDER_AVX):
+    """VertexSearch over contiguous stored rows (orc_flat_scan_mt).  rows: [n, dim] stored codes.  Returns slots, scores,
+    counts, wall seconds."""
+    q = _f32(queries).reshape(-1, dim); nq = len(q); n = len(rows)
+    sl = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32); cn = np.zeros(nq, np.int32); wall = C.c_double(0)
+    rc = lib().orc_flat_scan_mt(_p(rows), int(quant), C.c_uint64(n), C.c_uint32(dim), int(metric), int(order), _p(q), C.c_size_t(nq),
+                                int(k), int(bool(nearest)), int(shape), int(split), int(threads), int(bool(pin)), _p(sl), _p(sc), _p(cn),
+                                C.byref(wall))
+    if rc != 0:
+        raise ValueError("orc_flat_scan_mt: split > 1 needs threads == split")
+    return sl, sc, cn, wall.value

@@ -1,0 +1,280 @@
+"""Round-2 GPU parity cases: BASELINE.json configs[4] shape ("bf16" HNSW at efSearch 256 on a GPU-built graph), the
+Heuristic search algorithm, Insert with a nil entrypoint after Remove, transactional loads, odd FLAT dims, concurrent
+searches beside inserts / removes (the reference's RWMutex discipline, hnsw.go:51, hnsw_vertex.go:39)."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import assert_same_results, bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_build(gpu, X, lv, metric, quant, cfg=None, batch=64, ids=None):
+    import torch
+    n, d = X.shape
+    gh = gpu.Hnsw(d, metric, cfg, quantization=quant)
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    i = 0
+    while i < n:
+        b = int(min(n - i, max(1, min(batch, i // 16))))
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i,
+                             ids=None if ids is None else ids[i:i + b])
+        i += b
+    return gh
+
+
+@pytest.mark.parametrize("n,d", [(5000, 128), (1800, 768)])
+def test_c5_shape_bf16_hnsw_ef256_on_gpu_built_graph(gpu, n, d):
+    """configs[4]: cosine HNSW over the reference's "BF16" codes (= binary16, bf16.go:233-317), efSearch 256 (the HBM-visited
+    kernel), graph built by the GPU's batched Insert.  Checker: the oracle's canonical Hnsw.Search over the very arrays
+    copied out of HBM (stored codes, adjacency), query lowered as bf16_vectorstore.go:136 does: ids, score bits, counters."""
+    X = O.fill_normal(500 + d, (n, d)); lv = O.levels(501 + d, n)
+    gh = _gpu_build(gpu, X, lv, O.COSINE, O.Q_BF16, gpu.HnswCfg.default(ef_construction=100))
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    assert rows.dtype == np.uint16 and rows.shape == (n, d)
+    # the stored bits are Normalize + Lower of the input (hnsw.go:105-107 + bf16_quantization.go Lower)
+    want = np.stack([O.lower(O.Q_BF16, O.normalize(X[i])) for i in range(0, n, 97)])
+    assert np.array_equal(rows[::97], want)
+    Q = O.fill_normal(502 + d, (48, d))
+    for ef in (256, 128):
+        gi, gs, gc, st = gh.Search(Q, 10, ef=ef, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search(rows, O.Q_BF16, g["adj0"], g["upper_off"], g["adjU"], d, O.COSINE, g["entry"], g["entry_level"],
+                                          Q, 10, ef, threads=4)
+        assert st["n_visit_resets"] == 0
+        for qi in range(len(Q)):
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"q{qi} ef{ef}")
+        assert {k: st[k] for k in ost} == ost, (st, ost)
+
+
+def test_unknown_quantization_is_rejected_not_mapped(gpu):
+    for q in (4, 7, -1):
+        with pytest.raises(gpu.ColttError) as e:
+            gpu.Hnsw(16, O.L2, quantization=q)
+        assert e.value.code == -4  # "not support quantization type" (edge/vectorstore.go:79)
+        with pytest.raises(gpu.ColttError) as e:
+            gpu.FlatSpace(16, O.L2, q)
+        assert e.value.code == -4
+
+
+def test_hnsw_heuristic_algorithm(gpu):
+    """HnswSearchHeuristic with extendCandidates=false (selectNeighborsHeuristic, hnsw.go:399-447: the k nearest; the
+    keepPruned loop is dead code): build (batch 1 == the reference's sequential Insert) and search equal the oracle's LITERAL
+    restatement run with algo=1; extendCandidates=true is rejected."""
+    import torch
+    n, d = 600, 32
+    X = O.fill_normal(601, (n, d)); lv = O.levels(602, n); ids = np.arange(n, dtype=np.uint64) + np.uint64(9)
+    oh = O.Hnsw(d, O.COSINE, O.default_cfg(algo=1)); oh.insert_many(ids, X, lv)
+    gh = gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(algo=1))
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    gh.InsertBatchDevice(xd.data_ptr(), n, lv, batch=1, ids=ids)
+    go, oo = gh.Export(), oh.export(with_vectors=False)
+    for k in ("levels", "deleted", "row_offsets", "nbr"):
+        assert np.array_equal(go[k], oo[k]), k
+    assert np.array_equal(bits(go["nbr_dist"]), bits(oo["nbr_dist"]))
+    Q = O.fill_normal(603, (20, d))
+    gi, gs, gc = gh.Search(Q, 10, ef=50)
+    for qi in range(len(Q)):
+        wi, ws = oh.search(Q[qi], 10, mode=0, ef=50)   # literal Go heaps + selectNeighborsHeuristic
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
+    with pytest.raises(gpu.ColttError) as e:
+        gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(algo=1, extend_candidates=1))
+    assert e.value.code == -4
+
+
+def test_hnsw_insert_with_nil_entrypoint_after_remove(gpu):
+    """Remove can leave the index without an entrypoint (hnsw.go:197-217 CASes it to the removed vertex's closest neighbour,
+    nil when it has none); the next Insert stores its vertex at level 0 and makes it the entrypoint (hnsw.go:108-116).
+    insert(1); remove(1); insert(2) must work, and so must remove-everything-then-rebuild."""
+    d = 12
+    X = O.fill_normal(701, (40, d)); lv = O.levels(702, 40); lv[:3] = [2, 1, 3]
+    oh = O.Hnsw(d, O.L2); gh = gpu.Hnsw(d, O.L2)
+
+    def both(op, *a):
+        if op == "ins":
+            assert oh.insert(a[0], X[a[1]], int(lv[a[1]])) == 0; gh.Insert(a[0], X[a[1]], int(lv[a[1]]))
+        else:
+            assert oh.remove(a[0]) == 0; gh.Remove(a[0])
+
+    def same():
+        go, oo = gh.Export(), oh.export(with_vectors=False)
+        for k in ("ids", "levels", "deleted", "row_offsets", "nbr"):
+            assert np.array_equal(go[k], oo[k]), k
+        assert go["entry"] == oo["entry"]
+        gi, gs, gc = gh.Search(X[:6], 5, ef=16)
+        for qi in range(6):
+            wi, ws = oh.search(X[qi], 5, mode=1, ef=16)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
+
+    both("ins", 1, 0); both("rem", 1); same()
+    assert gh.Len() == 0 and gh.Export()["entry"] == -1
+    both("ins", 2, 1); same()                      # level forced to 0 although lv[1] = 1
+    assert gh.Export()["levels"][1] == 0
+    for i in range(2, 20): both("ins", 100 + i, i)
+    same()
+    for i in range(2, 20): both("rem", 100 + i)     # removing everything (the entrypoint among them, repeatedly)
+    both("rem", 2); same()
+    assert gh.Len() == 0
+    for i in range(20, 40): both("ins", 200 + i, i)
+    same()
+
+
+def test_failed_loads_leave_the_index_untouched(gpu):
+    """A truncated / corrupt stream is rejected BEFORE the object changes: config, graph and answers stay what they were
+    (Hnsw.Load hnsw_commit.go:164-278; LoadVertex none_vectorstore.go:425-516)."""
+    n, d = 400, 24
+    X = O.fill_normal(801, (n, d)); lv = O.levels(802, n); ids = np.arange(n, dtype=np.uint64) * np.uint64(5)
+    oh = O.Hnsw(d, O.COSINE, O.default_cfg(ef=31)); oh.insert_many(ids, X, lv)
+    gh = gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(ef=31)); gh.BulkLoad(oh.export(with_vectors=False), X)
+    Q = O.fill_normal(803, (10, d))
+    before = gh.Search(Q, 10, ef=40)
+    other = O.Hnsw(d, O.COSINE, O.default_cfg(m=8, ef=77)); other.insert_many(ids[:200], X[:200], lv[:200])
+    stream = other.commit(header=True)
+    for cut in (len(stream) // 3, len(stream) - 7, 30):
+        with pytest.raises(gpu.ColttError):
+            gh.Load(stream[:cut])
+        assert gh.cfg.ef == 31 and gh.cfg.m == 16 and gh.Len() == n       # cfg was NOT taken from the bad stream
+        after = gh.Search(Q, 10, ef=40)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(bits(before[1]), bits(after[1]))
+    assert gh.Load(stream) == 200 and gh.cfg.m == 8 and gh.cfg.ef == 77       # and a good stream still loads
+    # FLAT
+    of = O.Flat(d, O.L2, O.Q_F16); of.upsert(ids, X)
+    gf = gpu.FlatSpace(d, O.L2, O.Q_F16); gf.ChangedVertex(ids, X)
+    fb = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+    blob = of.save_vertex()
+    for bad in (blob[:len(blob) // 2], blob[:11]):
+        with pytest.raises(gpu.ColttError):
+            gf.LoadVertex(bad)
+        fa = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+        assert gf.LoadSize() == n and np.array_equal(fb[0], fa[0]) and np.array_equal(bits(fb[1]), bits(fa[1]))
+
+
+@pytest.mark.parametrize("d", [7, 9, 10, 50, 1])
+@pytest.mark.parametrize("quant", [O.Q_NONE, O.Q_F16])
+def test_flat_dims_not_multiple_of_four(gpu, d, quant):
+    """dim % 4 != 0: the query tile in LDS is padded to 16-byte rows; the scalar tail follows the AVX kernel's (avx.cpp:27-31)."""
+    n = 700
+    X = O.fill_normal(900 + d, (n, d)); ids = np.arange(n, dtype=np.uint64) + np.uint64(3)
+    Q = O.fill_normal(901 + d, (19, d))        # more than one 16-query tile, last one ragged
+    for metric in (O.COSINE, O.L2):
+        of = O.Flat(d, metric, quant); of.upsert(ids, X)
+        gf = gpu.FlatSpace(d, metric, quant); gf.ChangedVertex(ids, X)
+        for nearest in (True, False):
+            gi, gs, gc = gf.VertexSearch(Q, 7, gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE)
+            for qi in range(len(Q)):
+                wi, ws = of.search(Q[qi], 7, nearest=nearest, mode=2)
+                assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"d{d} q{qi} near{nearest}")
+
+
+def test_flat_upsert_overwrite_remove_rounds(gpu):
+    """several rounds of upsert (new + overwritten + repeated ids in one batch), removal and search against the oracle: the id
+    table on the device is patched incrementally (only the appended range / the moved slot is uploaded)."""
+    d = 16
+    rng = np.random.default_rng(11)
+    of = O.Flat(d, O.COSINE); gf = gpu.FlatSpace(d, O.COSINE)
+    Q = O.fill_normal(1000, (8, d))
+    live = set()
+    for rnd in range(6):
+        ids = rng.integers(0, 300, 120).astype(np.uint64)          # collisions with earlier rounds and inside the batch
+        V = O.fill_normal(1001 + rnd, (len(ids), d))
+        gf.ChangedVertex(ids, V)
+        for i in range(len(ids)): of.upsert(ids[i:i + 1], V[i:i + 1])  # sequential semantics: last one wins
+        live |= set(ids.tolist())
+        rem = rng.choice(sorted(live), 25, replace=False).astype(np.uint64)
+        gf.RemoveVertex(np.concatenate([rem, np.uint64([999999])])); of.remove(rem)
+        live -= set(rem.tolist())
+        assert gf.LoadSize() == len(of) == len(live)
+        gi, gs, gc = gf.VertexSearch(Q, 12, gpu.SELECT_NEAREST)
+        for qi in range(len(Q)):
+            wi, ws = of.search(Q[qi], 12, nearest=True, mode=2)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"round{rnd} q{qi}")
+
+
+def test_concurrent_searches_beside_inserts_and_removes(gpu, capsys):
+    """Searches hold the index lock shared (each on its own stream / workspaces), Insert and Remove hold it exclusive.
+    (1) 64 threads issuing single-query calls concurrently get exactly the batch answers (LDS- and HBM-visited kernels);
+    (2) while one thread applies a fixed sequence of inserts / removes, searcher threads keep running and only ever see
+        well-formed answers; once quiesced, the graph and the answers equal the oracle's serial application of the sequence."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, d = 4000, 48
+    X = O.fill_normal(1101, (n + 300, d)); lv = O.levels(1102, n + 300); ids = np.arange(n + 300, dtype=np.uint64)
+    oh = O.Hnsw(d, O.L2, O.default_cfg(efConstruction=60)); oh.insert_many(ids[:n], X[:n], lv[:n])
+    gh = gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(ef_construction=60)); gh.BulkLoad(oh.export(with_vectors=False), X[:n])
+    Q = O.fill_normal(1103, (256, d))
+    for ef in (64, 200):
+        want = gh.Search(Q, 10, ef=ef)
+
+        def one(i):
+            a = gh.Search(Q[i:i + 1], 10, ef=ef)
+            return np.array_equal(a[0][0], want[0][i]) and np.array_equal(bits(a[1][0]), bits(want[1][i]))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(64) as ex:
+            ok = list(ex.map(one, list(range(256)) * 4))
+        dt = time.perf_counter() - t0
+        assert all(ok)
+        with capsys.disabled():
+            print(f"\n[concurrency] 64 callers x 1-query HNSW calls, ef={ef}, {n}x{d}: {len(ok) / dt:.0f} queries/s "
+                  f"({dt / len(ok) * 64 * 1e3:.2f} ms per call at 64 in flight)")
+    # (2)
+    stop = threading.Event(); errors = []
+    valid_ids = set(range(n + 300))
+
+    def searcher(t):
+        rng = np.random.default_rng(t)
+        while not stop.is_set():
+            i = int(rng.integers(0, 250))
+            gi, gs, gc = gh.Search(Q[i:i + 4], 10, ef=int(rng.choice([48, 160])))
+            for r in range(4):
+                c = int(gc[r])
+                if c > 10 or not set(gi[r, :c].tolist()) <= valid_ids or np.any(np.diff(gs[r, :c]) < 0) or len(set(gi[r, :c].tolist())) != c:
+                    errors.append((t, i, gi[r], gs[r], c))
+    th = [threading.Thread(target=searcher, args=(t,)) for t in range(8)]
+    for t in th: t.start()
+    rng = np.random.default_rng(99)
+    victims = rng.choice(n, 150, replace=False)
+    try:
+        for j in range(300):
+            gh.Insert(int(ids[n + j]), X[n + j], int(lv[n + j])); assert oh.insert(ids[n + j], X[n + j], int(lv[n + j])) == 0
+            if j % 2 == 0:
+                v = int(victims[j // 2]); gh.Remove(v); assert oh.remove(v) == 0
+    finally:
+        stop.set()
+        for t in th: t.join()
+    assert not errors, errors[:2]
+    go, oo = gh.Export(), oh.export(with_vectors=False)
+    for k in ("ids", "levels", "deleted", "row_offsets", "nbr"):
+        assert np.array_equal(go[k], oo[k]), k
+    assert np.array_equal(bits(go["nbr_dist"]), bits(oo["nbr_dist"])) and go["entry"] == oo["entry"]
+    gi, gs, gc = gh.Search(Q[:40], 10, ef=80)
+    for qi in range(40):
+        wi, ws = oh.search(Q[qi], 10, mode=1, ef=80)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
+
+
+def test_concurrent_flat_searches_and_upserts(gpu):
+    """FLAT: concurrent callers (exact and MFMA modes) get the single-threaded answers; upserts interleave safely."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, d = 6000, 64
+    X = O.fill_normal(1201, (n, d)); ids = np.arange(n, dtype=np.uint64)
+    gf = gpu.FlatSpace(d, O.COSINE, O.Q_F16); gf.ChangedVertex(ids, X)
+    Q = O.fill_normal(1202, (64, d))
+    want = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST)
+
+    def one(i):
+        mode = gpu.MODE_MFMA if i % 2 else gpu.MODE_EXACT
+        a = gf.VertexSearch(Q[(i * 4) % 64:(i * 4) % 64 + 4], 10, gpu.SELECT_NEAREST, mode=mode)
+        lo = (i * 4) % 64
+        return np.array_equal(a[0], want[0][lo:lo + 4]) and np.array_equal(bits(a[1]), bits(want[1][lo:lo + 4]))
+    with ThreadPoolExecutor(16) as ex:
+        assert all(ex.map(one, range(96)))
+    # writers beside readers: re-upserting the SAME vectors never changes an answer
+    def writer(_):
+        for r in range(10):
+            gf.ChangedVertex(ids[r * 100:(r + 1) * 100], X[r * 100:(r + 1) * 100])
+        return True
+    with ThreadPoolExecutor(10) as ex:
+        res = list(ex.map(lambda i: writer(i) if i == 0 else one(i), range(40)))
+    assert all(res)

@@ -360,6 +360,33 @@ def test_csr_search_equals_canonical_search(metric, quant):
     assert [int(st[0]), int(st[1]), int(st[2])] == tot.tolist()
 
 
+def test_cpu_baseline_mt_drivers_equal_serial_oracle():
+    """bench.py's cpu_baseline runs native pinned threads inside the oracle (orc_csr_search_mt / orc_flat_scan_mt) over a
+    NUMA-interleaved copy of the corpus.  Threading must not change a bit: same slots, score bits and counters as the serial
+    calls; the FLAT driver (both `highCpu` split and one-query-per-thread, both decode shapes) equals Flat.search's canonical mode."""
+    n, d, k, ef = 1500, 40, 10, 64
+    X = O.fill_normal(171, (n, d)); lv = O.levels(172, n); ids = np.arange(n, dtype=np.uint64)
+    for metric, quant in ((O.COSINE, O.Q_NONE), (O.COSINE, O.Q_BF16), (O.L2, O.Q_F8)):
+        h = O.Hnsw(d, O.L2 if quant != O.Q_NONE else metric); h.insert_many(ids, X, lv)   # any valid graph will do
+        g = h.export()
+        adj0, upper_off, adjU = _csr_from_export(g, 32, 16)
+        f = O.Flat(d, metric, quant); f.upsert(ids, X)
+        stored = np.stack([f.get(i) for i in ids])                                         # Normalize + Lower applied
+        na = O.NumaArray(stored.shape, stored.dtype, threads=4); na.a[:] = stored
+        Q = O.fill_normal(173, (24, d))
+        ent, el = h.entry, int(g["levels"][h.entry])
+        s1 = O.csr_search(na.a, quant, adj0, upper_off, adjU, d, metric, ent, el, Q, k, ef, threads=1)
+        s4 = O.csr_search(na.a, quant, adj0, upper_off, adjU, d, metric, ent, el, Q, k, ef, threads=5)
+        assert np.array_equal(s1[0], s4[0]) and np.array_equal(bits(s1[1]), bits(s4[1])) and np.array_equal(s1[2], s4[2]) and s1[3] == s4[3]
+        for nearest in (True, False):
+            for shape, split, th in ((0, 1, 3), (1, 1, 4), (0, 16, 16), (1, 4, 4)):
+                sl, sc, cn, _ = O.flat_scan(na.a, quant, d, metric, Q, k, nearest=nearest, shape=shape, split=split, threads=th)
+                for qi in range(len(Q)):
+                    wi, ws = f.search(Q[qi], k, nearest=nearest, mode=2)
+                    assert np.array_equal(sl[qi], wi) and np.array_equal(bits(sc[qi]), bits(ws)), (metric, quant, nearest, shape, split, qi)
+        na.close()
+
+
 def test_canonical_form_equals_literal_go_heaps_on_random_configurations():
     """The foundation of every HNSW parity claim: the closed form the GPU runs (sorted result set, ascending-slot neighbour
     order, stale lowerBound, first ef-len0 admitted unconditionally) is the SAME function as the literal restatement with Go's
