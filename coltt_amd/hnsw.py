@@ -53,6 +53,11 @@ class Hnsw:
     def Dim(self):
         return self.dim
 
+    def Config(self):
+        """Hnsw.Config() (hnsw.go:92-94): the live configuration, re-read from the library."""
+        L.check(L.lib().coltt_hnsw_get_cfg(self.h, C.byref(self.cfg)))
+        return self.cfg
+
     def RandomLevel(self, u):
         """Hnsw.RandomLevel() (hnsw.go:280-282) for a uniform draw u in (0,1) supplied by the caller."""
         lv = C.c_int32(0)

@@ -136,10 +136,11 @@ def test_failed_loads_leave_the_index_untouched(gpu):
     for cut in (len(stream) // 3, len(stream) - 7, 30):
         with pytest.raises(gpu.ColttError):
             gh.Load(stream[:cut])
-        assert gh.cfg.ef == 31 and gh.cfg.m == 16 and gh.Len() == n       # cfg was NOT taken from the bad stream
+        c = gh.Config()
+        assert c.ef == 31 and c.m == 16 and gh.Len() == n                  # cfg was NOT taken from the bad stream
         after = gh.Search(Q, 10, ef=40)
         assert np.array_equal(before[0], after[0]) and np.array_equal(bits(before[1]), bits(after[1]))
-    assert gh.Load(stream) == 200 and gh.cfg.m == 8 and gh.cfg.ef == 77       # and a good stream still loads
+    assert gh.Load(stream) == 200 and gh.Config().m == 8 and gh.Config().ef == 77  # and a good stream still loads
     # FLAT
     of = O.Flat(d, O.L2, O.Q_F16); of.upsert(ids, X)
     gf = gpu.FlatSpace(d, O.L2, O.Q_F16); gf.ChangedVertex(ids, X)
