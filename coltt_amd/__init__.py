@@ -12,3 +12,5 @@ from .flat import FlatSpace  # noqa: F401
 from .hnsw import Hnsw, HnswCfg  # noqa: F401
 from .cflat import MultiVectorSpace  # noqa: F401
 from . import kernels  # noqa: F401
+from . import group  # noqa: F401
+from .group import Group  # noqa: F401

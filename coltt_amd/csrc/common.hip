@@ -97,3 +97,8 @@ const char* coltt_last_error(void) { return g_last_error.c_str(); }
 const char* coltt_version(void) { return "coltt_gpu 0.1 (gfx950)"; }
 
 }  // extern "C"
+
+#include "exact.hpp"
+extern "C" uint64_t coltt_shard_vertex_host(uint64_t id, uint64_t shard_count) {
+  return shard_count ? coltt::dev::shard_vertex(id, shard_count) : 0;
+}

@@ -137,6 +137,10 @@ int ensure_device();          // selects the process default device (coltt_init)
 int default_device();         // that device's index (after ensure_device succeeded)
 int use_device(int device);   // selects an object's device for the calling thread
 
+// stores / indexes on an explicit device (group.hip places one collection shard per GPU)
+int flat_create_on(int device, uint32_t dim, int metric, int quant, coltt_handle_t* out);
+int hnsw_create_on(int device, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out);
+
 inline size_t quant_bytes(int q) { return q == COLTT_Q_NONE ? 4 : (q == COLTT_Q_F8 ? 1 : 2); }
 
 // Quantisation dispatch.  The reference's "BF16" is IEEE binary16 (pkg/compresshelper/bf16.go:233-317 is float16.go:237-321

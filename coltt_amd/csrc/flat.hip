@@ -464,19 +464,29 @@ void commit_upsert(Flat* f, const UpsertPlan& p) {
 extern "C" {
 
 int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out) {
+  COLTT_TRY(ensure_device());
+  return coltt::flat_create_on(default_device(), dim, metric, quant, out);
+}
+
+}  // extern "C"
+
+// a store on an explicit device (collection groups place one shard per GPU)
+int coltt::flat_create_on(int device, uint32_t dim, int metric, int quant, coltt_handle_t* out) {
   if (!out) return fail(COLTT_E_INVALID, "flat_create: out is NULL");
   if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "flat_create: dim %u outside [1,8192]", dim);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "flat_create: bad metric %d", metric);
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");  // vectorstore.go:79
-  COLTT_TRY(ensure_device());
+  COLTT_TRY(use_device(device));
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
-  f->device = default_device();
+  f->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
   *out = Registry::get().add(f);
   return COLTT_OK;
 }
+
+extern "C" {
 
 int coltt_flat_destroy(coltt_handle_t h) {
   if (!Registry::get().erase(h)) return fail(COLTT_E_NOT_FOUND, "flat_destroy: unknown handle");

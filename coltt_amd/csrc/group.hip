@@ -1,0 +1,452 @@
+// group.hip — one collection partitioned over the GPUs of a node (BASELINE.json north_star).
+//
+// The reference has no multi-device code: its only "sharding" is the 16 in-process map shards chosen by
+// sharding.ShardVertex (pkg/sharding/shard.go:34-41) that `highCpu` scans with local queues and then merges
+// (edge/none_vectorstore.go:148-178).  A group is that shape stretched over devices:
+//   * SHARD layout: vertex `id` lives on shard ShardVertex(id, world) — the same FNV-1a rule; each shard is an ordinary FLAT
+//     store / HNSW index (flat.hip / hnsw.hip) on its own GPU; a query batch is searched by every shard on its own stream,
+//     the per-shard top-k are exchanged with ONE all-gather of packed {u64 id, f32 score, u32 valid} records (RCCL over
+//     xGMI: ncclCommInitAll in one process, ncclCommInitRank with one process per GPU) and merged on the host in the
+//     canonical (score, id) order — exactly the local-queue-then-global-queue structure of the reference;
+//   * REPLICA layout: every member holds the whole collection, a query batch is split across members, nothing is exchanged.
+// RCCL is loaded at run time (dlopen) so the library has no link-time dependency on it; when all members of a
+// single-process group sit on ONE device (tests on a 1-GPU box) RCCL refuses duplicate devices and the records travel
+// through pinned host memory instead — that is a transport choice, the merge is on the host either way.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "common.hpp"
+#include "exact.hpp"
+
+using namespace coltt;
+using namespace coltt::dev;
+
+namespace {
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------------
+typedef void* nccl_comm_t;
+struct NcclId { char internal[128]; };
+struct Rccl {
+  void* so = nullptr;
+  int (*GetUniqueId)(NcclId*) = nullptr;
+  int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+  int (*CommInitRank)(nccl_comm_t*, int, NcclId, int) = nullptr;
+  int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, nccl_comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // a copy that is already mapped (torch bundles one) is preferred: two RCCLs in one process is asking for trouble
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (r.so) break; }
+    if (!r.so) for (const char* n : names) { r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.so) break; }
+    if (!r.so) { r.err = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return; }
+#define COLTT_SYM(F, N) r.F = reinterpret_cast<decltype(r.F)>(dlsym(r.so, N)); if (!r.F) { r.err = std::string("librccl lacks ") + N; r.so = nullptr; return; }
+    COLTT_SYM(GetUniqueId, "ncclGetUniqueId") COLTT_SYM(CommInitAll, "ncclCommInitAll") COLTT_SYM(CommInitRank, "ncclCommInitRank")
+    COLTT_SYM(CommDestroy, "ncclCommDestroy") COLTT_SYM(AllGather, "ncclAllGather") COLTT_SYM(GroupStart, "ncclGroupStart")
+    COLTT_SYM(GroupEnd, "ncclGroupEnd") COLTT_SYM(GetErrorString, "ncclGetErrorString")
+#undef COLTT_SYM
+  });
+  return r.so ? &r : nullptr;
+}
+#define COLTT_NCCL(R, expr)                                                                                      \
+  do { int _e = (expr); if (_e != 0) return fail(COLTT_E_DEVICE, "%s: %s", #expr, (R)->GetErrorString(_e)); } while (0)
+
+// ---- packed per-shard answers ---------------------------------------------------------------------------------------------
+struct Rec { uint64_t id; float score; uint32_t valid; };  // 16 bytes
+static_assert(sizeof(Rec) == 16, "Rec");
+
+__global__ void pack_topk_kernel(const uint64_t* __restrict__ ids, const float* __restrict__ sc, const uint32_t* __restrict__ cnt,
+                                 uint32_t nq, uint32_t k, Rec* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)nq * k) return;
+  const uint32_t q = (uint32_t)(i / k), j = (uint32_t)(i - (size_t)q * k);
+  const bool v = j < cnt[q];
+  out[i] = Rec{v ? ids[i] : 0ull, v ? sc[i] : 0.f, v ? 1u : 0u};
+}
+
+struct Member {
+  int device = 0, rank = 0;
+  coltt_handle_t h = 0;
+  hipStream_t stream = nullptr;
+  nccl_comm_t comm = nullptr;
+  DevBuf d_q, d_ids, d_sc, d_cnt, d_pack, d_gather;
+};
+
+struct Group : Object {
+  int kind = 0, layout = 0, exchange = 0 /* in use: 1 RCCL, 2 host */, world = 0, rank_base = 0;
+  uint32_t dim = 0; int metric = 0, quant = 0;
+  std::vector<std::unique_ptr<Member>> m;  // DevBuf is neither copyable nor movable
+  std::mutex call_mu;  // one group call at a time (members' own locks still protect them against direct use)
+  Rec* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host staging for the gathered records
+  ~Group() override {
+    Rccl* r = rccl();
+    for (auto& xp : m) {
+      Member& x = *xp;
+      (void)hipSetDevice(x.device);
+      if (x.comm && r) (void)r->CommDestroy(x.comm);
+      if (x.stream) (void)hipStreamDestroy(x.stream);
+      if (x.h) { if (kind == COLTT_GROUP_FLAT) (void)coltt_flat_destroy(x.h); else (void)coltt_hnsw_destroy(x.h); }
+    }
+    if (h_stage) (void)hipHostFree(h_stage);
+  }
+  int stage(size_t bytes) {
+    if (bytes <= h_stage_bytes) return COLTT_OK;
+    if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; h_stage_bytes = 0; }
+    COLTT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_stage), bytes, hipHostMallocDefault));
+    h_stage_bytes = bytes;
+    return COLTT_OK;
+  }
+};
+
+// run f(i) for every local member on its own host thread (each selects its device); returns the first error
+template <class F> int for_members(Group* g, F&& f) {
+  const size_t n = g->m.size();
+  std::vector<int> rc(n, COLTT_OK); std::vector<std::string> msg(n);
+  auto body = [&](size_t i) { rc[i] = use_device(g->m[i]->device); if (rc[i] == COLTT_OK) rc[i] = f(i); if (rc[i] != COLTT_OK) msg[i] = g_last_error; };
+  if (n == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < n; i++) th.emplace_back(body, i);
+    for (auto& t : th) t.join();
+  }
+  for (size_t i = 0; i < n; i++) if (rc[i] != COLTT_OK) { g_last_error = "member " + std::to_string(i) + ": " + msg[i]; return rc[i]; }
+  return COLTT_OK;
+}
+
+// canonical order of the merge = the order every shard already returns: ascending (score, id)
+inline bool rec_less(const Rec& a, const Rec& b) { return a.score < b.score || (a.score == b.score && a.id < b.id); }
+
+}  // namespace
+
+// Host-side final merge (exported for the unit tests, which run without a device): recs = [world][nq][k] packed per-shard
+// answers, each shard's valid records ascending by (score, id).  nearest: the k smallest of the union; otherwise (edge
+// SELECT_REFERENCE) the k LARGEST — both returned ascending, as every single store returns them.
+extern "C" int coltt_group_merge_host(const void* recs_v, int world, size_t nq, uint32_t k, int nearest, uint64_t* out_ids,
+                                      float* out_scores, uint32_t* out_counts) {
+  if (!recs_v || world <= 0 || k == 0) return fail(COLTT_E_INVALID, "group_merge_host: bad arguments");
+  const Rec* recs = static_cast<const Rec*>(recs_v);
+  const size_t per = nq * (size_t)k;
+  std::vector<uint32_t> head((size_t)world), len((size_t)world);
+  std::vector<Rec> tmp(k);
+  for (size_t q = 0; q < nq; q++) {
+    size_t total = 0;
+    for (int s = 0; s < world; s++) {
+      const Rec* r = recs + (size_t)s * per + q * k;
+      uint32_t c = 0; while (c < k && r[c].valid) c++;
+      len[s] = c; head[s] = 0; total += c;
+    }
+    const uint32_t take = (uint32_t)std::min<size_t>(k, total);
+    // k-way selection over the sorted heads (world <= a few dozen: a linear scan of the heads beats a heap)
+    for (uint32_t j = 0; j < take; j++) {
+      int best = -1;
+      for (int s = 0; s < world; s++) {
+        if (head[s] >= len[s]) continue;
+        const Rec* r = recs + (size_t)s * per + q * k;
+        const Rec& cand = nearest ? r[head[s]] : r[len[s] - 1 - head[s]];
+        if (best < 0) { best = s; continue; }
+        const Rec* rb = recs + (size_t)best * per + q * k;
+        const Rec& cur = nearest ? rb[head[best]] : rb[len[best] - 1 - head[best]];
+        if (nearest ? rec_less(cand, cur) : rec_less(cur, cand)) best = s;
+      }
+      const Rec* rb = recs + (size_t)best * per + q * k;
+      tmp[j] = nearest ? rb[head[best]] : rb[len[best] - 1 - head[best]];
+      head[best]++;
+    }
+    for (uint32_t j = 0; j < take; j++) {
+      const Rec& r = nearest ? tmp[j] : tmp[take - 1 - j];  // farthest-k were picked largest first; return ascending
+      out_ids[q * k + j] = r.id; out_scores[q * k + j] = r.score;
+    }
+    out_counts[q] = take;
+  }
+  return COLTT_OK;
+}
+
+extern "C" {
+
+int coltt_group_unique_id(uint8_t* out) {
+  if (!out) return fail(COLTT_E_INVALID, "group_unique_id: NULL out");
+  Rccl* r = rccl();
+  if (!r) return fail(COLTT_E_UNSUPPORTED, "group_unique_id: librccl is not loadable in this process");
+  COLTT_TRY(ensure_device());
+  NcclId id;
+  COLTT_NCCL(r, r->GetUniqueId(&id));
+  std::memcpy(out, id.internal, COLTT_UNIQUE_ID_BYTES);
+  return COLTT_OK;
+}
+
+int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg,
+                       const coltt_group_opts* opts, coltt_handle_t* out) {
+  if (!out || !devices || n_devices <= 0 || n_devices > 64) return fail(COLTT_E_INVALID, "group_create: need 1..64 devices and an out handle");
+  coltt_group_opts o{}; if (opts) o = *opts;
+  if (o.kind != COLTT_GROUP_FLAT && o.kind != COLTT_GROUP_HNSW) return fail(COLTT_E_INVALID, "group_create: bad kind %d", o.kind);
+  if (o.layout != COLTT_LAYOUT_SHARD && o.layout != COLTT_LAYOUT_REPLICA) return fail(COLTT_E_INVALID, "group_create: bad layout %d", o.layout);
+  if (o.exchange < COLTT_EXCHANGE_AUTO || o.exchange > COLTT_EXCHANGE_HOST) return fail(COLTT_E_INVALID, "group_create: bad exchange %d", o.exchange);
+  const int world = o.world_size > 0 ? o.world_size : n_devices;
+  if (o.rank_base < 0 || o.rank_base + n_devices > world) return fail(COLTT_E_INVALID, "group_create: ranks [%d,%d) outside world %d", o.rank_base, o.rank_base + n_devices, world);
+  const bool multi_process = world > n_devices;
+  if (multi_process && o.layout != COLTT_LAYOUT_SHARD) return fail(COLTT_E_INVALID, "group_create: a replica group is per process (replicas exchange nothing)");
+  if (multi_process && !o.unique_id) return fail(COLTT_E_INVALID, "group_create: world_size > n_devices needs the shared unique_id (coltt_group_unique_id on one process)");
+  int n_dev = coltt_device_count();
+  bool distinct = true;
+  for (int i = 0; i < n_devices; i++) {
+    if (devices[i] < 0 || devices[i] >= n_dev) return fail(COLTT_E_INVALID, "group_create: device %d out of range [0,%d)", devices[i], n_dev);
+    for (int j = 0; j < i; j++) if (devices[j] == devices[i]) distinct = false;
+  }
+  auto g = std::make_shared<Group>();
+  g->kind = o.kind; g->layout = o.layout; g->world = world; g->rank_base = o.rank_base; g->dim = dim; g->metric = metric; g->quant = quant;
+  for (int i = 0; i < n_devices; i++) g->m.emplace_back(new Member());
+  for (int i = 0; i < n_devices; i++) {
+    Member& x = *g->m[(size_t)i];
+    x.device = devices[i]; x.rank = o.rank_base + i;
+    COLTT_TRY(use_device(x.device));
+    if (o.kind == COLTT_GROUP_FLAT) COLTT_TRY(flat_create_on(x.device, dim, metric, quant, &x.h));
+    else COLTT_TRY(hnsw_create_on(x.device, dim, metric, quant, cfg, &x.h));
+    COLTT_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+  }
+  // exchange transport
+  g->exchange = COLTT_EXCHANGE_HOST;
+  if (o.layout == COLTT_LAYOUT_SHARD && o.exchange != COLTT_EXCHANGE_HOST) {
+    Rccl* r = rccl();
+    const bool can = r && (distinct || n_devices == 1);
+    if (!can && (o.exchange == COLTT_EXCHANGE_RCCL || multi_process))
+      return fail(COLTT_E_UNSUPPORTED, "group_create: RCCL exchange unavailable (%s)", !r ? "librccl not loadable" : "a communicator cannot hold one device twice");
+    if (can) {
+      if (multi_process) {
+        NcclId id; std::memcpy(id.internal, o.unique_id, COLTT_UNIQUE_ID_BYTES);
+        COLTT_NCCL(r, r->GroupStart());
+        for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_NCCL(r, r->CommInitRank(&x.comm, world, id, x.rank)); }
+        COLTT_NCCL(r, r->GroupEnd());
+      } else {
+        std::vector<nccl_comm_t> comms((size_t)n_devices);
+        COLTT_NCCL(r, r->CommInitAll(comms.data(), n_devices, devices));
+        for (int i = 0; i < n_devices; i++) g->m[(size_t)i]->comm = comms[(size_t)i];
+      }
+      g->exchange = COLTT_EXCHANGE_RCCL;
+    }
+  } else if (multi_process) return fail(COLTT_E_UNSUPPORTED, "group_create: shards in several processes can only exchange through RCCL");
+  g->device = devices[0];
+  *out = Registry::get().add(g);
+  return COLTT_OK;
+}
+
+int coltt_group_destroy(coltt_handle_t h) {
+  if (!lookup<Group>(h)) return fail(COLTT_E_NOT_FOUND, "group_destroy: unknown handle");
+  Registry::get().erase(h);
+  return COLTT_OK;
+}
+
+int coltt_group_info(coltt_handle_t h, int32_t* n_local, int32_t* world, int32_t* exchange, int32_t* rank_base) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_info: unknown handle");
+  if (n_local) *n_local = (int32_t)g->m.size();
+  if (world) *world = g->world;
+  if (exchange) *exchange = g->exchange;
+  if (rank_base) *rank_base = g->rank_base;
+  return COLTT_OK;
+}
+
+int coltt_group_member(coltt_handle_t h, int i, coltt_handle_t* out) {
+  auto g = lookup<Group>(h);
+  if (!g || !out) return fail(COLTT_E_NOT_FOUND, "group_member: unknown handle");
+  if (i < 0 || (size_t)i >= g->m.size()) return fail(COLTT_E_INVALID, "group_member: index %d outside [0,%zu)", i, g->m.size());
+  *out = g->m[(size_t)i]->h;
+  return COLTT_OK;
+}
+
+int coltt_group_shard_of(coltt_handle_t h, uint64_t id, int32_t* out_shard) {
+  auto g = lookup<Group>(h);
+  if (!g || !out_shard) return fail(COLTT_E_NOT_FOUND, "group_shard_of: unknown handle");
+  *out_shard = g->layout == COLTT_LAYOUT_SHARD ? (int32_t)shard_vertex(id, (uint64_t)g->world) : -1;
+  return COLTT_OK;
+}
+
+int coltt_group_len(coltt_handle_t h, uint64_t* out) {
+  auto g = lookup<Group>(h);
+  if (!g || !out) return fail(COLTT_E_NOT_FOUND, "group_len: unknown handle");
+  uint64_t tot = 0;
+  for (size_t i = 0; i < g->m.size(); i++) {
+    uint64_t n = 0;
+    COLTT_TRY(g->kind == COLTT_GROUP_FLAT ? coltt_flat_len(g->m[i]->h, &n) : coltt_hnsw_len(g->m[i]->h, &n));
+    if (g->layout == COLTT_LAYOUT_REPLICA) { tot = n; break; }
+    tot += n;
+  }
+  *out = tot;
+  return COLTT_OK;
+}
+
+// ChangedVertex (FLAT) / Insert (HNSW) routed by ShardVertex(id, world).  A process is offered every vertex and keeps the
+// ones whose shard it hosts (out_kept); a replica group gives every vertex to every member.  levels: HNSW only.
+static int group_ingest(Group* g, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n, uint32_t batch, uint64_t* out_kept) {
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  const size_t nm = g->m.size();
+  std::vector<std::vector<size_t>> pick(nm);
+  for (size_t i = 0; i < n; i++) {
+    if (g->layout == COLTT_LAYOUT_REPLICA) { for (size_t j = 0; j < nm; j++) pick[j].push_back(i); continue; }
+    const int s = (int)shard_vertex(ids[i], (uint64_t)g->world) - g->rank_base;
+    if (s >= 0 && (size_t)s < nm) pick[(size_t)s].push_back(i);
+  }
+  uint64_t kept = 0;
+  for (auto& p : pick) kept += p.size();
+  if (out_kept) *out_kept = g->layout == COLTT_LAYOUT_REPLICA ? n : kept;
+  return for_members(g, [&](size_t j) -> int {
+    const auto& p = pick[j];
+    if (p.empty()) return COLTT_OK;
+    std::vector<uint64_t> sid(p.size()); std::vector<float> sv(p.size() * g->dim); std::vector<int32_t> sl;
+    for (size_t t = 0; t < p.size(); t++) { sid[t] = ids[p[t]]; std::memcpy(&sv[t * g->dim], vecs + p[t] * g->dim, (size_t)g->dim * 4); }
+    if (g->kind == COLTT_GROUP_FLAT) return coltt_flat_upsert(g->m[j]->h, sid.data(), sv.data(), p.size());
+    sl.resize(p.size());
+    for (size_t t = 0; t < p.size(); t++) sl[t] = levels[p[t]];
+    Member& x = *g->m[j];
+    COLTT_TRY(x.d_q.reserve(sv.size() * 4));
+    COLTT_HIP(hipMemcpyAsync(x.d_q.p, sv.data(), sv.size() * 4, hipMemcpyHostToDevice, x.stream));
+    COLTT_HIP(hipStreamSynchronize(x.stream));
+    return coltt_hnsw_insert_batch_device(x.h, sid.data(), 0, x.d_q.as<float>(), sl.data(), p.size(), batch ? batch : 1);
+  });
+}
+
+int coltt_group_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n, uint64_t* out_kept) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_upsert: unknown handle");
+  if (g->kind != COLTT_GROUP_FLAT) return fail(COLTT_E_INVALID, "group_upsert: not a FLAT group (use coltt_group_insert)");
+  if (n && (!ids || !vecs)) return fail(COLTT_E_INVALID, "group_upsert: NULL input");
+  ReadLock rl(g->rw);
+  return group_ingest(g.get(), ids, vecs, nullptr, n, 0, out_kept);
+}
+
+int coltt_group_insert(coltt_handle_t h, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n, uint32_t batch,
+                       uint64_t* out_kept) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_insert: unknown handle");
+  if (g->kind != COLTT_GROUP_HNSW) return fail(COLTT_E_INVALID, "group_insert: not an HNSW group (use coltt_group_upsert)");
+  if (n && (!ids || !vecs || !levels)) return fail(COLTT_E_INVALID, "group_insert: NULL input");
+  ReadLock rl(g->rw);
+  return group_ingest(g.get(), ids, vecs, levels, n, batch, out_kept);
+}
+
+int coltt_group_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_remove: unknown handle");
+  if (n && !ids) return fail(COLTT_E_INVALID, "group_remove: NULL ids");
+  ReadLock rl(g->rw);
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  const size_t nm = g->m.size();
+  std::vector<std::vector<uint64_t>> pick(nm);
+  for (size_t i = 0; i < n; i++) {
+    if (g->layout == COLTT_LAYOUT_REPLICA) { for (size_t j = 0; j < nm; j++) pick[j].push_back(ids[i]); continue; }
+    const int s = (int)shard_vertex(ids[i], (uint64_t)g->world) - g->rank_base;
+    if (s >= 0 && (size_t)s < nm) pick[(size_t)s].push_back(ids[i]);
+  }
+  return for_members(g.get(), [&](size_t j) -> int {
+    if (pick[j].empty()) return COLTT_OK;
+    if (g->kind == COLTT_GROUP_FLAT) return coltt_flat_remove(g->m[j]->h, pick[j].data(), pick[j].size());
+    for (uint64_t id : pick[j]) COLTT_TRY(coltt_hnsw_remove(g->m[j]->h, id));  // ItemNotFoundError surfaces as in the reference
+    return COLTT_OK;
+  });
+}
+
+// VertexSearch / Hnsw.Search over the whole collection.  d_queries_per_member != NULL: the batch already lives on every
+// member's device ([n_local] pointers, nq x dim f32 each); otherwise `queries` is a host array broadcast to the members.
+static int group_search(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
+                        int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  if (nq == 0) return COLTT_OK;
+  if (k == 0) return fail(COLTT_E_INVALID, "group_search: k must be >= 1");
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  const size_t nm = g->m.size();
+  const bool hn = g->kind == COLTT_GROUP_HNSW;
+  const int nearest = hn ? 1 : (select == COLTT_SELECT_NEAREST);
+  const size_t per = nq * (size_t)k;
+  if (g->layout == COLTT_LAYOUT_REPLICA) {
+    // the batch is split into contiguous slices, one per member; answers land in place — no exchange
+    return for_members(g, [&](size_t j) -> int {
+      const size_t lo = nq * j / nm, hi = nq * (j + 1) / nm;
+      if (hi == lo) return COLTT_OK;
+      Member& x = *g->m[j];
+      if (d_queries_per_member) {
+        COLTT_TRY(x.d_ids.reserve((hi - lo) * k * 8)); COLTT_TRY(x.d_sc.reserve((hi - lo) * k * 4)); COLTT_TRY(x.d_cnt.reserve((hi - lo) * 4));
+        const float* dq = d_queries_per_member[j] + lo * g->dim;
+        if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, hi - lo, k, ef_override, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), nullptr));
+        else COLTT_TRY(coltt_flat_search_device(x.h, dq, hi - lo, k, select, mode, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>()));
+        COLTT_HIP(hipMemcpyAsync(out_ids + lo * k, x.d_ids.p, (hi - lo) * k * 8, hipMemcpyDeviceToHost, x.stream));
+        COLTT_HIP(hipMemcpyAsync(out_scores + lo * k, x.d_sc.p, (hi - lo) * k * 4, hipMemcpyDeviceToHost, x.stream));
+        COLTT_HIP(hipMemcpyAsync(out_counts + lo, x.d_cnt.p, (hi - lo) * 4, hipMemcpyDeviceToHost, x.stream));
+        COLTT_HIP(hipStreamSynchronize(x.stream));
+        return COLTT_OK;
+      }
+      if (hn) return coltt_hnsw_search(x.h, queries + lo * g->dim, hi - lo, k, ef_override, out_ids + lo * k, out_scores + lo * k, out_counts + lo, nullptr);
+      return coltt_flat_search(x.h, queries + lo * g->dim, hi - lo, k, select, mode, out_ids + lo * k, out_scores + lo * k, out_counts + lo);
+    });
+  }
+  // ---- SHARD layout: every member searches the whole batch on its shard ...
+  COLTT_TRY(for_members(g, [&](size_t j) -> int {
+    Member& x = *g->m[j];
+    const float* dq;
+    if (d_queries_per_member) dq = d_queries_per_member[j];
+    else {
+      COLTT_TRY(x.d_q.reserve(nq * g->dim * 4));
+      COLTT_HIP(hipMemcpyAsync(x.d_q.p, queries, nq * g->dim * 4, hipMemcpyHostToDevice, x.stream));
+      COLTT_HIP(hipStreamSynchronize(x.stream));
+      dq = x.d_q.as<float>();
+    }
+    COLTT_TRY(x.d_ids.reserve(per * 8)); COLTT_TRY(x.d_sc.reserve(per * 4)); COLTT_TRY(x.d_cnt.reserve(nq * 4));
+    COLTT_TRY(x.d_pack.reserve(per * sizeof(Rec)));
+    if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, nq, k, ef_override, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), nullptr));
+    else COLTT_TRY(coltt_flat_search_device(x.h, dq, nq, k, select, mode, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>()));
+    pack_topk_kernel<<<ceil_div(per, 256), 256, 0, x.stream>>>(x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), (uint32_t)nq, k, x.d_pack.as<Rec>());
+    COLTT_HIP(hipGetLastError());
+    if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(x.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
+    return COLTT_OK;
+  }));
+  // ---- ... ONE all-gather of the packed per-shard top-k (RCCL over xGMI), then the host-side final merge
+  COLTT_TRY(g->stage((size_t)g->world * per * sizeof(Rec)));
+  if (g->exchange == COLTT_EXCHANGE_RCCL) {
+    Rccl* r = rccl();
+    COLTT_NCCL(r, r->GroupStart());
+    for (auto& xp : g->m) { Member& x = *xp;
+      COLTT_TRY(use_device(x.device));
+      COLTT_NCCL(r, r->AllGather(x.d_pack.p, x.d_gather.p, per * sizeof(Rec), 0 /*ncclInt8*/, x.comm, x.stream));
+    }
+    COLTT_NCCL(r, r->GroupEnd());
+    Member& x0 = *g->m[0];
+    COLTT_TRY(use_device(x0.device));
+    COLTT_HIP(hipMemcpyAsync(g->h_stage, x0.d_gather.p, (size_t)g->world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.stream));
+    for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+  } else {
+    for (size_t j = 0; j < nm; j++) {
+      Member& x = *g->m[j];
+      COLTT_TRY(use_device(x.device));
+      COLTT_HIP(hipMemcpyAsync(g->h_stage + (size_t)x.rank * per, x.d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.stream));
+    }
+    for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+  }
+  return coltt_group_merge_host(g->h_stage, g->world, nq, k, nearest, out_ids, out_scores, out_counts);
+}
+
+int coltt_group_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode, uint32_t ef_override,
+                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_search: unknown handle");
+  if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "group_search: NULL buffer");
+  ReadLock rl(g->rw);
+  return group_search(g.get(), queries, nullptr, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
+}
+
+int coltt_group_search_device(coltt_handle_t h, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select, int mode,
+                              uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_search_device: unknown handle");
+  if (nq && (!d_queries_per_member || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "group_search_device: NULL buffer");
+  ReadLock rl(g->rw);
+  return group_search(g.get(), nullptr, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
+}
+
+}  // extern "C"

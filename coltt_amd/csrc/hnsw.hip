@@ -813,11 +813,19 @@ int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* 
 extern "C" {
 
 int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out) {
+  COLTT_TRY(ensure_device());
+  return coltt::hnsw_create_on(default_device(), dim, metric, quant, cfg, out);
+}
+
+}  // extern "C"
+
+// NewHnsw on an explicit device (collection groups place one shard per GPU)
+int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out) {
   if (!out) return fail(COLTT_E_INVALID, "hnsw_create: out is NULL");
   if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "hnsw_create: dim %u outside [1,8192]", dim);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "hnsw_create: bad metric %d", metric);
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");
-  COLTT_TRY(ensure_device());
+  COLTT_TRY(use_device(device));
   auto x = std::make_shared<Hnsw>();
   x->dim = dim; x->metric = metric; x->quant = quant;
   x->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
@@ -834,11 +842,13 @@ int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg*
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
-  x->device = default_device();
+  x->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   *out = Registry::get().add(x);
   return COLTT_OK;
 }
+
+extern "C" {
 
 int coltt_hnsw_destroy(coltt_handle_t h) {
   if (!Registry::get().erase(h)) return fail(COLTT_E_NOT_FOUND, "hnsw_destroy: unknown handle");

@@ -203,6 +203,58 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
 /* last kernel timing of the handle's search stream, measured with hipEvents (milliseconds) */
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms);
 
+/* ---- collection groups: ONE collection partitioned over the GPUs of a node (BASELINE.json north_star) ----
+ * The reference has no multi-device code; its sharding rule and merge shape are the ones `highCpu` uses for its 16
+ * in-process map shards: vertex `id` lives on shard sharding.ShardVertex(id, world) (pkg/sharding/shard.go:34-41), every
+ * shard is searched with a local queue, the local results are merged into one queue (edge/none_vectorstore.go:148-178).
+ * SHARD layout: each member is an ordinary FLAT store / HNSW index on its own GPU; a search = per-member search on per-member
+ * streams + ONE all-gather of packed {u64 id, f32 score, u32 valid} records (RCCL over xGMI; ncclCommInitAll in one process,
+ * ncclCommInitRank with one process per GPU) + host-side merge in the canonical (score, id) order.  REPLICA layout: every
+ * member holds everything, a query batch is split across members, nothing is exchanged.
+ * RCCL is dlopen'ed on first use (no link-time dependency).  EXCHANGE_HOST / AUTO on a group whose members share one device
+ * (RCCL refuses a device twice) moves the records through pinned host memory instead; the merge is on the host either way. */
+enum { COLTT_GROUP_FLAT = 0, COLTT_GROUP_HNSW = 1 };
+enum { COLTT_LAYOUT_SHARD = 0, COLTT_LAYOUT_REPLICA = 1 };
+enum { COLTT_EXCHANGE_AUTO = 0, COLTT_EXCHANGE_RCCL = 1, COLTT_EXCHANGE_HOST = 2 };
+#define COLTT_UNIQUE_ID_BYTES 128
+typedef struct coltt_group_opts {
+  int32_t kind;               /* COLTT_GROUP_FLAT (edge vectorspace) | COLTT_GROUP_HNSW (core vectorindex)                  */
+  int32_t layout;             /* COLTT_LAYOUT_SHARD | COLTT_LAYOUT_REPLICA                                                  */
+  int32_t exchange;           /* COLTT_EXCHANGE_AUTO | _RCCL (fail if unavailable) | _HOST                                  */
+  int32_t world_size;         /* shards in the whole collection; 0 => n_devices (single process)                            */
+  int32_t rank_base;          /* shard number of devices[0]; this process hosts shards rank_base .. rank_base+n_devices-1   */
+  const uint8_t* unique_id;   /* COLTT_UNIQUE_ID_BYTES from coltt_group_unique_id(), the same in every process; NULL if one */
+} coltt_group_opts;
+int coltt_group_unique_id(uint8_t* out /*[COLTT_UNIQUE_ID_BYTES]*/);
+int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg,
+                       const coltt_group_opts* opts, coltt_handle_t* out);
+int coltt_group_destroy(coltt_handle_t h);
+int coltt_group_info(coltt_handle_t h, int32_t* n_local, int32_t* world, int32_t* exchange_in_use, int32_t* rank_base);
+/* the i-th local member's own handle (a coltt_flat_* / coltt_hnsw_* handle): device-resident ingest goes straight to it */
+int coltt_group_member(coltt_handle_t h, int i, coltt_handle_t* out);
+int coltt_group_shard_of(coltt_handle_t h, uint64_t id, int32_t* out_shard);
+/* ChangedVertex (FLAT) / Insert (HNSW) routed by ShardVertex(id, world).  A process is OFFERED every vertex and keeps those
+ * whose shard it hosts (*out_kept); a replica group gives every vertex to every member. */
+int coltt_group_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n, uint64_t* out_kept);
+int coltt_group_insert(coltt_handle_t h, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n, uint32_t batch,
+                       uint64_t* out_kept);
+int coltt_group_remove(coltt_handle_t h, const uint64_t* ids, size_t n);
+int coltt_group_len(coltt_handle_t h, uint64_t* out);   /* vertices hosted by THIS process (replica: of one member) */
+/* VertexSearch / Hnsw.Search over the whole collection; results on the host, rows ascending by (score, id).
+ * select / mode: FLAT only; ef_override: HNSW only.  In a multi-process group every process must make the same call. */
+int coltt_group_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode, uint32_t ef_override,
+                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+/* same, the query batch already resident on every local member's device: d_queries_per_member[i] -> [nq][dim] f32 */
+int coltt_group_search_device(coltt_handle_t h, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select, int mode,
+                              uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+/* the host-side final merge on its own (no device needed): recs = [world][nq][k] packed 16-byte records {u64 id, f32 score,
+ * u32 valid}, each shard's valid records ascending by (score, id); nearest != 0: the k smallest of the union, else the k
+ * largest (edge.PriorityQueue semantics), both returned ascending. */
+int coltt_group_merge_host(const void* recs, int world, size_t nq, uint32_t k, int nearest, uint64_t* out_ids, float* out_scores,
+                           uint32_t* out_counts);
+/* sharding.ShardVertex on the host (pkg/sharding/shard.go:34-41): the routing rule of a group, no device needed */
+uint64_t coltt_shard_vertex_host(uint64_t id, uint64_t shard_count);
+
 #ifdef __cplusplus
 }
 #endif

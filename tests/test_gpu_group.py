@@ -1,0 +1,112 @@
+"""Collection groups on the GPU (BASELINE.json configs[4] layout on ONE device: N members share device 0, so the packed
+per-shard answers travel through pinned host memory; a 1-member group exercises the RCCL all-gather itself —
+ncclCommInitAll refuses the same device twice).  Parity: per-shard oracle search + the oracle-side merge of the union."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import assert_same_results, bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _shards(ids, G):
+    return np.array([O.shard_vertex(int(i), G) for i in ids])
+
+
+@pytest.mark.parametrize("G", [4, 8])
+@pytest.mark.parametrize("quant,metric", [(O.Q_NONE, O.COSINE), (O.Q_F16, O.L2)])
+def test_flat_group_equals_unsharded_store_and_per_shard_oracle(gpu, G, quant, metric):
+    """FLAT is exact, so a sharded collection must answer EXACTLY like the unsharded store, in both select directions."""
+    from coltt_amd import group as GG
+    n, d, k = 3000, 40, 10
+    X = O.fill_normal(1300 + G, (n, d)); ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919) + np.uint64(13))
+    grp = gpu.Group([0] * G, d, metric, quant, kind=GG.GROUP_FLAT)
+    assert grp.info() == {"n_local": G, "world": G, "exchange": "host", "rank_base": 0}
+    assert grp.ChangedVertex(ids, X) == n and grp.Len() == n
+    sh = _shards(ids, G)
+    for i in (0, 5, 77): assert grp.shard_of(ids[i]) == sh[i]
+    whole = O.Flat(d, metric, quant); whole.upsert(ids, X)
+    parts = []
+    for s in range(G):
+        f = O.Flat(d, metric, quant); f.upsert(ids[sh == s], X[sh == s]); parts.append(f)
+    Q = O.fill_normal(1301, (21, d))
+    for nearest in (True, False):
+        gi, gs, gc = grp.Search(Q, k, select=gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE)
+        for qi in range(len(Q)):
+            wi, ws = whole.search(Q[qi], k, nearest=nearest, mode=2)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi} near{nearest}")
+            # the reference's own shape: local queues per shard, merged into the global queue
+            u = sorted((float(s_), int(i_)) for p in parts for i_, s_ in zip(*p.search(Q[qi], k, nearest=nearest, mode=2)))
+            want = u[:k] if nearest else u[-k:]
+            assert [(float(gs[qi, j]), int(gi[qi, j])) for j in range(gc[qi])] == want
+    # removal is routed too
+    grp.Remove(ids[:50]); whole.remove(ids[:50])
+    gi, gs, gc = grp.Search(Q[:5], k)
+    for qi in range(5):
+        wi, ws = whole.search(Q[qi], k, nearest=True, mode=2)
+        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws)
+    assert grp.Len() == n - 50
+
+
+@pytest.mark.parametrize("G", [4, 8])
+def test_hnsw_bf16_ef256_sharded_by_shard_vertex(gpu, G):
+    """configs[4] on one device: "bf16" HNSW shards (ShardVertex(id, G)), efSearch 256, per-shard search + exact merge.
+    Checker per shard: the oracle's canonical search over that shard's arrays copied out of HBM; then the merged answer must
+    be the k best of the union; and against the unsharded exact scan the recall must be high."""
+    from coltt_amd import group as GG
+    n, d, k, ef = 6000, 64, 10, 256
+    X = O.fill_normal(1400 + G, (n, d)); lv = O.levels(1401 + G, n)
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(104729) + np.uint64(5)
+    grp = gpu.Group([0] * G, d, O.COSINE, O.Q_BF16, kind=GG.GROUP_HNSW, cfg=gpu.HnswCfg.default(ef_construction=80))
+    for b in range(0, n, 1000):   # several ingest calls; batch 1 inside a shard == the reference's sequential Insert
+        assert grp.Insert(ids[b:b + 1000], X[b:b + 1000], lv[b:b + 1000], batch=1) == 1000
+    assert grp.Len() == n
+    sh = _shards(ids, G)
+    Q = O.fill_normal(1402, (32, d))
+    gi, gs, gc = grp.Search(Q, k, ef=ef)
+    per_shard = []
+    for s in range(G):
+        m = gpu.Hnsw.__new__(gpu.Hnsw); m.h = grp.member(s); m.dim = d; m.quantization = O.Q_BF16; m.cfg = gpu.HnswCfg()
+        m.Config()
+        g = m.ExportRaw(); rows = m.FetchRows(); ex = m.Export()
+        assert np.array_equal(np.sort(ex["ids"]), np.sort(ids[sh == s]))             # routing: exactly this shard's vertices
+        sl, sc, cn, _, _ = O.csr_search(rows, O.Q_BF16, g["adj0"], g["upper_off"], g["adjU"], d, O.COSINE, g["entry"], g["entry_level"], Q, k, ef, threads=2)
+        per_shard.append((ex["ids"], sl, sc, cn))
+        m.h = None                                                                    # the group owns the member
+    for qi in range(len(Q)):
+        u = sorted((float(sc[qi, j]), int(idv[sl[qi, j]])) for idv, sl, sc, cn in per_shard for j in range(cn[qi]))[:k]
+        assert [(float(gs[qi, j]), int(gi[qi, j])) for j in range(gc[qi])] == u, qi
+        got_bits = bits(gs[qi, :gc[qi]])
+        assert np.array_equal(got_bits, bits(np.float32([x[0] for x in u])))
+    fl = gpu.FlatSpace(d, O.COSINE, O.Q_BF16); fl.ChangedVertex(ids, X)
+    ti, ts, tc = fl.VertexSearch(Q, k, gpu.SELECT_NEAREST)
+    rec = np.mean([len(set(gi[q].tolist()) & set(ti[q].tolist())) / k for q in range(len(Q))])
+    assert rec > 0.95, rec
+
+
+def test_group_rccl_allgather_single_member_and_replica_layout(gpu):
+    """(1) a 1-member group with exchange = RCCL: ncclCommInitAll + ncclAllGather really run (world 1) and the answers equal
+    the plain store's; (2) REPLICA layout: the batch is split over the members, nothing is exchanged, same answers."""
+    from coltt_amd import group as GG
+    n, d, k = 2000, 32, 10
+    X = O.fill_normal(1500, (n, d)); ids = np.arange(n, dtype=np.uint64) + np.uint64(100)
+    fl = gpu.FlatSpace(d, O.L2); fl.ChangedVertex(ids, X)
+    Q = O.fill_normal(1501, (37, d))
+    want = fl.VertexSearch(Q, k, gpu.SELECT_NEAREST)
+    g1 = gpu.Group([0], d, O.L2, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_RCCL)
+    assert g1.info()["exchange"] == "rccl"
+    g1.ChangedVertex(ids, X)
+    a = g1.Search(Q, k)
+    assert np.array_equal(a[0], want[0]) and np.array_equal(bits(a[1]), bits(want[1])) and np.array_equal(a[2], want[2])
+    with pytest.raises(gpu.ColttError):
+        gpu.Group([0, 0], d, O.L2, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_RCCL)   # a communicator cannot hold a device twice
+    g3 = gpu.Group([0, 0, 0], d, O.L2, kind=GG.GROUP_FLAT, layout=GG.LAYOUT_REPLICA)
+    assert g3.ChangedVertex(ids, X) == n and g3.Len() == n
+    b = g3.Search(Q, k)
+    assert np.array_equal(b[0], want[0]) and np.array_equal(bits(b[1]), bits(want[1])) and np.array_equal(b[2], want[2])
+    # device-resident query batch per member
+    import torch
+    qd = torch.from_numpy(Q).cuda(); torch.cuda.synchronize()
+    c = g3.SearchDevice([qd.data_ptr()] * 3, len(Q), k)
+    assert np.array_equal(c[0], want[0]) and np.array_equal(bits(c[1]), bits(want[1]))
