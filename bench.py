@@ -1,19 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec at recall@10 for HNSW search on MI355X (BASELINE.json metric), one process per GPU.
 
-Workload (config.workload): BASELINE.json configs[3] — core/vectorindex HNSW, M=16 (mMax0=32), efSearch=128,
-10M x 768 float32, cosine, k=10, synthetic random-normal vectors generated in HBM.  A "step" is one call of
-Hnsw.Search for a batch of `--queries` queries (inputs already resident in HBM).  The index is built on the GPU by the
-library's own batched Insert (outside the timed region), searched by the hand-written HIP kernel, and checked:
-recall@10 against the exact FLAT scan (COLTT_SELECT_NEAREST), and a sample of queries bit-for-bit against the CPU
-oracle on the exported graph.
+Headline workload (config.workload, `value`): BASELINE.json configs[3] — core/vectorindex HNSW, M=16 (mMax0=32),
+efSearch=128, efConstruction=200, 10M x 768 float32, cosine, k=10, synthetic random-normal vectors generated in HBM.
+A "step" is one call of Hnsw.Search for a batch of `--queries` queries already resident in HBM.  The index is built on the
+GPU by the library's own batched Insert (outside the timed region).
+
+At N=1 the same run also records (all in the ONE JSON line, so the driver's record holds them):
+  operating_point : the north-star point "recall@10 >= 0.98, 10M x 768 f16 HNSW, 1 GPU" on a structured dataset
+                    (low-rank Gaussian mixture + noise; iid random-normal 768-d has no neighbourhood structure, see
+                    recall_note): smallest ef of the sweep that reaches the recall, queries/s at that ef, its own roofline,
+                    and the CPU baseline AT THE SAME ef.
+  secondary.c2/c3 : BASELINE.json configs[1] (FLAT cosine 1M x 768 f32, batch 64) and configs[2] (FLAT 10M x 768 f16
+                    codes, batch 256) through the matrix-core candidate path, with the binding roof named (HBM; the f16 MFMA
+                    fraction beside it), the exact-mode cross-check and the CPU legs of BASELINE.md §2.
+cpu_baseline = the oracle (a restatement of the reference's Go/AVX path) on the host cores, as NATIVE pinned threads over a
+NUMA-interleaved copy of the very arrays the GPU walks (oracle/coltt_oracle.cpp: orc_csr_search_mt / orc_flat_scan_mt),
+1 / 16 / all cores with the scaling factor and the DRAM rate it implies; the same sample is compared GPU-vs-oracle
+bit-for-bit (ids, score bits, traversal counters).
 
 N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), --mode:
-  replica (default): the 10M index fits one GPU (30.7 GB of 288 GB), so every rank holds a replica and searches its
-           own slice of the query stream — no data-path collective; value = total queries / max-over-ranks time.
-  shard  : the collection is partitioned N ways (ids i with i % N == rank), every rank searches every query on its
-           shard, per-shard top-k is exchanged with ONE all-gather (RCCL over xGMI) and merged on the host of rank 0
-           (north-star layout; BASELINE.json configs[4]).
+  replica (default): the 10M index fits one GPU (30.7 GB of 288 GB), so every rank holds a replica and searches its own
+           slice of the query stream — no data-path collective; value = total queries / max-over-ranks time.  The same run
+           then ALSO exercises the north-star layout as `secondary.shard` (below), so a scaling run records both.
+  shard  : the collection is partitioned N ways by sharding.ShardVertex(id, N) (pkg/sharding/shard.go:34-41), every rank
+           searches every query on its shard through the library's collection group (coltt_group_*: ncclCommInitRank,
+           ONE RCCL all-gather of the packed per-shard top-k over xGMI, host-side merge) — BASELINE.json configs[4] layout.
+           The C5 shape itself: `--mode shard --quant 3 --ef 256 --n 40000000` on 8 GPUs.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,7 +43,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable by a float4 copy)
+MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak
+QBYTES = {0: 4, 1: 2, 2: 1, 3: 2}
+QNAME = {0: "float32", 1: "f16 codes", 2: "f8 codes", 3: "bf16(=binary16) codes"}
 
 
 def parse():
@@ -46,67 +62,386 @@ def parse():
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--efc", type=int, default=200, help="efConstruction (reference default 200)")
     ap.add_argument("--build-batch", type=int, default=16384)
-    ap.add_argument("--quant", type=int, default=0, help="0 f32 (configs[3]); 1 f16 codes")
+    ap.add_argument("--quant", type=int, default=0, help="0 f32 (configs[3]); 1 f16 codes; 3 'bf16' (= binary16) codes")
     ap.add_argument("--mode", choices=["replica", "shard"], default="replica")
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-time budget of each all-cores CPU leg")
     ap.add_argument("--seed", type=int, default=0xC0177)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-device exist only to smoke-test the N>1 plumbing on a 1-GPU box")
     ap.add_argument("--share-device", action="store_true", help="every rank uses cuda:0 (plumbing test only)")
     ap.add_argument("--dataset", default="normal",
-                    help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R = x = A z, z ~ N(0, I_R) "
-                         "(structured data with intrinsic dimension R, where recall is meaningful)")
-    ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve (sample only)")
+                    help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
+                         "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
+    ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--op-dataset", default="lowrank:32:1.0:64")
+    ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
+    ap.add_argument("--op-recall", type=float, default=0.98)
+    ap.add_argument("--shard-leg-n", type=int, default=0, help="vectors in the whole sharded collection of the secondary.shard leg (0 = --n)")
     return ap.parse_args()
 
 
-def make_rows(torch, dev, c, dim, gen, args, basis):
-    """one chunk of synthetic vectors in HBM"""
-    if basis is None:
-        x = torch.randn((c, dim), device=dev, dtype=torch.float32, generator=gen)
-    else:
-        z = torch.randn((c, basis.shape[0]), device=dev, dtype=torch.float32, generator=gen)
-        x = (z @ basis).contiguous()
-    # the library reads this buffer on ITS OWN stream: the producer (torch's stream) must be finished first
-    torch.cuda.synchronize()
-    return x
+# ----------------------------------------------------------------------------------------------- synthetic data in HBM
+class Dataset:
+    def __init__(self, torch, dev, dim, spec):
+        self.torch, self.dev, self.dim, self.spec = torch, dev, dim, spec
+        self.basis = self.centres = None; self.sigma = 0.0
+        if spec.startswith("lowrank"):
+            p = spec.split(":")
+            r = int(p[1]) if len(p) > 1 else 32
+            self.sigma = float(p[2]) if len(p) > 2 else 0.0
+            nc = int(p[3]) if len(p) > 3 else 0
+            g = torch.Generator(device=dev); g.manual_seed(0xBA515)
+            self.basis = torch.randn((r, dim), device=dev, dtype=torch.float32, generator=g)
+            if nc > 0:
+                self.centres = 2.0 * torch.randn((nc, r), device=dev, dtype=torch.float32, generator=g)
+
+    def rows(self, c, gen):
+        """one chunk of synthetic vectors in HBM"""
+        t = self.torch
+        if self.basis is None:
+            x = t.randn((c, self.dim), device=self.dev, dtype=t.float32, generator=gen)
+        else:
+            z = t.randn((c, self.basis.shape[0]), device=self.dev, dtype=t.float32, generator=gen)
+            if self.centres is not None:
+                z = z + self.centres[t.randint(0, self.centres.shape[0], (c,), device=self.dev, generator=gen)]
+            x = z @ self.basis
+            if self.sigma:
+                x = x + self.sigma * t.randn((c, self.dim), device=self.dev, dtype=t.float32, generator=gen)
+            x = x.contiguous()
+        # the library reads this buffer on ITS OWN stream: the producer (torch's stream) must be finished first
+        t.cuda.synchronize()
+        return x
 
 
-def make_basis(torch, dev, dim, args):
-    if not args.dataset.startswith("lowrank"):
-        return None
-    r = int(args.dataset.split(":")[1]) if ":" in args.dataset else 32
-    g = torch.Generator(device=dev); g.manual_seed(0xBA515)
-    return torch.randn((r, dim), device=dev, dtype=torch.float32, generator=g)
-
-
-def build_index(G, torch, dev, n, dim, args, seed, id_base=0):
-    """Generate n random-normal vectors in HBM chunk by chunk and Insert them (batched builder)."""
-    cfg = G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc)
-    h = G.Hnsw(dim, G.COSINE, cfg, quantization=args.quant)
-    gen = torch.Generator(device=dev); gen.manual_seed(seed)
-    basis = make_basis(torch, dev, dim, args)
+def draw_levels(n, m, seed):
     rng = np.random.default_rng(seed ^ 0x1E7E1)
-    mult = 1.0 / np.log(float(args.m))
-    levels = np.floor(-np.log(1.0 - rng.random(n)) * mult).astype(np.int32)  # RandomExponential (gomath/rand.go:42-44)
-    chunk = min(n, 1 << 20)
-    done = 0
+    return np.floor(-np.log(1.0 - rng.random(n)) * (1.0 / np.log(float(m)))).astype(np.int32)  # RandomExponential (gomath/rand.go:42-44)
+
+
+def build_index(G, torch, dev, ds, n, dim, args, seed, quant, ids=None, h=None, ef=None):
+    """Generate n vectors in HBM chunk by chunk and Insert them (batched builder).  ids: explicit u64 ids (shards)."""
+    if h is None:
+        h = G.Hnsw(dim, G.COSINE, G.HnswCfg.default(m=args.m, ef=ef or args.ef, ef_construction=args.efc), quantization=quant)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    levels = draw_levels(n, args.m, seed)
+    chunk = min(n, 1 << 20); done = 0
     t0 = time.time()
     while done < n:
         c = min(chunk, n - done)
-        x = make_rows(torch, dev, c, dim, gen, args, basis)
-        # batch schedule: grow geometrically so a batch never exceeds 1/32 of the graph it is linked against
+        x = ds.rows(c, gen)
         i = 0
-        while i < c:
+        while i < c:  # batch schedule: grow geometrically so a batch never exceeds 1/32 of the graph it is linked against
             cur = done + i
             b = int(min(c - i, max(1, min(args.build_batch, cur // 32))))
-            h.InsertBatchDevice(x.data_ptr() + i * dim * 4, b, levels[cur:cur + b], batch=b, first_id=id_base + cur)
+            h.InsertBatchDevice(x.data_ptr() + i * dim * 4, b, levels[cur:cur + b], batch=b, first_id=cur,
+                                ids=None if ids is None else ids[cur:cur + b])
             i += b
         done += c
         del x
     torch.cuda.synchronize()
-    return h, time.time() - t0, levels
+    return h, time.time() - t0
+
+
+def fill_flat(G, torch, dev, ds, n, dim, quant, seed):
+    """a FLAT store holding the same vectors as an index built with `seed` (same generator stream => same bits)"""
+    fl = G.FlatSpace(dim, G.COSINE, quant); fl.Reserve(n)
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    chunk = min(n, 1 << 20); done = 0
+    while done < n:
+        c = min(chunk, n - done)
+        x = ds.rows(c, gen)
+        fl.ChangedVertexDevice(x.data_ptr(), c, first_id=done)
+        done += c
+        del x
+    return fl
+
+
+class Out:
+    def __init__(self, torch, dev, nq, k):
+        self.ids = torch.empty((nq, k), device=dev, dtype=torch.int64)
+        self.sc = torch.empty((nq, k), device=dev, dtype=torch.float32)
+        self.cnt = torch.empty((nq,), device=dev, dtype=torch.int32)
+
+    def ptrs(self):
+        return self.ids.data_ptr(), self.sc.data_ptr(), self.cnt.data_ptr()
+
+
+def hnsw_bytes_per_query(nd, ne, dim, quant, m):
+    """algorithmic bytes per query: n_dist rows + n_exp adjacency rows + one visited word per evaluation"""
+    return nd * dim * QBYTES[quant] + ne * (2 * m) * 4 + nd * 4
+
+
+def recall_curve(G, torch, fl, h, q, rq, k, efs):
+    """recall@k of Hnsw.Search at each ef against the exact nearest-k from the parity-checked FLAT kernel"""
+    dev = q.device
+    t = Out(torch, dev, rq, k)
+    fl.VertexSearchDevice(q.data_ptr(), rq, k, *t.ptrs(), select=G.SELECT_NEAREST)
+    truth = t.ids.cpu().numpy()
+    o = Out(torch, dev, rq, k)
+    curve = {}
+    for ef in efs:
+        try:
+            h.SearchDevice(q.data_ptr(), rq, k, *o.ptrs(), ef=ef)
+            ids = o.ids.cpu().numpy()
+            curve[str(ef)] = sum(len(set(truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
+        except Exception as e:
+            curve[str(ef)] = f"failed: {e}"
+    return curve
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline legs
+def host_copy_of_index(O, h, dim, quant, threads):
+    """rows + adjacency of the index copied out of HBM into NUMA-interleaved host buffers"""
+    g = h.ExportRaw()
+    n = g["n"]
+    dt = O.QUANT_DTYPE[quant]
+    rows = O.NumaArray((n, dim), dt, threads)
+    step = max(1, (1 << 30) // (dim * np.dtype(dt).itemsize))
+    for b in range(0, n, step):
+        h.FetchRows(b, min(step, n - b), out=rows.a[b:b + step])
+    adj0 = O.NumaArray(g["adj0"].shape, np.uint32, threads); adj0.a[:] = g["adj0"]
+    return rows, adj0, g
+
+
+def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m):
+    """Hnsw.Search on the host cores over the SAME graph: 1 thread (latency), 16 threads, all cores (throughput)."""
+    import psutil
+    threads = O.cpu_count()
+    need = h.Len() * dim * QBYTES[quant] * 1.15 + h.Len() * 2 * m * 4 * 2.2
+    if psutil.virtual_memory().available < need:
+        return {"error": f"host RAM too small for a copy of the index ({need / 2**30:.0f} GiB needed)"}
+    rows, adj0, g = host_copy_of_index(O, h, dim, quant, threads)
+    try:
+        q_host = q_dev.cpu().numpy()
+        common = dict(upper_off=g["upper_off"], adjU=g["adjU"], dim=dim, metric=O.COSINE, entry=int(g["entry"]), entry_level=int(g["entry_level"]), k=k, ef=ef)
+
+        def run(qs, th):
+            return O.csr_search(rows.a, quant, adj0.a, queries=qs, threads=th, pin=True, **common)
+        r1 = run(q_host[:8], 1); lat = r1[4] / 8                       # single-thread latency
+        legs = {}
+        for th in sorted({1, min(16, threads), threads}):
+            sample = int(max(th, min(len(q_host), args.cpu_seconds / lat * th * (0.6 if th > 16 else 1.0))))
+            sample = min(sample - sample % th if sample >= th else th, len(q_host))
+            r = run(q_host[:sample], th)
+            legs[th] = {"queries_per_s": sample / r[4], "sample": sample, "res": r}
+        best = legs[threads]
+        sample = best["sample"]; res = best["res"]
+        stream = O.membw(rows.a, threads)
+        bpq = hnsw_bytes_per_query(res[3]["n_dist"] / sample, res[3]["n_exp"] / sample, dim, quant, m)
+        st = h.SearchDevice(q_dev.data_ptr(), sample, k, *out.ptrs(), ef=ef)   # parity of the sample: GPU == oracle
+        gi = out.ids[:sample].cpu().numpy(); gs = out.sc[:sample].cpu().numpy()
+        same = bool(np.array_equal(gi, res[0].astype(np.int64)) and np.array_equal(gs.view(np.uint32), res[1].view(np.uint32)))
+        same_counters = bool(res[3]["n_dist"] == st["n_dist"] and res[3]["n_exp"] == st["n_exp"] and res[3]["n_hops"] == st["n_hops"])
+        qps = {str(t): v["queries_per_s"] for t, v in legs.items()}
+        return {"value": best["queries_per_s"], "unit": "queries/s", "cores": threads, "kind": "port", "ef": ef,
+                "sample": f"{sample} of the step's queries on the full {g['n']}x{dim} index ({QNAME[quant]}{'' if quant == 0 else ', both operands decoded per pair as the reference does'}), "
+                          f"oracle contiguous variant, {threads} native threads pinned 1:1 to the allowed CPUs (1 query per thread), rows and level-0 adjacency in "
+                          f"NUMA-interleaved memory ({O.lib().orc_numa_nodes()} node(s), mbind={'ok' if rows.flags & 1 else 'refused -> parallel first touch'}, THP advised={bool(rows.flags & 2)})",
+                "queries_per_s_by_threads": qps, "single_thread_latency_ms": lat * 1e3,
+                "parallel_efficiency": best["queries_per_s"] / (threads * legs[1]["queries_per_s"]),
+                "dram_GBps_all_cores": best["queries_per_s"] * bpq / 1e9, "dram_stream_read_GBps_all_cores": stream,
+                "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
+    finally:
+        rows.close(); adj0.close()
+
+
+def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=None):
+    """BASELINE.md §2 FLAT legs over the store's own rows copied out of HBM: reference-shaped arithmetic (both operands
+    decoded per pair) on 1 thread, 16 threads splitting ONE query (`highCpu`, none_vectorstore.go:148-178) and one query
+    per core on all cores; for quantised rows also the decode-once variant."""
+    threads = O.cpu_count()
+    dt = O.QUANT_DTYPE[quant]
+    rows = O.NumaArray((n_rows, dim), dt, threads)
+    try:
+        step = max(1, (1 << 30) // (dim * np.dtype(dt).itemsize))
+        for b in range(0, n_rows, step):
+            fl.FetchRows(b, min(step, n_rows - b), out=rows.a[b:b + step])
+        q = q_dev.cpu().numpy()
+        bytes_per_query = n_rows * dim * QBYTES[quant]
+        stream = O.membw(rows.a, threads)
+        r1 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:1], k, nearest=True, shape=0, split=1, threads=1)
+        lat = r1[3]
+        legs = {"1": {"queries_per_s": 1.0 / lat, "ms_per_query": lat * 1e3}}
+        s16 = min(16, threads)
+        nq16 = int(max(1, min(len(q), args.cpu_seconds / 2 / (lat / s16))))
+        r16 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nq16], k, nearest=True, shape=0, split=s16, threads=s16)
+        legs[f"{s16} (highCpu: one query split {s16} ways)"] = {"queries_per_s": nq16 / r16[3], "ms_per_query": r16[3] / nq16 * 1e3}
+        nqa = int(min(len(q), max(threads, (args.cpu_seconds / lat) * threads * 0.25)))
+        nqa -= nqa % threads if nqa >= threads else 0
+        ra = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nqa], k, nearest=True, shape=0, split=1, threads=threads)
+        legs[f"{threads} (one query per core)"] = {"queries_per_s": nqa / ra[3], "GBps": nqa / ra[3] * bytes_per_query / 1e9}
+        res = {"value": nqa / ra[3], "unit": "queries/s", "cores": threads, "kind": "port",
+               "sample": f"{nqa} queries over {n_rows}x{dim} {QNAME[quant]} rows copied out of HBM (NUMA-interleaved), contiguous variant, reference arithmetic "
+                         f"(Normalize, Lower, decode both operands per pair, AVX-order distance, bounded queue), native pinned threads",
+               "by_threads": legs, "bytes_per_query": bytes_per_query, "dram_stream_read_GBps_all_cores": stream,
+               "parallel_efficiency": (nqa / ra[3]) / (threads / lat)}
+        if quant != 0:
+            rd = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nqa], k, nearest=True, shape=1, split=1, threads=threads)
+            res["decode_once_variant_queries_per_s"] = nqa / rd[3]
+        if gpu_ids is not None:
+            m = min(len(gpu_ids), nqa)
+            res["gpu_equals_oracle_on_sample"] = bool(np.array_equal(gpu_ids[:m].astype(np.uint64), ra[0][:m]) and
+                                                      np.array_equal(gpu_sc[:m].view(np.uint32), ra[1][:m].view(np.uint32)))
+        return res
+    finally:
+        rows.close()
+
+
+# ----------------------------------------------------------------------------------------------- extra legs (N = 1)
+def leg_operating_point(G, torch, dev, O, args, dim, k):
+    """north-star point: recall@10 >= 0.98 on 10M x 768 f16 HNSW, structured data; own roofline; CPU baseline at the same ef"""
+    n, quant, nq = args.n, 1, args.queries
+    ds = Dataset(torch, dev, dim, args.op_dataset)
+    seed = args.seed + 101
+    h, build_s = build_index(G, torch, dev, ds, n, dim, args, seed, quant)
+    fl = fill_flat(G, torch, dev, ds, n, dim, quant, seed)
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 7)
+    q = ds.rows(nq, qgen)
+    efs = [int(e) for e in args.op_ef_sweep.split(",") if e]
+    rq = min(args.recall_queries, nq)
+    rec = recall_curve(G, torch, fl, h, q, rq, k, efs)
+    fl.close()
+    ok = [ef for ef in efs if isinstance(rec[str(ef)], float) and rec[str(ef)] >= args.op_recall]
+    ef_op = min(ok) if ok else max(efs)
+    out = Out(torch, dev, nq, k)
+    h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef_op)      # warm-up (allocates the visited workspace)
+    torch.cuda.synchronize()
+    steps = max(3, min(args.steps, 10)); ms = []; st_tot = {"n_dist": 0, "n_exp": 0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef_op)
+        ms.append(h.last_kernel_ms()); st_tot["n_dist"] += st["n_dist"]; st_tot["n_exp"] += st["n_exp"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nd = st_tot["n_dist"] / (steps * nq); ne = st_tot["n_exp"] / (steps * nq)
+    bpq = hnsw_bytes_per_query(nd, ne, dim, quant, args.m)
+    launch_s = float(np.mean(ms)) / 1e3
+    qps_curve = {}
+    for ef in efs:
+        h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef); qps_curve[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_hnsw(G, torch, O, h, args, dim, quant, ef_op, q, k, out, args.m)
+        except Exception as e:
+            cpu = {"error": str(e)}
+    h.close()
+    res = {"workload": f"core/vectorindex HNSW M={args.m} efConstruction={args.efc}, {n}x{dim} f16 codes, cosine, k={k}, dataset {args.op_dataset} "
+                       f"(x = mu_c + A z + sigma eps), {nq} queries/step",
+           "target_recall_at_10": args.op_recall, "ef": ef_op, "recall_at_10": rec[str(ef_op)], "reached": bool(ok),
+           "value": steps * nq / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "recall_vs_ef": rec, "qps_vs_ef": qps_curve, "build_s": build_s,
+           "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bpq},
+           "roofline": {"bound": "hbm", "achieved": bpq * nq / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bpq * nq / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "hnsw_search_kernel (HBM-visited, 2-byte rows)",
+                        "avg_launch_ms": launch_s * 1e3},
+           "cpu_baseline": cpu}
+    if cpu and "value" in cpu:
+        res["gpu_over_cpu"] = res["value"] / cpu["value"]
+    return res
+
+
+def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
+    """BASELINE.json configs[1] / configs[2]: batched FLAT scan through the matrix-core candidate path"""
+    ds = Dataset(torch, dev, dim, "normal")
+    fl = fill_flat(G, torch, dev, ds, n, dim, quant, args.seed + (202 if quant == 0 else 303))
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 11)
+    q = ds.rows(batch, qgen)
+    out = Out(torch, dev, batch, k)
+    reps = 8 if quant == 0 else 4
+
+    def run(mode, reps):
+        ms = []
+        for r in range(reps + 1):
+            fl.VertexSearchDevice(q.data_ptr(), batch, k, *out.ptrs(), select=G.SELECT_NEAREST, mode=mode)
+            if r: ms.append(fl.last_kernel_ms())
+        return float(np.mean(ms)) / 1e3, out.ids.cpu().numpy().copy(), out.sc.cpu().numpy().copy()
+    te, ei, es = run(G.MODE_EXACT, 1)
+    tm, mi, msc = run(G.MODE_MFMA, reps)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fl.VertexSearchDevice(q.data_ptr(), batch, k, *out.ptrs(), select=G.SELECT_NEAREST, mode=G.MODE_MFMA)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    nbytes = n * dim * QBYTES[quant]; flops = 2.0 * n * dim * batch
+    res = {"workload": f"edge FLAT cosine, {n}x{dim} {QNAME[quant]}, batch {batch}, k={k}, nearest-k, matrix-core candidates + exact re-score (BASELINE.json {tag})",
+           "value": batch / wall, "unit": "queries/s", "ms_per_batch_wall": wall * 1e3, "ms_per_batch_kernels": tm * 1e3,
+           "exact_mode_ms_per_batch": te * 1e3, "identical_to_exact_mode": bool(np.array_equal(ei, mi) and np.array_equal(es.view(np.uint32), msc.view(np.uint32))),
+           "roofline": {"bound": "hbm", "achieved": nbytes / tm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / tm / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "flat_mfma_cos_kernel + pick/rescore/select chain (hipEvent pair around the whole search on its stream)",
+                        "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
+                        "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
+                                 "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}
+    if not args.no_cpu_baseline:
+        try:
+            rows_cpu = min(n, cpu_rows)
+            full = rows_cpu == n
+            c = cpu_flat(O, fl, dim, quant, q, k, rows_cpu, args, mi if full else None, msc if full else None)
+            if not full:
+                c["sample"] += f"; run on the first {rows_cpu} rows and to be scaled by {n / rows_cpu:.0f}x for the full scan (BASELINE.md §2 allows the slice)"
+                c["value_scaled_to_full_scan"] = c["value"] * rows_cpu / n
+            res["cpu_baseline"] = c
+        except Exception as e:
+            res["cpu_baseline"] = {"error": str(e)}
+    fl.close()
+    return res
+
+
+def leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k):
+    """north-star layout: ShardVertex partition, per-shard HNSW, ONE RCCL all-gather of packed top-k inside the library
+    (coltt_group_*), host merge.  Each rank generates only its own shard's vectors."""
+    from coltt_amd import group as GG
+    n_total = args.shard_leg_n or args.n
+    L = G.lib()
+    uid = None
+    if world > 1:
+        box = [GG.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    # ids of the whole collection are 0..n_total-1; this rank keeps those that ShardVertex sends here (computed on the GPU)
+    all_ids = np.arange(n_total, dtype=np.uint64)
+    sh = np.empty(n_total, np.uint64)
+    for b in range(0, n_total, 1 << 24):
+        e = min(n_total, b + (1 << 24))
+        G.check(L.coltt_shard_vertex(G.vp(all_ids[b:e]), C.c_size_t(e - b), C.c_uint64(world), G.vp(sh[b:e])))
+    my_ids = np.ascontiguousarray(all_ids[sh == rank]); del all_ids, sh
+    grp = GG.Group([local], dim, G.COSINE, args.quant, kind=GG.GROUP_HNSW, layout=GG.LAYOUT_SHARD,
+                   cfg=G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc),
+                   exchange=GG.EXCHANGE_RCCL if world > 1 else GG.EXCHANGE_AUTO, world_size=world, rank_base=rank, uid=uid)
+    member = G.Hnsw.from_handle(grp.member(0), dim, G.COSINE, args.quant)
+    ds = Dataset(torch, dev, dim, args.dataset)
+    _, build_s = build_index(G, torch, dev, ds, len(my_ids), dim, args, args.seed + 7919 * (rank + 1), args.quant, ids=my_ids, h=member)
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5)     # the SAME query stream on every rank
+    nq = args.queries
+    q = ds.rows(nq, qgen)
+    out = (np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32))
+
+    def step():
+        grp.SearchDevice([q.data_ptr()], nq, k, ef=args.ef, out=out)
+    return grp, member, step, {"shard_rows": int(len(my_ids)), "build_s": build_s, "exchange": grp.info()["exchange"], "n_total": n_total}, out
+
+
+def timed(torch, dist, world, cdev, steps, warmup, step):
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
 
 
 def main():
@@ -126,225 +461,155 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL
         else:
             dist.init_process_group(args.backend)
-    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective payloads live
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where torch collective payloads live
     import coltt_amd as G
+    from coltt_amd import _lib as GL
+    G.check, G.vp = GL.check, GL.vp
     L = G.lib()
     assert L.coltt_init(local) == 0, L.coltt_last_error()
 
-    n_total, dim, k = args.n, args.dim, args.k
+    n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
-    n_local = (n_total - rank + world - 1) // world if shard else n_total
-    # replica mode: same seed on every rank => identical replicas; shard mode: rank-specific stream
-    seed = args.seed + (rank * 7919 if shard else 0)
-    h, build_s, levels = build_index(G, torch, dev, n_local, dim, args, seed, id_base=0)
+    default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
+    legs = [] if world > 1 else (["op", "c2", "c3"] if (args.legs == "auto" and default_size) else
+                                 [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
+    ds = Dataset(torch, dev, dim, args.dataset)
+    kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
+    shard_info = None
+    if shard:
+        grp, h, gstep, shard_info, gout = leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k)
+        build_s = shard_info["build_s"]; seed = None
 
-    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + (0 if shard else rank))
-    nq = args.queries
-    qbasis = make_basis(torch, dev, dim, args)
-    queries = [make_rows(torch, dev, nq, dim, qgen, args, qbasis) for _ in range(min(2, args.steps + args.warmup))]
-    out_ids = torch.empty((nq, k), device=dev, dtype=torch.int64)
-    out_sc = torch.empty((nq, k), device=dev, dtype=torch.float32)
-    out_cnt = torch.empty((nq,), device=dev, dtype=torch.int32)
-    from coltt_amd import dist as D
-    merged = []
+        def step(i):
+            gstep()
+            kernel_ms.append(h.last_kernel_ms())
+    else:
+        seed = args.seed      # replica mode: same seed on every rank => identical replicas
+        h, build_s = build_index(G, torch, dev, ds, n_total, dim, args, seed, args.quant)
+        qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + rank)
+        queries = [ds.rows(nq, qgen) for _ in range(min(2, args.steps + args.warmup))]
+        out = Out(torch, dev, nq, k)
 
-    def step(i):
-        q = queries[i % len(queries)]
-        st = h.SearchDevice(q.data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
-        if shard:
-            gid = out_ids * world + rank  # shard-local id -> collection id (ids with id % world == rank live here)
-            gi, gs, gc = D.allgather_topk(gid.to(cdev), out_sc.to(cdev), out_cnt.to(cdev))  # ONE RCCL all-gather per tensor over xGMI
-            if rank == 0:                                             # host-side final merge (north star)
-                merged.append(D.merge_topk(gi.cpu().numpy().astype(np.uint64), gs.cpu().numpy(), gc.cpu().numpy(), k, True))
-        return st
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    kernel_ms = []
-    stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        st = step(args.warmup + i)
-        kernel_ms.append(h.last_kernel_ms())  # hipEvent pair recorded on the library's search stream
-        for kk in stats: stats[kk] += st[kk]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def step(i):
+            st = h.SearchDevice(queries[i % len(queries)].data_ptr(), nq, k, *out.ptrs(), ef=args.ef)
+            if i >= args.warmup:
+                kernel_ms.append(h.last_kernel_ms())  # hipEvent pair recorded on the library's search stream
+                for kk in stats: stats[kk] += st[kk]
+    dt = timed(torch, dist, world, cdev, args.steps, args.warmup, step)
+    kernel_ms = kernel_ms[-args.steps:]
     total_q = args.steps * nq * (1 if shard else world)
     qps = total_q / dt
 
-    res = None
-    if rank == 0:
-        # ---- roofline of the dominant kernel (hnsw_search_kernel): algorithmic bytes per query
-        s_bytes = {0: 4, 1: 2, 2: 1, 3: 2}[args.quant]
-        nd = stats["n_dist"] / (args.steps * nq); ne = stats["n_exp"] / (args.steps * nq)
-        bytes_per_query = nd * dim * s_bytes + ne * (2 * args.m) * 4 + nd * 4
-        launch_s = float(np.mean(kernel_ms)) / 1e3
-        achieved = bytes_per_query * nq / launch_s / 1e9
-        # ---- recall@10 vs the exact scan on a sample
-        rq = min(args.recall_queries, nq)
-        fl = None
-        recall = None
+    secondary = {}
+    if world > 1 and not shard:
+        # the same scaling run also exercises the north-star layout (never allowed to kill the headline)
         try:
-            ids_h = out_ids[:rq].cpu().numpy() if not shard else None
-            if not shard:
-                q = queries[(args.warmup + args.steps - 1) % len(queries)]
-                st = h.SearchDevice(q.data_ptr(), rq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
-                ids_h = out_ids[:rq].cpu().numpy()
-                recall = exact_recall(G, torch, dev, h, args, seed, n_local, dim, q, rq, k, ids_h)
-        except Exception as e:  # recall is reported, never allowed to kill the bench line
-            recall = f"failed: {e}"
-        # ---- throughput along the same ef curve (one full step of nq queries per ef, kernel time): with recall_vs_ef this
-        # gives "queries/s at recall@10 = r" points, the form BASELINE.json's metric is quoted in
-        qps_vs_ef = None
-        if not shard:
+            grp2, m2, gstep2, info2, _ = leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k)
+            dts = timed(torch, dist, world, cdev, max(2, min(args.steps, 5)), 1, lambda i: gstep2())
+            info2.update({"value": max(2, min(args.steps, 5)) * nq / dts, "unit": "queries/s (every query visits every shard)",
+                          "workload": f"HNSW {info2['n_total']}x{dim} {QNAME[args.quant]} partitioned {world} ways by ShardVertex, efSearch={args.ef}, "
+                                      f"coltt_group_search_device: per-shard search + ONE RCCL all-gather of packed top-k + host merge"})
+            secondary["shard"] = info2
+            grp2.close()
+        except Exception as e:
+            secondary["shard"] = {"error": str(e)}
+
+    if rank == 0:
+        O = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+        recall = None; qps_vs_ef = None; cpu = None
+        if shard:
+            nd = ne = None
+            bytes_per_query = None
+        else:
+            nd = stats["n_dist"] / (args.steps * nq); ne = stats["n_exp"] / (args.steps * nq)
+            bytes_per_query = hnsw_bytes_per_query(nd, ne, dim, args.quant, args.m)
+            efs = [args.ef] + [int(e) for e in args.ef_curve.split(",") if e]
+            q = queries[(args.warmup + args.steps - 1) % len(queries)]
+            try:
+                fl = fill_flat(G, torch, dev, ds, n_total, dim, args.quant, seed)
+                recall = recall_curve(G, torch, fl, h, q, min(args.recall_queries, nq), k, efs)
+                fl.close()
+            except Exception as e:  # recall is reported, never allowed to kill the bench line
+                recall = f"failed: {e}"
             qps_vs_ef = {}
-            for ef in [args.ef] + [int(e) for e in args.ef_curve.split(",") if e]:
+            for ef in efs:  # one full step per ef, kernel time: with recall_vs_ef this gives "queries/s at recall@10 = r" points
                 try:
-                    h.SearchDevice(queries[0].data_ptr(), nq, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=ef)
+                    h.SearchDevice(queries[0].data_ptr(), nq, k, *out.ptrs(), ef=ef)
                     qps_vs_ef[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
                 except Exception as e:
                     qps_vs_ef[str(ef)] = f"failed: {e}"
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
+            if O is not None and world == 1:
+                try:
+                    cpu = cpu_hnsw(G, torch, O, h, args, dim, args.quant, args.ef, queries[0], k, out, args.m)
+                except Exception as e:
+                    cpu = {"error": str(e)}
+        launch_s = float(np.mean(kernel_ms)) / 1e3
+        roof = None
+        if bytes_per_query is not None:
+            achieved = bytes_per_query * nq / launch_s / 1e9
+            tr, tr_src = pmc_traffic(args, n_total, dim, nq)
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": tr, "traffic_source": tr_src, "kernel": "hnsw_search_kernel", "avg_launch_ms": launch_s * 1e3}
+        h.close()
+        op = None
+        if "op" in legs:
             try:
-                cpu = cpu_baseline(G, torch, h, args, dim, queries[0], k, out_ids, out_sc, out_cnt)
+                op = leg_operating_point(G, torch, dev, O, args, dim, k)
             except Exception as e:
-                cpu = {"error": str(e)}
+                op = {"error": str(e)}
+        for tag, (fn, fq, fb, cfgname, cpu_rows) in {"c2": (1_000_000, 0, 64, "configs[1]", 1_000_000), "c3": (10_000_000, 1, 256, "configs[2]", 1_000_000)}.items():
+            if tag in legs:
+                try:
+                    secondary[tag] = leg_flat(G, torch, dev, O, args, dim, k, fn, fq, fb, cfgname, cpu_rows)
+                except Exception as e:
+                    secondary[tag] = {"error": str(e)}
         res = {
             "metric": "queries/sec @ recall@10, 10Mx768 HNSW", "value": qps, "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.quant == 0 else "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {0: "f32", 1: "f16", 2: "f8", 3: "f16"}[args.quant], "data": "synthetic",
             "config": {"workload": f"core/vectorindex HNSW M={args.m} efSearch={args.ef} efConstruction={args.efc}, "
-                                   f"{n_total}x{dim} {'float32' if args.quant == 0 else 'f16 codes'}, cosine, k={k}, "
-                                   f"{nq} queries/step/rank, mode={'shard+allgather' if shard else ('replica' if world > 1 else 'single')}",
+                                   f"{n_total}x{dim} {QNAME[args.quant]}, cosine, k={k}, {nq} queries/step/rank, "
+                                   f"mode={'shard (ShardVertex) + RCCL all-gather of per-shard top-k + host merge' if shard else ('replica' if world > 1 else 'single')}",
                        "n": n_total, "dim": dim, "queries_per_step": nq, "ef": args.ef, "build_batch": args.build_batch},
             "recall_at_10": recall[str(args.ef)] if isinstance(recall, dict) else recall,
             "recall_vs_ef": recall if isinstance(recall, dict) else None,
             "qps_vs_ef": qps_vs_ef,
             "recall_note": ("iid random-normal 768-d has no neighbourhood structure (all cosine distances are 1 +- 0.04): any HNSW "
                             "that visits ~4e3 of 1e7 points finds ~0.1 % of the exact top-10; GPU answers equal the CPU oracle's on "
-                            "the same graph (cpu_baseline.gpu_equals_oracle_on_sample). See --dataset lowrank:R and DESIGN.md §6."
+                            "the same graph (cpu_baseline.gpu_equals_oracle_on_sample).  The recall >= 0.98 operating point of the north star "
+                            "is measured in `operating_point` on a structured dataset."
                             if args.dataset == "normal" else f"structured dataset {args.dataset}"),
             "dataset": args.dataset, "build_s": build_s,
             "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bytes_per_query, "visit_resets": stats["n_visit_resets"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args, n_total, dim, nq), "kernel": "hnsw_search_kernel", "avg_launch_ms": launch_s * 1e3},
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "operating_point": op,
+            "secondary": secondary or None,
+            "shard": shard_info,
         }
         print(json.dumps(res), flush=True)
+    else:
+        h.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def pmc_traffic(args, n, dim, nq):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json),
-    reported only when it was measured on this very workload; null otherwise."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json, made by
+    tools/pmc_traffic.py from the raw CSV kept next to it), reported only when it was measured on this very workload."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
-        return None
+        return None, None
     try:
         t = json.load(open(p))
         key = f"hnsw n={n} dim={dim} quant={args.quant} ef={args.ef} m={args.m} queries={nq} dataset={args.dataset}"
-        return t.get(key, {}).get("hbm_bytes_per_launch")
+        rec = t.get(key, {})
+        return rec.get("hbm_bytes_per_launch"), (f"profiles/{rec['source']}" if rec.get("source") else None)
     except Exception:
-        return None
-
-
-def exact_recall(G, torch, dev, h, args, seed, n, dim, q, rq, k, ann_ids):
-    """recall@k of the HNSW answers against the exact nearest-k from the parity-checked FLAT kernel.  The FLAT store is
-    filled by re-generating the same vectors (same generator stream) so no second copy has to cross PCIe."""
-    fl = G.FlatSpace(dim, G.COSINE, args.quant)
-    fl.Reserve(n)
-    gen = torch.Generator(device=dev); gen.manual_seed(seed)
-    basis = make_basis(torch, dev, dim, args)
-    chunk = min(n, 1 << 20); done = 0
-    while done < n:
-        c = min(chunk, n - done)
-        x = make_rows(torch, dev, c, dim, gen, args, basis)
-        fl.ChangedVertexDevice(x.data_ptr(), c, first_id=done)
-        done += c
-        del x
-    ti = torch.empty((rq, k), device=dev, dtype=torch.int64); ts = torch.empty((rq, k), device=dev, dtype=torch.float32)
-    tc = torch.empty((rq,), device=dev, dtype=torch.int32)
-    fl.VertexSearchDevice(q.data_ptr(), rq, k, ti.data_ptr(), ts.data_ptr(), tc.data_ptr(), select=G.SELECT_NEAREST)
-    truth = ti.cpu().numpy()
-    fl.close()
-
-    def rec(ids):
-        return sum(len(set(truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
-    curve = {str(args.ef): rec(ann_ids)}
-    oi = torch.empty((rq, k), device=dev, dtype=torch.int64); osc = torch.empty((rq, k), device=dev, dtype=torch.float32)
-    oc = torch.empty((rq,), device=dev, dtype=torch.int32)
-    for ef in [int(e) for e in args.ef_curve.split(",") if e]:
-        try:
-            h.SearchDevice(q.data_ptr(), rq, k, oi.data_ptr(), osc.data_ptr(), oc.data_ptr(), ef=ef)
-            curve[str(ef)] = rec(oi.cpu().numpy())
-        except Exception as e:
-            curve[str(ef)] = f"failed: {e}"
-    return curve
-
-
-def cpu_baseline(G, torch, h, args, dim, q_dev, k, out_ids, out_sc, out_cnt):
-    """The CPU oracle (a restatement of the reference's Go/AVX path: oracle/coltt_oracle.cpp, 'contiguous' variant)
-    searching the SAME graph on the host cores, on a bounded sample of the same queries; also cross-checks the GPU
-    answers and traversal counters for that sample bit-for-bit."""
-    import psutil
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    Lo = O.lib()
-    g = h.ExportRaw()
-    n = g["n"]
-    need = n * dim * {0: 4, 1: 2, 2: 1, 3: 2}[args.quant] * 1.1 + g["adj0"].nbytes * 2
-    if psutil.virtual_memory().available < need:
-        return {"error": f"host RAM too small for a copy of the index ({need / 2**30:.0f} GiB needed)"}
-    w0, wu = 2 * args.m, args.m
-    adj0, upper_off, adjU = g["adj0"], g["upper_off"], g["adjU"]   # the very arrays the GPU walks, copied out of HBM
-    rows = h.FetchRows()                                            # stored (normalised) f32 rows, copied out of HBM
-    ent, ent_lv = int(g["entry"]), int(g["entry_level"])
-    threads = os.cpu_count() or 1
-    q_host = q_dev.cpu().numpy()
-
-    def run(qs):
-        m = len(qs)
-        sl = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32); cn = np.empty(m, np.int32); st = (C.c_uint64 * 3)()
-        Lo.orc_csr_search(rows.ctypes.data_as(C.c_void_p), int(args.quant), adj0.ctypes.data_as(C.c_void_p), upper_off.ctypes.data_as(C.c_void_p),
-                          adjU.ctypes.data_as(C.c_void_p), None, C.c_uint32(w0), C.c_uint32(wu), C.c_uint32(dim), 0, 0, C.c_int32(ent),
-                          C.c_int32(ent_lv), qs.ctypes.data_as(C.c_void_p), C.c_size_t(m), k, args.ef, sl.ctypes.data_as(C.c_void_p),
-                          sc.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p), st)
-        return sl, sc, cn, (st[0], st[1], st[2])
-
-    # calibrate on a few queries, then size the sample for ~cpu-seconds of wall time on all cores
-    t0 = time.perf_counter(); sl1, sc1, cn1, st1 = run(np.ascontiguousarray(q_host[:8])); t1 = (time.perf_counter() - t0) / 8
-    sample = int(max(threads, min(len(q_host), args.cpu_seconds / t1 * threads)))
-    sample -= sample % threads
-    parts = np.array_split(np.ascontiguousarray(q_host[:sample]), threads)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        outs = list(ex.map(run, parts))
-    wall = time.perf_counter() - t0
-    # parity of the sample: GPU answers == oracle answers (slots, score bits)
-    st = h.SearchDevice(q_dev.data_ptr(), sample, k, out_ids.data_ptr(), out_sc.data_ptr(), out_cnt.data_ptr(), ef=args.ef)
-    gi = out_ids[:sample].cpu().numpy(); gs = out_sc[:sample].cpu().numpy()
-    ci = np.concatenate([o[0] for o in outs]); cs = np.concatenate([o[1] for o in outs])
-    cstat = np.sum([o[3] for o in outs], axis=0)
-    same = bool(np.array_equal(gi, ci.astype(np.int64)) and np.array_equal(gs.view(np.uint32), cs.view(np.uint32)))
-    same_counters = bool(int(cstat[0]) == st["n_dist"] and int(cstat[1]) == st["n_exp"])
-    return {"value": sample / wall, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} of the step's queries on the full {n}x{dim} index ({'f32 rows' if args.quant == 0 else '2-/1-byte codes decoded per pair'}), oracle contiguous variant, {threads} threads "
-                      f"(1 query per thread); single-thread latency {t1 * 1e3:.2f} ms/query",
-            "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
+        return None, None
 
 
 if __name__ == "__main__":

@@ -614,6 +614,19 @@ int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row) {
   return COLTT_OK;
 }
 
+int coltt_flat_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows, uint64_t* out_ids) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_fetch_rows: unknown handle");
+  if (n == 0) return COLTT_OK;
+  ReadLock g(f->rw);
+  COLTT_TRY(use_device(f->device));
+  if (first_slot + n > f->n) return fail(COLTT_E_INVALID, "flat_fetch_rows: range outside [0,%llu)", (unsigned long long)f->n);
+  const size_t rb = (size_t)f->dim * quant_bytes(f->quant);
+  if (out_rows) COLTT_HIP(hipMemcpy2D(out_rows, rb, f->rows.as<uint8_t>() + first_slot * f->stride, f->stride, rb, n, hipMemcpyDeviceToHost));
+  if (out_ids) for (uint64_t i = 0; i < n; i++) out_ids[i] = f->dense ? f->dense_base + first_slot + i : f->h_ids[first_slot + i];
+  return COLTT_OK;
+}
+
 int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,
                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
   auto f = lookup<Flat>(h);

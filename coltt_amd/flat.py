@@ -18,6 +18,8 @@ class FlatSpace:
         self.h = h
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.h = None
         if getattr(self, "h", None) is not None:
             L.lib().coltt_flat_destroy(self.h)
             self.h = None
@@ -68,6 +70,23 @@ class FlatSpace:
         dt = {L.Q_NONE: np.float32, L.Q_F8: np.uint8}.get(self.quantization, np.uint16)
         o = np.empty(self.dim, dt)
         L.check(L.lib().coltt_flat_get(self.h, C.c_uint64(int(id_)), L.vp(o)))
+        return o
+
+    def FetchRows(self, first=0, n=None, out=None, with_ids=False):
+        """stored rows [first, first+n) in scan order (bulk coltt_flat_get); `out` may be a preallocated array."""
+        n = self.LoadSize() - first if n is None else n
+        dt = {L.Q_NONE: np.float32, L.Q_F8: np.uint8}.get(self.quantization, np.uint16)
+        if out is None:
+            out = np.empty((n, self.dim), dt)
+        ids = np.empty(n, np.uint64) if with_ids else None
+        L.check(L.lib().coltt_flat_fetch_rows(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out), L.vp(ids)))
+        return (out, ids) if with_ids else out
+
+    @classmethod
+    def from_handle(cls, h, dim, distance, quantization):
+        """wrap a handle owned by someone else (a group member): close() will not destroy it"""
+        o = cls.__new__(cls)
+        o.h, o.dim, o.distance, o.quantization, o._borrowed = h, int(dim), distance, quantization, True
         return o
 
     # -- VertexSearch (edge/none_vectorstore.go:129-180) for a batch of targets

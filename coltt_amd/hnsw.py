@@ -34,7 +34,18 @@ class Hnsw:
         self.cfg = HnswCfg()
         L.check(L.lib().coltt_hnsw_get_cfg(self.h, C.byref(self.cfg)))
 
+    @classmethod
+    def from_handle(cls, h, dim, distance, quantization):
+        """wrap a handle owned by someone else (a group member): close() will not destroy it"""
+        o = cls.__new__(cls)
+        o.h, o.dim, o.distance, o.quantization, o._borrowed = h, int(dim), distance, quantization, True
+        o.cfg = HnswCfg()
+        o.Config()
+        return o
+
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self.h = None
         if getattr(self, "h", None) is not None:
             L.lib().coltt_hnsw_destroy(self.h)
             self.h = None
@@ -143,12 +154,13 @@ class Hnsw:
         L.check(L.lib().coltt_hnsw_export_raw(self.h, C.byref(ns), C.byref(nu), C.byref(ent), C.byref(el), L.vp(adj0), L.vp(uo), L.vp(adjU)))
         return {"adj0": adj0, "upper_off": uo, "adjU": adjU, "entry": ent.value, "entry_level": el.value, "n": ns.value}
 
-    def FetchRows(self, first=0, n=None):
+    def FetchRows(self, first=0, n=None, out=None):
         ns = C.c_uint64(0)
         L.check(L.lib().coltt_hnsw_export_raw(self.h, C.byref(ns), None, None, None, None, None, None))
         n = ns.value - first if n is None else n
         dt = {L.Q_NONE: np.float32, L.Q_F8: np.uint8}.get(self.quantization, np.uint16)
-        out = np.empty((n, self.dim), dt)
+        if out is None:
+            out = np.empty((n, self.dim), dt)
         L.check(L.lib().coltt_hnsw_fetch_rows(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out)))
         return out
 

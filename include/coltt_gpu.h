@@ -89,6 +89,9 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n);
 int coltt_flat_len(coltt_handle_t h, uint64_t* out);
 /* stored (lowered) bits of one vertex — what SaveVertex serialises (none_vectorstore.go:308-390) */
 int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row);
+/* stored rows [first_slot, first_slot + n) in scan order, and their ids — the bulk form of coltt_flat_get (what SaveVertex
+ * walks); either output may be NULL */
+int coltt_flat_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows, uint64_t* out_ids);
 /* VertexSearch for a batch of queries (edge/none_vectorstore.go:129-180; f16_vectorstore.go:131-186).
  * out_ids/out_scores are [nq][k]; out_counts[q] = min(k, len).  Rows ascending by (score, id). */
 int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,

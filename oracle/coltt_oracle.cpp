@@ -823,10 +823,39 @@ static inline const uint32_t* csr_row(const CsrGraph& g, uint32_t s, int level, 
   if (level == 0) { w = g.w0; return g.adj0 + (size_t)s * g.w0; }
   w = g.wu; return g.adjU + ((size_t)g.upper_off[s] + (uint32_t)(level - 1)) * g.wu;
 }
+// Per-thread scratch reused across queries.  The reference allocates a fresh visited map and fresh heaps per query and leaves
+// them to the Go GC (hnsw.go:346-352); doing the same with malloc/free from 256 threads serialises them on the kernel's
+// address-space lock (heap trims / re-faults), which would make the all-cores baseline an artefact.  Set semantics are unchanged.
+struct VisitedTable {  // open addressing, generation-stamped (O(1) clear), grows at 50 % load
+  std::vector<uint32_t> key, gen; uint32_t cur = 0, mask = 0, count = 0;
+  void reset(size_t expect) {
+    size_t cap = 1024; while (cap < expect * 4) cap <<= 1;
+    if (key.size() < cap) { key.assign(cap, 0); gen.assign(cap, 0); cur = 0; }
+    mask = (uint32_t)key.size() - 1; count = 0;
+    if (++cur == 0) { std::fill(gen.begin(), gen.end(), 0u); cur = 1; }
+  }
+  bool insert(uint32_t k) {  // true = newly inserted
+    if ((size_t)count * 2 > key.size()) grow();
+    uint32_t h = (k * 2654435761u) & mask;
+    while (gen[h] == cur) { if (key[h] == k) return false; h = (h + 1) & mask; }
+    gen[h] = cur; key[h] = k; count++;
+    return true;
+  }
+  void grow() {
+    std::vector<uint32_t> ok, og; ok.swap(key); og.swap(gen);
+    const uint32_t oc = cur;
+    key.assign(ok.size() * 2, 0); gen.assign(ok.size() * 2, 0); mask = (uint32_t)key.size() - 1; cur = 1; count = 0;
+    for (size_t i = 0; i < ok.size(); i++) if (og[i] == oc) insert(ok[i]);
+  }
+};
+struct CsrScratch { std::vector<float> qn, rowbuf; std::vector<uint8_t> qlow; std::vector<RItem> res, adm; VisitedTable visited; };
+
 static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int32_t* out_slots, float* out_scores, uint64_t* st) {
-  std::vector<float> qn(g.dim), rowbuf(g.dim); const float* q = query;
+  static thread_local CsrScratch S;
+  std::vector<float>& qn = S.qn; std::vector<float>& rowbuf = S.rowbuf; std::vector<uint8_t>& qlow = S.qlow;
+  qn.resize(g.dim); rowbuf.resize(g.dim);
+  const float* q = query;
   if (g.metric == METRIC_COS) { normalize(query, qn.data(), g.dim); q = qn.data(); }
-  std::vector<uint8_t> qlow;
   if (g.quant != Q_NONE) {  // the query is lowered too, then both operands are decoded per pair (f16_vectorstore.go:136, f16_quantization.go:35-45)
     qlow.resize((size_t)g.dim * quant_bytes(g.quant)); lower(g.quant, q, g.dim, qlow.data());
     raise(g.quant, qlow.data(), g.dim, qn.data()); q = qn.data();
@@ -854,9 +883,9 @@ static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int3
       ep = (uint32_t)closest;
     }
   }
-  std::vector<RItem> res; res.push_back({D(ep), (int32_t)ep, false});
-  std::unordered_set<uint32_t> visited; visited.reserve((size_t)ef * g.w0); visited.insert(ep);
-  std::vector<RItem> adm;
+  std::vector<RItem>& res = S.res; res.clear(); res.reserve((size_t)ef + g.w0 + 1); res.push_back({D(ep), (int32_t)ep, false});
+  VisitedTable& visited = S.visited; visited.reset((size_t)ef * g.w0); visited.insert(ep);
+  std::vector<RItem>& adm = S.adm;
   for (;;) {
     int ci = -1;
     for (int i = 0; i < (int)res.size(); i++) if (!res[i].expanded) { ci = i; break; }
@@ -868,7 +897,7 @@ static int csr_search(const CsrGraph& g, const float* query, int k, int ef, int3
     for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
       uint32_t nb = row[j];
       if (csr_deleted(g, nb)) continue;
-      if (!visited.insert(nb).second) continue;
+      if (!visited.insert(nb)) continue;
       float d = D(nb);
       if (free_slots > 0) { adm.push_back({d, (int32_t)nb, false}); free_slots--; }
       else if (d < lowerBound) adm.push_back({d, (int32_t)nb, false});
@@ -1400,6 +1429,24 @@ void* orc_numa_alloc(size_t bytes, int n_threads, int* out_flags) {
   return p;
 }
 void orc_numa_free(void* p, size_t bytes) { if (p) munmap(p, bytes ? bytes : 1); }
+
+// Streaming-read bandwidth of `bytes` of `p` on n_threads pinned threads (GB/s): the DRAM ceiling the CPU legs are quoted against.
+double orc_membw(const void* p, size_t bytes, int n_threads, int reps) {
+  if (n_threads < 1) n_threads = 1;
+  if (reps < 1) reps = 1;
+  std::vector<double> sink((size_t)n_threads, 0.0);
+  const size_t n8 = bytes / 32;
+  double w = run_threads(n_threads, 1, [&](int t) {
+    const v8f* a = (const v8f*)p; v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < reps; r++) {
+      const size_t lo = n8 * (size_t)t / (size_t)n_threads, hi = n8 * (size_t)(t + 1) / (size_t)n_threads;
+      for (size_t i = lo; i < hi; i++) { v8f x; std::memcpy(&x, &a[i], 32); acc += x; }
+    }
+    sink[(size_t)t] = acc[0] + acc[3];
+  });
+  double chk = 0; for (double v : sink) chk += v;
+  return (chk == 12345.678 ? 0.0 : 1.0) * (double)bytes * reps / w / 1e9;
+}
 
 // Hnsw.Search for nq queries on n_threads native threads (one query per thread at a time, work pulled from a shared counter).
 // Returns the wall time of the parallel region through *wall_s.  stats3 is summed over all queries.

@@ -460,3 +460,11 @@ def flat_scan(rows, quant, dim, metric, queries, k, nearest=True, shape=0, split
     if rc != 0:
         raise ValueError("orc_flat_scan_mt: split > 1 needs threads == split")
     return sl, sc, cn, wall.value
+
+
+def membw(arr, threads=None, reps=1, max_bytes=8 << 30):
+    """streaming-read GB/s over (a prefix of) arr on pinned threads — the DRAM ceiling quoted beside the CPU legs"""
+    L = lib(); L.orc_membw.restype = C.c_double
+    L.orc_membw.argtypes = [_vp, C.c_size_t, C.c_int, C.c_int]
+    nbytes = int(min(arr.nbytes, max_bytes))
+    return float(L.orc_membw(arr.ctypes.data_as(_vp), C.c_size_t(nbytes), int(threads or cpu_count()), int(reps)))
