@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("COLTT_OUT", os.path.join(HERE, "libcoltt_gpu.so"))
-OBJ = os.path.join(HERE, "csrc", "_obj")
+OBJ = os.environ.get("COLTT_OBJ", os.path.join(HERE, "csrc", "_obj"))
 # -ffp-contract=off : the exact-order kernels must never fuse a*b+c (the reference's AVX code has no FMA).
 # denormals are kept (no -fgpu-flush-denormals-to-zero): the "f8" codec decodes to an f32 denormal.
 EXTRA = os.environ.get("COLTT_EXTRA_FLAGS", "").split()

@@ -17,6 +17,8 @@
 #include "exact.hpp"
 #include "prep.hpp"
 #include "flat_mfma.hpp"
+#include "flat_mfma2.hpp"
+#include "flat_mfma3.hpp"
 #include "select.hpp"
 
 using namespace coltt;
@@ -24,6 +26,7 @@ using namespace coltt::dev;
 
 namespace {
 
+constexpr uint64_t ROW_SLACK = 512;  // see Flat::reserve
 constexpr int QB = 16;            // queries per row read in the exact scan (dim <= 1024; 4 above that: LDS query tile)
 
 // ---------------------------------------------------------------------------------------------------
@@ -189,8 +192,10 @@ struct Flat : Object {
     if (rows_needed <= cap) return COLTT_OK;
     uint64_t ncap = std::max<uint64_t>(rows_needed, cap + cap / 2);
     ncap = std::max<uint64_t>(ncap, 1024);
-    COLTT_TRY(rows.reserve(ncap * stride, true, stream));
-    COLTT_TRY(norms.reserve(ncap * 4, true, stream));
+    // ROW_SLACK rows (and norms) behind the capacity: the matrix-core scan fetches whole 256/384-row tiles without clamping
+    // the last one (flat_mfma3.hpp); what it reads there is never scored
+    COLTT_TRY(rows.reserve((ncap + ROW_SLACK) * stride, true, stream));
+    COLTT_TRY(norms.reserve((ncap + 2 * ROW_SLACK) * 4, true, stream));
     if (!dense) COLTT_TRY(ids.reserve(ncap * 8, true, stream));
     cap = ncap;
     return COLTT_OK;
@@ -302,9 +307,44 @@ int search_group_exact(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neare
   return COLTT_OK;
 }
 
+// COLTT_MFMA_GEN=1 selects the first-generation kernel (register-staged 128-row tiles) for A/B measurements; default is the
+// LDS-DMA ring (flat_mfma2.hpp).
+static int mfma_generation() {
+  static const int v = [] { const char* e = getenv("COLTT_MFMA_GEN"); return e && *e ? atoi(e) : 3; }();
+  return v;
+}
+
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                       unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
+                       unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed) {
+  if (mfma_generation() >= 3) {
+#ifdef COLTT_M3_BM
+    constexpr int BM = (!AF32 && BN == 256) ? COLTT_M3_BM : M2_BM;
+#else
+    constexpr int BM = M2_BM;
+#endif
+    auto kern = seed ? flat_mfma3_kernel<BN, AF32, true, BM> : flat_mfma3_kernel<BN, AF32, false, BM>;
+    const size_t lds = M3Geom<BN, AF32, BM>::LDS;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t tiles = (e - b + BM - 1) / BM;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+                                          nearest, cand, cnt, cap);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
+  if (mfma_generation() != 1) {
+    // seed = the first, unfiltered segment (every score passes, e - b <= cap): candidates are written in place, no atomics
+    auto kern = seed ? flat_mfma2_kernel<BN, AF32, true> : flat_mfma2_kernel<BN, AF32, false>;
+    const size_t lds = M2Geom<BN, AF32>::LDS;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+                                          nearest, cand, cnt, cap);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
   auto kern = flat_mfma_cos_kernel<BN, AF32>;
   const size_t lds = mfma_lds_bytes<BN>();
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -318,17 +358,16 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
 
 template <int BN>
 int launch_mfma_scan(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                     unsigned long long* cand, uint32_t* cnt, uint32_t cap) {
-  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
-  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap);
+                     unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed) {
+  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed);
+  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed);
 }
 
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
 int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
-                      uint32_t* d_out_cnt, uint32_t cap, bool* used_fallback) {
+                      uint32_t* d_out_cnt, uint32_t cap, uint32_t* ovf) {
   uint32_t* cnt = c->w_cnt.as<uint32_t>();
   uint32_t* thr = cnt + 256;
-  uint32_t* ovf = cnt + 512;
   unsigned long long* cur = c->w_cand.as<unsigned long long>();
   unsigned long long* oth = c->w_cand2.as<unsigned long long>();
   const uint64_t* ids = f->dense ? nullptr : f->ids.as<uint64_t>();
@@ -336,12 +375,12 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   const float* qn = c->w_qn.as<float>() + q0;
   _Float16* q16 = c->w_q16.as<_Float16>();
   const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
-  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, q16);
-  init_group_kernel<<<1, 256, 0, c->stream>>>(cnt, thr, ovf, nearest);
+  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, q16, cnt, thr, ovf, nearest);
   auto scan = [&](uint64_t b, uint64_t e) -> int {
-    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
-    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap));
+    const bool seed = b == 0 && e - b <= cap;
+    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
+    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
+    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
     flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     std::swap(cur, oth);
     return COLTT_OK;
@@ -352,17 +391,12 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   // ONE big segment left p = k/8192 for the whole scan: 72 % of the wave-blocks took the element path, 12k survivors/query.)
   // (the seed is small: all of its s0 x g scores are appended through atomics — 8192 rows x 256 queries took 0.7 ms)
   uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(1024, 16ull * k)});
-  for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * 8)) COLTT_TRY(scan(b, e));
-  struct { uint32_t cnt[256]; } hc;
-  uint32_t h_ovf = 0;
-  COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
-  COLTT_HIP(hipMemcpyAsync(hc.cnt, cnt, 256 * 4, hipMemcpyDeviceToHost, c->stream));
-  COLTT_HIP(hipStreamSynchronize(c->stream));
-  if (h_ovf) { *used_fallback = true; return COLTT_OK; }  // candidate list overflowed: caller re-runs the group in exact mode
-  uint32_t maxc = 0;
-  for (int i = 0; i < g; i++) maxc = std::max(maxc, hc.cnt[i]);
-  if (maxc) {
-    dim3 grid(ceil_div(maxc, 32), g);
+  static const uint64_t grow = [] { const char* e = getenv("COLTT_MFMA_GROW"); long v = e && *e ? atol(e) : 16; return (uint64_t)(v < 2 ? 2 : v); }();
+  for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * grow)) COLTT_TRY(scan(b, e));
+  // exact re-score of the survivors + the ordinary select, queued behind the scans with no host round trip in between; the
+  // overflow flag is read once at the end (a group whose candidate list overflowed is re-run in exact mode by the caller)
+  {
+    dim3 grid(16, g);
     if (f->quant == COLTT_Q_NONE) flat_rescore_kernel<Q_NONE><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
     else flat_rescore_kernel<Q_F16><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
   }
@@ -381,21 +415,36 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
   if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * f->dim * 2)); }
-  COLTT_TRY(c->w_cnt.reserve(4096));
+  const size_t n_groups = (nq + gq - 1) / gq;
+  COLTT_TRY(c->w_cnt.reserve(4096 + n_groups * 4));
+  uint32_t* d_ovf = c->w_cnt.as<uint32_t>() + 1024;   // one overflow flag per matrix-core group, checked once after the last group
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
-  for (size_t q0 = 0; q0 < nq; q0 += gq) {
-    int g = (int)std::min<size_t>(gq, nq - q0);
-    if (mfma) {
-      bool fb = false;
-      COLTT_TRY(search_group_mfma(f, c, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, &fb));
+  if (mfma) {
+    for (size_t q0 = 0, gi = 0; q0 < nq; q0 += gq, gi++) {
+      int g = (int)std::min<size_t>(gq, nq - q0);
+      COLTT_TRY(search_group_mfma(f, c, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, d_ovf + gi));
       f->mfma_groups.fetch_add(1);
-      if (!fb) continue;
+    }
+    COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+    std::vector<uint32_t> h_ovf(n_groups);
+    COLTT_HIP(hipMemcpyAsync(h_ovf.data(), d_ovf, n_groups * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipStreamSynchronize(c->stream));
+    bool any = false;
+    for (size_t gi = 0; gi < n_groups; gi++) {
+      if (!h_ovf[gi]) continue;  // candidate list overflowed (adversarial data): that group is re-run in exact mode
+      any = true;
       f->mfma_fallbacks.fetch_add(1);
+      const size_t q0 = gi * gq; const int g = (int)std::min<size_t>(gq, nq - q0);
       for (size_t s = 0; s < (size_t)g; s += scan_qb(f))
         COLTT_TRY(search_group_exact(f, c, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
-    } else {
-      COLTT_TRY(search_group_exact(f, c, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     }
+    if (any) COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
+  for (size_t q0 = 0; q0 < nq; q0 += gq) {
+    int g = (int)std::min<size_t>(gq, nq - q0);
+    COLTT_TRY(search_group_exact(f, c, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
   }
   COLTT_HIP(hipEventRecord(c->ev1, c->stream));
   COLTT_HIP(hipGetLastError());

@@ -44,7 +44,13 @@ constexpr float MF_MARGIN_F32 = 2.6e-3f;
 template <int BN> constexpr size_t mfma_lds_bytes() { return (size_t)2 * (MF_BM + BN) * MF_LD * 2 + MF_BM * 4; }
 
 // queries as f16 [BN][dim]: exact for the 2-byte stores (q_eff went through Lower), rounded to nearest for f32 stores
-__global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq, int bn, int dim, _Float16* __restrict__ q16) {
+// (also resets the group state cnt[256] | thr[256] | overflow: one launch less in the chain)
+__global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq, int bn, int dim, _Float16* __restrict__ q16,
+                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ thr, uint32_t* __restrict__ overflow, int nearest) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 256) { cnt[threadIdx.x] = 0; thr[threadIdx.x] = nearest ? 0xffffffffu : 0u; }
+    if (threadIdx.x == 0) *overflow = 0;
+  }
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)bn * dim) return;
   int q = (int)(i / dim);
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
 }
 
 // Exact re-score of the survivors: lane pair per (query, candidate); the key's score half is replaced by the exact score.
+// Grid-stride over the query's list, so the launch needs no host-side knowledge of the list lengths (no mid-chain sync).
 template <int QUANT>
 __global__ __launch_bounds__(64) void flat_rescore_kernel(const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms, int dim,
@@ -311,14 +318,15 @@ __global__ __launch_bounds__(64) void flat_rescore_kernel(const uint8_t* __restr
                                                          uint32_t cap) {
   const int q = blockIdx.y;
   const int lane = threadIdx.x, half = lane & 1;
-  const uint32_t j = blockIdx.x * 32 + (lane >> 1);
   const uint32_t c = cnt_all[q] < cap ? cnt_all[q] : cap;
-  if (blockIdx.x * 32 >= c) return;
   unsigned long long* cand = cand_all + (size_t)q * cap;
-  const bool valid = j < c;
-  const uint32_t slot = (uint32_t)cand[valid ? j : 0];
-  float d = pair_distance<M_COS, QUANT, 4>(rows + (size_t)slot * stride, q_eff + (size_t)q * dim, dim, qnorms[q], norms[slot], half);
-  if (valid && half == 0) cand[j] = ((unsigned long long)score_key(d) << 32) | slot;
+  for (uint32_t j0 = blockIdx.x * 32; j0 < c; j0 += gridDim.x * 32) {
+    const uint32_t j = j0 + (lane >> 1);
+    const bool valid = j < c;
+    const uint32_t slot = (uint32_t)cand[valid ? j : 0];
+    float d = pair_distance<M_COS, QUANT, 4>(rows + (size_t)slot * stride, q_eff + (size_t)q * dim, dim, qnorms[q], norms[slot], half);
+    if (valid && half == 0) cand[j] = ((unsigned long long)score_key(d) << 32) | slot;
+  }
 }
 
 }  // namespace dev
