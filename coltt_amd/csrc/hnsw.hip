@@ -1275,6 +1275,26 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
   return COLTT_OK;
 }
 
+int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_level) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_get: unknown handle");
+  ReadLock g(x->rw);
+  COLTT_TRY(use_device(x->device));
+  uint64_t slot;
+  if (x->dense) {
+    if (id < x->dense_base || id >= x->dense_base + x->n) return fail(COLTT_E_NOT_FOUND, "Item not found");
+    slot = id - x->dense_base;
+    if ((x->h_del[slot >> 5] >> (slot & 31)) & 1u) return fail(COLTT_E_NOT_FOUND, "Item not found");
+  } else {
+    auto it = x->id2slot.find(id);
+    if (it == x->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "Item not found");  // ItemNotFoundError (hnsw.go:177,188)
+    slot = it->second;
+  }
+  if (out_row) COLTT_HIP(hipMemcpy(out_row, x->rows.as<uint8_t>() + slot * x->stride, (size_t)x->dim * quant_bytes(x->quant), hipMemcpyDeviceToHost));
+  if (out_level) *out_level = x->h_levels[slot];
+  return COLTT_OK;
+}
+
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms) {
   if (!out_ms) return fail(COLTT_E_INVALID, "last_kernel_ms: NULL out");
   if (auto x = lookup<Hnsw>(h)) { *out_ms = x->last_ms.load(); return COLTT_OK; }

@@ -69,6 +69,13 @@ class Hnsw:
         L.check(L.lib().coltt_hnsw_get_cfg(self.h, C.byref(self.cfg)))
         return self.cfg
 
+    def Get(self, id_):
+        """Hnsw.Get(id) / GetVertex(id) (hnsw.go:169-189): (stored vector, level) of a live vertex."""
+        dt = {L.Q_NONE: np.float32, L.Q_F8: np.uint8}.get(self.quantization, np.uint16)
+        o = np.empty(self.dim, dt); lv = C.c_int32(0)
+        L.check(L.lib().coltt_hnsw_get(self.h, C.c_uint64(int(id_)), L.vp(o), C.byref(lv)))
+        return o, lv.value
+
     def RandomLevel(self, u):
         """Hnsw.RandomLevel() (hnsw.go:280-282) for a uniform draw u in (0,1) supplied by the caller."""
         lv = C.c_int32(0)

@@ -1,50 +1,96 @@
 package colttgpu
 
-/*
-#include "coltt_gpu.h"
-*/
-import "C"
-
 import (
+	"fmt"
 	"time"
-	"unsafe"
 )
 
 // Batcher coalesces the reference's one-query-per-RPC calls (core/core.go:633-695, edge/edge.go:610-690) into GPU batches:
-// goroutines enqueue a query and block on a channel; the collector flushes when MaxBatch queries are waiting or
-// MaxWait elapsed and issues ONE coltt_hnsw_search with nq = len(batch).
+// goroutines enqueue a query and block on a channel; the collector flushes when MaxBatch queries are waiting or MaxWait
+// elapsed since the first of them and issues ONE batched search per distinct k.  Same semantics as the compiled C++ twin
+// include/coltt_batcher.hpp (which is the one exercised on the GPU here — no Go toolchain in the build container):
+//   - queries are GROUPED BY k: HNSW searches with ef = max(cfg.ef, k), so answers for different k are not prefixes of one
+//     another; a k = 10 query batched with a k = 500 query must get exactly what a single-query call returns;
+//   - k == 0 answers immediately with an empty result (hnsw.go:243-278 returns no rows), it never reaches the backend;
+//   - len(query) != dim is an error for THAT caller only (C never reads past a short Go slice).
+//
+// Backend is any batched search: HnswBackend / FlatBackend below, or a test double.
+type Backend func(queries []float32, nq int, k uint32) (ids []uint64, scores []float32, counts []uint32, err error)
+
+type BatchItem struct {
+	Id    uint64
+	Score float32
+}
+
 type Batcher struct {
-	x        *Hnsw
+	dim      int
+	backend  Backend
 	MaxBatch int
 	MaxWait  time.Duration
 	in       chan *pending
+	quit     chan struct{}
 }
 
 type pending struct {
 	q    []float32
-	k    uint
+	k    uint32
 	done chan batchResult
 }
 type batchResult struct {
-	res SearchResult
-	err error
+	items []BatchItem
+	err   error
 }
 
-func NewBatcher(x *Hnsw, maxBatch int, maxWait time.Duration) *Batcher {
-	b := &Batcher{x: x, MaxBatch: maxBatch, MaxWait: maxWait, in: make(chan *pending, 4*maxBatch)}
+func NewBatcher(dim int, backend Backend, maxBatch int, maxWait time.Duration) *Batcher {
+	if maxBatch < 1 {
+		maxBatch = 1
+	}
+	b := &Batcher{dim: dim, backend: backend, MaxBatch: maxBatch, MaxWait: maxWait, in: make(chan *pending, 4*maxBatch),
+		quit: make(chan struct{})}
 	go b.loop()
 	return b
 }
 
-func (b *Batcher) Search(q []float32, k uint) (SearchResult, error) {
-	p := &pending{q: q, k: k, done: make(chan batchResult, 1)}
-	b.in <- p
+func (b *Batcher) Close() { close(b.quit) }
+
+// HnswBackend / FlatBackend: the two searches that need batching (BASELINE.json configs 2-5)
+func HnswBackend(h Handle, dim uint32, ef uint32) Backend {
+	return func(q []float32, nq int, k uint32) ([]uint64, []float32, []uint32, error) {
+		return HnswSearch(h, dim, q, nq, k, ef)
+	}
+}
+func FlatBackend(h Handle, dim uint32, sel, mode int) Backend {
+	return func(q []float32, nq int, k uint32) ([]uint64, []float32, []uint32, error) {
+		return FlatSearch(h, dim, q, nq, k, sel, mode, nil, false)
+	}
+}
+
+// Search blocks until the batch this query rode in has been answered.  The query is copied before it is queued.
+func (b *Batcher) Search(q []float32, k uint) ([]BatchItem, error) {
+	if len(q) != b.dim {
+		return nil, fmt.Errorf("Dim Length UnmatchdError: expect dimension: [%d], but got [%d]", b.dim, len(q))
+	}
+	if k == 0 {
+		return []BatchItem{}, nil
+	}
+	p := &pending{q: append([]float32(nil), q...), k: uint32(k), done: make(chan batchResult, 1)}
+	select {
+	case b.in <- p:
+	case <-b.quit:
+		return nil, fmt.Errorf("batcher closed")
+	}
 	r := <-p.done
-	return r.res, r.err
+	return r.items, r.err
 }
 
 func (b *Batcher) loop() {
-	for first := range b.in {
+	for {
+		var first *pending
+		select {
+		case first = <-b.in:
+		case <-b.quit:
+			return
+		}
 		batch := []*pending{first}
 		timer := time.NewTimer(b.MaxWait)
 	collect:
@@ -62,39 +108,33 @@ func (b *Batcher) loop() {
 }
 
 func (b *Batcher) flush(batch []*pending) {
-	var kmax uint
+	byK := map[uint32][]*pending{}
+	var order []uint32
 	for _, p := range batch {
-		if p.k > kmax {
-			kmax = p.k
+		if _, ok := byK[p.k]; !ok {
+			order = append(order, p.k)
 		}
+		byK[p.k] = append(byK[p.k], p)
 	}
-	nq, dim := len(batch), int(b.x.dim)
-	flat := make([]float32, nq*dim) // the library copies inputs before returning: no Go pointer is retained
-	for i, p := range batch {
-		copy(flat[i*dim:], p.q)
-	}
-	ids := make([]uint64, nq*int(kmax))
-	sc := make([]float32, nq*int(kmax))
-	cnt := make([]uint32, nq)
-	rc := C.coltt_hnsw_search(b.x.h, (*C.float)(unsafe.Pointer(&flat[0])), C.size_t(nq), C.uint32_t(kmax), 0,
-		(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&sc[0])), (*C.uint32_t)(unsafe.Pointer(&cnt[0])), nil)
-	err := toErr(rc)
-	for i, p := range batch {
-		if err != nil {
-			p.done <- batchResult{nil, err}
-			continue
+	for _, k := range order {
+		grp := byK[k]
+		nq := len(grp)
+		flat := make([]float32, nq*b.dim) // the library copies inputs before returning: no Go pointer is retained
+		for i, p := range grp {
+			copy(flat[i*b.dim:], p.q)
 		}
-		n := int(cnt[i])
-		if n > int(p.k) {
-			n = int(p.k) // identical to a single-query call whenever kmax <= cfg.ef (then ef = cfg.ef for everyone); group by k otherwise
+		ids, sc, cnt, err := b.backend(flat, nq, k)
+		for i, p := range grp {
+			if err != nil {
+				p.done <- batchResult{nil, err}
+				continue
+			}
+			n := int(cnt[i])
+			items := make([]BatchItem, n)
+			for j := 0; j < n; j++ {
+				items[j] = BatchItem{Id: ids[i*int(k)+j], Score: sc[i*int(k)+j]}
+			}
+			p.done <- batchResult{items, nil}
 		}
-		res := make(SearchResult, n)
-		b.x.mu.RLock()
-		for j := 0; j < n; j++ {
-			id := ids[i*int(kmax)+j]
-			res[j] = SearchResultItem{Id: id, Score: sc[i*int(kmax)+j], Metadata: b.x.meta[id]}
-		}
-		b.x.mu.RUnlock()
-		p.done <- batchResult{res, nil}
 	}
 }

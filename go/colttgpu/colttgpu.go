@@ -1,234 +1,353 @@
-// Package colttgpu — cgo shim that puts libcoltt_gpu.so behind the reference's Go interfaces.
+// Package colttgpu — the cgo layer under the two drop-in packages of this directory tree:
 //
-// NOT COMPILED in the build container (no Go toolchain there); shipped as source for the maintainer.  It mirrors
-//   edge.vectorspace      (edge/vectorstore.go:30-49)        -> GpuVecSpace
-//   *vectorindex.Hnsw     (core/vectorindex/hnsw.go:43-54)   -> Hnsw
-// Metadata never crosses the boundary: the shim keeps id -> Metadata and re-attaches it after each call.
+//	go/vectorindex  replacement body for github.com/sjy-dv/coltt/core/vectorindex   (*Hnsw and friends)
+//	go/edge         one extra file for package github.com/sjy-dv/coltt/edge          (gpuVecSpace, an edge.vectorspace)
+//
+// NOT COMPILED in the build container (no Go toolchain there); shipped as source for the maintainer (INTEGRATION.md).
+// Rules kept here once so the callers cannot get them wrong:
+//   - no Go pointer is retained by C: every call copies in / out before it returns;
+//   - coltt_last_error() is thread-local and a goroutine may migrate between OS threads across cgo calls, so every
+//     call + error fetch runs under runtime.LockOSThread (Call);
+//   - slices handed to C are validated against `dim` first — C never reads past a short Go slice.
 package colttgpu
 
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../coltt_amd -lcoltt_gpu -Wl,-rpath,${SRCDIR}/../../coltt_amd
+#include <stdlib.h>
 #include "coltt_gpu.h"
 */
 import "C"
 
 import (
-	"context"
 	"errors"
 	"fmt"
-	"math/rand"
-	"sync"
+	"runtime"
 	"unsafe"
 )
 
 var (
-	ItemNotFoundError      = errors.New("Item not found")      // core/vectorindex/hnsw.go:39
-	ItemAlreadyExistsError = errors.New("Item already exists") // core/vectorindex/hnsw.go:40
+	ErrNotFound = errors.New("Item not found")      // core/vectorindex/hnsw.go:39 ItemNotFoundError
+	ErrExists   = errors.New("Item already exists") // core/vectorindex/hnsw.go:40 ItemAlreadyExistsError
 )
 
-func toErr(rc C.int) error {
+type Handle = C.coltt_handle_t
+
+// HnswCfg mirrors coltt_hnsw_cfg (hnswConfig, core/vectorindex/hnsw_config.go:135-162).
+type HnswCfg struct {
+	M, MMax, MMax0, Ef, EfConstruction, Algo int32
+	LevelMultiplier                          float32
+	ExtendCandidates, KeepPruned             int32
+}
+
+func (c *HnswCfg) c() C.coltt_hnsw_cfg {
+	return C.coltt_hnsw_cfg{m: C.int32_t(c.M), m_max: C.int32_t(c.MMax), m_max0: C.int32_t(c.MMax0), ef: C.int32_t(c.Ef),
+		ef_construction: C.int32_t(c.EfConstruction), algo: C.int32_t(c.Algo), level_multiplier: C.float(c.LevelMultiplier),
+		extend_candidates: C.int32_t(c.ExtendCandidates), keep_pruned: C.int32_t(c.KeepPruned)}
+}
+
+// call runs one C entry point and turns its status into a Go error on the SAME OS thread that made the call.
+func call(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	rc := f()
 	switch rc {
 	case C.COLTT_OK:
 		return nil
 	case C.COLTT_E_NOT_FOUND:
-		return ItemNotFoundError
+		return ErrNotFound
 	case C.COLTT_E_EXISTS:
-		return ItemAlreadyExistsError
+		return ErrExists
 	}
 	return errors.New(C.GoString(C.coltt_last_error()))
 }
 
-type Metadata map[string]any
-
-type SearchResultItem struct {
-	Id       uint64
-	Metadata map[string]any
-	Score    float32
-}
-type SearchResult []SearchResultItem
-
-// ---------------------------------------------------------------------------------------------- HNSW
-type Hnsw struct {
-	h    C.coltt_handle_t
-	dim  uint
-	mu   sync.RWMutex
-	meta map[uint64]Metadata
-}
-
-// NewHnsw(dim, distancer, options...) — core/vectorindex/hnsw.go:56.  metric: 0 cosine-dot, 1 l2.
-func NewHnsw(dim uint, metric int, cfg *C.coltt_hnsw_cfg) (*Hnsw, error) {
-	x := &Hnsw{dim: dim, meta: map[uint64]Metadata{}}
-	if err := toErr(C.coltt_hnsw_create(C.uint32_t(dim), C.int(metric), C.COLTT_Q_NONE, cfg, &x.h)); err != nil {
-		return nil, err
+func checkDim(v []float32, dim uint32, n int) error {
+	if n == 0 || uint64(len(v)) != uint64(dim)*uint64(n) {
+		// edge/none_vectorstore.go:86-88
+		return fmt.Errorf("Dim Length UnmatchdError: expect dimension: [%d], but got [%d]", dim, len(v)/max1(n))
 	}
-	return x, nil
-}
-
-// Insert(id, value, metadata, vertexLevel) — hnsw.go:104
-func (x *Hnsw) Insert(id uint64, value []float32, metadata Metadata, vertexLevel int) error {
-	if uint(len(value)) != x.dim {
-		return fmt.Errorf("Dim Length UnmatchdError: expect dimension: [%d], but got [%d]", x.dim, len(value))
-	}
-	if err := toErr(C.coltt_hnsw_insert(x.h, C.uint64_t(id), (*C.float)(unsafe.Pointer(&value[0])), C.int32_t(vertexLevel))); err != nil {
-		return err
-	}
-	x.mu.Lock()
-	x.meta[id] = metadata
-	x.mu.Unlock()
 	return nil
 }
-
-// Remove(id) — hnsw.go:191
-func (x *Hnsw) Remove(id uint64) error {
-	if err := toErr(C.coltt_hnsw_remove(x.h, C.uint64_t(id))); err != nil {
-		return err
+func max1(n int) int {
+	if n < 1 {
+		return 1
 	}
-	x.mu.Lock()
-	delete(x.meta, id)
-	x.mu.Unlock()
-	return nil
+	return n
 }
-
-// Search(ctx, query, k) — hnsw.go:243.  One query per call as in the reference; see batcher.go for coalescing.
-func (x *Hnsw) Search(_ context.Context, query []float32, k uint) (SearchResult, error) {
-	if k == 0 {
-		return SearchResult{}, nil
-	}
-	ids := make([]uint64, k)
-	sc := make([]float32, k)
-	var cnt C.uint32_t
-	rc := C.coltt_hnsw_search(x.h, (*C.float)(unsafe.Pointer(&query[0])), 1, C.uint32_t(k), 0,
-		(*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&sc[0])), &cnt, nil)
-	if err := toErr(rc); err != nil {
-		return nil, err
-	}
-	res := make(SearchResult, int(cnt))
-	x.mu.RLock()
-	for i := range res {
-		res[i] = SearchResultItem{Id: ids[i], Score: sc[i], Metadata: x.meta[ids[i]]}
-	}
-	x.mu.RUnlock()
-	return res, nil
-}
-
-func (x *Hnsw) Len() int { var n C.uint64_t; C.coltt_hnsw_len(x.h, &n); return int(n) }
-
-// RandomLevel mirrors (*vectorindex.Hnsw).RandomLevel (hnsw.go:280-282): the uniform draw stays on the Go side
-// (math/rand, as in the reference), the library applies gomath.Floor(-gomath.Log(u) * levelMultiplier).
-func (x *Hnsw) RandomLevel() int {
-	u := rand.Float32()
-	for u <= 0 { // the reference would produce Floor(+Inf); redraw instead
-		u = rand.Float32()
-	}
-	var lv C.int32_t
-	C.coltt_hnsw_random_level(x.h, C.float(u), &lv)
-	return int(lv)
-}
-func (x *Hnsw) Dim() uint32 { return uint32(x.dim) }
-func (x *Hnsw) Close()    { C.coltt_hnsw_destroy(x.h) }
-
-// ---------------------------------------------------------------------------------------------- edge FLAT
-type ENode struct {
-	Vector   []float32
-	Metadata map[string]interface{}
-}
-
-// GpuVecSpace satisfies the vector half of edge.vectorspace (edge/vectorstore.go:30-49); the inverted index, metadata
-// analyzers and persistence stay in package edge and call into this type.
-type GpuVecSpace struct {
-	h        C.coltt_handle_t
-	dim      uint32
-	distance int
-	quant    int
-	mu       sync.RWMutex
-	meta     map[uint64]map[string]interface{}
-}
-
-func NewGpuVecSpace(dim uint32, distance, quantization int) (*GpuVecSpace, error) {
-	s := &GpuVecSpace{dim: dim, distance: distance, quant: quantization, meta: map[uint64]map[string]interface{}{}}
-	if err := toErr(C.coltt_flat_create(C.uint32_t(dim), C.int(distance), C.int(quantization), &s.h)); err != nil {
-		return nil, err // "not support quantization type" for unknown enums (edge/vectorstore.go:79)
-	}
-	return s, nil
-}
-
-// ChangedVertex — edge/none_vectorstore.go:66-103 (primary-key lookup / analyzers / inverted.Add happen in the caller)
-func (s *GpuVecSpace) ChangedVertex(commitId uint64, data ENode) error {
-	if s.dim != uint32(len(data.Vector)) {
-		return fmt.Errorf("Dim Length UnmatchdError: expect dimension: [%d], but got [%d]", s.dim, len(data.Vector))
-	}
-	id := C.uint64_t(commitId)
-	if err := toErr(C.coltt_flat_upsert(s.h, &id, (*C.float)(unsafe.Pointer(&data.Vector[0])), 1)); err != nil {
-		return err
-	}
-	s.mu.Lock()
-	s.meta[commitId] = data.Metadata
-	s.mu.Unlock()
-	return nil
-}
-
-// RemoveVertex — edge/none_vectorstore.go:118-124, after SearchMultiFilter resolved dropFilter to ids
-func (s *GpuVecSpace) RemoveVertex(dropIds []uint64) error {
-	if len(dropIds) == 0 {
+func fptr(v []float32) *C.float {
+	if len(v) == 0 {
 		return nil
 	}
-	if err := toErr(C.coltt_flat_remove(s.h, (*C.uint64_t)(unsafe.Pointer(&dropIds[0])), C.size_t(len(dropIds)))); err != nil {
+	return (*C.float)(unsafe.Pointer(&v[0]))
+}
+func uptr(v []uint64) *C.uint64_t {
+	if len(v) == 0 {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(&v[0]))
+}
+func bptr(v []byte) *C.uint8_t {
+	if len(v) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&v[0]))
+}
+
+func Init(device int) error { return call(func() C.int { return C.coltt_init(C.int(device)) }) }
+
+// ------------------------------------------------------------------------------------------------ HNSW
+func HnswCreate(dim uint32, metric, quant int, cfg *HnswCfg) (Handle, error) {
+	var h Handle
+	cc := cfg.c()
+	err := call(func() C.int { return C.coltt_hnsw_create(C.uint32_t(dim), C.int(metric), C.int(quant), &cc, &h) })
+	return h, err
+}
+func HnswDestroy(h Handle) { C.coltt_hnsw_destroy(h) }
+func HnswGetCfg(h Handle) (HnswCfg, error) {
+	var c C.coltt_hnsw_cfg
+	err := call(func() C.int { return C.coltt_hnsw_get_cfg(h, &c) })
+	return HnswCfg{int32(c.m), int32(c.m_max), int32(c.m_max0), int32(c.ef), int32(c.ef_construction), int32(c.algo),
+		float32(c.level_multiplier), int32(c.extend_candidates), int32(c.keep_pruned)}, err
+}
+func HnswInsert(h Handle, dim uint32, id uint64, v []float32, level int) error {
+	if err := checkDim(v, dim, 1); err != nil {
 		return err
 	}
-	s.mu.Lock()
-	for _, id := range dropIds {
-		delete(s.meta, id)
-	}
-	s.mu.Unlock()
-	return nil
+	return call(func() C.int { return C.coltt_hnsw_insert(h, C.uint64_t(id), fptr(v), C.int32_t(level)) })
+}
+func HnswRemove(h Handle, id uint64) error {
+	return call(func() C.int { return C.coltt_hnsw_remove(h, C.uint64_t(id)) })
+}
+func HnswLen(h Handle) int {
+	var n C.uint64_t
+	C.coltt_hnsw_len(h, &n)
+	return int(n)
 }
 
-// VertexSearch — edge/none_vectorstore.go:129-180.  COLTT_SELECT_REFERENCE reproduces the reference's queue exactly
-// (it keeps the K LARGEST distances, edge/priority_queue.go:46-55).
-func (s *GpuVecSpace) VertexSearch(target []float32, topK int, _ bool) ([]*SearchResultItem, error) {
-	return s.search(target, topK, nil)
+// HnswSearch: nq queries (row-major), k results each; returns ids, scores [nq*k] and counts [nq].
+func HnswSearch(h Handle, dim uint32, queries []float32, nq int, k uint32, ef uint32) ([]uint64, []float32, []uint32, error) {
+	if nq == 0 || k == 0 {
+		return nil, nil, make([]uint32, nq), nil
+	}
+	if err := checkDim(queries, dim, nq); err != nil {
+		return nil, nil, nil, err
+	}
+	ids := make([]uint64, nq*int(k))
+	sc := make([]float32, nq*int(k))
+	cnt := make([]uint32, nq)
+	err := call(func() C.int {
+		return C.coltt_hnsw_search(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.uint32_t(ef), uptr(ids), fptr(sc),
+			(*C.uint32_t)(unsafe.Pointer(&cnt[0])), nil)
+	})
+	return ids, sc, cnt, err
+}
+func HnswRandomLevel(h Handle, u float32) (int, error) {
+	var lv C.int32_t
+	err := call(func() C.int { return C.coltt_hnsw_random_level(h, C.float(u), &lv) })
+	return int(lv), err
 }
 
-// FilterableVertexSearch — edge/none_vectorstore.go:182-253, candidates = invertedIndex.SearchWithExpression(filter)
-func (s *GpuVecSpace) FilterableVertexSearch(candidates []uint64, target []float32, topK int, _ bool) ([]*SearchResultItem, error) {
-	if candidates == nil {
-		candidates = []uint64{}
-	}
-	return s.search(target, topK, candidates)
+// HnswGet: stored (normalised) f32 vector and level of a live vertex (hnsw.go:169-189).
+func HnswGet(h Handle, dim uint32, id uint64) ([]float32, int, error) {
+	v := make([]float32, dim)
+	var lv C.int32_t
+	err := call(func() C.int { return C.coltt_hnsw_get(h, C.uint64_t(id), unsafe.Pointer(&v[0]), &lv) })
+	return v, int(lv), err
 }
 
-func (s *GpuVecSpace) search(target []float32, topK int, cand []uint64) ([]*SearchResultItem, error) {
-	if topK <= 0 {
-		return []*SearchResultItem{}, nil
+// HnswSlots: ids of every slot in slot order and the deleted flags (what Commit walks).
+func HnswSlots(h Handle) (ids []uint64, deleted []byte, entryLevel int, err error) {
+	var ns, nr, ne C.uint64_t
+	var ent C.int32_t
+	if err = call(func() C.int { return C.coltt_hnsw_export(h, &ns, &nr, &ne, nil, nil, nil, nil, nil, nil, &ent) }); err != nil {
+		return
 	}
-	ids := make([]uint64, topK)
-	sc := make([]float32, topK)
-	var cnt C.uint32_t
-	var rc C.int
-	if cand == nil {
-		rc = C.coltt_flat_search(s.h, (*C.float)(unsafe.Pointer(&target[0])), 1, C.uint32_t(topK), C.COLTT_SELECT_REFERENCE,
-			C.COLTT_MODE_EXACT, (*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&sc[0])), &cnt)
+	ids = make([]uint64, int(ns))
+	deleted = make([]byte, int(ns))
+	lv := make([]int32, int(ns))
+	if ns > 0 {
+		err = call(func() C.int {
+			return C.coltt_hnsw_export(h, &ns, &nr, &ne, uptr(ids), (*C.int32_t)(unsafe.Pointer(&lv[0])), bptr(deleted), nil, nil, nil, &ent)
+		})
+	}
+	if err == nil && ent >= 0 {
+		entryLevel = int(lv[int(ent)])
 	} else {
-		var cp *C.uint64_t
-		if len(cand) > 0 {
-			cp = (*C.uint64_t)(unsafe.Pointer(&cand[0]))
-		}
-		rc = C.coltt_flat_search_ids(s.h, (*C.float)(unsafe.Pointer(&target[0])), 1, C.uint32_t(topK), C.COLTT_SELECT_REFERENCE,
-			cp, C.size_t(len(cand)), (*C.uint64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&sc[0])), &cnt)
+		entryLevel = -1
 	}
-	if err := toErr(rc); err != nil {
+	return
+}
+
+// HnswCommit: Hnsw.Commit stream (hnsw_commit.go:69-162); metaBlobs[slot] = that vertex's Metadata in stream encoding
+// (metadata.go:31-74), nil = empty map.
+func HnswCommit(h Handle, header bool, metaBlobs [][]byte) ([]byte, error) {
+	n := len(metaBlobs)
+	// C arrays of blob pointers live in C memory for the duration of the call (no Go pointer to Go pointer crosses cgo)
+	var cptr **C.uint8_t
+	var clen *C.uint32_t
+	var pins []unsafe.Pointer
+	if n > 0 {
+		cptr = (**C.uint8_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+		clen = (*C.uint32_t)(C.malloc(C.size_t(n) * 4))
+		defer C.free(unsafe.Pointer(cptr))
+		defer C.free(unsafe.Pointer(clen))
+		ps := unsafe.Slice(cptr, n)
+		ls := unsafe.Slice(clen, n)
+		for i, b := range metaBlobs {
+			if len(b) == 0 {
+				ps[i], ls[i] = nil, 0
+				continue
+			}
+			p := C.CBytes(b)
+			pins = append(pins, p)
+			ps[i], ls[i] = (*C.uint8_t)(p), C.uint32_t(len(b))
+		}
+		defer func() {
+			for _, p := range pins {
+				C.free(p)
+			}
+		}()
+	}
+	hd := C.int(0)
+	if header {
+		hd = 1
+	}
+	var need C.uint64_t
+	if err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, nil, 0, &need) }); err != nil {
 		return nil, err
 	}
-	out := make([]*SearchResultItem, int(cnt))
-	s.mu.RLock()
-	for i := range out {
-		out[i] = &SearchResultItem{Id: ids[i], Score: sc[i], Metadata: s.meta[ids[i]]}
-	}
-	s.mu.RUnlock()
-	return out, nil
+	out := make([]byte, int(need))
+	err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, bptr(out), need, &need) })
+	return out[:int(need)], err
 }
 
-func (s *GpuVecSpace) Dim() uint32     { return s.dim }
-func (s *GpuVecSpace) LoadSize() int64 { var n C.uint64_t; C.coltt_flat_len(s.h, &n); return int64(n) }
-func (s *GpuVecSpace) Close()          { C.coltt_flat_destroy(s.h) }
+// HnswLoad: Hnsw.Load (hnsw_commit.go:164-278) straight into HBM; returns each vertex's id and the position of its
+// metadata blob inside data (the caller decodes the msgpack values).
+func HnswLoad(h Handle, header bool, data []byte, dim uint32) (ids []uint64, metaOff []uint64, metaLen []uint32, err error) {
+	capN := uint64(len(data))/uint64(14+4*dim) + 1 // a vertex record is at least 8 + 4 + 4*dim + 2 bytes
+	ids = make([]uint64, capN)
+	metaOff = make([]uint64, capN)
+	metaLen = make([]uint32, capN)
+	hd := C.int(0)
+	if header {
+		hd = 1
+	}
+	var n C.uint64_t
+	err = call(func() C.int {
+		return C.coltt_hnsw_load(h, hd, bptr(data), C.uint64_t(len(data)), &n, uptr(ids), uptr(metaOff),
+			(*C.uint32_t)(unsafe.Pointer(&metaLen[0])), C.uint64_t(capN))
+	})
+	if err != nil {
+		return nil, nil, nil, err
+	}
+	return ids[:n], metaOff[:n], metaLen[:n], nil
+}
+
+// ------------------------------------------------------------------------------------------------ FLAT
+const (
+	SelectReference = int(C.COLTT_SELECT_REFERENCE) // what edge.PriorityQueue does: keeps the K LARGEST distances (priority_queue.go:39-55)
+	SelectNearest   = int(C.COLTT_SELECT_NEAREST)
+	ModeExact       = int(C.COLTT_MODE_EXACT)
+	ModeMFMA        = int(C.COLTT_MODE_MFMA)
+)
+
+func FlatCreate(dim uint32, metric, quant int) (Handle, error) {
+	var h Handle
+	err := call(func() C.int { return C.coltt_flat_create(C.uint32_t(dim), C.int(metric), C.int(quant), &h) })
+	return h, err
+}
+func FlatDestroy(h Handle) { C.coltt_flat_destroy(h) }
+func FlatLen(h Handle) int64 {
+	var n C.uint64_t
+	C.coltt_flat_len(h, &n)
+	return int64(n)
+}
+func FlatUpsert(h Handle, dim uint32, ids []uint64, vecs []float32) error {
+	if len(ids) == 0 {
+		return nil
+	}
+	if err := checkDim(vecs, dim, len(ids)); err != nil {
+		return err
+	}
+	return call(func() C.int { return C.coltt_flat_upsert(h, uptr(ids), fptr(vecs), C.size_t(len(ids))) })
+}
+func FlatRemove(h Handle, ids []uint64) error {
+	if len(ids) == 0 {
+		return nil
+	}
+	return call(func() C.int { return C.coltt_flat_remove(h, uptr(ids), C.size_t(len(ids))) })
+}
+
+// FlatSearch: cand == nil -> VertexSearch over the whole store; otherwise FilterableVertexSearch over the candidate ids.
+func FlatSearch(h Handle, dim uint32, queries []float32, nq int, k uint32, sel, mode int, cand []uint64, filtered bool) ([]uint64, []float32, []uint32, error) {
+	if nq == 0 || k == 0 {
+		return nil, nil, make([]uint32, nq), nil
+	}
+	if err := checkDim(queries, dim, nq); err != nil {
+		return nil, nil, nil, err
+	}
+	ids := make([]uint64, nq*int(k))
+	sc := make([]float32, nq*int(k))
+	cnt := make([]uint32, nq)
+	cp := (*C.uint32_t)(unsafe.Pointer(&cnt[0]))
+	var err error
+	if !filtered {
+		err = call(func() C.int {
+			return C.coltt_flat_search(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.int(sel), C.int(mode), uptr(ids), fptr(sc), cp)
+		})
+	} else {
+		err = call(func() C.int {
+			return C.coltt_flat_search_ids(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.int(sel), uptr(cand), C.size_t(len(cand)), uptr(ids), fptr(sc), cp)
+		})
+	}
+	return ids, sc, cnt, err
+}
+
+// FlatSaveVertex / FlatLoadVertex: the edge `.vertex` stream (none_vectorstore.go:308-516 and the f16/f8/bf16 twins).
+func FlatSaveVertex(h Handle, metaIds []uint64, metaBlobs [][]byte) ([]byte, error) {
+	n := len(metaIds)
+	var cptr **C.uint8_t
+	var clen *C.uint32_t
+	var pins []unsafe.Pointer
+	if n > 0 {
+		cptr = (**C.uint8_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+		clen = (*C.uint32_t)(C.malloc(C.size_t(n) * 4))
+		defer C.free(unsafe.Pointer(cptr))
+		defer C.free(unsafe.Pointer(clen))
+		ps := unsafe.Slice(cptr, n)
+		ls := unsafe.Slice(clen, n)
+		for i, b := range metaBlobs {
+			p := C.CBytes(b)
+			pins = append(pins, p)
+			ps[i], ls[i] = (*C.uint8_t)(p), C.uint32_t(len(b))
+		}
+		defer func() {
+			for _, p := range pins {
+				C.free(p)
+			}
+		}()
+	}
+	var need C.uint64_t
+	if err := call(func() C.int { return C.coltt_flat_save_vertex(h, uptr(metaIds), cptr, clen, C.uint64_t(n), nil, 0, &need) }); err != nil {
+		return nil, err
+	}
+	out := make([]byte, int(need))
+	err := call(func() C.int { return C.coltt_flat_save_vertex(h, uptr(metaIds), cptr, clen, C.uint64_t(n), bptr(out), need, &need) })
+	return out[:int(need)], err
+}
+func FlatLoadVertex(h Handle, data []byte, elemBytes int, dim uint32) (ids []uint64, metaOff []uint64, metaLen []uint32, err error) {
+	capN := uint64(len(data))/uint64(16+uint32(elemBytes)*dim) + 1 // key u64 + vecLen u32 + codes + metaCount u32
+	ids = make([]uint64, capN)
+	metaOff = make([]uint64, capN)
+	metaLen = make([]uint32, capN)
+	var n C.uint64_t
+	err = call(func() C.int {
+		return C.coltt_flat_load_vertex(h, bptr(data), C.uint64_t(len(data)), &n, uptr(ids), uptr(metaOff),
+			(*C.uint32_t)(unsafe.Pointer(&metaLen[0])), C.uint64_t(capN))
+	})
+	if err != nil {
+		return nil, nil, nil, err
+	}
+	return ids[:n], metaOff[:n], metaLen[:n], nil
+}

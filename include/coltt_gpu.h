@@ -201,7 +201,10 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
  * padded with 0xffffffff.  NULL arrays => sizes only. */
 int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper_rows, int32_t* entry_slot,
                           int32_t* entry_level, uint32_t* adj0, uint32_t* upper_off, uint32_t* adjU);
-/* Hnsw.Get(id)-style read-back (hnsw.go:169-178) for a slot range: the stored (normalised / lowered) row bytes. */
+/* Hnsw.Get(id) / Hnsw.GetVertex(id) (hnsw.go:169-189): the stored (normalised / lowered) vector and the level of one live
+ * vertex; COLTT_E_NOT_FOUND = ItemNotFoundError.  Either output may be NULL. */
+int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_level);
+/* the same read-back for a slot range (bulk): the stored row bytes. */
 int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows);
 /* last kernel timing of the handle's search stream, measured with hipEvents (milliseconds) */
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms);

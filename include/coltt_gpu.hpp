@@ -6,7 +6,9 @@
 //   coltt::Hnsw      <->  *vectorindex.Hnsw           (core/vectorindex/hnsw.go:43-54)
 // Metadata maps stay with the caller: results carry ids and scores only.
 #pragma once
+#include <cmath>
 #include <cstdint>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -33,11 +35,25 @@ using Vector = std::vector<float>;                                 // edge.Vecto
 struct SearchResultItem { uint64_t Id; float Score; };             // edge/priority_queue.go:27-31 minus Metadata
 using SearchResult = std::vector<SearchResultItem>;
 
-// edge.vectorspace implemented on the GPU
+// edge.Metadata (edge/edge_metadata.go:25-55): what CreateCollection fixes for a collection.  IndexType carries the caller's
+// index features by name (edge.IndexFeature is the inverted index's business — pkg/inverted is out of scope).
+struct CollectionMetadata {
+  uint32_t Dim = 0; int Distance = COLTT_COSINE; int Quantization = COLTT_Q_NONE; bool Versioning = false;
+  std::map<std::string, std::string> IndexType;
+};
+
+// edge.vectorspace implemented on the GPU — all 16 methods of edge/vectorstore.go:30-49.  Metadata maps and the inverted
+// index stay with the caller: ChangedVertex / RemoveVertex / FilterableVertexSearch take the ids the
+// caller's index resolved, Save/LoadVertexInverted carry the caller's serialized index as an opaque blob, results carry
+// ids and scores.  (The Go file go/edge/gpu_vectorstore.go is the variant that owns those parts inside package edge.)
 class VecSpace {
  public:
   VecSpace(uint32_t dim, int distance /*COLTT_COSINE|EUCLIDEAN*/, int quantization /*COLTT_Q_**/)
-      : dim_(dim), distance_(distance), quant_(quantization) { check(coltt_flat_create(dim, distance, quantization, &h_)); }
+      : dim_(dim), distance_(distance), quant_(quantization) {
+    meta_.Dim = dim; meta_.Distance = distance; meta_.Quantization = quantization;
+    check(coltt_flat_create(dim, distance, quantization, &h_));
+  }
+  explicit VecSpace(const CollectionMetadata& m) : VecSpace(m.Dim, m.Distance, m.Quantization) { meta_ = m; }
   ~VecSpace() { if (h_) coltt_flat_destroy(h_); }
   VecSpace(const VecSpace&) = delete;
   VecSpace& operator=(const VecSpace&) = delete;
@@ -82,21 +98,62 @@ class VecSpace {
     check(coltt_flat_load_vertex(h_, data.data(), data.size(), &n, nullptr, nullptr, nullptr, 0));
     return n;
   }
+  // SaveVertexMetadata / LoadVertexMetadata (none_vectorstore.go:255-274): the collection metadata as JSON; loading re-checks
+  // it against the device store (dim / distance / quantisation are fixed at creation).
+  std::string SaveVertexMetadata() const {
+    std::string j = "{\"dim\":" + std::to_string(meta_.Dim) + ",\"distance\":" + std::to_string(meta_.Distance) + ",\"quantization\":" +
+                    std::to_string(meta_.Quantization) + ",\"versioning\":" + (meta_.Versioning ? "true" : "false") + ",\"index_type\":{";
+    bool first = true;
+    for (auto& kv : meta_.IndexType) { j += (first ? "\"" : ",\"") + kv.first + "\":\"" + kv.second + "\""; first = false; }
+    return j + "}}";
+  }
+  void LoadVertexMetadata(const std::string& /*collectionName*/, const CollectionMetadata& m) {
+    if (m.Dim != dim_ || m.Distance != distance_ || m.Quantization != quant_)
+      throw Error(COLTT_E_INVALID, "LoadVertexMetadata: dim / distance / quantization differ from the device store's");
+    meta_ = m;
+  }
+  // SaveVertexInverted / LoadVertexInverted (:276-283): the caller's inverted index, carried opaquely
+  const std::vector<uint8_t>& SaveVertexInverted() const { return inverted_blob_; }
+  void LoadVertexInverted(const std::vector<uint8_t>& data) { inverted_blob_ = data; }
   int Quantization() const { return quant_; }
   int Distance() const { return distance_; }
   uint32_t Dim() const { return dim_; }
   int64_t LoadSize() const { uint64_t n = 0; check(coltt_flat_len(h_, &n)); return (int64_t)n; }
+  const std::map<std::string, std::string>& Indexer() const { return meta_.IndexType; }
+  bool Versional() const { return meta_.Versioning; }
   coltt_handle_t handle() const { return h_; }
 
  private:
   coltt_handle_t h_ = 0; uint32_t dim_; int distance_, quant_;
+  CollectionMetadata meta_; std::vector<uint8_t> inverted_blob_;
 };
+
+// functional options of NewHnsw (hnsw_config.go:57-109) as a fluent builder: HnswOptions().M(32).Ef(64).SearchAlgorithm(1)
+struct HnswOptions {
+  coltt_hnsw_cfg c{16, -1, -1, 20, 200, 0, -1.f, 0, 1};   // newHnswConfig defaults (hnsw_config.go:135-162)
+  int quantization = COLTT_Q_NONE;
+  HnswOptions& LevelMultiplier(float v) { c.level_multiplier = v; return *this; }
+  HnswOptions& Ef(int v) { c.ef = v; return *this; }
+  HnswOptions& EfConstruction(int v) { c.ef_construction = v; return *this; }
+  HnswOptions& M(int v) { c.m = v; return *this; }
+  HnswOptions& Mmax(int v) { c.m_max = v; return *this; }
+  HnswOptions& Mmax0(int v) { c.m_max0 = v; return *this; }
+  HnswOptions& SearchAlgorithm(int v /*0 HnswSearchSimple, 1 HnswSearchHeuristic*/) { c.algo = v; return *this; }
+  HnswOptions& HeuristicExtendCandidates(bool v) { c.extend_candidates = v; return *this; }
+  HnswOptions& HeuristicKeepPruned(bool v) { c.keep_pruned = v; return *this; }
+  HnswOptions& Quantization(int q) { quantization = q; return *this; }   // extension: BASELINE.json configs[4]
+};
+struct ProtoConfig {   // hnsw_config.go:123-133
+  std::string SearchAlgorithm; float LevelMultiplier; int Ef, EfConstruction, M, MMax, MMax0; bool HeuristicExtendCandidates, HeuristicKeepPruned;
+};
+struct Vertex { uint64_t Id; Vector Vec; int Level; };   // what GetVertex hands out (hnsw_vertex.go:54-68), minus Metadata
 
 // *vectorindex.Hnsw implemented on the GPU
 class Hnsw {
  public:
+  Hnsw(uint32_t dim, int distance, const HnswOptions& o) : Hnsw(dim, distance, &o.c, o.quantization) {}
   // NewHnsw(dim, distancer, options...) (hnsw.go:56-73)
-  Hnsw(uint32_t dim, int distance, const coltt_hnsw_cfg* cfg = nullptr, int quantization = COLTT_Q_NONE) : dim_(dim) {
+  Hnsw(uint32_t dim, int distance, const coltt_hnsw_cfg* cfg = nullptr, int quantization = COLTT_Q_NONE) : dim_(dim), distance_(distance) {
     check(coltt_hnsw_create(dim, distance, quantization, cfg, &h_));
   }
   ~Hnsw() { if (h_) coltt_hnsw_destroy(h_); }
@@ -129,11 +186,31 @@ class Hnsw {
   // RandomLevel() (hnsw.go:280-282) for the caller's uniform draw u in (0,1)
   int RandomLevel(float u) const { int32_t lv = 0; check(coltt_hnsw_random_level(h_, u, &lv)); return lv; }
   uint32_t Dim() const { return dim_; }
-  coltt_hnsw_cfg Config() const { coltt_hnsw_cfg c; check(coltt_hnsw_get_cfg(h_, &c)); return c; }
+  coltt_hnsw_cfg RawConfig() const { coltt_hnsw_cfg c; check(coltt_hnsw_get_cfg(h_, &c)); return c; }
+  ProtoConfig Config() const {   // hnsw.go:86-98
+    coltt_hnsw_cfg c = RawConfig();
+    return {c.algo == 0 ? "simple" : "heuristic", c.level_multiplier, c.ef, c.ef_construction, c.m, c.m_max, c.m_max0,
+            c.extend_candidates != 0, c.keep_pruned != 0};
+  }
+  std::string Distance() const { return distance_ == COLTT_COSINE ? "cosine-dot" : "l2-squared"; }   // Space.Type(), space.go:69,101
+  // Get(id) / GetVertex(id) (hnsw.go:169-189): the STORED (normalised) vector; ItemNotFoundError for unknown / removed ids
+  Vector Get(uint64_t id) const { Vector v(dim_); check(coltt_hnsw_get(h_, id, v.data(), nullptr)); return v; }
+  Vertex GetVertex(uint64_t id) const { Vertex x{id, Vector(dim_), 0}; int32_t lv = 0; check(coltt_hnsw_get(h_, id, x.Vec.data(), &lv)); x.Level = lv; return x; }
+  // BytesSize() (hnsw.go:476-490): the reference's host-side estimate — pointers per vertex by level + vector bytes
+  // (HNSW_VERTEX_EDGE_BYTES 12, HNSW_VERTEX_MUTEX_BYTES 24, hnsw_vertex.go:27-28); metadata bytes are the caller's to add
+  uint64_t BytesSize() const {
+    coltt_hnsw_cfg c = RawConfig();
+    uint64_t ns = 0, nu = 0; int32_t ent = -1, el = 0;
+    check(coltt_hnsw_export_raw(h_, &ns, &nu, &ent, &el, nullptr, nullptr, nullptr));
+    const int maxLevel = ent >= 0 ? el : 10;
+    double ptr = c.m_max0 * 12.0 + 24.0;
+    for (int i = 1; i < maxLevel; i++) ptr += (c.m_max * 12.0 + 24.0) * std::exp((double)i / -(double)c.level_multiplier);
+    return (uint64_t)std::floor((double)Len() * ptr) + (uint64_t)Len() * dim_ * 4;
+  }
   coltt_handle_t handle() const { return h_; }
 
  private:
-  coltt_handle_t h_ = 0; uint32_t dim_;
+  coltt_handle_t h_ = 0; uint32_t dim_; int distance_ = COLTT_COSINE;
 };
 
 }  // namespace coltt

@@ -69,6 +69,28 @@ int main() {
     EXPECT(common >= 7);
     if (q < 3) { std::printf("hnsw q%d:", q); for (auto& r : rb) std::printf(" %llu/%08x", (unsigned long long)r.Id, *(const unsigned*)&r.Score); std::printf("\n"); }
   }
+  // ---- the rest of the *vectorindex.Hnsw surface core uses (core/core.go:232-236, 439, 512, 607): Config, Distance, Get,
+  // GetVertex, BytesSize, functional options
+  {
+    coltt::Hnsw o(d, COLTT_EUCLIDEAN, coltt::HnswOptions().M(8).Ef(33).EfConstruction(50).SearchAlgorithm(1));
+    coltt::ProtoConfig pc = o.Config();
+    EXPECT(pc.SearchAlgorithm == "heuristic" && pc.M == 8 && pc.MMax == 8 && pc.MMax0 == 16 && pc.Ef == 33 && pc.EfConstruction == 50);
+    EXPECT(std::fabs(pc.LevelMultiplier - 1.0f / std::log(8.0f)) < 1e-6f && pc.HeuristicKeepPruned && !pc.HeuristicExtendCandidates);
+    EXPECT(o.Distance() == "l2-squared" && a.Distance() == "cosine-dot");
+    try { coltt::Hnsw bad(d, COLTT_COSINE, coltt::HnswOptions().SearchAlgorithm(1).HeuristicExtendCandidates(true)); EXPECT(false); }
+    catch (const coltt::Error& e) { EXPECT(e.code == COLTT_E_UNSUPPORTED); }   // undefined behaviour in the reference: rejected
+    for (int i = 0; i < 40; i++) o.Insert(7 + i, X[i], i % 3);
+    coltt::Vertex v = o.GetVertex(7 + 5);
+    EXPECT(v.Id == 12 && v.Level == 2 && v.Vec.size() == (size_t)d && std::memcmp(v.Vec.data(), X[5].data(), d * 4) == 0);  // l2: stored as given
+    EXPECT(o.GetVertex(7).Level == 0);                                          // the first vertex is forced to level 0
+    try { o.Get(99999); EXPECT(false); } catch (const coltt::ItemNotFoundError&) {}
+    o.Remove(12);
+    try { o.GetVertex(12); EXPECT(false); } catch (const coltt::ItemNotFoundError&) {}
+    EXPECT(o.BytesSize() > (uint64_t)o.Len() * d * 4);
+    // cosine: Get returns the NORMALISED vector (Insert normalises, hnsw.go:105-107)
+    coltt::Vector g0 = a.Get(1001); double nn = 0; for (float f : g0) nn += (double)f * f;
+    EXPECT(std::fabs(nn - 1.0) < 1e-5);
+  }
   // ---- edge.vectorspace
   coltt::VecSpace s(d, COLTT_COSINE, COLTT_Q_F16);
   for (int i = 0; i < n; i++) s.ChangedVertex(50 + i, X[i]);
@@ -87,6 +109,20 @@ int main() {
   for (size_t i = 0; i < near.size(); i++) EXPECT(near[i].Id == near2[i].Id && std::memcmp(&near[i].Score, &near2[i].Score, 4) == 0);
   auto filt = s.FilterableVertexSearch({51, 53, 60, 61}, X[3], 3, COLTT_SELECT_NEAREST);
   EXPECT(filt.size() == 3 && filt[0].Id == 53);
+  // the remaining vectorspace methods (edge/vectorstore.go:36-48): metadata / inverted blobs / accessors
+  {
+    coltt::CollectionMetadata m; m.Dim = d; m.Distance = COLTT_COSINE; m.Quantization = COLTT_Q_F16; m.Versioning = true;
+    m.IndexType["user_id"] = "primary,string";
+    coltt::VecSpace u(m);
+    EXPECT(u.Dim() == (uint32_t)d && u.Distance() == COLTT_COSINE && u.Quantization() == COLTT_Q_F16 && u.Versional() && u.Indexer().count("user_id") == 1);
+    EXPECT(u.SaveVertexMetadata().find("\"quantization\":1") != std::string::npos);
+    u.LoadVertexInverted({1, 2, 3}); EXPECT(u.SaveVertexInverted().size() == 3);
+    coltt::CollectionMetadata w = m; w.Dim = d + 1;
+    try { u.LoadVertexMetadata("c", w); EXPECT(false); } catch (const coltt::Error&) {}
+    u.LoadVertexMetadata("c", m);
+    s.RemoveVertex({53});
+    EXPECT(s.LoadSize() == n - 1 && s.VertexSearch(X[3], 1, false, COLTT_SELECT_NEAREST)[0].Id != 53);
+  }
   std::printf(fails ? "FAILED %d checks\n" : "mirror ok\n", fails);
   return fails ? 1 : 0;
 }
