@@ -279,3 +279,29 @@ def test_concurrent_flat_searches_and_upserts(gpu):
     with ThreadPoolExecutor(10) as ex:
         res = list(ex.map(lambda i: writer(i) if i == 0 else one(i), range(40)))
     assert all(res)
+
+
+def test_gpu_reproduces_the_independent_python_golden(gpu):
+    """tests/golden/hnsw_pyref.npz comes from oracle/pyref.py — the second restatement, written from the Go text.  The HIP path
+    (sequential Insert, Remove, Insert after removals, Search; Simple and Heuristic) must reproduce graph, edge distances, ids and
+    score bits."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hnsw_pyref.npz"))
+    for ci in range(int(z["n_cases"])):
+        c = {k[len(f"c{ci}_"):]: z[k] for k in z.files if k.startswith(f"c{ci}_")}
+        d, metric, m, efc, algo, k, ef = (int(v) for v in c["cfg"])
+        gh = gpu.Hnsw(d, metric, gpu.HnswCfg.default(m=m, ef_construction=efc, algo=algo))
+        for i in range(len(c["ids"])):
+            gh.Insert(int(c["ids"][i]), c["X"][i], int(c["levels"][i]))
+        for i in c["removed"]:
+            gh.Remove(int(i))
+        for i in range(len(c["y_ids"])):
+            gh.Insert(int(c["y_ids"][i]), c["Y"][i], int(c["y_levels"][i]))
+        g = gh.Export()
+        assert np.array_equal(g["levels"], c["g_levels"]) and np.array_equal(g["deleted"], c["g_deleted"]), ci
+        assert np.array_equal(g["row_offsets"], c["g_row_offsets"]) and np.array_equal(g["nbr"], c["g_nbr"]), ci
+        assert np.array_equal(bits(g["nbr_dist"]), bits(c["g_nbr_dist"])) and g["entry"] == int(c["g_entry"]), ci
+        gi, gs, gc = gh.Search(c["Q"], k, ef=ef)
+        for qi in range(len(c["Q"])):
+            n = int(c["res_n"][qi])
+            assert gc[qi] == n and np.array_equal(gi[qi, :n], c["res_ids"][qi, :n]) and np.array_equal(bits(gs[qi, :n]), bits(c["res_scores"][qi, :n])), (ci, qi)
