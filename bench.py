@@ -621,7 +621,7 @@ def pmc_traffic(args, n, dim, nq):
         t = json.load(open(p))
         key = f"hnsw n={n} dim={dim} quant={args.quant} ef={args.ef} m={args.m} queries={nq} dataset={args.dataset}"
         rec = t.get(key, {})
-        return rec.get("hbm_bytes_per_launch"), (f"profiles/{rec['source']}" if rec.get("source") else None)
+        return rec.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
     except Exception:
         return None, None
 

@@ -513,8 +513,7 @@ void commit_upsert(Flat* f, const UpsertPlan& p) {
 extern "C" {
 
 int coltt_flat_create(uint32_t dim, int metric, int quant, coltt_handle_t* out) {
-  COLTT_TRY(ensure_device());
-  return coltt::flat_create_on(default_device(), dim, metric, quant, out);
+  return coltt::flat_create_on(-1 /* the process default device, selected after the arguments have been validated */, dim, metric, quant, out);
 }
 
 }  // extern "C"
@@ -525,7 +524,7 @@ int coltt::flat_create_on(int device, uint32_t dim, int metric, int quant, coltt
   if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "flat_create: dim %u outside [1,8192]", dim);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "flat_create: bad metric %d", metric);
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");  // vectorstore.go:79
-  COLTT_TRY(use_device(device));
+  if (device < 0) { COLTT_TRY(ensure_device()); device = default_device(); } else COLTT_TRY(use_device(device));
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;

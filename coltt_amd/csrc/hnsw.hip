@@ -813,8 +813,7 @@ int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* 
 extern "C" {
 
 int coltt_hnsw_create(uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out) {
-  COLTT_TRY(ensure_device());
-  return coltt::hnsw_create_on(default_device(), dim, metric, quant, cfg, out);
+  return coltt::hnsw_create_on(-1 /* the process default device, selected after the arguments have been validated */, dim, metric, quant, cfg, out);
 }
 
 }  // extern "C"
@@ -825,7 +824,6 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "hnsw_create: dim %u outside [1,8192]", dim);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "hnsw_create: bad metric %d", metric);
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");
-  COLTT_TRY(use_device(device));
   auto x = std::make_shared<Hnsw>();
   x->dim = dim; x->metric = metric; x->quant = quant;
   x->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
@@ -842,6 +840,7 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
+  if (device < 0) { COLTT_TRY(ensure_device()); device = default_device(); } else COLTT_TRY(use_device(device));
   x->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   *out = Registry::get().add(x);
