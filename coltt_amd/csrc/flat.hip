@@ -183,6 +183,7 @@ struct Flat : Object {
   std::atomic<float> last_ms{0.f};   // kernel time of the most recently finished search call
   CtxPool<FCtx> pool;
   DevBuf w_raw, w_slots;             // ingest staging
+  DevBuf d_maxn; float max_norm = 0.f;  // running upper bound of ||row||^2 (bits, atomicMax on the device): scales the Euclidean matrix-core margin
   std::atomic<uint64_t> mfma_groups{0}, mfma_fallbacks{0};  // groups served by the MFMA path / sent back to the exact path
   ~Flat() override {
     (void)hipSetDevice(device);
@@ -219,7 +220,8 @@ int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_
   dev::launch_prep_rows<QUANT>(f->stream, d_raw, n, (int)f->dim, f->metric == COLTT_COSINE, d_slots, slot_base,
                                f->rows.as<uint8_t>(), f->stride);
   row_norms_kernel<QUANT><<<ceil_div(n * 2, 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, d_slots,
-                                                                       slot_base, n, (int)f->dim, f->norms.as<float>());
+                                                                       slot_base, n, (int)f->dim, f->norms.as<float>(), f->d_maxn.as<uint32_t>());
+  COLTT_HIP(hipMemcpyAsync(&f->max_norm, f->d_maxn.p, 4, hipMemcpyDeviceToHost, f->stream));  // complete at the caller's stream sync
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -323,7 +325,8 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
 #else
     constexpr int BM = M2_BM;
 #endif
-    auto kern = seed ? flat_mfma3_kernel<BN, AF32, true, BM> : flat_mfma3_kernel<BN, AF32, false, BM>;
+    auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma3_kernel<BN, AF32, true, BM, M_COS> : flat_mfma3_kernel<BN, AF32, false, BM, M_COS>)
+                                          : (seed ? flat_mfma3_kernel<BN, AF32, true, BM, M_L2> : flat_mfma3_kernel<BN, AF32, false, BM, M_L2>);
     const size_t lds = M3Geom<BN, AF32, BM>::LDS;
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + BM - 1) / BM;
@@ -363,6 +366,14 @@ int launch_mfma_scan(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q
   return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed);
 }
 
+// relative error bound of the Euclidean candidate value s~^2 against the exact s^2, in units of (||q||^2 + ||r||^2): D * 2^-24 from
+// the f32 accumulation of exact f16 products, 2^-10 more when f32 rows (and queries) are rounded to binary16 on their way into
+// LDS, and 3 * D * 2^-24 for the f32 rounding inside the two norms and the reference's own difference-form sum
+float l2_eps(const Flat* f) {
+  const float acc = (float)f->dim * 5.9604645e-8f;
+  return 4.0f * acc + (f->quant == COLTT_Q_NONE ? 9.8e-4f : 0.f);
+}
+
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
 int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
                       uint32_t* d_out_cnt, uint32_t cap, uint32_t* ovf) {
@@ -381,7 +392,10 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
     if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
     else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
     else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
-    flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
+    if (f->metric == COLTT_COSINE)
+      flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
+    else  // Euclidean: |s~^2 - s^2| <= eps * (||q||^2 + ||r||^2), eps = dot error (+ f16 rounding of f32 rows) + f32 rounding of the norms / the exact sum
+      flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, 2.0f * l2_eps(f), ovf, qn, f->max_norm);
     std::swap(cur, oth);
     return COLTT_OK;
   };
@@ -397,8 +411,10 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   // overflow flag is read once at the end (a group whose candidate list overflowed is re-run in exact mode by the caller)
   {
     dim3 grid(16, g);
-    if (f->quant == COLTT_Q_NONE) flat_rescore_kernel<Q_NONE><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
-    else flat_rescore_kernel<Q_F16><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap);
+#define COLTT_RS(M, Q) flat_rescore_kernel<M, Q><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap)
+    if (f->metric == COLTT_COSINE) { if (f->quant == COLTT_Q_NONE) COLTT_RS(M_COS, Q_NONE); else COLTT_RS(M_COS, Q_F16); }
+    else { if (f->quant == COLTT_Q_NONE) COLTT_RS(M_L2, Q_NONE); else COLTT_RS(M_L2, Q_F16); }
+#undef COLTT_RS
   }
   flat_select_kernel<<<g, 256, 0, c->stream>>>(cur, cnt, thr, cap, k, nearest, ids, f->dense_base, ovf, d_out_ids + q0 * k, d_out_sc + q0 * k, d_out_cnt + q0);
   COLTT_HIP(hipGetLastError());
@@ -410,7 +426,12 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
                     uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt) {
   const int nearest = select == COLTT_SELECT_NEAREST;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
-  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && f->metric == COLTT_COSINE &&
+  // matrix-core candidates: cosine with every kernel generation; Euclidean (s~^2 = ||q||^2 + ||r||^2 - 2 dot, exact re-score) with
+  // the third-generation kernel, as long as every stored norm is finite (max_norm bounds the margin)
+  // (f32 rows are rounded to binary16 for candidate generation: ||row||^2 <= 4e9 keeps every element inside its range)
+  const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && f->max_norm == f->max_norm &&
+                     f->max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
+  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (f->metric == COLTT_COSINE || l2_ok) &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
@@ -530,6 +551,8 @@ int coltt::flat_create_on(int device, uint32_t dim, int metric, int quant, coltt
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
   f->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+  COLTT_TRY(f->d_maxn.reserve(16));
+  COLTT_HIP(hipMemsetAsync(f->d_maxn.p, 0, 16, f->stream));
   *out = Registry::get().add(f);
   return COLTT_OK;
 }
@@ -781,7 +804,8 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
       uint32_t grid = ceil_div(m * f->dim, 256);
       uint8_t* R = f->rows.as<uint8_t>();
 #define COLTT_BE(Q) do { be_codes_kernel<Q><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b); \
-        row_norms_kernel<Q><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>()); } while (0)
+        row_norms_kernel<Q><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>(), f->d_maxn.as<uint32_t>()); \
+        (void)hipMemcpyAsync(&f->max_norm, f->d_maxn.p, 4, hipMemcpyDeviceToHost, f->stream); } while (0)
       COLTT_DISPATCH_QUANT(f->quant, COLTT_BE)
 #undef COLTT_BE
       COLTT_HIP(hipGetLastError());
@@ -836,6 +860,14 @@ int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uin
   }
   *out_len = w.n;
   if (out && w.n > cap) return fail(COLTT_E_INVALID, "flat_save_vertex: buffer too small");
+  return COLTT_OK;
+}
+
+int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fallbacks) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_stats: unknown handle");
+  if (mfma_groups) *mfma_groups = f->mfma_groups.load();
+  if (mfma_fallbacks) *mfma_fallbacks = f->mfma_fallbacks.load();
   return COLTT_OK;
 }
 

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(MF_NT, (MF_BM <= 64 ? 3 : (MF_BK <= 32 ? 2 : 1))) v
 // bound as the next scan threshold.  One block of 256 threads per query.
 __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long* __restrict__ src_all, unsigned long long* __restrict__ dst_all,
                                                        uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all, uint32_t cap,
-                                                       uint32_t k, int nearest, float margin, uint32_t* __restrict__ overflow) {
+                                                       uint32_t k, int nearest, float margin, uint32_t* __restrict__ overflow,
+                                                       const float* __restrict__ qn_l2 = nullptr, float max_row_norm = 0.f) {
   __shared__ uint32_t hist[256], wsum[4];
   __shared__ uint32_t s_digit, s_need, s_n;
   const int q = blockIdx.x, tid = threadIdx.x;
@@ -295,6 +296,8 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
     }
     // k-th best approximate score, widened by the margin in the "worse" direction
     float t = key_score(prefix ^ flip);
+    // Euclidean candidates carry s~^2 = ||q||^2 + ||r||^2 - 2 dot~; its error scales with the norms: margin * (||q||^2 + max ||r||^2)
+    if (qn_l2) margin = qn_l2[q] <= 4.0e9f ? margin * (qn_l2[q] + max_row_norm) : __builtin_inff();   // out-of-range query: keep everything (-> exact fallback)
     float b = nearest ? t + margin : t - margin;
     bound_key = score_key(b) ^ flip;
     if (bound_key < prefix) bound_key = prefix;  // NaN / saturation guard
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
 
 // Exact re-score of the survivors: lane pair per (query, candidate); the key's score half is replaced by the exact score.
 // Grid-stride over the query's list, so the launch needs no host-side knowledge of the list lengths (no mid-chain sync).
-template <int QUANT>
+template <int METRIC, int QUANT>
 __global__ __launch_bounds__(64) void flat_rescore_kernel(const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms, int dim,
                                                          unsigned long long* __restrict__ cand_all, const uint32_t* __restrict__ cnt_all,
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64) void flat_rescore_kernel(const uint8_t* __restr
     const uint32_t j = j0 + (lane >> 1);
     const bool valid = j < c;
     const uint32_t slot = (uint32_t)cand[valid ? j : 0];
-    float d = pair_distance<M_COS, QUANT, 4>(rows + (size_t)slot * stride, q_eff + (size_t)q * dim, dim, qnorms[q], norms[slot], half);
+    float d = pair_distance<METRIC, QUANT, 4>(rows + (size_t)slot * stride, q_eff + (size_t)q * dim, dim, qnorms[q], norms[slot], half);
     if (valid && half == 0) cand[j] = ((unsigned long long)score_key(d) << 32) | slot;
   }
 }

@@ -72,19 +72,42 @@ template <int N> __device__ __forceinline__ void m2_wait_vmcnt() {
 // two halves and each half costs ONE atomicAdd (count first, reserve, then store) instead of one dependent atomic round trip
 // per passing element, and (b) the unfiltered SEED segment takes no atomics at all: every score passes, so entry (row - begin)
 // of the query's list is simply written in place and the count is the segment length.
-template <bool SEED>
+// Euclidean columns (METRIC == M_L2): the candidate value is s~^2 = ||q||^2 + ||r||^2 - 2 dot (monotone in the distance; the
+// exact re-score produces the reference's sqrt form).  QCol then means: iq = ||q||^2, tf = threshold on s~^2, lo / hi = bounds on
+// t = ||r||^2 - 2 dot (nearest: hit iff min t <= lo; farthest: hit iff max t >= hi), and `ir` carries the RAW row norms.
+__device__ __forceinline__ QCol m2_query_col_l2(int qidx, int nq, const float* __restrict__ qnorms, const uint32_t* __restrict__ thr, int nearest) {
+  QCol c; c.qidx = qidx;
+  const bool live = qidx < nq;
+  const float nqv = live ? qnorms[qidx] : 0.f;
+  c.iq = nqv;
+  const uint32_t t = live ? thr[qidx] : (nearest ? 0u : 0xffffffffu);
+  if (nearest) {
+    c.tf = !live ? -__builtin_inff() : (t == 0xffffffffu ? __builtin_inff() : key_score(t));
+    c.lo = !live ? -__builtin_inff() : (c.tf - nqv) + MF_BLOCK_SLACK * (fabsf(c.tf) + nqv);   // NaN norms: every compare fails -> `hit`
+    c.hi = __builtin_inff();
+  } else {
+    c.tf = !live ? __builtin_inff() : (t == 0u ? -__builtin_inff() : key_score(t));
+    c.lo = -__builtin_inff();
+    c.hi = !live ? __builtin_inff() : (c.tf - nqv) - MF_BLOCK_SLACK * (fabsf(c.tf) + nqv);
+  }
+  return c;
+}
+
+template <bool SEED, int METRIC = M_COS>
 __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&ir)[4], bool bad, const QCol& qc, int nearest, int nq,
                                               uint64_t rbase, uint64_t begin, uint64_t end, unsigned long long* __restrict__ cand,
                                               uint32_t* __restrict__ cnt, uint32_t cap, float* ep) {
   float t[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) t[r] = acc[r] * ir[r >> 2][r & 3];
+  for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
+  // the approximate candidate value of element r from its parked t
+  auto value = [&](float tv) { return METRIC == M_COS ? fabsf(1.0f - tv * qc.iq) : qc.iq + tv; };
   if constexpr (SEED) {
     if (qc.qidx < nq) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
-        const float s = fabsf(1.0f - t[r] * qc.iq);
+        const float s = value(t[r]);
         if (gr < end) cand[(size_t)qc.qidx * cap + (uint32_t)(gr - begin)] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
       }
       if (rbase == begin) cnt[qc.qidx] = (uint32_t)(end - begin);
@@ -95,11 +118,19 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
 #pragma unroll
   for (int r = 1; r < 16; r++) mx = __builtin_fmaxf(mx, t[r]);
   bool hit;
-  if (nearest) hit = !(mx < qc.lo);
-  else {
+  if constexpr (METRIC == M_COS) {
+    if (nearest) hit = !(mx < qc.lo);
+    else {
 #pragma unroll
-    for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
-    hit = !(mn > qc.lo) || !(mx < qc.hi);
+      for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
+      hit = !(mn > qc.lo) || !(mx < qc.hi);
+    }
+  } else {
+    if (nearest) {
+#pragma unroll
+      for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
+      hit = !(mn > qc.lo);
+    } else hit = !(mx < qc.hi);
   }
   if (!(hit || bad)) return;
 #pragma unroll 1
@@ -110,7 +141,7 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
 #pragma unroll 1
     for (int r8 = 0; r8 < 8; r8++) {
       const int r = h * 8 + r8;
-      const float s = fabsf(1.0f - reinterpret_cast<volatile float*>(ep)[r8] * qc.iq);
+      const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
       const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
       const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
       if (pass && gr < end && qc.qidx < nq) mask |= 1u << r8;
@@ -121,7 +152,7 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
       for (int r8 = 0; r8 < 8; r8++) {
         if (!((mask >> r8) & 1u)) continue;
         const int r = h * 8 + r8;
-        const float s = fabsf(1.0f - reinterpret_cast<volatile float*>(ep)[r8] * qc.iq);
+        const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
         const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
         if (idx < cap) cand[(size_t)qc.qidx * cap + idx] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
         idx++;

@@ -65,7 +65,7 @@ template <int BN, bool AF32, int BM = M2_BM> struct M3Geom {
   static_assert((NSA - 2) * NA_I < 64 && (NSB - 2) * (NB_I + NN_I) < 64, "vmcnt range");
 };
 
-template <int BN, bool AF32, bool SEED, int BM = M2_BM>
+template <int BN, bool AF32, bool SEED, int BM = M2_BM, int METRIC = M_COS>
 __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, uint64_t begin, uint64_t end,
     const _Float16* __restrict__ q16, const float* __restrict__ qnorms, int nq, int dim, const uint32_t* __restrict__ thr,
@@ -89,7 +89,9 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
   if ((uint64_t)blockIdx.x >= ntiles) return;
   QCol qc[TN];
 #pragma unroll
-  for (int tn = 0; tn < TN; tn++) qc[tn] = mf_query_col(wn * (BN / WN) + tn * 32 + (lane & 31), nq, qnorms, thr, nearest);
+  for (int tn = 0; tn < TN; tn++)
+    qc[tn] = METRIC == M_COS ? mf_query_col(wn * (BN / WN) + tn * 32 + (lane & 31), nq, qnorms, thr, nearest)
+                             : m2_query_col_l2(wn * (BN / WN) + tn * 32 + (lane & 31), nq, qnorms, thr, nearest);
 
   // ---- loader state ---------------------------------------------------------------------------------------------------------
   // Every DMA is `global_load_lds_* voffset, sbase`: the per-lane part of the address is ONE 32-bit register per stream that
@@ -213,12 +215,20 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
 #pragma unroll
       for (int gq = 0; gq < 4; gq++) {
         const f32x4 raw = *reinterpret_cast<const f32x4*>(tn_raw + wm * WROWS + tm * 32 + 8 * gq + 4 * (lane >> 5));
-        ir[gq] = f32x4{rsqrtf(raw.x), rsqrtf(raw.y), rsqrtf(raw.z), rsqrtf(raw.w)};
+        ir[gq] = METRIC == M_COS ? f32x4{rsqrtf(raw.x), rsqrtf(raw.y), rsqrtf(raw.z), rsqrtf(raw.w)} : raw;   // Euclidean: raw ||row||^2
       }
-      const bool bad = mf_bad_norms(ir);
+      bool bad;
+      if constexpr (METRIC == M_COS) bad = mf_bad_norms(ir);
+      else {  // a non-finite norm always takes the element path
+        bad = false;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) bad |= !(ir[gq][j] >= 0.f && ir[gq][j] < __builtin_inff());
+      }
       const uint64_t rbase = row0 + wm * WROWS + tm * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int tn = 0; tn < TN; tn++) m2_emit_block<SEED>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep);
+      for (int tn = 0; tn < TN; tn++) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep);
     }
   }
   m2_wait_vmcnt<0>();

@@ -80,13 +80,18 @@ inline void launch_prep_rows(hipStream_t st, const float* raw, uint64_t n, int d
 // ||row||^2 in AVX order, one lane pair per row.
 template <int QUANT>
 __global__ void row_norms_kernel(const uint8_t* __restrict__ rows, size_t stride, const uint32_t* __restrict__ slots,
-                                 uint64_t slot_base, uint64_t n, int dim, float* __restrict__ norms) {
+                                 uint64_t slot_base, uint64_t n, int dim, float* __restrict__ norms, uint32_t* __restrict__ max_bits = nullptr) {
   uint64_t pair = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   int half = threadIdx.x & 1;
   bool valid = pair < n;
   uint64_t slot = valid ? (slots ? slots[pair] : slot_base + pair) : (slots ? slots[0] : slot_base);
   float s = pair_sqnorm<QUANT>(rows + slot * stride, dim, half);
-  if (valid && half == 0) norms[slot] = s;
+  if (valid && half == 0) {
+    norms[slot] = s;
+    // running upper bound of ||row||^2 over everything ever stored (bit pattern order == value order for s >= 0; NaN sorts
+    // above +inf, so a store that ever held a non-finite row keeps its matrix-core Euclidean path switched off)
+    if (max_bits) atomicMax(max_bits, __float_as_uint(s));
+  }
 }
 
 // query side of VertexSearch: Normalize (none_vectorstore.go:131-133), Lower (f16_vectorstore.go:136) and the

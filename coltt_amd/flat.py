@@ -125,6 +125,11 @@ class FlatSpace:
         L.check(L.lib().coltt_flat_load_vertex(self.h, L.vp(b), C.c_uint64(len(b)), C.byref(n), None, None, None, C.c_uint64(0)))
         return n.value
 
+    def Stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        L.check(L.lib().coltt_flat_stats(self.h, C.byref(a), C.byref(b)))
+        return {"mfma_groups": a.value, "mfma_fallbacks": b.value}
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

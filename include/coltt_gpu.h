@@ -98,6 +98,9 @@ int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
 int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, int select, int mode,
                              uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts);
+/* how many <= 256-query groups went through the matrix cores since creation, and how many of those overflowed their candidate
+ * list and were re-run in exact mode (adversarial data only; the answers are the exact mode's either way) */
+int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fallbacks);
 /* FilterableVertexSearch (edge/none_vectorstore.go:182-253): the candidate ids come from the roaring
  * index (pkg/inverted/search.go:113-119) on the Go side; ids not present are skipped (:201). */
 int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,

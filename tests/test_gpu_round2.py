@@ -305,3 +305,49 @@ def test_gpu_reproduces_the_independent_python_golden(gpu):
         for qi in range(len(c["Q"])):
             n = int(c["res_n"][qi])
             assert gc[qi] == n and np.array_equal(gi[qi, :n], c["res_ids"][qi, :n]) and np.array_equal(bits(gs[qi, :n]), bits(c["res_scores"][qi, :n])), (ci, qi)
+
+
+@pytest.mark.parametrize("quant", [O.Q_NONE, O.Q_F16, O.Q_BF16])
+@pytest.mark.parametrize("shape", ["plain", "norms", "dups"])
+def test_flat_mfma_euclidean_equals_exact_mode(gpu, quant, shape):
+    """Euclidean collections on the matrix cores (pkg/distance/space.go:61-63 is a selectable edge metric): candidates from
+    s~^2 = ||q||^2 + ||r||^2 - 2 dot with a norm-scaled margin, exact re-score — ids, ranks and score bits must equal the exact
+    mode's in both select directions; rows of very different norms, and stored duplicates of the query (distance 0, where
+    s~^2 can come out negative), included."""
+    n, d, k = 20000, 128, 10
+    X = O.fill_normal(1600, (n, d))
+    if shape == "norms":
+        X = X * np.exp(O.fill_normal(1601, (n, 1)) * 1.5).astype(np.float32)       # norms spread over ~3 orders of magnitude
+    Q = O.fill_normal(1602, (70, d))                                                # 70: one 64-query tile + a ragged one
+    if shape == "dups":
+        X[100:170] = Q; X[300:370] = Q * np.float32(1.0 + 2 ** -12)                # exact and near duplicates
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
+    gf = gpu.FlatSpace(d, O.L2, quant); gf.ChangedVertex(ids, X)
+    for sel in (gpu.SELECT_NEAREST, gpu.SELECT_REFERENCE):
+        e = gf.VertexSearch(Q, k, sel, mode=gpu.MODE_EXACT)
+        m = gf.VertexSearch(Q, k, sel, mode=gpu.MODE_MFMA)
+        assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1])) and np.array_equal(e[2], m[2]), (quant, shape, sel)
+    st = gf.Stats()
+    assert st["mfma_groups"] == 2 and st["mfma_fallbacks"] == 0, st     # the matrix-core path really served both searches
+    of = O.Flat(d, O.L2, quant); of.upsert(ids, X)
+    m = gf.VertexSearch(Q[:6], k, gpu.SELECT_NEAREST, mode=gpu.MODE_MFMA)
+    for qi in range(6):
+        wi, ws = of.search(Q[qi], k, nearest=True, mode=2)
+        assert_same_results(m[0][qi, :m[2][qi]], m[1][qi, :m[2][qi]], wi, ws, f"q{qi}")
+
+
+def test_flat_mfma_euclidean_768_and_nonfinite_rows(gpu):
+    n, d, k = 30000, 768, 10
+    X = O.fill_normal(1700, (n, d)); ids = np.arange(n, dtype=np.uint64)
+    Q = O.fill_normal(1701, (33, d))
+    gf = gpu.FlatSpace(d, O.L2, O.Q_F16); gf.ChangedVertex(ids, X)
+    e = gf.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_EXACT)
+    m = gf.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_MFMA)
+    assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1])) and gf.Stats() == {"mfma_groups": 1, "mfma_fallbacks": 0}
+    # a row with an infinite norm switches the Euclidean matrix-core path off for the store (the margin is scaled by the largest
+    # norm): answers still equal the exact mode's
+    Y = X[:5].copy(); Y[2, 7] = np.float32(1e30)
+    g2 = gpu.FlatSpace(d, O.L2); g2.ChangedVertex(ids, X); g2.ChangedVertex(ids[:5] + np.uint64(10**6), Y)
+    e = g2.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_EXACT)
+    m = g2.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_MFMA)
+    assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1])) and g2.Stats()["mfma_groups"] == 0

@@ -16,8 +16,10 @@ def main():
     assert G.lib().coltt_init(0) == 0
     cases = [(1_000_000, 768, 0, 64), (10_000_000, 768, 1, 256)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
     dev = torch.device("cuda", 0)
-    for n, dim, quant, batch in cases:
-        fl = G.FlatSpace(dim, G.COSINE, quant); fl.Reserve(n)
+    for case in cases:
+        n, dim, quant, batch = case[:4]
+        metric = case[4] if len(case) > 4 else G.COSINE   # 5th field: 0 cosine, 1 euclidean
+        fl = G.FlatSpace(dim, metric, quant); fl.Reserve(n)
         gen = torch.Generator(device=dev); gen.manual_seed(1)
         done = 0
         while done < n:
@@ -37,7 +39,7 @@ def main():
             if r: ms.append(fl.last_kernel_ms())
         s = {0: 4, 1: 2, 2: 1, 3: 2}[quant]
         t = float(np.median(ms))
-        print(f"{os.path.basename(os.environ.get('COLTT_LIB', 'default'))} gen={os.environ.get('COLTT_MFMA_GEN', '2')} {n}x{dim} q{quant} b{batch}: {t:.3f} ms  {n * dim * s / t / 1e9:.3f} TB/s "
+        print(f"{os.path.basename(os.environ.get('COLTT_LIB', 'default'))} gen={os.environ.get('COLTT_MFMA_GEN', '2')} {n}x{dim} q{quant} b{batch} {'cos' if metric == 0 else 'l2'} {fl.Stats()}: {t:.3f} ms  {n * dim * s / t / 1e9:.3f} TB/s "
               f"{2.0 * n * dim * batch / t / 1e9:.0f} TFLOP/s  (min {min(ms):.3f})", flush=True)
         fl.close()
 
