@@ -96,6 +96,70 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 }
 
 
+// Hnsw.Search on FOUR waves per query (search_level_mw): the latency path for small batches — the reference serves one query
+// per RPC (core/core.go:633-667).  One 256-thread workgroup per query at a time, queries pulled from a global counter.
+template <int METRIC, int QUANT, bool VISG>
+__global__ __launch_bounds__(256) void hnsw_search_mw_kernel(GraphView g, int32_t entry, int32_t entry_level,
+                                                            const float* __restrict__ q_eff, const float* __restrict__ qnorms,
+                                                            uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
+                                                            uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
+                                                            float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                            unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
+                                                            size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WaveCtx w;
+  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  w.qs = reinterpret_cast<float*>(smem);
+  w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
+  MwExchange* xs = reinterpret_cast<MwExchange*>(w.res0 + 2 * (size_t)ef_pad);
+  uint8_t* stage = reinterpret_cast<uint8_t*>(xs + 1);                                   // [32][stride] rows of the chunk being expanded
+  w.vis = reinterpret_cast<uint32_t*>(stage + (size_t)MW_ROWS * g.stride);
+  w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
+  w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
+  if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
+  for (;;) {
+    __syncthreads();   // everybody is done with the previous query's LDS state (and with ctl[2])
+    if (threadIdx.x == 0) xs->ctl[2] = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t qi = xs->ctl[2];
+    if (qi >= nq) break;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
+    for (int e = threadIdx.x; e < g.dim; e += 256) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    w.qnorm = qnorms[qi];
+    __syncthreads();
+    uint32_t cur = (uint32_t)entry; float curd = 0.f;
+    if (wave == 0) {  // entry distance + greedy descent on the upper levels: a handful of 16-neighbour hops, one wave (hnsw.go:253-256)
+      curd = eval_pair<METRIC, QUANT, PROF_SEARCH_MW>(g, w, cur, lane & 1);
+      curd = __shfl(curd, 0, 64);
+      w.n_dist += 1;
+      for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF_SEARCH_MW>(g, w, cur, curd, l, lane);
+      w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    }
+    uint32_t len; int buf;
+    search_level_mw<METRIC, QUANT, VISG>(g, w, xs, stage, cur, curd, ef, 0, lane, wave, len, buf);
+    if (wave == 0) {
+      uint32_t n = len < k ? len : k;
+      const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
+      for (uint32_t i = lane; i < n; i += 64) {
+        unsigned long long e = res[i];
+        uint32_t slot = (uint32_t)e >> 1;
+        out_ids[(size_t)qi * k + i] = g.ids ? g.ids[slot] : (uint64_t)slot;
+        out_scores[(size_t)qi * k + i] = __uint_as_float((uint32_t)(e >> 32));
+      }
+      if (lane == 0) {
+        out_counts[qi] = n;
+        atomicAdd(&stats[0], (unsigned long long)w.n_dist);
+        atomicAdd(&stats[1], (unsigned long long)w.n_exp);
+        atomicAdd(&stats[2], (unsigned long long)w.n_hops);
+        if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
+      }
+    }
+  }
+  if constexpr (VISG) { if (threadIdx.x == 0) vis_epoch[blockIdx.x] = w.epoch; }
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // Graph construction (Hnsw.Insert, hnsw.go:104-167) for a batch of new vertices against the frozen graph.
 // Phase A (this kernel, one wave per new vertex): greedy descent above the vertex level (:126-130), then per
@@ -481,8 +545,32 @@ int launch_search(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_
   return COLTT_OK;
 }
 
+// multi-wave (latency) launch: one 4-wave workgroup per query in flight, at most one per CU
+template <int METRIC, int QUANT>
+int launch_search_mw(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
+                     uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
+  auto kern = sg.visg ? hnsw_search_mw_kernel<METRIC, QUANT, true> : hnsw_search_mw_kernel<METRIC, QUANT, false>;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats,
+                                         x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
+                                         x->w_vepoch.as<uint32_t>() + region_base);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// Batches of at most COLTT_MW_MAX_NQ queries take the 256-thread staged kernel (search_level_mw).  OFF by default (0): measured
+// at 10 M x 768 f32, ef 128 it is SLOWER than one wave per query (1 query: 1.46 ms vs 1.24 ms; 128 queries: 2.02 vs 1.71 ms —
+// profiles/r02_latency.json): the single-wave walk already overlaps the next adjacency row with the distance evaluation, and the
+// workgroup barriers + the LDS round trip cost more than the wider fetch saves.  Kept as an opt-in experiment; its answers and
+// counters are bit-identical to the single-wave kernel (tests run both).
+uint32_t mw_max_nq() {
+  const char* e = getenv("COLTT_MW_MAX_NQ");
+  return e && *e ? (uint32_t)atoi(e) : 0u;
+}
+
 int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
-                  uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats) {
+                  uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, bool force_single_wave = false) {
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (nq == 0) return COLTT_OK;
   if (k == 0) return fail(COLTT_E_INVALID, "hnsw_search: k must be >= 1");
@@ -504,7 +592,24 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
   SearchGeom sg = search_geom(x, ef);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
-  uint32_t grid = std::min<uint32_t>((uint32_t)std::min<size_t>(nq, 0xffffffffu), resident_waves(sg, x->quant));
+  // opt-in staged kernel.  Its LDS hash must never need the reset path, so it gets the largest table that fits beside the staging
+  // area (one workgroup per CU); if even that is too small for this ef the single-wave kernel serves the call.
+  bool mw = nq <= mw_max_nq() && !force_single_wave;
+  if (mw) {
+    SearchGeom m = sg;
+    // LDS: query + result set + exchange words + the staging area (32 rows) + the visited hash
+    const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * m.ef_pad * 8 + sizeof(MwExchange) + (size_t)MW_ROWS * x->stride;
+    if (x->stride > MW_MAX_STRIDE || x->cfg.m_max0 > 1024) mw = false;               // rows too long to stage 32 at a time
+    else if (m.visg) { m.hcap = 64; m.lds = fixed + 256; }
+    else {
+      m.hcap = 16384; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;
+      m.lds = fixed + (size_t)m.hcap * 4;
+      if (m.lds > 160 * 1024 || (m.hcap / 4) * 3 < ef * 34u + 64u) mw = false;        // table too small to be sure: single-wave kernel
+    }
+    if (mw && m.lds > 160 * 1024) mw = false;
+    if (mw) sg = m;
+  }
+  uint32_t grid = mw ? std::min<uint32_t>((uint32_t)nq, 256u) : std::min<uint32_t>((uint32_t)std::min<size_t>(nq, 0xffffffffu), resident_waves(sg, x->quant));
   RegionLease lease;
   if (sg.visg) { acquire_regions(x, grid, lease); grid = lease.count; }
   const float* d_q = queries;
@@ -521,7 +626,8 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
 #define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
-#define COLTT_LS(Q) rc = x->metric == COLTT_COSINE ? launch_search<M_COS, Q>(COLTT_LS_ARGS) : launch_search<M_L2, Q>(COLTT_LS_ARGS)
+#define COLTT_LS(Q) rc = mw ? (x->metric == COLTT_COSINE ? launch_search_mw<M_COS, Q>(COLTT_LS_ARGS) : launch_search_mw<M_L2, Q>(COLTT_LS_ARGS)) \
+                            : (x->metric == COLTT_COSINE ? launch_search<M_COS, Q>(COLTT_LS_ARGS) : launch_search<M_L2, Q>(COLTT_LS_ARGS))
   COLTT_DISPATCH_QUANT(x->quant, COLTT_LS)
 #undef COLTT_LS
 #undef COLTT_LS_ARGS
@@ -552,6 +658,8 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   x->last_ms.store(ms);
+  if (mw && (h_stats[4] & 8ull))  // the multi-wave kernel's visited table would have needed a reset: same call on the single-wave kernel
+    return search_common(x, c, queries, on_device, nq, k, ef_override, out_ids, out_scores, out_counts, stats, true);
   if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_search: traversal watchdog tripped (code %llu)", h_stats[4]);
   if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }
   return COLTT_OK;

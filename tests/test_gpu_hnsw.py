@@ -20,9 +20,17 @@ def oracle_index(n, d, metric, seed, cfg=None, remove=0):
     return X, ids, h
 
 
+@pytest.fixture(params=["0", "128"], ids=["one-wave-per-query", "four-waves-per-query"])
+def mw(request, monkeypatch):
+    """COLTT_MW_MAX_NQ: batches up to that size take the multi-wave (latency) kernel; 0 = always one wave per query.  Both kernels
+    must give the oracle's ids, score bits and traversal counters."""
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("metric", [O.COSINE, O.L2])
 @pytest.mark.parametrize("n,d", [(1000, 128), (3000, 64), (1500, 768)])
-def test_hnsw_search_parity(gpu, metric, n, d):
+def test_hnsw_search_parity(gpu, mw, metric, n, d):
     X, ids, oh = oracle_index(n, d, metric, seed=40 + d)
     g = oh.export(with_vectors=False)
     gh = gpu.Hnsw(d, metric)
@@ -42,7 +50,7 @@ def test_hnsw_search_parity(gpu, metric, n, d):
         assert {k: st[k] for k in tot} == tot, (st, tot)
 
 
-def test_hnsw_with_removed_vertices_and_small_k(gpu):
+def test_hnsw_with_removed_vertices_and_small_k(gpu, mw):
     n, d = 1200, 32
     X, ids, oh = oracle_index(n, d, O.COSINE, seed=7, remove=200)
     gh = gpu.Hnsw(d, O.COSINE)
@@ -70,7 +78,7 @@ def test_hnsw_empty_and_tiny(gpu):
 
 
 @pytest.mark.parametrize("quant,d", [(O.Q_F16, 64), (O.Q_F8, 64), (O.Q_F16, 24), (O.Q_F16, 77), (O.Q_F16, 784), (O.Q_F8, 77)])
-def test_hnsw_quantised_rows(gpu, quant, d):
+def test_hnsw_quantised_rows(gpu, mw, quant, d):
     """2-/1-byte stored codes (BASELINE configs[4]): distances as the edge quantised stores compute them —
     decode(query') vs decode(row).  Oracle: an f32 index over the decoded vectors gives the same arithmetic.
     Dims cover the wide 16-byte walk of 2-byte rows: even / odd 8-element group counts (64 / 24), odd + scalar tail (77),
@@ -235,7 +243,7 @@ def test_hnsw_commit_load_streams(gpu):
     e = gpu.Hnsw(d, O.COSINE); assert e.Load(e.Commit()) == 0             # empty index round trip
 
 
-def test_hnsw_ragged_dim_large_ef_and_k_above_ef(gpu):
+def test_hnsw_ragged_dim_large_ef_and_k_above_ef(gpu, mw):
     """dim not a multiple of 8 (scalar tail of the AVX kernels), ef = 1024 (largest LDS geometry), k > cfg.ef (ef = max(ef, k))."""
     n, d = 2500, 20
     X, ids, oh = oracle_index(n, d, O.COSINE, seed=111)

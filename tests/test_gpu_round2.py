@@ -27,11 +27,13 @@ def _gpu_build(gpu, X, lv, metric, quant, cfg=None, batch=64, ids=None):
     return gh
 
 
+@pytest.mark.parametrize("mwq", ["0", "128"])
 @pytest.mark.parametrize("n,d", [(5000, 128), (1800, 768)])
-def test_c5_shape_bf16_hnsw_ef256_on_gpu_built_graph(gpu, n, d):
+def test_c5_shape_bf16_hnsw_ef256_on_gpu_built_graph(gpu, monkeypatch, mwq, n, d):
     """configs[4]: cosine HNSW over the reference's "BF16" codes (= binary16, bf16.go:233-317), efSearch 256 (the HBM-visited
     kernel), graph built by the GPU's batched Insert.  Checker: the oracle's canonical Hnsw.Search over the very arrays
     copied out of HBM (stored codes, adjacency), query lowered as bf16_vectorstore.go:136 does: ids, score bits, counters."""
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", mwq)   # one wave per query / four waves per query (HBM-visited variants of both)
     X = O.fill_normal(500 + d, (n, d)); lv = O.levels(501 + d, n)
     gh = _gpu_build(gpu, X, lv, O.COSINE, O.Q_BF16, gpu.HnswCfg.default(ef_construction=100))
     g = gh.ExportRaw(); rows = gh.FetchRows()
@@ -351,3 +353,20 @@ def test_flat_mfma_euclidean_768_and_nonfinite_rows(gpu):
     e = g2.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_EXACT)
     m = g2.VertexSearch(Q, k, gpu.SELECT_NEAREST, mode=gpu.MODE_MFMA)
     assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1])) and g2.Stats()["mfma_groups"] == 0
+
+
+def test_multi_wave_latency_path_falls_back_when_its_visited_table_is_too_small(gpu, monkeypatch):
+    """ef far beyond what the multi-wave kernel's LDS visited table can hold without its reset path: the call is served by the
+    single-wave kernel instead (host-side guard, or err 8 from the kernel) and the answers stay exact."""
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", "128"); monkeypatch.setenv("COLTT_VISG", "0")
+    n, d = 20000, 8
+    X = O.fill_normal(1800, (n, d)); lv = O.levels(1801, n)
+    gh = _gpu_build(gpu, X, lv, O.L2, O.Q_NONE, gpu.HnswCfg.default(ef_construction=40), batch=1024)
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    Q = O.fill_normal(1802, (5, d))
+    for ef in (600, 2500):
+        gi, gs, gc, st = gh.Search(Q, 10, ef=ef, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search(rows, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], Q, 10, ef)
+        for qi in range(len(Q)):
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"ef{ef} q{qi}")
+        assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"]
