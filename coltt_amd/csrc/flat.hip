@@ -18,7 +18,7 @@
 #include "prep.hpp"
 #include "flat_mfma.hpp"
 #include "flat_mfma2.hpp"
-#include "flat_mfma3.hpp"
+#include "flat_mfma4.hpp"
 #include "select.hpp"
 
 using namespace coltt;
@@ -319,6 +319,18 @@ static int mfma_generation() {
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                        unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed) {
+  if (mfma_generation() >= 4 && !(seed && BN == 256)) {   // (the batch-256 seed instance would spill: it stays on generation 3)
+    auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma4_kernel<BN, AF32, true, M_COS> : flat_mfma4_kernel<BN, AF32, false, M_COS>)
+                                          : (seed ? flat_mfma4_kernel<BN, AF32, true, M_L2> : flat_mfma4_kernel<BN, AF32, false, M_L2>);
+    const size_t lds = M3Geom<BN, AF32, M2_BM>::LDS;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+                                          nearest, cand, cnt, cap);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
   if (mfma_generation() >= 3) {
 #ifdef COLTT_M3_BM
     constexpr int BM = (!AF32 && BN == 256) ? COLTT_M3_BM : M2_BM;
@@ -432,7 +444,7 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && f->max_norm == f->max_norm &&
                      f->max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
   const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (f->metric == COLTT_COSINE || l2_ok) &&
-                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim <= 4096 && total > 0;
+                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim >= 128 && f->dim <= 4096 && total > 0;   // (dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile)
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
   if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * f->dim * 2)); }

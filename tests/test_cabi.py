@@ -19,6 +19,16 @@ def test_library_is_built_in_tree_and_exports_header():
     assert b"gfx950" in L.coltt_version()
 
 
+def test_library_was_compiled_from_exactly_these_sources():
+    """content hashes, not mtimes: the .so that ships to the GPU box must be the build of the sources beside it"""
+    from coltt_amd import build as B
+    if os.environ.get("COLTT_LIB"):
+        pytest.skip("a variant library is loaded")
+    m = B.verify()
+    assert set(m["objects"]) == {s[:-4] + ".o" for s in B.sources()}
+    assert m["library_sha256"] == B._sha(coltt_amd.lib_path())
+
+
 def test_no_cpu_fallback_without_device():
     L = coltt_amd.lib()
     if L.coltt_device_count() > 0:
