@@ -199,6 +199,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     else vis_insert(w.vis, w.hcap_mask, ep);
   }
   uint32_t len = 1, vis_count = 1;
+  uint32_t scan_lo = 0;   // every member before this index is expanded (pop scans start at its 64-entry chunk)
   bool had_reset = false;
   uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE;
   wave_sync();
@@ -210,7 +211,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
     unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
     // ---- pop: the smallest unexpanded member (cj = the unexpanded member after it, see the adjacency prefetch)
     int ci = -1, cj = -1;
-    for (uint32_t base = 0; base < len; base += 64) {
+    for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
       uint32_t i = base + lane;
       bool un = i < len && !(res[i] & 1ull);
       unsigned long long m = __ballot(un);
@@ -222,6 +223,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       }
     }
     if (ci < 0) break;
+    scan_lo = (uint32_t)ci + 1;
     COLTT_PT(w, 0)  // pop scan
     unsigned long long ce = res[ci];
     const unsigned long long runner_key = cj >= 0 ? (res[cj] & ~1ull) : ~0ull;
@@ -335,33 +337,42 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       }
       if (last_chunk) { COLTT_PREFETCH_NEXT() }
       if (m == 0) continue;
-      // ---- merge the m admitted (d, slot) into the sorted result set, keep the ef smallest
-      unsigned long long* dst = w.res0 + (size_t)(buf ^ 1) * w.ef_pad;
-      uint32_t mypos = 0;
+      // ---- merge the m admitted (d, slot) into the sorted result set, keep the ef smallest.  IN PLACE, from the tail down to
+      // the chunk of the smallest new key: members before it do not move (at ef 1024 most admissions land near the tail, so
+      // most of the set is never touched).  A member at index i moves to i + #{new keys that sort before it}; new key j sorts
+      // before it iff its insertion point pos_j <= i (keys are distinct), so the shift is counted on 32-bit positions.
+      // Descending chunk order makes the move safe: targets lie at most m <= 32 entries above, i.e. in entries already moved.
+      uint32_t mypos = 0xffffffffu;
       if (adm) {  // lower_bound over the sorted result set
         uint32_t lo = 0, hi = len;
         while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (res[mid] < mykey) lo = mid + 1; else hi = mid; }
         mypos = lo;
       }
-      for (uint32_t base = 0; base < len; base += 64) {
-        uint32_t i = base + lane;
-        unsigned long long e = i < len ? res[i] : ~0ull;
-        uint32_t shift = 0;
-        unsigned long long am = A;
-        while (am) {
-          int j = __builtin_ctzll(am); am &= am - 1;
-          unsigned long long kj = readlane_u64(mykey, j);
-          shift += (kj < e) ? 1u : 0u;
+      const uint32_t minpos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, __builtin_ctzll(__ballot(adm && myrank == 0)));
+      scan_lo = minpos < scan_lo ? minpos : scan_lo;   // the new keys are unexpanded
+      wave_sync();
+      if (len) {
+        for (int base = (int)((len - 1) & ~63u); base >= (int)(minpos & ~63u); base -= 64) {
+          const uint32_t i = (uint32_t)base + lane;
+          const unsigned long long e = i < len ? res[i] : ~0ull;
+          uint32_t shift = 0;
+          unsigned long long am = A;
+          while (am) {
+            int j = __builtin_ctzll(am); am &= am - 1;
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mypos, j);
+            shift += (pj <= i) ? 1u : 0u;
+          }
+          wave_sync();   // every lane holds its member before any lane overwrites one
+          const uint32_t np = i + shift;
+          if (i < len && shift && np < ef) res[np] = e;
         }
-        uint32_t np = i + shift;
-        if (i < len && np < ef) dst[np] = e;
       }
+      wave_sync();
       {
         uint32_t np = mypos + myrank;
-        if (adm && np < ef) dst[np] = mykey;
+        if (adm && np < ef) res[np] = mykey;
       }
       len = len + m < ef ? len + m : ef;
-      buf ^= 1;
       wave_sync();
       COLTT_PT(w, 4)  // merge
     }
