@@ -434,7 +434,8 @@ int ensure_visg(Hnsw* x) {
   if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
   size_t free_b = 0, total_b = 0;
   COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
-  const uint64_t budget = std::min<uint64_t>(total_b / 4, free_b / 2);
+  uint64_t budget = std::min<uint64_t>(total_b / 4, free_b / 2);
+  if (const char* e = getenv("COLTT_VISG_BUDGET_MB")) { if (*e) budget = std::min<uint64_t>(budget, (uint64_t)atol(e) << 20); }  // test knob
   const uint64_t regions = std::min<uint64_t>(VIS_MAX_REGIONS, budget / stride);
   x->vis_stride = stride;
   x->vis_regions = 0;

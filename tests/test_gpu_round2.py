@@ -370,3 +370,26 @@ def test_multi_wave_latency_path_falls_back_when_its_visited_table_is_too_small(
         for qi in range(len(Q)):
             assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"ef{ef} q{qi}")
         assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"]
+
+
+@pytest.mark.parametrize("budget_mb,expect", [("4", "capped at"), ("0", "using the LDS hash")])
+def test_hbm_visited_workspace_cap_transitions(gpu, monkeypatch, capfd, budget_mb, expect):
+    """The HBM visited set takes cap bytes x <= 2048 regions, bounded by a quarter of device memory (20 GB at 10 M; at 40 M on
+    one GPU the bound bites).  COLTT_VISG_BUDGET_MB shrinks the bound so both transitions run here: fewer regions than resident
+    workgroups (the launch shrinks to the lease), and fewer than 256 (the LDS hash serves ef > 128 too).  Either way a line
+    on stderr says so and the answers and counters stay the oracle's."""
+    monkeypatch.setenv("COLTT_VISG_BUDGET_MB", budget_mb); monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
+    n, d = 4000, 32
+    X = O.fill_normal(1900, (n, d)); lv = O.levels(1901, n)
+    gh = _gpu_build(gpu, X, lv, O.L2, O.Q_NONE, gpu.HnswCfg.default(ef_construction=40), batch=512)   # efConstruction <= 128: no byte map yet
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    Q = O.fill_normal(1902, (700, d))    # more queries than the capped launch has workgroups
+    capfd.readouterr()
+    for ef in (300, 200):
+        gi, gs, gc, st = gh.Search(Q, 10, ef=ef, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search(rows, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], Q, 10, ef, threads=4)
+        for qi in range(len(Q)):
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"ef{ef} q{qi}")
+        assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"]
+    err = capfd.readouterr().err
+    assert expect in err, err
