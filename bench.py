@@ -35,6 +35,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -515,19 +516,6 @@ def main():
     qps = total_q / dt
 
     secondary = {}
-    if world > 1 and not shard:
-        # the same scaling run also exercises the north-star layout (never allowed to kill the headline)
-        try:
-            grp2, m2, gstep2, info2, _ = leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k)
-            dts = timed(torch, dist, world, cdev, max(2, min(args.steps, 5)), 1, lambda i: gstep2())
-            info2.update({"value": max(2, min(args.steps, 5)) * nq / dts, "unit": "queries/s (every query visits every shard)",
-                          "workload": f"HNSW {info2['n_total']}x{dim} {QNAME[args.quant]} partitioned {world} ways by ShardVertex, efSearch={args.ef}, "
-                                      f"coltt_group_search_device: per-shard search + ONE RCCL all-gather of packed top-k + host merge"})
-            secondary["shard"] = info2
-            grp2.close()
-        except Exception as e:
-            secondary["shard"] = {"error": str(e)}
-
     if rank == 0:
         O = None
         if not args.no_cpu_baseline:
@@ -603,9 +591,49 @@ def main():
             "secondary": secondary or None,
             "shard": shard_info,
         }
-        print(json.dumps(res), flush=True)
     else:
         h.close()
+        res = None
+
+    # ---- N > 1: the same scaling run also exercises the north-star layout (ShardVertex partition + RCCL all-gather inside the
+    # library).  It runs LAST, with the headline record already assembled, under a watchdog: a rank that fails inside a collective
+    # would leave the others waiting for ever, and a secondary leg must never cost the headline line.
+    printed = threading.Lock()
+
+    def emit():
+        if rank == 0 and printed.acquire(blocking=False):
+            res["secondary"] = secondary or None
+            print(json.dumps(res), flush=True)
+
+    if world > 1 and not shard:
+        finished = threading.Event()
+        limit = float(os.environ.get("COLTT_SHARD_LEG_TIMEOUT_S", "420"))
+
+        def watchdog():
+            if not finished.wait(limit):
+                secondary.setdefault("shard", {"error": f"no answer within {limit:.0f} s (a rank failed or hung inside the exchange); headline unaffected"})
+                emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            grp2, m2, gstep2, info2, _ = leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k)
+            nst = max(2, min(args.steps, 5))
+            dts = timed(torch, dist, world, cdev, nst, 1, lambda i: gstep2())
+            info2.update({"value": nst * nq / dts, "unit": "queries/s (every query visits every shard)",
+                          "workload": f"HNSW {info2['n_total']}x{dim} {QNAME[args.quant]} partitioned {world} ways by ShardVertex, efSearch={args.ef}, "
+                                      f"coltt_group_search_device: per-shard search + ONE RCCL all-gather of packed top-k + host merge"})
+            secondary["shard"] = info2
+            grp2.close()
+        except Exception as e:
+            secondary["shard"] = {"error": str(e)}
+        emit()                      # the line is out before the closing barrier
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        finally:
+            finished.set()
+        return
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -110,3 +110,21 @@ def test_group_rccl_allgather_single_member_and_replica_layout(gpu):
     qd = torch.from_numpy(Q).cuda(); torch.cuda.synchronize()
     c = g3.SearchDevice([qd.data_ptr()] * 3, len(Q), k)
     assert np.array_equal(c[0], want[0]) and np.array_equal(bits(c[1]), bits(want[1]))
+
+
+def test_group_rccl_init_rank_path_single_process(gpu):
+    """the one-process-per-GPU bootstrap (coltt_group_unique_id + ncclCommInitRank), run here with a world of one: the path
+    bench.py's sharded leg takes under torch.distributed.run, with torch's own RCCL communicator alive in the same process."""
+    from coltt_amd import group as GG
+    n, d, k = 1500, 32, 10
+    X = O.fill_normal(1600, (n, d)); ids = np.arange(n, dtype=np.uint64)
+    fl = gpu.FlatSpace(d, O.COSINE); fl.ChangedVertex(ids, X)
+    Q = O.fill_normal(1601, (21, d))
+    want = fl.VertexSearch(Q, k, gpu.SELECT_NEAREST)
+    uid = GG.unique_id()
+    g = gpu.Group([0], d, O.COSINE, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_RCCL, world_size=1, rank_base=0, uid=uid)
+    assert g.info()["exchange"] == "rccl" and g.info()["world"] == 1
+    g.ChangedVertex(ids, X)
+    a = g.Search(Q, k)
+    assert np.array_equal(a[0], want[0]) and np.array_equal(bits(a[1]), bits(want[1]))
+    g.close()
