@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
-  w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
+  w.vis = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
   w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
   if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
-  w.vis = reinterpret_cast<uint32_t*>(w.res0 + 2 * (size_t)ef_pad);
+  w.vis = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
   w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
   if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
@@ -508,7 +508,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   SearchGeom s;
   s.ef = ef;
   s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * s.ef_pad * 8;
+  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8;   // query + result set (merged in place)
   // LDS visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
   s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
   // large ef x dim: shrink it until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps results exact;

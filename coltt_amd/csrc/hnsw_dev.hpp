@@ -2,7 +2,8 @@
 //
 // One wave64 owns one query (or one vertex being inserted).  State in LDS, per wave:
 //   qs   [dim] f32         the query as the distance kernel sees it (normalised / decoded)
-//   res  [2][ef_pad] u64   result set, sorted ascending, double-buffered; entry = d_bits<<32 | slot<<1 | expanded
+//   res  [ef_pad] u64      result set, sorted ascending, merged in place (the staged multi-wave kernel keeps two buffers);
+//                          entry = d_bits<<32 | slot<<1 | expanded
 //   vis  [hcap] u32        open-addressed visited set (slots), linear probing, EMPTY = 0xffffffff   (VISG = false)
 // or, VISG = true, the visited set lives in HBM: one byte per slot in a region private to the workgroup, holding the epoch of
 // the last traversal that visited the slot (no clearing between traversals; wiped when the 8-bit epoch wraps).  That costs one

@@ -258,8 +258,8 @@ def test_hnsw_ragged_dim_large_ef_and_k_above_ef(gpu, mw):
 
 
 def test_hnsw_visited_set_reset_keeps_results_exact(gpu, monkeypatch):
-    """ef = 3000 on a small dense graph with the LDS visited set forced (COLTT_VISG=0; above ef 128 the default is the HBM byte
-    map): the bounded hash (16384 slots here) is reset-and-reseeded; results stay exact."""
+    """ef = 4096 (the maximum) on a small dense graph with the LDS visited set forced (COLTT_VISG=0; above ef 128 the default is the HBM byte
+    map): the bounded hash (16384 slots beside the 32 KB result set) is reset-and-reseeded; results stay exact."""
     monkeypatch.setenv("COLTT_VISG", "0")
     n, d = 60000, 8
     X = O.fill_normal(121, (n, d)); lv = O.levels(122, n); ids = np.arange(n, dtype=np.uint64)
@@ -273,9 +273,9 @@ def test_hnsw_visited_set_reset_keeps_results_exact(gpu, monkeypatch):
     g = gh.Export(); g["vectors"] = X
     oh = O.Hnsw(d, O.L2, O.default_cfg(efConstruction=40)); oh.load(g)
     Q = O.fill_normal(123, (6, d))
-    gi, gs, gc, st = gh.Search(Q, 10, ef=3000, with_stats=True)
+    gi, gs, gc, st = gh.Search(Q, 10, ef=4096, with_stats=True)
     for qi in range(len(Q)):
-        wi, ws = oh.search(Q[qi], 10, mode=1, ef=3000)
+        wi, ws = oh.search(Q[qi], 10, mode=1, ef=4096)
         assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"q{qi}")
     assert st["n_visit_resets"] > 0, st
 
