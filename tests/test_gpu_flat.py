@@ -193,3 +193,39 @@ def test_flat_config0_full_size_single_queries(gpu):
             for mode in (gpu.MODE_EXACT, gpu.MODE_MFMA):
                 gi, gs, gc = gf.VertexSearch(Q[qi:qi + 1], 10, select, mode=mode)
                 assert_same_results(gi[0, :gc[0]], gs[0, :gc[0]], wi, ws, f"q{qi} sel{select} mode{mode}")
+
+
+@pytest.mark.parametrize("gen", ["3", "4"])
+@pytest.mark.parametrize("metric,quant", [(O.COSINE, O.Q_F16), (O.L2, O.Q_F16), (O.COSINE, O.Q_NONE)])
+def test_flat_mfma_many_tiles_per_workgroup_smallest_dim(gpu, metric, quant, gen, monkeypatch):
+    """200 k x 128: 782 row tiles over 256 persistent workgroups (three or four tiles each, the raw-norm parity buffers flip with
+    every tile) at the SMALLEST dim the matrix-core mode takes (4 K steps per tile: the DMA rings run three tiles ahead of the
+    epilogue).  Ragged batch, batch 256 and a last tile of 64 rows; both kernel generations; == exact mode bit for bit.
+    (dim 96 / 64 / 32 are served by the exact scan: `Stats()` shows no matrix-core group.)"""
+    import subprocess, sys, os, json
+    # the generation is read once per process: run the comparison in a child so both generations are really exercised
+    code = f"""
+import numpy as np, json, sys
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+import coltt_amd as G
+from oracle import oracle as O
+assert G.lib().coltt_init(0) == 0
+n, d = 200_000 + 64, 128
+X = O.fill_normal(41, (n, d)); ids = np.arange(n, dtype=np.uint64)
+gf = G.FlatSpace(d, {metric}, {quant}); gf.ChangedVertex(ids, X)
+ok = True
+for nq in (256, 37):
+    Q = O.fill_normal(42 + nq, (nq, d))
+    for k, sel in ((10, G.SELECT_NEAREST), (33, G.SELECT_REFERENCE)):
+        e = gf.VertexSearch(Q, k, sel, G.MODE_EXACT); m = gf.VertexSearch(Q, k, sel, G.MODE_MFMA)
+        ok &= bool(np.array_equal(e[0], m[0]) and np.array_equal(e[1].view(np.uint32), m[1].view(np.uint32)) and np.array_equal(e[2], m[2]))
+st = gf.Stats()
+small = G.FlatSpace(96, {metric}, {quant}); small.ChangedVertex(ids[:3000], O.fill_normal(43, (3000, 96)))
+small.VertexSearch(O.fill_normal(44, (8, 96)), 5, G.SELECT_NEAREST, G.MODE_MFMA)
+print(json.dumps({{"ok": ok, "groups": st["mfma_groups"], "fallbacks": st["mfma_fallbacks"], "small_groups": small.Stats()["mfma_groups"]}}))
+"""
+    env = dict(os.environ, COLTT_MFMA_GEN=gen)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["ok"] and r["groups"] > 0 and r["small_groups"] == 0, r
