@@ -149,6 +149,26 @@ def test_hnsw_gpu_build_batched(gpu):
     assert rec > 0.9, rec
 
 
+def test_hnsw_gpu_build_bench_schedule_100k(gpu):
+    """The builder exactly as bench.py drives it — cosine, batches growing to 1/32 of the graph (3 125 vertices here, the 16 384
+    cap is the same code path) — on 100 000 x 32: the whole graph (levels, every edge list, stored edge distances, entrypoint)
+    equals the oracle's batched-insert restatement bit for bit.  (The 10 M bench graph itself is validated by search parity on
+    the exported arrays; this is build parity at the largest size the CPU oracle builds in about half a minute.)"""
+    import torch
+    n, d = 100_000, 32
+    X = O.fill_normal(171, (n, d)); lv = O.levels(172, n); ids = np.arange(n, dtype=np.uint64)
+    sched = lambda i: max(1, min(16384, i // 32))
+    oh = O.Hnsw(d, O.COSINE, O.default_cfg(efConstruction=64)); oh.insert_batched(ids, X, lv, 0, schedule=sched)
+    gh = gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(ef_construction=64))
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    i = 0
+    while i < n:
+        b = min(sched(i), n - i)
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i)
+        i += b
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
+
+
 def test_hnsw_remove_parity(gpu):
     import torch
     n, d = 500, 32
