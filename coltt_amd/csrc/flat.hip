@@ -416,7 +416,8 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   // query, and the epilogue's element path (mf_emit_block) is practically never taken.  (One unfiltered seed followed by
   // ONE big segment left p = k/8192 for the whole scan: 72 % of the wave-blocks took the element path, 12k survivors/query.)
   // (the seed is small: all of its s0 x g scores are appended through atomics — 8192 rows x 256 queries took 0.7 ms)
-  uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(1024, 16ull * k)});
+  static const uint64_t seed_rows = [] { const char* e = getenv("COLTT_MFMA_SEED"); long v = e && *e ? atol(e) : 1024; return (uint64_t)(v < 256 ? 256 : v); }();
+  uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(seed_rows, 16ull * k)});
   static const uint64_t grow = [] { const char* e = getenv("COLTT_MFMA_GROW"); long v = e && *e ? atol(e) : 16; return (uint64_t)(v < 2 ? 2 : v); }();
   for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * grow)) COLTT_TRY(scan(b, e));
   // exact re-score of the survivors + the ordinary select, queued behind the scans with no host round trip in between; the

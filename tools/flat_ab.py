@@ -39,7 +39,7 @@ def main():
             if r: ms.append(fl.last_kernel_ms())
         s = {0: 4, 1: 2, 2: 1, 3: 2}[quant]
         t = float(np.median(ms))
-        print(f"{os.path.basename(os.environ.get('COLTT_LIB', 'default'))} gen={os.environ.get('COLTT_MFMA_GEN', '2')} {n}x{dim} q{quant} b{batch} {'cos' if metric == 0 else 'l2'} {fl.Stats()}: {t:.3f} ms  {n * dim * s / t / 1e9:.3f} TB/s "
+        print(f"{os.path.basename(os.environ.get('COLTT_LIB', 'default'))} gen={os.environ.get('COLTT_MFMA_GEN', 'default(3)')} {n}x{dim} q{quant} b{batch} {'cos' if metric == 0 else 'l2'} {fl.Stats()}: {t:.3f} ms  {n * dim * s / t / 1e9:.3f} TB/s "
               f"{2.0 * n * dim * batch / t / 1e9:.0f} TFLOP/s  (min {min(ms):.3f})", flush=True)
         fl.close()
 
