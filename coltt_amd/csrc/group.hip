@@ -221,11 +221,19 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
     if (!can && (o.exchange == COLTT_EXCHANGE_RCCL || multi_process))
       return fail(COLTT_E_UNSUPPORTED, "group_create: RCCL exchange unavailable (%s)", !r ? "librccl not loadable" : "a communicator cannot hold one device twice");
     if (can) {
-      if (multi_process) {
+      if (multi_process || o.unique_id) {   // rank-wise bootstrap (the only way across processes; also taken when an id is handed in)
         NcclId id; std::memcpy(id.internal, o.unique_id, COLTT_UNIQUE_ID_BYTES);
         COLTT_NCCL(r, r->GroupStart());
-        for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_NCCL(r, r->CommInitRank(&x.comm, world, id, x.rank)); }
-        COLTT_NCCL(r, r->GroupEnd());
+        int bad = 0; std::string why;
+        for (auto& xp : g->m) {
+          Member& x = *xp;
+          if (use_device(x.device) != COLTT_OK) { bad = -1; why = g_last_error; break; }
+          const int e = r->CommInitRank(&x.comm, world, id, x.rank);
+          if (e != 0) { bad = e; why = std::string("ncclCommInitRank: ") + r->GetErrorString(e); break; }
+        }
+        const int ge = r->GroupEnd();   // always closed, also after a failure inside the group
+        if (bad) return fail(COLTT_E_DEVICE, "group_create: %s", why.c_str());
+        if (ge != 0) return fail(COLTT_E_DEVICE, "group_create: ncclGroupEnd: %s", r->GetErrorString(ge));
       } else {
         std::vector<nccl_comm_t> comms((size_t)n_devices);
         COLTT_NCCL(r, r->CommInitAll(comms.data(), n_devices, devices));
@@ -411,11 +419,15 @@ static int group_search(Group* g, const float* queries, const float* const* d_qu
   if (g->exchange == COLTT_EXCHANGE_RCCL) {
     Rccl* r = rccl();
     COLTT_NCCL(r, r->GroupStart());
+    int bad = 0; std::string why;
     for (auto& xp : g->m) { Member& x = *xp;
-      COLTT_TRY(use_device(x.device));
-      COLTT_NCCL(r, r->AllGather(x.d_pack.p, x.d_gather.p, per * sizeof(Rec), 0 /*ncclInt8*/, x.comm, x.stream));
+      if (use_device(x.device) != COLTT_OK) { bad = -1; why = g_last_error; break; }
+      const int e = r->AllGather(x.d_pack.p, x.d_gather.p, per * sizeof(Rec), 0 /*ncclInt8*/, x.comm, x.stream);
+      if (e != 0) { bad = e; why = std::string("ncclAllGather: ") + r->GetErrorString(e); break; }
     }
-    COLTT_NCCL(r, r->GroupEnd());
+    const int ge = r->GroupEnd();   // always closed, also after a failure inside the group
+    if (bad) return fail(COLTT_E_DEVICE, "group_search: %s", why.c_str());
+    if (ge != 0) return fail(COLTT_E_DEVICE, "group_search: ncclGroupEnd: %s", r->GetErrorString(ge));
     Member& x0 = *g->m[0];
     COLTT_TRY(use_device(x0.device));
     COLTT_HIP(hipMemcpyAsync(g->h_stage, x0.d_gather.p, (size_t)g->world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.stream));
