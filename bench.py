@@ -385,7 +385,7 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
            "value": batch / wall, "unit": "queries/s", "ms_per_batch_wall": wall * 1e3, "ms_per_batch_kernels": tm * 1e3,
            "exact_mode_ms_per_batch": te * 1e3, "identical_to_exact_mode": bool(np.array_equal(ei, mi) and np.array_equal(es.view(np.uint32), msc.view(np.uint32))),
            "roofline": {"bound": "hbm", "achieved": nbytes / tm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / tm / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "flat_mfma_cos_kernel + pick/rescore/select chain (hipEvent pair around the whole search on its stream)",
+                        "traffic": None, "kernel": "flat_mfma3_kernel + pick/rescore/select chain (hipEvent pair around the whole search on its stream)",
                         "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
                         "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
                                  "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}

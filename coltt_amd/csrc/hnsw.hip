@@ -96,8 +96,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 }
 
 
-// Hnsw.Search on FOUR waves per query (search_level_mw): the latency path for small batches — the reference serves one query
-// per RPC (core/core.go:633-667).  One 256-thread workgroup per query at a time, queries pulled from a global counter.
+// Hnsw.Search with a 256-thread workgroup per query (search_level_mw: rows of an expansion staged in LDS by all four waves,
+// evaluated by wave 0) — the opt-in experiment for small batches; the reference serves one query per RPC (core/core.go:633-667).
+// One workgroup per query at a time, queries pulled from a global counter.  Measured slower than one wave per query (see
+// mw_max_nq()); kept for the record and covered by the same parity tests.
 template <int METRIC, int QUANT, bool VISG>
 __global__ __launch_bounds__(256) void hnsw_search_mw_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                             const float* __restrict__ q_eff, const float* __restrict__ qnorms,

@@ -33,7 +33,7 @@ def test_c5_shape_bf16_hnsw_ef256_on_gpu_built_graph(gpu, monkeypatch, mwq, n, d
     """configs[4]: cosine HNSW over the reference's "BF16" codes (= binary16, bf16.go:233-317), efSearch 256 (the HBM-visited
     kernel), graph built by the GPU's batched Insert.  Checker: the oracle's canonical Hnsw.Search over the very arrays
     copied out of HBM (stored codes, adjacency), query lowered as bf16_vectorstore.go:136 does: ids, score bits, counters."""
-    monkeypatch.setenv("COLTT_MW_MAX_NQ", mwq)   # one wave per query / four waves per query (HBM-visited variants of both)
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", mwq)   # one wave per query / the opt-in 256-thread staged kernel (HBM-visited variants of both)
     X = O.fill_normal(500 + d, (n, d)); lv = O.levels(501 + d, n)
     gh = _gpu_build(gpu, X, lv, O.COSINE, O.Q_BF16, gpu.HnswCfg.default(ef_construction=100))
     g = gh.ExportRaw(); rows = gh.FetchRows()
