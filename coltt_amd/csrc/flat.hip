@@ -195,7 +195,14 @@ struct Flat : Object {
     ncap = std::max<uint64_t>(ncap, 1024);
     // ROW_SLACK rows (and norms) behind the capacity: the matrix-core scan fetches whole 256/384-row tiles without clamping
     // the last one (flat_mfma3.hpp); what it reads there is never scored
+    // ... and everything behind the stored rows is ZERO: for dim % 32 != 0 the last K step of a row reads into its (zeroed)
+    // padding and the head of the next row, against zero query columns — finite garbage is harmless there, NaN bits are not
+    const size_t old_bytes = rows.cap;
     COLTT_TRY(rows.reserve((ncap + ROW_SLACK) * stride, true, stream));
+    if (rows.cap > old_bytes) {
+      COLTT_HIP(hipMemsetAsync(rows.as<uint8_t>() + old_bytes, 0, rows.cap - old_bytes, stream));
+      COLTT_HIP(hipStreamSynchronize(stream));
+    }
     COLTT_TRY(norms.reserve((ncap + 2 * ROW_SLACK) * 4, true, stream));
     if (!dense) COLTT_TRY(ids.reserve(ncap * 8, true, stream));
     cap = ncap;
@@ -318,7 +325,7 @@ static int mfma_generation() {
 
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                       unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed) {
+                       unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim) {
   if (mfma_generation() >= 4 && !(seed && BN == 256)) {   // (the batch-256 seed instance would spill: it stays on generation 3)
     auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma4_kernel<BN, AF32, true, M_COS> : flat_mfma4_kernel<BN, AF32, false, M_COS>)
                                           : (seed ? flat_mfma4_kernel<BN, AF32, true, M_L2> : flat_mfma4_kernel<BN, AF32, false, M_L2>);
@@ -326,7 +333,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -343,7 +350,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + BM - 1) / BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -355,7 +362,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -365,7 +372,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
   uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
-  kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, (int)f->dim, thr,
+  kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
                                       nearest, cand, cnt, cap);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
@@ -373,9 +380,9 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
 
 template <int BN>
 int launch_mfma_scan(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                     unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed) {
-  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed);
-  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed);
+                     unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim) {
+  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim);
+  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim);
 }
 
 // relative error bound of the Euclidean candidate value s~^2 against the exact s^2, in units of (||q||^2 + ||r||^2): D * 2^-24 from
@@ -398,12 +405,13 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   const float* qn = c->w_qn.as<float>() + q0;
   _Float16* q16 = c->w_q16.as<_Float16>();
   const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
-  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * f->dim, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, q16, cnt, thr, ovf, nearest);
+  const int dimp = (int)((f->dim + MF_BK - 1) / MF_BK * MF_BK);   // K padded to whole steps with zero query columns
+  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * dimp, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, dimp, q16, cnt, thr, ovf, nearest);
   auto scan = [&](uint64_t b, uint64_t e) -> int {
     const bool seed = b == 0 && e - b <= cap;
-    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
-    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
-    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed));
+    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
+    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
+    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
     if (f->metric == COLTT_COSINE)
       flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     else  // Euclidean: |s~^2 - s^2| <= eps * (||q||^2 + ||r||^2), eps = dot error (+ f16 rounding of f32 rows) + f32 rounding of the norms / the exact sum
@@ -444,11 +452,16 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // (f32 rows are rounded to binary16 for candidate generation: ||row||^2 <= 4e9 keeps every element inside its range)
   const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && f->max_norm == f->max_norm &&
                      f->max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
+  // K need not be a multiple of the 32-column step with the DMA kernels: the query tile is zero-padded and the rows' overhang
+  // (padding, head of the next row — all finite as long as no stored norm ever was non-finite; Flat::reserve zeroes the rest)
+  // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
+  const bool finite_rows = f->max_norm == f->max_norm && f->max_norm < 3.0e38f;
+  const bool k_ok = f->dim % MF_BK == 0 || (mfma_generation() >= 2 && finite_rows);
   const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (f->metric == COLTT_COSINE || l2_ok) &&
-                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && f->dim % MF_BK == 0 && f->dim >= 128 && f->dim <= 4096 && total > 0;   // (dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile)
+                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 128 && f->dim <= 4096 && total > 0;
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
-  if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * f->dim * 2)); }
+  if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * ((f->dim + MF_BK - 1) / MF_BK * MF_BK) * 2)); }
   const size_t n_groups = (nq + gq - 1) / gq;
   COLTT_TRY(c->w_cnt.reserve(4096 + n_groups * 4));
   uint32_t* d_ovf = c->w_cnt.as<uint32_t>() + 1024;   // one overflow flag per matrix-core group, checked once after the last group

@@ -229,3 +229,26 @@ print(json.dumps({{"ok": ok, "groups": st["mfma_groups"], "fallbacks": st["mfma_
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["ok"] and r["groups"] > 0 and r["small_groups"] == 0, r
+
+
+@pytest.mark.parametrize("d", [130, 200, 300])
+@pytest.mark.parametrize("metric,quant", [(O.COSINE, O.Q_F16), (O.L2, O.Q_BF16), (O.COSINE, O.Q_NONE), (O.L2, O.Q_NONE)])
+def test_flat_mfma_dims_not_multiple_of_32(gpu, metric, quant, d):
+    """K is padded to whole 32-column steps with zero QUERY columns; the rows' overhang (their zeroed padding and the head of the
+    next row) multiplies zeros.  70 000 rows (274 tiles: some workgroups take two), a ragged batch: ids, ranks and score bits equal
+    exact mode, and the matrix cores really served the call.  A store that ever held a non-finite row stays on the exact scan
+    (its bits could sit in another row's overhang): same answers, no matrix-core group."""
+    n = 70_000
+    X = O.fill_normal(300 + d, (n, d)).astype(np.float32); ids = np.arange(n, dtype=np.uint64)
+    gf = gpu.FlatSpace(d, metric, quant); gf.ChangedVertex(ids, X)
+    Q = O.fill_normal(301 + d, (70, d))
+    for k, sel in ((10, gpu.SELECT_NEAREST), (40, gpu.SELECT_REFERENCE)):
+        e = gf.VertexSearch(Q, k, sel, gpu.MODE_EXACT); m = gf.VertexSearch(Q, k, sel, gpu.MODE_MFMA)
+        assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1])) and np.array_equal(e[2], m[2]), (k, sel)
+    served = gf.Stats()["mfma_groups"]
+    assert served > 0
+    bad = X[:1].copy(); bad[0, 3] = np.inf
+    gf.ChangedVertex(np.array([n], dtype=np.uint64), bad)
+    e = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST, gpu.MODE_EXACT); m = gf.VertexSearch(Q, 10, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
+    assert np.array_equal(e[0], m[0]) and np.array_equal(bits(e[1]), bits(m[1]))
+    assert gf.Stats()["mfma_groups"] == served
