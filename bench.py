@@ -279,6 +279,15 @@ def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=Non
         nq16 = int(max(1, min(len(q), args.cpu_seconds / 2 / (lat / s16))))
         r16 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nq16], k, nearest=True, shape=0, split=s16, threads=s16)
         legs[f"{s16} (highCpu: one query split {s16} ways)"] = {"queries_per_s": nq16 / r16[3], "ms_per_query": r16[3] / nq16 * 1e3}
+        # the reference's MEMORY shape too (16 maps id -> ENode, one heap allocation per stored vector, scanned in map order, both
+        # decoded operands allocated per pair): one thread, and highCpu = one goroutine per map
+        rs1 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:1], k, nearest=True, shape=2, split=1, threads=1)
+        legs["1 (reference-shaped: 16 maps of per-vector allocations)"] = {"queries_per_s": 1.0 / rs1[3], "ms_per_query": rs1[3] * 1e3}
+        same_shape = bool(np.array_equal(rs1[0], r1[0]) and np.array_equal(rs1[1].view(np.uint32), r1[1].view(np.uint32)))
+        if threads >= 16:
+            nqr = int(max(1, min(len(q), args.cpu_seconds / 2 / (rs1[3] / 16))))
+            rs16 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nqr], k, nearest=True, shape=2, split=16, threads=16)
+            legs["16 (reference-shaped, highCpu: one thread per map)"] = {"queries_per_s": nqr / rs16[3], "ms_per_query": rs16[3] / nqr * 1e3}
         best_q, best_th, ra, nqa = 0.0, threads, None, 0
         for th in [t for t in thread_counts(threads) if t >= 16]:
             nq_t = int(min(len(q), max(th, (args.cpu_seconds / lat) * min(th, 32) * 0.5)))
@@ -291,7 +300,7 @@ def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=Non
                "sample": f"{nqa} queries over {n_rows}x{dim} {QNAME[quant]} rows copied out of HBM (NUMA-interleaved), contiguous variant, reference arithmetic "
                          f"(Normalize, Lower, decode both operands per pair, AVX-order distance, bounded queue), native pinned threads, best thread count of the sweep",
                "by_threads": legs, "bytes_per_query": bytes_per_query, "dram_stream_read_GBps_by_threads": stream,
-               "parallel_efficiency_at_best": best_q / (best_th / lat)}
+               "parallel_efficiency_at_best": best_q / (best_th / lat), "reference_shaped_equals_contiguous": same_shape}
         if quant != 0:
             rd = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nqa], k, nearest=True, shape=1, split=1, threads=best_th)
             res["decode_once_variant_queries_per_s"] = nqa / rd[3]

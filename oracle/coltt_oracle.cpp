@@ -1503,7 +1503,30 @@ int orc_flat_scan_mt(const void* rows_v, int quant, uint64_t n, uint32_t dim, in
     lower(quant, &qn[i * dim], dim, &qlow[i * rb]);
     if (quant != Q_NONE) raise(quant, &qlow[i * rb], dim, &qn[i * dim]);  // the decoded query (shape 1 uses it directly)
   }
+  // shape 2 = the reference's MEMORY shape as well (none_vectorstore.go:40-47, 135-178): 16 maps id -> ENode, every stored vector
+  // its own heap allocation, scanned in map order; Similarity allocates both decoded operands per pair (f16_quantization.go:35-45).
+  // Built here, outside the timed region; with split = 16 thread t scans map t, which is what highCpu does.
+  std::vector<std::unordered_map<uint64_t, std::vector<uint8_t>>> shards;
+  if (shape == 2) {
+    shards.resize(16);
+    for (uint64_t r = 0; r < n; r++) shards[(size_t)shard_vertex(r, 16)].emplace(r, std::vector<uint8_t>(rows + r * rb, rows + (r + 1) * rb));
+    if (split != 1 && split != 16) return -1;
+  }
+  auto scan_shard = [&](size_t qi, size_t sh, TopK& tk) {
+    const float* qd = &qn[qi * dim]; const uint8_t* ql = &qlow[qi * rb];
+    for (const auto& kv : shards[sh]) {
+      float sc;
+      if (quant == Q_NONE) sc = dist(metric, order, qd, (const float*)kv.second.data(), dim);
+      else { std::vector<float> a(dim), b(dim); raise(quant, ql, dim, a.data()); raise(quant, kv.second.data(), dim, b.data()); sc = dist(metric, order, a.data(), b.data(), dim); }
+      tk.add({sc, kv.first});
+    }
+  };
   auto scan = [&](size_t qi, uint64_t lo, uint64_t hi, TopK& tk, float* bx, float* by) {
+    if (shape == 2) {  // lo/hi select whole maps: [0,n) = all sixteen, the t-th sixteenth = map t
+      if (lo == 0 && hi == n) { for (size_t sh = 0; sh < 16; sh++) scan_shard(qi, sh, tk); }
+      else scan_shard(qi, (size_t)((lo * 16 + n / 2) / (n ? n : 1)), tk);
+      return;
+    }
     const float* qd = &qn[qi * dim]; const uint8_t* ql = &qlow[qi * rb];
     for (uint64_t r = lo; r < hi; r++) {
       const uint8_t* row = rows + r * rb; float sc;

@@ -363,7 +363,8 @@ def test_csr_search_equals_canonical_search(metric, quant):
 def test_cpu_baseline_mt_drivers_equal_serial_oracle():
     """bench.py's cpu_baseline runs native pinned threads inside the oracle (orc_csr_search_mt / orc_flat_scan_mt) over a
     NUMA-interleaved copy of the corpus.  Threading must not change a bit: same slots, score bits and counters as the serial
-    calls; the FLAT driver (both `highCpu` split and one-query-per-thread, both decode shapes) equals Flat.search's canonical mode."""
+    calls; the FLAT driver (both `highCpu` split and one-query-per-thread, both decode shapes and the reference's memory shape — 16
+    maps of per-vector allocations) equals Flat.search's canonical mode."""
     n, d, k, ef = 1500, 40, 10, 64
     X = O.fill_normal(171, (n, d)); lv = O.levels(172, n); ids = np.arange(n, dtype=np.uint64)
     for metric, quant in ((O.COSINE, O.Q_NONE), (O.COSINE, O.Q_BF16), (O.L2, O.Q_F8)):
@@ -379,7 +380,7 @@ def test_cpu_baseline_mt_drivers_equal_serial_oracle():
         s4 = O.csr_search(na.a, quant, adj0, upper_off, adjU, d, metric, ent, el, Q, k, ef, threads=5)
         assert np.array_equal(s1[0], s4[0]) and np.array_equal(bits(s1[1]), bits(s4[1])) and np.array_equal(s1[2], s4[2]) and s1[3] == s4[3]
         for nearest in (True, False):
-            for shape, split, th in ((0, 1, 3), (1, 1, 4), (0, 16, 16), (1, 4, 4)):
+            for shape, split, th in ((0, 1, 3), (1, 1, 4), (0, 16, 16), (1, 4, 4), (2, 1, 1), (2, 1, 3), (2, 16, 16)):   # 2 = reference memory shape
                 sl, sc, cn, _ = O.flat_scan(na.a, quant, d, metric, Q, k, nearest=nearest, shape=shape, split=split, threads=th)
                 for qi in range(len(Q)):
                     wi, ws = f.search(Q[qi], k, nearest=nearest, mode=2)
