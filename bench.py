@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,c1,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -495,7 +495,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "c2", "c3"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "c1", "c2", "c3"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -570,10 +570,12 @@ def main():
                 op = leg_operating_point(G, torch, dev, O, args, dim, k)
             except Exception as e:
                 op = {"error": str(e)}
-        for tag, (fn, fq, fb, cfgname, cpu_rows) in {"c2": (1_000_000, 0, 64, "configs[1]", 1_000_000), "c3": (10_000_000, 1, 256, "configs[2]", 1_000_000)}.items():
+        for tag, (fn, fd, fq, fb, cfgname, cpu_rows) in {"c1": (100_000, 128, 0, 1, "configs[0]: the reference's own CPU-runnable case, one query per call", 100_000),
+                                                         "c2": (1_000_000, dim, 0, 64, "configs[1]", 1_000_000),
+                                                         "c3": (10_000_000, dim, 1, 256, "configs[2]", 1_000_000)}.items():
             if tag in legs:
                 try:
-                    secondary[tag] = leg_flat(G, torch, dev, O, args, dim, k, fn, fq, fb, cfgname, cpu_rows)
+                    secondary[tag] = leg_flat(G, torch, dev, O, args, fd, k, fn, fq, fb, cfgname, cpu_rows)
                 except Exception as e:
                     secondary[tag] = {"error": str(e)}
         res = {
