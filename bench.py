@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,c1,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -101,7 +101,9 @@ class Dataset:
     def rows(self, c, gen):
         """one chunk of synthetic vectors in HBM"""
         t = self.torch
-        if self.basis is None:
+        if self.spec == "uniform":      # the reference's own benchmark data: rand.Float32() per element (benchmark/coltt_search.go:50-63)
+            x = t.rand((c, self.dim), device=self.dev, dtype=t.float32, generator=gen)
+        elif self.basis is None:
             x = t.randn((c, self.dim), device=self.dev, dtype=t.float32, generator=gen)
         else:
             z = t.randn((c, self.basis.shape[0]), device=self.dev, dtype=t.float32, generator=gen)
@@ -215,7 +217,7 @@ def host_copy_of_index(O, h, dim, quant, threads):
     return rows, adj0, g
 
 
-def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m):
+def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None):
     """Hnsw.Search on the host cores over the SAME graph: 1 thread (latency), 16 threads, all cores (throughput)."""
     import psutil
     threads = O.cpu_count()
@@ -231,7 +233,7 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m):
             return O.csr_search(rows.a, quant, adj0.a, queries=qs, threads=th, pin=True, **common)
         r1 = run(q_host[:8], 1); lat = r1[4] / 8                       # single-thread latency
         legs = {}
-        for th in thread_counts(threads):
+        for th in (counts or thread_counts(threads)):
             sample = int(max(th, min(len(q_host), args.cpu_seconds / lat * min(th, 32))))
             sample = min(sample - sample % th if sample >= th else th, len(q_host))
             r = run(q_host[:sample], th)
@@ -367,6 +369,40 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
     return res
 
 
+def leg_published_hnsw_point(G, torch, dev, O, args, k):
+    """The one HNSW number the reference publishes (UPDATE-LOG.md:142): 1 M vectors, 128-d random-uniform, top-10,
+    ONE query per call, 0.87 ms mean through gRPC on the author's laptop.  Same shape here: default config (M=16, efSearch=20,
+    efConstruction=200, cosine), graph built on the GPU, then single-query calls (wall time of the C-ABI call) and one batch."""
+    n, dim, nq = 1_000_000, 128, 10_000
+    ds = Dataset(torch, dev, dim, "uniform")
+
+    class A: m = 16; ef = 20; efc = 200; build_batch = args.build_batch
+    h, build_s = build_index(G, torch, dev, ds, n, dim, A, args.seed + 404, 0)
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 13)
+    q = ds.rows(nq, qgen)
+    out = Out(torch, dev, nq, k)
+    wall = []
+    for i in range(300):
+        t0 = time.perf_counter()
+        h.SearchDevice(q.data_ptr() + i * dim * 4, 1, k, *out.ptrs())
+        wall.append(time.perf_counter() - t0)
+    h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs())
+    batch_ms = h.last_kernel_ms()
+    res = {"workload": f"core/vectorindex HNSW defaults (M=16 efSearch=20 efConstruction=200), {n}x{dim} float32 uniform[0,1), cosine, k={k}: the reference's published "
+                       f"search point (0.87 ms/query through gRPC, UPDATE-LOG.md:142; build 2 897 s through gRPC, benchmark/coltt_core.go:107-116)",
+           "single_query_call_ms_median": float(np.median(wall[20:]) * 1e3), "single_query_call_ms_p99": float(np.percentile(wall[20:], 99) * 1e3),
+           "batch_of_10000_queries_per_s": nq / (batch_ms / 1e3), "build_s": build_s, "published_reference_ms_per_query": 0.87}
+    if O is not None:
+        try:
+            A.ef = 20
+            c = cpu_hnsw(G, torch, O, h, args, dim, 0, 20, q, k, out, 16, counts=[1, min(16, O.cpu_count())])
+            res["cpu_baseline"] = {kk: c[kk] for kk in ("single_thread_latency_ms", "queries_per_s_by_threads", "gpu_equals_oracle_on_sample", "counters_equal", "sample") if kk in c} if "error" not in c else c
+        except Exception as e:
+            res["cpu_baseline"] = {"error": str(e)}
+    h.close()
+    return res
+
+
 def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
     """BASELINE.json configs[1] / configs[2]: batched FLAT scan through the matrix-core candidate path"""
     ds = Dataset(torch, dev, dim, "normal")
@@ -495,7 +531,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "c1", "c2", "c3"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -570,6 +606,11 @@ def main():
                 op = leg_operating_point(G, torch, dev, O, args, dim, k)
             except Exception as e:
                 op = {"error": str(e)}
+        if "h1" in legs:
+            try:
+                secondary["h1"] = leg_published_hnsw_point(G, torch, dev, O, args, k)
+            except Exception as e:
+                secondary["h1"] = {"error": str(e)}
         for tag, (fn, fd, fq, fb, cfgname, cpu_rows) in {"c1": (100_000, 128, 0, 1, "configs[0]: the reference's own CPU-runnable case, one query per call", 100_000),
                                                          "c2": (1_000_000, dim, 0, 64, "configs[1]", 1_000_000),
                                                          "c3": (10_000_000, dim, 1, 256, "configs[2]", 1_000_000)}.items():
