@@ -430,7 +430,8 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
            "value": batch / wall, "unit": "queries/s", "ms_per_batch_wall": wall * 1e3, "ms_per_batch_kernels": tm * 1e3,
            "exact_mode_ms_per_batch": te * 1e3, "identical_to_exact_mode": bool(np.array_equal(ei, mi) and np.array_equal(es.view(np.uint32), msc.view(np.uint32))),
            "roofline": {"bound": "hbm", "achieved": nbytes / tm / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / tm / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "flat_mfma3_kernel + pick/rescore/select chain (hipEvent pair around the whole search on its stream)",
+                        "traffic": flat_pmc_traffic(n, dim, quant, batch)[0], "traffic_source": flat_pmc_traffic(n, dim, quant, batch)[1],
+                        "kernel": "flat_mfma3_kernel + pick/rescore/select chain (hipEvent pair around the whole search on its stream)",
                         "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
                         "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
                                  "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}
@@ -689,6 +690,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def flat_pmc_traffic(n, dim, quant, batch):
+    """HBM bytes per FLAT batch from the committed PMC pass (tools/pmc_traffic.py --flat), only for the very shape it was taken on"""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(p)).get(f"flat n={n} dim={dim} quant={quant} batch={batch}", {})
+        return rec.get("hbm_bytes_per_batch"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
+    except Exception:
+        return None, None
 
 
 def pmc_traffic(args, n, dim, nq):

@@ -140,3 +140,23 @@ def test_pmc_traffic_tool_on_a_synthetic_counter_csv(tmp_path):
     rec = json.load(open(out))[f"hnsw n={n} dim={dim} quant=0 ef=128 m=16 queries={nq} dataset=normal"]
     assert abs(rec["hbm_bytes_per_launch"] - true_bytes_per_launch) / true_bytes_per_launch < 1e-9
     assert abs(rec["traffic_over_algorithmic"] - true_bytes_per_launch / (1_150_000.0 * nq)) < 1e-9
+
+
+def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
+    """`--flat`: the committed raw PMC pass over tools/flat_ab.py -> per-search HBM traffic of the matrix-core FLAT chain (every
+    dispatch of a search summed), and the key bench.py's FLAT legs look up.  Traffic must sit within a few % above the row bytes."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import pmc_traffic as T
+    src = os.path.join(root, "profiles", "r02_pmc_flat_fetch_size_raw.csv")
+    out = tmp_path / "t.json"
+    T.main([src, "--flat", "1000000,768,0,64", "10000000,768,1,256", "--out", str(out)])
+    t = json.load(open(out))
+    for key, alg in (("flat n=1000000 dim=768 quant=0 batch=64", 1_000_000 * 768 * 4), ("flat n=10000000 dim=768 quant=1 batch=256", 10_000_000 * 768 * 2)):
+        r = t[key]
+        assert r["algorithmic_bytes_per_batch"] == alg and r["searches_used"] >= 3
+        assert 1.0 <= r["traffic_over_algorithmic"] < 1.1, r
+    committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert all(k in committed for k in t)

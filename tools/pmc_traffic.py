@@ -55,12 +55,63 @@ def calibrate(flat_launches, rows, stride):
     return known_kib / mean, {"launches": len(vals), "FETCH_SIZE_KiB_mean": mean, "known_KiB": known_kib}
 
 
+def flat_searches(path, counter="FETCH_SIZE"):
+    """FLAT matrix-core searches in a PMC pass over tools/flat_ab.py: every search starts with mfma_prep_queries_kernel and ends
+    with flat_select_kernel; returns [(query-tile width BN, summed counter over the dispatches of the search)]."""
+    per = collections.OrderedDict()
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            key = (int(r["Dispatch_Id"]), r["Kernel_Name"])
+            per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
+    out, cur = [], None
+    for (_, name), v in sorted(per.items()):
+        if "mfma_prep_queries" in name:
+            cur = {"bn": None, "sum": 0.0}; out.append(cur)
+        if cur is None or not any(t in name for t in ("mfma", "flat_pick", "flat_rescore", "flat_select")):
+            continue
+        cur["sum"] += v
+        for bn in (64, 128, 256):
+            if f"kernelILi{bn}E" in name:
+                cur["bn"] = bn
+    return [(c["bn"], c["sum"]) for c in out if c["bn"]]
+
+
+def main_flat(a):
+    """`--flat n,dim,quant,batch [...]`: one table entry per case of the tools/flat_ab.py run profiled in `csv` (same order)."""
+    table = json.load(open(a.out)) if os.path.exists(a.out) else {}
+    found = flat_searches(a.csv)
+    for case in a.flat:
+        n, dim, quant, batch = (int(v) for v in case.split(","))
+        bn = 64 if batch <= 64 else (128 if batch <= 128 else 256)
+        vals = [v for b, v in found if b == bn]
+        if not vals:
+            sys.exit(f"no matrix-core search with a {bn}-wide query tile in {a.csv}")
+        mean_kib = sum(vals) / len(vals)
+        algorithmic = n * dim * (4 if quant == 0 else 2)
+        traffic = mean_kib * 1024.0 * 2.0
+        key = f"flat n={n} dim={dim} quant={quant} batch={batch}"
+        table[key] = {"hbm_bytes_per_batch": traffic, f"FETCH_SIZE_KiB_mean_of_{len(vals)}_searches": mean_kib,
+                      "correction": "x2: gfx950 FETCH_SIZE under-counts this library's 16 B/lane streams (factor 1.997 calibrated on flat_scan_kernel in the "
+                                    "hnsw pass; the LDS-DMA rows are 16 B/lane loads as well); summed over every dispatch of a search (scan segments, picks, re-score, select)",
+                      "algorithmic_bytes_per_batch": algorithmic, "traffic_over_algorithmic": traffic / algorithmic, "source": os.path.basename(a.csv),
+                      "searches_used": len(vals)}
+        print(key, "->", json.dumps(table[key], indent=1))
+    json.dump(table, open(a.out, "w"), indent=1)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("csv")
-    ap.add_argument("--bench-json", required=True, help="file holding the JSON line bench.py printed in the same run")
+    ap.add_argument("--bench-json", help="file holding the JSON line bench.py printed in the same run (hnsw mode)")
+    ap.add_argument("--flat", nargs="*", help="FLAT mode: the n,dim,quant,batch cases of the tools/flat_ab.py run that was profiled")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args(argv)
+    if a.flat:
+        return main_flat(a)
+    if not a.bench_json:
+        ap.error("--bench-json or --flat is required")
     b = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
     cfg = b["config"]
     n, dim, nq, ef = cfg["n"], cfg["dim"], cfg["queries_per_step"], cfg["ef"]
