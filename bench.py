@@ -361,7 +361,8 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
            "recall_vs_ef": rec, "qps_vs_ef": qps_curve, "build_s": build_s,
            "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bpq},
            "roofline": {"bound": "hbm", "achieved": bpq * nq / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bpq * nq / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "hnsw_search_kernel (HBM-visited, 2-byte rows)",
+                        "frac": bpq * nq / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[0],
+                        "traffic_source": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[1], "kernel": "hnsw_search_kernel (HBM-visited, 2-byte rows)",
                         "avg_launch_ms": launch_s * 1e3},
            "cpu_baseline": cpu}
     if cpu and "value" in cpu:
@@ -702,7 +703,7 @@ def flat_pmc_traffic(n, dim, quant, batch):
         return None, None
 
 
-def pmc_traffic(args, n, dim, nq):
+def pmc_traffic(args, n, dim, nq, quant=None, ef=None, dataset=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (profiles/pmc_traffic.json, made by
     tools/pmc_traffic.py from the raw CSV kept next to it), reported only when it was measured on this very workload."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -710,7 +711,8 @@ def pmc_traffic(args, n, dim, nq):
         return None, None
     try:
         t = json.load(open(p))
-        key = f"hnsw n={n} dim={dim} quant={args.quant} ef={args.ef} m={args.m} queries={nq} dataset={args.dataset}"
+        key = (f"hnsw n={n} dim={dim} quant={args.quant if quant is None else quant} ef={args.ef if ef is None else ef} m={args.m} queries={nq} "
+               f"dataset={args.dataset if dataset is None else dataset}")
         rec = t.get(key, {})
         return rec.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
     except Exception:

@@ -33,9 +33,13 @@ def read_counter(path, counter="FETCH_SIZE"):
     out = collections.defaultdict(list)
     for (_, name, grid), v in per_dispatch.items():
         if "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
-            short = "hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds"
+            q = name.split("hnsw_search_kernel<")[1].split(",")[1].strip() if "hnsw_search_kernel<" in name else "0"   # <METRIC, QUANT, VISG>
+            short = ("hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds") + ("" if q == "0" else f"/q{q}")
+        elif "flat_scan_kernel" in name:   # flat_scan_kernel<METRIC, QUANT, ...>: the calibration launches of each row format apart
+            q = name.split("flat_scan_kernel<")[1].split(",")[1].strip() if "flat_scan_kernel<" in name else "0"
+            short = "flat_scan_kernel" if q == "0" else f"flat_scan_kernel/q{q}"
         else:
-            short = "flat_scan_kernel" if "flat_scan_kernel" in name else name[:40]
+            short = name[:40]
         out[short].append((grid, v))
     return out
 
@@ -105,6 +109,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("csv")
     ap.add_argument("--bench-json", help="file holding the JSON line bench.py printed in the same run (hnsw mode)")
+    ap.add_argument("--leg", default="headline", choices=["headline", "op"], help="which HNSW leg of the bench line (hnsw mode)")
     ap.add_argument("--flat", nargs="*", help="FLAT mode: the n,dim,quant,batch cases of the tools/flat_ab.py run that was profiled")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args(argv)
@@ -117,16 +122,28 @@ def main(argv=None):
     n, dim, nq, ef = cfg["n"], cfg["dim"], cfg["queries_per_step"], cfg["ef"]
     quant = 0 if b["dtype"] == "f32" else 1
     m = int(cfg["workload"].split("M=")[1].split()[0])
+    if a.leg == "op":   # the recall >= 0.98 leg of the same run: f16 codes, its own ef, its own dataset
+        op = b["operating_point"]
+        b = dict(op, dataset=op["workload"].split("dataset ")[1].split(" ")[0])
+        quant, ef = 1, op["ef"]
     stride = ((dim * (4 if quant == 0 else 2) + 15) // 16) * 16
     c = read_counter(a.csv)
     # the timed steps: `nq` queries at efSearch `ef` -> the LDS-visited variant up to ef 128, the HBM-visited one above; among its
     # dispatches the steps are the ones sharing the most frequent grid size (the recall pass and the ef curve use other shapes)
-    hs = c.get("hnsw_search_kernel/hbm" if ef > 128 else "hnsw_search_kernel/lds", [])
+    hs = c.get(("hnsw_search_kernel/hbm" if ef > 128 else "hnsw_search_kernel/lds") + ("" if quant == 0 else f"/q{quant}"), [])
     if not hs:
         sys.exit("no hnsw_search_kernel dispatches with FETCH_SIZE in " + a.csv)
     full = collections.Counter(g for g, _ in hs).most_common(1)[0][0]
     vals = [v for g, v in hs if g == full]
-    factor, cal = calibrate(c.get("flat_scan_kernel", []), n, stride)
+    # launches of the same grid may still differ in efSearch (the ef sweeps use the persistent grid too): the timed steps are the
+    # largest group of launches whose counter values agree within 3 %
+    best = []
+    for v0 in vals:
+        grp = [v for v in vals if abs(v - v0) <= 0.03 * v0]
+        if len(grp) > len(best):
+            best = grp
+    vals = best
+    factor, cal = calibrate(c.get("flat_scan_kernel" if quant == 0 else f"flat_scan_kernel/q{quant}", []), n, stride)
     if factor is None or not (1.9 < factor < 2.1):
         print(f"warning: calibration factor {factor} outside 2.0 +- 5 % — using it anyway; check the flat_scan launches", file=sys.stderr)
     factor = factor or 2.0
