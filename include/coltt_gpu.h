@@ -40,8 +40,10 @@ enum { COLTT_Q_NONE = 0, COLTT_Q_F16 = 1, COLTT_Q_F8 = 2, COLTT_Q_BF16 = 3 };
 enum { COLTT_SELECT_REFERENCE = 0, COLTT_SELECT_NEAREST = 1 };
 /* FLAT arithmetic.  EXACT = the reference AVX summation order, bit-identical scores
  * (pkg/distance/simd/cpp/avx.cpp:15-32,51-75).  MFMA = matrix-core candidate generation followed by an
- * EXACT re-score of the survivors (returned scores are still bit-exact; the candidate SET is exact
- * unless two scores differ by less than the MFMA rounding error, ~1e-6 relative). */
+ * EXACT re-score of the survivors: candidates are kept within a margin of twice the proven error bound of
+ * the approximate score, so the candidate set is a superset of the exact top-k and ids, ranks and score
+ * bits EQUAL the EXACT mode's.  Served for cosine and Euclidean, f32 / 2-byte rows, 128 <= dim <= 4096;
+ * anything else (f8 rows, smaller dims, the id-list scan) silently runs EXACT — same answers. */
 enum { COLTT_MODE_EXACT = 0, COLTT_MODE_MFMA = 1 };
 
 /* ---- process / device ------------------------------------------------------------------------ */
