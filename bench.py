@@ -567,7 +567,7 @@ def main():
         O = None
         if not args.no_cpu_baseline:
             from oracle import oracle as O
-        recall = None; qps_vs_ef = None; cpu = None
+        recall = None; qps_vs_ef = None; cpu = None; host_boundary = None
         if shard:
             nd = ne = None
             bytes_per_query = None
@@ -589,6 +589,16 @@ def main():
                     qps_vs_ef[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
                 except Exception as e:
                     qps_vs_ef[str(ef)] = f"failed: {e}"
+            # the same step through the HOST-buffer entry point (coltt_hnsw_search: queries copied in, answers copied out over
+            # PCIe inside the call) — reported beside `value`, never as `value`
+            try:
+                qh = queries[0].cpu().numpy(); tw = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); h.Search(qh, k, ef=args.ef); tw.append(time.perf_counter() - t0)
+                host_boundary = {"queries_per_s": nq / min(tw), "ms_per_step": min(tw) * 1e3,
+                                 "note": "coltt_hnsw_search with pageable host buffers (what a cgo caller hands over): H2D of the query batch + kernel + D2H of ids/scores/counts"}
+            except Exception as e:
+                host_boundary = {"error": str(e)}
             if O is not None and world == 1:
                 try:
                     cpu = cpu_hnsw(G, torch, O, h, args, dim, args.quant, args.ef, queries[0], k, out, args.m)
@@ -640,6 +650,7 @@ def main():
             "dataset": args.dataset, "build_s": build_s,
             "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bytes_per_query, "visit_resets": stats["n_visit_resets"]},
             "roofline": roof,
+            "pcie_inclusive": host_boundary,
             "cpu_baseline": cpu,
             "operating_point": op,
             "secondary": secondary or None,
