@@ -6,6 +6,7 @@ namespace coltt {
 namespace dev {
 
 constexpr uint32_t K_MAX = 2048;  // largest top-k served by flat_select's LDS rank sort
+constexpr uint32_t SELECT_SMALL = 512;  // candidate lists up to this long are rank-sorted whole (no radix passes)
 
 // ---------------------------------------------------------------------------------------------------
 // Selection: the bounded queue + ToSlice of edge.PriorityQueue (edge/priority_queue.go:39-69) in closed
@@ -37,6 +38,33 @@ static __global__ __launch_bounds__(256) void flat_select_kernel(
     return;
   }
   const uint32_t flip = nearest ? 0u : 0xffffffffu;  // key' = key ^ flip : we want the kk smallest key'
+  // ---- short lists (what is left behind a tight threshold, and every matrix-core search after its exact re-score): one LDS
+  // rank sort of ALL candidates by (key', id') replaces the radix passes — same total order, same survivors, ~5x less latency
+  if (c <= SELECT_SMALL) {
+    const uint64_t idflip_s = nearest ? 0ull : ~0ull;
+    for (uint32_t i = tid; i < c; i += 256) {
+      const unsigned long long e = cand[i];
+      sel_key[i] = (uint32_t)(e >> 32) ^ flip; sel_slot[i] = (uint32_t)e; sel_id[i] = slot_id(ids, dense_base, (uint32_t)e) ^ idflip_s;
+    }
+    __syncthreads();   // every candidate is in LDS: the list can be rewritten in place
+    for (uint32_t i = tid; i < c; i += 256) {
+      const uint32_t ki = sel_key[i]; const uint64_t ii = sel_id[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < c; j++) {
+        const uint32_t kj = sel_key[j]; const uint64_t ij = sel_id[j];
+        rank += (kj < ki) || (kj == ki && ij < ii);
+      }
+      if (rank >= kk) continue;
+      const uint32_t pos = nearest ? rank : (kk - 1 - rank);
+      const uint32_t key = ki ^ flip;
+      out_ids[(size_t)q * k + pos] = ii ^ idflip_s;
+      out_scores[(size_t)q * k + pos] = key_score(key);
+      cand[pos] = ((unsigned long long)key << 32) | sel_slot[i];
+      if (rank == kk - 1) thr_all[q] = (kk == k) ? key : (nearest ? 0xffffffffu : 0u);   // the boundary key is the next threshold
+    }
+    if (tid == 0) { out_counts[q] = kk; cnt_all[q] = kk; }
+    return;
+  }
   // ---- pass 1: radix-select the kk-th smallest key'
   uint32_t prefix = 0, mask = 0, need = kk;
   for (int pass = 3; pass >= 0; pass--) {
