@@ -192,7 +192,12 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
           } else a[tm] = *reinterpret_cast<const half8*>(Ab + tm * 32 * 64 + fa[kk][0]);
         }
 #pragma unroll
-        for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const half8*>(Bb + tn * 32 * 64 + fb[kk]);
+        for (int tn = 0; tn < TN; tn++) {
+#ifdef COLTT_M3_FAKE_FEWER_READS   // ablation only (WRONG answers): a third fewer fragment reads per step, same MFMA count — what a 128 x 128 wave tile would save
+          if (tn & 1) { b[tn] = b[tn - 1]; continue; }
+#endif
+          b[tn] = *reinterpret_cast<const half8*>(Bb + tn * 32 * 64 + fb[kk]);
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; tm++)
 #pragma unroll
