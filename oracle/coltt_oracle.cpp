@@ -377,9 +377,17 @@ template <bool MAX> struct GoHeap {
 // on heap/sort tie handling: key = (score bits as f32 compare, then 64-bit tiebreak).
 // ------------------------------------------------------------------------------------------------
 struct Scored { float score; uint64_t tie; };
+// Canonical (score, id) order = order of the sortable key of the score's IEEE bits (negative values below positive ones, a NaN
+// score — a zero-norm operand under cosine — after +Inf): a TOTAL order, equal to the value order for every ordinary score.  The
+// reference's queue compares NaN priorities with `<` (false both ways): its order is then not defined, and mode 0 / 1 (the literal
+// Go heap) keep exactly that behaviour.
+static inline uint32_t score_sort_key(float f) {
+  uint32_t u; std::memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 static inline bool scored_less(const Scored& x, const Scored& y) {
-  if (x.score < y.score) return true;
-  if (y.score < x.score) return false;
+  const uint32_t kx = score_sort_key(x.score), ky = score_sort_key(y.score);
+  if (kx != ky) return kx < ky;
   return x.tie < y.tie;
 }
 
@@ -569,9 +577,14 @@ static GoHeap<true> search_level_literal(Hnsw* h, const float* q, int32_t ep, in
 // smallest.  This is the algorithm the HIP kernel runs.  Equal to the literal form whenever no two
 // distinct vertices have bit-equal distances to the query.
 struct RItem { float d; int32_t slot; bool expanded; };
+// Order of the canonical result set = order of the key (IEEE bits of d, slot).  Distances are |1 - x| or a square root, i.e. never
+// negative, so for every ordinary value this IS (d, slot); a NaN distance (a stored vector whose norm underflows to zero under
+// cosine) sorts after +Inf instead of comparing "equal to everything", which keeps the order total.  The reference's heaps have no
+// defined order for NaN priorities (Less is false both ways), so with NaN distances neither form reproduces the Go code.
 static inline bool ritem_less(const RItem& a, const RItem& b) {
-  if (a.d < b.d) return true;
-  if (b.d < a.d) return false;
+  uint32_t ka, kb;
+  std::memcpy(&ka, &a.d, 4); std::memcpy(&kb, &b.d, 4);
+  if (ka != kb) return ka < kb;
   return a.slot < b.slot;
 }
 static std::vector<RItem> search_level_canon(Hnsw* h, const float* q, int32_t ep, int ef, int level) {

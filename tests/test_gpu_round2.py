@@ -393,3 +393,34 @@ def test_hbm_visited_workspace_cap_transitions(gpu, monkeypatch, capfd, budget_m
         assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"]
     err = capfd.readouterr().err
     assert expect in err, err
+
+
+def test_nan_distances_have_one_total_order_on_both_sides(gpu):
+    """Found by tools/fuzz_parity.py: stored vectors whose norm underflows to zero under cosine (f8 codes decode to denormals; a
+    zero vector) give NaN distances.  The reference's heaps compare NaN priorities with `<` (false both ways), so their order is
+    not defined there; the canonical order used here is the order of the score's IEEE bits (NaN after +Inf) on the GPU AND in the
+    oracle — FLAT farthest-k / nearest-k and an HNSW walk over such data agree bit for bit."""
+    n, d = 3000, 4
+    X = O.fill_normal(2100, (n, d)); X[5] = 0.0; X[77] = 0.0
+    ids = np.arange(n, dtype=np.uint64)
+    Q = O.fill_normal(2101, (12, d))
+    for quant in (O.Q_F8, O.Q_NONE):
+        gf = gpu.FlatSpace(d, O.COSINE, quant); gf.ChangedVertex(ids, X)
+        of = O.Flat(d, O.COSINE, quant); of.upsert(ids, X)
+        saw_nan = False
+        for sel in (gpu.SELECT_REFERENCE, gpu.SELECT_NEAREST):
+            gi, gs, gc = gf.VertexSearch(Q, 40, sel)
+            saw_nan |= bool(np.isnan(gs).any())
+            for qi in range(len(Q)):
+                wi, ws = of.search(Q[qi], 40, nearest=bool(sel), mode=2)
+                assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"flat quant{quant} sel{sel} q{qi}")
+        assert saw_nan, "the case must really contain NaN scores"
+    lv = O.levels(2102, n, 8)
+    gh = _gpu_build(gpu, X, lv, O.COSINE, O.Q_F8, gpu.HnswCfg.default(m=8, ef_construction=16), batch=256)
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    for ef in (64, 300):
+        gi, gs, gc, st = gh.Search(Q, 10, ef=ef, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search(rows, O.Q_F8, g["adj0"], g["upper_off"], g["adjU"], d, O.COSINE, g["entry"], g["entry_level"], Q, 10, ef)
+        for qi in range(len(Q)):
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"hnsw ef{ef} q{qi}")
+        assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"]

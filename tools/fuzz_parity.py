@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity: random operation sequences on FLAT stores and HNSW indexes (upsert / overwrite / remove /
+search in every mode / filtered scan / save-load round trips; sequential and batched inserts / removes / searches at random ef, k)
+— every answer compared bit for bit with the CPU oracle driven through the same sequence.
+`python tools/fuzz_parity.py [seconds] [seed]`; exits non-zero at the first mismatch and prints the seed and the step."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def same(a_ids, a_sc, b_ids, b_sc):
+    return (len(a_ids) == len(b_ids) and np.array_equal(np.asarray(a_ids, np.uint64), np.asarray(b_ids, np.uint64))
+            and np.array_equal(np.ascontiguousarray(a_sc, np.float32).view(np.uint32), np.ascontiguousarray(b_sc, np.float32).view(np.uint32)))
+
+
+def fuzz_flat(G, O, rng, log):
+    d = int(rng.choice([7, 32, 100, 128, 130, 200, 256, 768]))
+    metric = int(rng.integers(0, 2)); quant = int(rng.choice([O.Q_NONE, O.Q_F16, O.Q_F8, O.Q_BF16]))
+    gf = G.FlatSpace(d, metric, quant); of = O.Flat(d, metric, quant)
+    live = {}
+    nxt = 1
+    log(f"flat d={d} metric={metric} quant={quant}")
+    for step in range(int(rng.integers(4, 10))):
+        op = rng.choice(["add", "add", "add", "overwrite", "remove", "search", "search", "filter", "saveload"])
+        if op == "add" or not live:
+            n = int(rng.choice([1, 37, 900, 5000, 40000]))
+            ids = (np.arange(nxt, nxt + n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 44); nxt += n
+            X = O.fill_normal(int(rng.integers(1, 1 << 30)), (n, d))
+            if rng.random() < 0.1: X[int(rng.integers(0, n))] = 0.0          # a zero vector (cosine: NaN norm path)
+            if n > 10 and rng.random() < 0.3: X[1:4] = X[0]                   # exact duplicates: ties
+            gf.ChangedVertex(ids, X); of.upsert(ids, X)
+            for i in ids: live[int(i)] = 1
+        elif op == "overwrite":
+            ks = np.array(list(live)[:: max(1, len(live) // 50)], dtype=np.uint64)
+            X = O.fill_normal(int(rng.integers(1, 1 << 30)), (len(ks), d))
+            gf.ChangedVertex(ks, X); of.upsert(ks, X)
+        elif op == "remove":
+            ks = np.array(list(live)[int(rng.integers(0, 7)):: max(2, len(live) // 40)], dtype=np.uint64)
+            if len(ks) == len(live): ks = ks[:-1]
+            if len(ks):
+                gf.RemoveVertex(ks); of.remove(ks)
+                for i in ks: live.pop(int(i))
+        elif op == "saveload":
+            blob = gf.SaveVertex()
+            g2 = G.FlatSpace(d, metric, quant); g2.LoadVertex(blob)
+            assert g2.LoadSize() == gf.LoadSize() == len(of), ("saveload size", step)
+            gf = g2
+        else:
+            nq = int(rng.choice([1, 3, 17, 70, 200])); k = int(rng.choice([1, 5, 10, 64, 300]))
+            Q = O.fill_normal(int(rng.integers(1, 1 << 30)), (nq, d))
+            if op == "filter":
+                cand = np.array(list(live)[:: max(1, len(live) // int(rng.integers(1, 400) + 1))], dtype=np.uint64)
+                sel = int(rng.integers(0, 2))
+                gi, gs, gc = gf.FilterableVertexSearch(cand, Q, k, sel)
+                for qi in range(min(nq, 6)):
+                    wi, ws = of.search(Q[qi], k, nearest=bool(sel), mode=2, cand=cand)
+                    assert same(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws), ("filter", step, qi, d, metric, quant, k, sel)
+            else:
+                for sel in (0, 1):
+                    for mode in (G.MODE_EXACT, G.MODE_MFMA):
+                        gi, gs, gc = gf.VertexSearch(Q, k, sel, mode)
+                        for qi in range(min(nq, 5)):
+                            wi, ws = of.search(Q[qi], k, nearest=bool(sel), mode=2)
+                            assert same(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws), ("search", step, qi, d, metric, quant, k, sel, mode, len(live))
+        assert gf.LoadSize() == len(of) == len(live), ("size", step)
+    gf.close()
+
+
+def fuzz_hnsw(G, O, rng, log):
+    import torch
+    d = int(rng.choice([4, 24, 64, 128, 768]))
+    metric = int(rng.integers(0, 2)); quant = int(rng.choice([O.Q_NONE, O.Q_NONE, O.Q_F16, O.Q_BF16, O.Q_F8]))
+    m = int(rng.choice([4, 8, 16])); efc = int(rng.choice([16, 40, 100, 200])); algo = 0   # (the CSR oracle driver runs the Simple select; Heuristic is covered by tests/)
+    n = int(rng.choice([60, 400, 3000] if d >= 128 else [60, 400, 3000, 12000]))
+    cfg_g = G.HnswCfg.default(m=m, ef_construction=efc, algo=algo, ef=int(rng.choice([8, 20, 64])))
+    X = O.fill_normal(int(rng.integers(1, 1 << 30)), (n, d)); lv = O.levels(int(rng.integers(1, 1 << 30)), n, m)
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(11400714819323198485 % (1 << 63))) % np.uint64(1 << 50)
+    log(f"hnsw n={n} d={d} metric={metric} quant={quant} m={m} efc={efc} algo={algo}")
+    # the oracle decodes what the GPU stores: build the oracle over the lowered vectors with the matching metric (as the tests do)
+    sequential = n <= 400 and rng.random() < 0.5
+    gh = G.Hnsw(d, metric, cfg_g, quantization=quant)
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    if sequential:
+        gh.InsertBatchDevice(xd.data_ptr(), n, lv, batch=1, ids=ids)
+    else:
+        i = 0
+        while i < n:
+            b = int(min(n - i, max(1, min(int(rng.choice([16, 256, 4096])), i // 16))))
+            gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, ids=ids[i:i + b]); i += b
+    removed = []
+    if rng.random() < 0.5:
+        for j in rng.choice(n, size=min(n // 3, int(rng.integers(1, 60))), replace=False):
+            gh.Remove(int(ids[j])); removed.append(int(j))
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    del_bits = None
+    if removed:
+        del_bits = np.zeros((n + 31) // 32, np.uint32)
+        for j in removed: del_bits[j >> 5] |= np.uint32(1 << (j & 31))
+    if g["entry"] < 0:      # everything reachable was removed: nothing to search
+        gh.close(); return
+    Q = O.fill_normal(int(rng.integers(1, 1 << 30)), (int(rng.choice([1, 9, 40])), d))
+    for ef in (int(rng.choice([1, 7, 20])), int(rng.choice([64, 128])), int(rng.choice([129, 300, 1000, 4096]))):
+        k = int(rng.choice([1, 10, min(ef, 50)])); k = min(k, max(ef, 1))
+        for visg in ("0", "1", None):
+            if visg is None: os.environ.pop("COLTT_VISG", None)
+            else: os.environ["COLTT_VISG"] = visg
+            gi, gs, gc, st = gh.Search(Q, k, ef=ef, with_stats=True)
+            sl, sc, cn, ost, _ = O.csr_search(rows, quant, g["adj0"], g["upper_off"], g["adjU"], d, metric, g["entry"], g["entry_level"], Q, k, max(ef, k),
+                                              del_bits=del_bits, threads=2)
+            for qi in range(len(Q)):
+                want = ids[sl[qi, :cn[qi]].astype(np.int64)]          # slot = insertion index
+                assert same(gi[qi, :gc[qi]], gs[qi, :gc[qi]], want, sc[qi, :cn[qi]]), ("hnsw search", qi, ef, k, visg, n, d, metric, quant, m, efc, algo, len(removed))
+            assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"], ("counters", ef, k, visg, st, ost)
+    os.environ.pop("COLTT_VISG", None)
+    # Commit -> Load round trip keeps answers (the reference stream stores f32 vectors: f32 indexes only)
+    if quant == O.Q_NONE:
+        # (Load renumbers the slots in stream order — tombstoned vertices are not stored — so the canonical neighbour order, and with
+        #  it an approximate answer, may differ from the index that was committed: the loaded index is compared with the ORACLE
+        #  loaded from the same bytes, which is what "drop-in" means for a stream written by either side)
+        blob = gh.Commit()
+        g2 = G.Hnsw(d, metric, cfg_g, quantization=quant); g2.Load(blob)
+        assert g2.Len() == gh.Len(), "commit/load size"
+        oh = O.Hnsw(d, metric, O.default_cfg(m=m, efConstruction=efc, ef=cfg_g.ef)); oh.load_stream(blob)
+        b = g2.Search(Q, 5, ef=50)
+        for qi in range(len(Q)):
+            wi, ws = oh.search(Q[qi], 5, mode=1, ef=50)
+            assert same(b[0][qi, :b[2][qi]], b[1][qi, :b[2][qi]], wi, ws), ("commit/load vs oracle", qi)
+        g2.close()
+    gh.close()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xffffff
+    import coltt_amd as G
+    from oracle import oracle as O
+    assert G.lib().coltt_init(0) == 0
+    t0 = time.time(); rounds = 0
+    while time.time() - t0 < budget:
+        rs = seed + rounds
+        rng = np.random.default_rng(rs)
+        msgs = []
+        try:
+            (fuzz_flat if rounds % 2 == 0 else fuzz_hnsw)(G, O, rng, msgs.append)
+        except Exception as e:
+            print(f"FUZZ FAILURE seed={rs} {' | '.join(msgs)}: {type(e).__name__}: {e}", flush=True)
+            raise
+        rounds += 1
+    print(f"fuzz ok: {rounds} rounds in {time.time() - t0:.0f} s, seeds {seed}..{seed + rounds - 1}")
+
+
+if __name__ == "__main__":
+    main()
