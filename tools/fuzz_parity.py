@@ -133,6 +133,45 @@ def fuzz_hnsw(G, O, rng, log):
     gh.close()
 
 
+def fuzz_group(G, O, rng, log):
+    """a FLAT collection group of 2-5 members on this one GPU (ShardVertex routing, host exchange, k-way merge) against the ORACLE
+    store holding the same vertices, through random upserts / overwrites / removes"""
+    from coltt_amd import group as GG
+    d = int(rng.choice([8, 96, 128, 256])); metric = int(rng.integers(0, 2)); quant = int(rng.choice([O.Q_NONE, O.Q_F16, O.Q_BF16]))
+    nm = int(rng.integers(2, 6)); layout = GG.LAYOUT_SHARD if rng.random() < 0.7 else GG.LAYOUT_REPLICA
+    log(f"group members={nm} layout={layout} d={d} metric={metric} quant={quant}")
+    grp = G.Group([0] * nm, d, metric, quant, kind=GG.GROUP_FLAT, layout=layout)
+    of = O.Flat(d, metric, quant)
+    live = {}; nxt = 1
+    for step in range(int(rng.integers(3, 8))):
+        op = rng.choice(["add", "add", "overwrite", "remove", "search", "search"])
+        if op == "add" or not live:
+            n = int(rng.choice([1, 50, 3000, 20000]))
+            ids = (np.arange(nxt, nxt + n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15 % (1 << 62))) % np.uint64(1 << 48); nxt += n
+            X = O.fill_normal(int(rng.integers(1, 1 << 30)), (n, d))
+            grp.ChangedVertex(ids, X); of.upsert(ids, X)
+            for i in ids: live[int(i)] = 1
+        elif op == "overwrite":
+            ks = np.array(list(live)[:: max(1, len(live) // 30)], dtype=np.uint64)
+            X = O.fill_normal(int(rng.integers(1, 1 << 30)), (len(ks), d))
+            grp.ChangedVertex(ks, X); of.upsert(ks, X)
+        elif op == "remove":
+            ks = np.array(list(live)[1:: max(2, len(live) // 25)], dtype=np.uint64)
+            if len(ks) and len(ks) < len(live):
+                grp.RemoveVertex(ks) if hasattr(grp, "RemoveVertex") else grp.Remove(ks); of.remove(ks)
+                for i in ks: live.pop(int(i))
+        else:
+            nq = int(rng.choice([1, 9, 80])); k = int(rng.choice([1, 10, 100])); Q = O.fill_normal(int(rng.integers(1, 1 << 30)), (nq, d))
+            for sel in (0, 1):
+                for mode in (G.MODE_EXACT, G.MODE_MFMA):
+                    a = grp.Search(Q, k, select=sel, mode=mode)
+                    for qi in range(min(nq, 5)):
+                        wi, ws = of.search(Q[qi], k, nearest=bool(sel), mode=2)
+                        assert same(a[0][qi, :a[2][qi]], a[1][qi, :a[2][qi]], wi, ws), ("group search", step, qi, k, sel, mode, len(live))
+        assert grp.Len() == len(live), ("group size", step, grp.Len(), len(live))
+    grp.close()
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xffffff
@@ -145,7 +184,7 @@ def main():
         rng = np.random.default_rng(rs)
         msgs = []
         try:
-            (fuzz_flat if rounds % 2 == 0 else fuzz_hnsw)(G, O, rng, msgs.append)
+            (fuzz_flat, fuzz_hnsw, fuzz_group)[rounds % 3](G, O, rng, msgs.append)
         except Exception as e:
             print(f"FUZZ FAILURE seed={rs} {' | '.join(msgs)}: {type(e).__name__}: {e}", flush=True)
             raise
