@@ -213,4 +213,45 @@ class Hnsw {
   coltt_handle_t h_ = 0; uint32_t dim_; int distance_ = COLTT_COSINE;
 };
 
+// One collection over the GPUs of a node (BASELINE.json configs[4]): ShardVertex routing (pkg/sharding/shard.go:34-41), one FLAT
+// store or HNSW graph per device, per-member search + one RCCL all-gather (or, members sharing a device, host staging) + the
+// local-queue-then-global-queue merge of edge/none_vectorstore.go:148-178.  Thin wrapper over coltt_group_*.
+class Group {
+ public:
+  Group(const std::vector<int>& devices, uint32_t dim, int distance, int quantization, int kind /*COLTT_GROUP_FLAT | _HNSW*/,
+        int layout = COLTT_LAYOUT_SHARD, const coltt_hnsw_cfg* cfg = nullptr, int exchange = COLTT_EXCHANGE_AUTO) : dim_(dim), kind_(kind) {
+    coltt_group_opts o{}; o.kind = kind; o.layout = layout; o.exchange = exchange;
+    check(coltt_group_create(devices.data(), (int)devices.size(), dim, distance, quantization, cfg, &o, &h_));
+  }
+  ~Group() { if (h_) coltt_group_destroy(h_); }
+  Group(const Group&) = delete;
+  Group& operator=(const Group&) = delete;
+  int ShardOf(uint64_t id) const { int32_t s = 0; check(coltt_group_shard_of(h_, id, &s)); return s; }   // sharding.ShardVertex(id, world)
+  coltt_handle_t Member(int i) const { coltt_handle_t m = 0; check(coltt_group_member(h_, i, &m)); return m; }
+  uint64_t Len() const { uint64_t n = 0; check(coltt_group_len(h_, &n)); return n; }
+  // ChangedVertex (FLAT groups) / Insert (HNSW groups) for n vertices, row-major vectors; returns how many this process hosts
+  uint64_t ChangedVertex(const std::vector<uint64_t>& ids, const std::vector<float>& vecs) {
+    if (vecs.size() != ids.size() * dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    uint64_t kept = 0; check(coltt_group_upsert(h_, ids.data(), vecs.data(), ids.size(), &kept)); return kept;
+  }
+  uint64_t Insert(const std::vector<uint64_t>& ids, const std::vector<float>& vecs, const std::vector<int32_t>& levels, uint32_t batch = 1) {
+    if (vecs.size() != ids.size() * dim_ || levels.size() != ids.size()) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    uint64_t kept = 0; check(coltt_group_insert(h_, ids.data(), vecs.data(), levels.data(), ids.size(), batch, &kept)); return kept;
+  }
+  void Remove(const std::vector<uint64_t>& ids) { check(coltt_group_remove(h_, ids.data(), ids.size())); }
+  // one query over the whole collection (rows ascending by (score, id)); select / mode: FLAT groups, ef: HNSW groups
+  SearchResult Search(const Vector& query, unsigned k, int select = COLTT_SELECT_NEAREST, int mode = COLTT_MODE_EXACT, uint32_t ef = 0) const {
+    if (query.size() != dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    std::vector<uint64_t> ids(k); std::vector<float> sc(k); uint32_t n = 0;
+    check(coltt_group_search(h_, query.data(), 1, k, select, mode, ef, ids.data(), sc.data(), &n));
+    SearchResult r(n);
+    for (uint32_t i = 0; i < n; i++) r[i] = {ids[i], sc[i]};
+    return r;
+  }
+  coltt_handle_t handle() const { return h_; }
+
+ private:
+  coltt_handle_t h_ = 0; uint32_t dim_; int kind_;
+};
+
 }  // namespace coltt

@@ -123,6 +123,24 @@ int main() {
     s.RemoveVertex({53});
     EXPECT(s.LoadSize() == n - 1 && s.VertexSearch(X[3], 1, false, COLTT_SELECT_NEAREST)[0].Id != 53);
   }
+  // ---- a collection group: three FLAT members on this one GPU answer like the single store (same stored bits, same order)
+  {
+    coltt::Group grp({0, 0, 0}, d, COLTT_COSINE, COLTT_Q_F16, COLTT_GROUP_FLAT);
+    std::vector<uint64_t> gids; std::vector<float> flat;
+    for (int i = 0; i < n; i++) { gids.push_back(50 + i); flat.insert(flat.end(), X[i].begin(), X[i].end()); }
+    EXPECT(grp.ChangedVertex(gids, flat) == (uint64_t)n && grp.Len() == (uint64_t)n);
+    EXPECT(grp.ShardOf(53) >= 0 && grp.ShardOf(53) < 3);
+    coltt::VecSpace ref(d, COLTT_COSINE, COLTT_Q_F16);
+    for (int i = 0; i < n; i++) ref.ChangedVertex(50 + i, X[i]);
+    for (int sel : {COLTT_SELECT_NEAREST, COLTT_SELECT_REFERENCE}) {
+      auto a = grp.Search(X[5], 10, sel);
+      auto b = ref.VertexSearch(X[5], 10, false, sel);
+      EXPECT(a.size() == b.size());
+      for (size_t i = 0; i < a.size() && i < b.size(); i++) EXPECT(a[i].Id == b[i].Id && std::memcmp(&a[i].Score, &b[i].Score, 4) == 0);
+    }
+    grp.Remove({55});
+    EXPECT(grp.Len() == (uint64_t)n - 1 && grp.Search(X[5], 1)[0].Id != 55);
+  }
   std::printf(fails ? "FAILED %d checks\n" : "mirror ok\n", fails);
   return fails ? 1 : 0;
 }
