@@ -133,6 +133,40 @@ def fuzz_hnsw(G, O, rng, log):
     gh.close()
 
 
+def fuzz_hnsw_build(G, O, rng, log):
+    """GRAPH parity: the GPU builder driven through a random sequence of batched inserts (batch 1 = the reference's sequential
+    Insert) and removes — the oracle goes through the same sequence — then every level, edge list, stored edge distance, tombstone
+    and the entrypoint must be equal (f32 rows; quantised rows are covered by the search rounds)."""
+    import torch
+    d = int(rng.choice([3, 16, 48, 128])); metric = int(rng.integers(0, 2))
+    m = int(rng.choice([4, 8, 16])); efc = int(rng.choice([8, 32, 64, 200]))
+    n = int(rng.choice([40, 300, 2500]))
+    X = O.fill_normal(int(rng.integers(1, 1 << 30)), (n, d)); lv = O.levels(int(rng.integers(1, 1 << 30)), n, m)
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(7919) + np.uint64(17)) % np.uint64(1 << 40)
+    log(f"build n={n} d={d} metric={metric} m={m} efc={efc}")
+    gh = G.Hnsw(d, metric, G.HnswCfg.default(m=m, ef_construction=efc))
+    oh = O.Hnsw(d, metric, O.default_cfg(m=m, efConstruction=efc))
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    i = 0; live = []
+    while i < n:
+        if live and rng.random() < 0.25:     # remove a few (possibly the entrypoint, possibly everything that is left)
+            for _ in range(int(rng.integers(1, 6))):
+                if not live: break
+                j = live.pop(int(rng.integers(0, len(live))))
+                gh.Remove(int(ids[j])); assert oh.remove(int(ids[j])) == 0
+        b = int(min(n - i, rng.choice([1, 1, 2, 7, 64, 512])))
+        if b > 1: b = int(max(1, min(b, max(1, len(live) // 8))))      # a batch is linked against the graph before it: keep it a fraction of it
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, ids=ids[i:i + b])
+        oh.insert_batched(ids[i:i + b], X[i:i + b], lv[i:i + b], b)
+        live.extend(range(i, i + b)); i += b
+    go = gh.Export(); oo = oh.export(with_vectors=False)
+    for key in ("ids", "levels", "deleted", "row_offsets", "nbr"):
+        assert np.array_equal(go[key], oo[key]), ("graph", key)
+    assert np.array_equal(go["nbr_dist"].view(np.uint32), oo["nbr_dist"].view(np.uint32)), "edge distances"
+    assert go["entry"] == oo["entry"] and gh.Len() == len(oh) == len(live), "entry / len"
+    gh.close()
+
+
 def fuzz_group(G, O, rng, log):
     """a FLAT collection group of 2-5 members on this one GPU (ShardVertex routing, host exchange, k-way merge) against the ORACLE
     store holding the same vertices, through random upserts / overwrites / removes"""
@@ -184,7 +218,7 @@ def main():
         rng = np.random.default_rng(rs)
         msgs = []
         try:
-            (fuzz_flat, fuzz_hnsw, fuzz_group)[rounds % 3](G, O, rng, msgs.append)
+            (fuzz_flat, fuzz_hnsw, fuzz_group, fuzz_hnsw_build)[rounds % 4](G, O, rng, msgs.append)
         except Exception as e:
             print(f"FUZZ FAILURE seed={rs} {' | '.join(msgs)}: {type(e).__name__}: {e}", flush=True)
             raise
