@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3 ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,f3 ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -404,6 +404,41 @@ def leg_published_hnsw_point(G, torch, dev, O, args, k):
     return res
 
 
+def leg_filtered(G, torch, dev, O, args, dim, k):
+    """SURVEY §8 f3, reported separately: FilterableVertexSearch (edge/none_vectorstore.go:182-253) — the inverted index hands over
+    an ascending id list (roaring ToArray), the library translates ids to slots on the host and runs the exact-order GATHER scan
+    over those rows only.  1 M x 768 f32, every 10th id a candidate, one query per call (what the reference's RPC does) and 16."""
+    n = 1_000_000
+    ds = Dataset(torch, dev, dim, "normal")
+    fl = fill_flat(G, torch, dev, ds, n, dim, 0, args.seed + 505)
+    cand = np.arange(0, n, 10, dtype=np.uint64)
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 17)
+    q = ds.rows(16, qgen).cpu().numpy()
+    out = {}
+    for nq in (1, 16):
+        fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST)
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter(); r = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST); t.append(time.perf_counter() - t0)
+        ms = fl.last_kernel_ms()
+        out[f"batch_{nq}"] = {"call_ms": float(np.median(t)) * 1e3, "kernels_ms": ms, "queries_per_s": nq / float(np.median(t)),
+                               "gathered_GBps": len(cand) * dim * 4 / (ms / 1e3) / 1e9}
+    res = {"workload": f"edge FLAT FilterableVertexSearch, {n}x{dim} float32, {len(cand)} candidate ids (every 10th), cosine, k={k}, exact-order gather scan",
+           "candidates": int(len(cand)), **out,
+           "note": "call_ms includes the host id -> slot translation and the H2D copy of the slot list; the rows of a gather scan are not contiguous (3 KB each)"}
+    if O is not None:
+        try:
+            rows = fl.FetchRows(0, n)
+            sub = np.ascontiguousarray(rows[::10])
+            sl, sc, cn, w = O.flat_scan(sub, 0, dim, O.COSINE, q[:1], k, nearest=True, shape=0, split=1, threads=1)
+            res["cpu_baseline"] = {"ms_per_query_1_thread_contiguous_candidates": w * 1e3,
+                                   "gpu_equals_oracle": bool(np.array_equal(r[0][0] if len(r[0]) == 1 else fl.FilterableVertexSearch(cand, q[:1], k, G.SELECT_NEAREST)[0][0], (sl[0] * 10).astype(np.uint64)))}
+        except Exception as e:
+            res["cpu_baseline"] = {"error": str(e)}
+    fl.close()
+    return res
+
+
 def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
     """BASELINE.json configs[1] / configs[2]: batched FLAT scan through the matrix-core candidate path"""
     ds = Dataset(torch, dev, dim, "normal")
@@ -533,7 +568,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "f3"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -618,6 +653,11 @@ def main():
                 op = leg_operating_point(G, torch, dev, O, args, dim, k)
             except Exception as e:
                 op = {"error": str(e)}
+        if "f3" in legs:
+            try:
+                secondary["f3"] = leg_filtered(G, torch, dev, O, args, dim, k)
+            except Exception as e:
+                secondary["f3"] = {"error": str(e)}
         if "h1" in legs:
             try:
                 secondary["h1"] = leg_published_hnsw_point(G, torch, dev, O, args, k)
