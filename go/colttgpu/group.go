@@ -19,15 +19,15 @@ import (
 // NOT COMPILED here (no Go toolchain in the build container); the same ABI is driven by tests/test_gpu_group.py and bench.py.
 
 const (
-	GroupFlat = C.COLTT_GROUP_FLAT // members are edge-style FLAT stores
-	GroupHnsw = C.COLTT_GROUP_HNSW // members are core/vectorindex HNSW graphs
+	GroupFlat = int(C.COLTT_GROUP_FLAT) // members are edge-style FLAT stores
+	GroupHnsw = int(C.COLTT_GROUP_HNSW) // members are core/vectorindex HNSW graphs
 
-	LayoutShard   = C.COLTT_LAYOUT_SHARD   // vertex id lives on shard ShardVertex(id, world)
-	LayoutReplica = C.COLTT_LAYOUT_REPLICA // every member holds everything; query batches are split
+	LayoutShard   = int(C.COLTT_LAYOUT_SHARD)   // vertex id lives on shard ShardVertex(id, world)
+	LayoutReplica = int(C.COLTT_LAYOUT_REPLICA) // every member holds everything; query batches are split
 
-	ExchangeAuto = C.COLTT_EXCHANGE_AUTO
-	ExchangeRccl = C.COLTT_EXCHANGE_RCCL
-	ExchangeHost = C.COLTT_EXCHANGE_HOST
+	ExchangeAuto = int(C.COLTT_EXCHANGE_AUTO)
+	ExchangeRccl = int(C.COLTT_EXCHANGE_RCCL)
+	ExchangeHost = int(C.COLTT_EXCHANGE_HOST)
 )
 
 // GroupOpts mirrors coltt_group_opts.  WorldSize / RankBase / UniqueID are only needed when the collection spans more than one
@@ -44,7 +44,7 @@ type Group struct {
 }
 
 func GroupUniqueID() ([]byte, error) {
-	id := make([]byte, C.COLTT_UNIQUE_ID_BYTES)
+	id := make([]byte, int(C.COLTT_UNIQUE_ID_BYTES))
 	err := call(func() C.int { return C.coltt_group_unique_id(bptr(id)) })
 	return id, err
 }
@@ -54,8 +54,8 @@ func NewGroup(devices []int, dim uint32, metric, quant int, cfg *HnswCfg, o Grou
 	if len(devices) == 0 {
 		return nil, fmt.Errorf("colttgpu: a group needs at least one device")
 	}
-	if o.UniqueID != nil && len(o.UniqueID) != C.COLTT_UNIQUE_ID_BYTES {
-		return nil, fmt.Errorf("colttgpu: unique id must be %d bytes", C.COLTT_UNIQUE_ID_BYTES)
+	if o.UniqueID != nil && len(o.UniqueID) != int(C.COLTT_UNIQUE_ID_BYTES) {
+		return nil, fmt.Errorf("colttgpu: unique id must be %d bytes", int(C.COLTT_UNIQUE_ID_BYTES))
 	}
 	devs := make([]C.int, len(devices))
 	for i, d := range devices {
