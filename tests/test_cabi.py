@@ -160,3 +160,27 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
         assert 1.0 <= r["traffic_over_algorithmic"] < 1.1, r
     committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     assert all(k in committed for k in t)
+
+
+def test_trace_by_grid_tool_separates_launch_shapes(tmp_path):
+    """tools/trace_by_grid.py: rocprofv3's --stats averages every launch of a kernel NAME; the per-(kernel, grid) table keeps the
+    10 000-query steps apart from single-query calls of the same kernel, and its largest-cluster average ignores an outlier shape."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = ["Kernel_Name,Grid_Size_X,Start_Timestamp,End_Timestamp"]
+    k = '"void (anonymous namespace)::hnsw_search_kernel<0, 0, false>(coltt::dev::GraphView, int, int)"'
+    for i in range(6):
+        rows.append(f"{k},65536,{i * 100_000_000},{i * 100_000_000 + 22_700_000 + i * 1000}")
+    rows.append(f"{k},65536,900000000,901050000")                    # another leg's batch on the same grid
+    for i in range(50):
+        rows.append(f"{k},64,{2_000_000_000 + i * 1_000_000},{2_000_000_000 + i * 1_000_000 + 90_000}")   # single-query calls
+    p = tmp_path / "t_kernel_trace.csv"; p.write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_by_grid.py"), str(p), "0"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    import csv
+    import io
+    t = {int(r["Grid_Size_X"]): r for r in csv.DictReader(io.StringIO(out.stdout))}
+    assert int(t[65536]["Calls"]) == 7 and abs(float(t[65536]["MedianMs"]) - 22.70) < 0.01
+    assert int(t[65536]["LargestClusterCalls"]) == 6 and abs(float(t[65536]["LargestClusterAverageMs"]) - 22.7025) < 0.001
+    assert int(t[64]["Calls"]) == 50 and abs(float(t[64]["AverageMs"]) - 0.09) < 1e-6
