@@ -101,7 +101,7 @@ int coltt_cflat_create(uint32_t dim, int metric, uint32_t n_fields, coltt_handle
   if (n_fields == 0 || n_fields > CF_MAX_FIELDS) return fail(COLTT_E_INVALID, "cflat_create: n_fields %u outside [1,%d]", n_fields, CF_MAX_FIELDS);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "cflat_create: bad metric %d", metric);
   if ((size_t)n_fields * dim * 4 > 150 * 1024) return fail(COLTT_E_UNSUPPORTED, "cflat_create: n_fields x dim too large for the LDS query tile");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   auto c = std::make_shared<CFlat>();
   c->dim = dim; c->nf = n_fields; c->metric = metric; c->stride = ((size_t)dim * 4 + 15) & ~(size_t)15;
   COLTT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -130,7 +130,7 @@ int coltt_cflat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs,
   if (n == 0) return COLTT_OK;
   if (!ids || !vecs) return fail(COLTT_E_INVALID, "cflat_upsert: NULL input");
   WriteLock g(c->rw);
-  COLTT_TRY(use_device(c->device));
+  COLTT_DEVICE(c->device);
   for (size_t i = 0; i < n; i++) {  // one vertex at a time keeps "last write wins" trivially right; this path is not hot
     uint32_t slot;
     auto it = c->id2slot.find(ids[i]);
@@ -156,7 +156,7 @@ int coltt_cflat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
   if (!c) return fail(COLTT_E_NOT_FOUND, "cflat_remove: unknown handle");
   if (n && !ids) return fail(COLTT_E_INVALID, "cflat_remove: NULL ids");
   WriteLock g(c->rw);
-  COLTT_TRY(use_device(c->device));
+  COLTT_DEVICE(c->device);
   for (size_t i = 0; i < n; i++) {
     auto it = c->id2slot.find(ids[i]);
     if (it == c->id2slot.end()) continue;
@@ -187,7 +187,7 @@ int coltt_cflat_search(coltt_handle_t h, const float* queries, const uint32_t* r
   if (!queries || !ratios || !include || !out_ids || !out_scores || !out_counts) return fail(COLTT_E_INVALID, "cflat_search: NULL buffer");
   if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "cflat_search: k=%u outside [1,%u]", k, K_MAX);
   WriteLock g(c->rw);
-  COLTT_TRY(use_device(c->device));
+  COLTT_DEVICE(c->device);
   const size_t per = (size_t)c->nf * c->dim;
   const uint32_t cap = std::max<uint32_t>(65536u, 8u * k);
   COLTT_TRY(c->w_raw.reserve(per * 4)); COLTT_TRY(c->w_q.reserve(per * 4)); COLTT_TRY(c->w_qn.reserve(c->nf * 4 + 256));

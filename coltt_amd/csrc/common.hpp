@@ -135,7 +135,28 @@ template <class T> std::shared_ptr<T> lookup(coltt_handle_t h) {
 
 int ensure_device();          // selects the process default device (coltt_init) for the calling thread
 int default_device();         // that device's index (after ensure_device succeeded)
-int use_device(int device);   // selects an object's device for the calling thread
+int use_device(int device);   // selects an object's device for the calling thread (worker threads of the library only)
+
+// Entry points run on the CALLER's thread (a cgo call, a torch program's Python thread), whose current HIP device is the caller's
+// business: the object's device is selected for the duration of the call and the caller's device is put back on every exit path.
+class DeviceScope {
+ public:
+  DeviceScope() = default;
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+  ~DeviceScope() { if (prev_ >= 0 && prev_ != cur_) (void)hipSetDevice(prev_); }
+  int enter(int device) {  // device < 0: the process default (coltt_init)
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    if (device < 0) { COLTT_TRY(ensure_device()); cur_ = default_device(); return COLTT_OK; }
+    COLTT_TRY(use_device(device));
+    cur_ = device;
+    return COLTT_OK;
+  }
+  int device() const { return cur_; }
+ private:
+  int prev_ = -1, cur_ = -1;
+};
+#define COLTT_DEVICE(dev) ::coltt::DeviceScope coltt_dev_scope_; COLTT_TRY(coltt_dev_scope_.enter(dev))
 
 // stores / indexes on an explicit device (group.hip places one collection shard per GPU)
 int flat_create_on(int device, uint32_t dim, int metric, int quant, coltt_handle_t* out);

@@ -576,7 +576,7 @@ int coltt::flat_create_on(int device, uint32_t dim, int metric, int quant, coltt
   if (dim == 0 || dim > 8192) return fail(COLTT_E_INVALID, "flat_create: dim %u outside [1,8192]", dim);
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "flat_create: bad metric %d", metric);
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");  // vectorstore.go:79
-  if (device < 0) { COLTT_TRY(ensure_device()); device = default_device(); } else COLTT_TRY(use_device(device));
+  COLTT_DEVICE(device); device = coltt_dev_scope_.device();
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
@@ -599,7 +599,7 @@ int coltt_flat_reserve(coltt_handle_t h, uint64_t n_rows) {
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_reserve: unknown handle");
   WriteLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   return f->reserve(n_rows);
 }
 
@@ -609,7 +609,7 @@ int coltt_flat_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, 
   if (n == 0) return COLTT_OK;
   if (!ids || !vecs) return fail(COLTT_E_INVALID, "flat_upsert: NULL input");
   WriteLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   COLTT_TRY(f->undense());
   UpsertPlan pl;
   COLTT_TRY(plan_upsert(f.get(), ids, 0, n, pl));
@@ -643,7 +643,7 @@ int coltt_flat_upsert_device(coltt_handle_t h, const uint64_t* ids, uint64_t fir
   if (n == 0) return COLTT_OK;
   if (!d_vecs) return fail(COLTT_E_INVALID, "flat_upsert_device: NULL vectors");
   WriteLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   if (!ids && f->dense && (f->n == 0 || first_id == f->dense_base + f->n)) {  // append-only dense fast path
     if (f->n + n > 0xffffffffull) return fail(COLTT_E_UNSUPPORTED, "flat upsert: more than 2^32-1 rows in one store");
     COLTT_TRY(f->reserve(f->n + n));
@@ -672,7 +672,7 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
   if (n == 0) return COLTT_OK;
   if (!ids) return fail(COLTT_E_INVALID, "flat_remove: NULL ids");
   WriteLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   COLTT_TRY(f->undense());
   for (size_t i = 0; i < n; i++) {
     auto it = f->id2slot.find(ids[i]);
@@ -708,7 +708,7 @@ int coltt_flat_get(coltt_handle_t h, uint64_t id, void* out_row) {
   auto f = lookup<Flat>(h);
   if (!f || !out_row) return fail(COLTT_E_NOT_FOUND, "flat_get: unknown handle");
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   uint64_t slot;
   if (f->dense) { if (id < f->dense_base || id >= f->dense_base + f->n) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = id - f->dense_base; }
   else { auto it = f->id2slot.find(id); if (it == f->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "NodeID: %llu is not found", (unsigned long long)id); slot = it->second; }
@@ -721,7 +721,7 @@ int coltt_flat_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_fetch_rows: unknown handle");
   if (n == 0) return COLTT_OK;
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   if (first_slot + n > f->n) return fail(COLTT_E_INVALID, "flat_fetch_rows: range outside [0,%llu)", (unsigned long long)f->n);
   const size_t rb = (size_t)f->dim * quant_bytes(f->quant);
   if (out_rows) COLTT_HIP(hipMemcpy2D(out_rows, rb, f->rows.as<uint8_t>() + first_slot * f->stride, f->stride, rb, n, hipMemcpyDeviceToHost));
@@ -735,7 +735,7 @@ int coltt_flat_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search: NULL buffer");
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   CtxLease<FCtx> ctx(f->pool);
   if (!ctx.c) return COLTT_E_DEVICE;
   return flat_search_common(f.get(), ctx.c, queries, false, nq, k, select, mode, nullptr, f->n, out_ids, out_scores, out_counts, false);
@@ -747,7 +747,7 @@ int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_device: unknown handle");
   if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "flat_search_device: NULL buffer");
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   CtxLease<FCtx> ctx(f->pool);
   if (!ctx.c) return COLTT_E_DEVICE;
   return flat_search_common(f.get(), ctx.c, d_queries, true, nq, k, select, mode, nullptr, f->n, d_out_ids, d_out_scores, d_out_counts, true);
@@ -761,7 +761,7 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search_ids: NULL buffer");
   if (n_cand && !cand_ids) return fail(COLTT_E_INVALID, "flat_search_ids: NULL candidates");
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   // id -> slot; ids that are not stored are skipped (none_vectorstore.go:201 `if node, ok := ...; ok`);
   // a repeated candidate id is scored once (roaring64 ToArray yields a set, pkg/inverted/search.go:113-119)
   std::vector<uint32_t> slots;
@@ -789,7 +789,7 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_load_vertex: unknown handle");
   if (!buf && len) return fail(COLTT_E_INVALID, "flat_load_vertex: NULL buffer");
   WriteLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   FBER r{buf, len};
   const size_t eb = quant_bytes(f->quant);
   std::vector<uint64_t> ids, voff, moff; std::vector<uint32_t> mlen;
@@ -864,7 +864,7 @@ int coltt_flat_save_vertex(coltt_handle_t h, const uint64_t* meta_ids, const uin
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_save_vertex: unknown handle");
   if (!out_len) return fail(COLTT_E_INVALID, "flat_save_vertex: out_len is NULL");
   ReadLock g(f->rw);
-  COLTT_TRY(use_device(f->device));
+  COLTT_DEVICE(f->device);
   const size_t eb = quant_bytes(f->quant);
   std::unordered_map<uint64_t, uint64_t> meta_of;
   for (uint64_t i = 0; i < n_meta; i++) if (meta_ids && meta_blobs && meta_blobs[i] && meta_lens[i] >= 4) meta_of[meta_ids[i]] = i;

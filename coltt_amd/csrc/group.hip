@@ -177,7 +177,7 @@ int coltt_group_unique_id(uint8_t* out) {
   if (!out) return fail(COLTT_E_INVALID, "group_unique_id: NULL out");
   Rccl* r = rccl();
   if (!r) return fail(COLTT_E_UNSUPPORTED, "group_unique_id: librccl is not loadable in this process");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   NcclId id;
   COLTT_NCCL(r, r->GetUniqueId(&id));
   std::memcpy(out, id.internal, COLTT_UNIQUE_ID_BYTES);
@@ -208,7 +208,7 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
   for (int i = 0; i < n_devices; i++) {
     Member& x = *g->m[(size_t)i];
     x.device = devices[i]; x.rank = o.rank_base + i;
-    COLTT_TRY(use_device(x.device));
+    COLTT_DEVICE(x.device);
     if (o.kind == COLTT_GROUP_FLAT) COLTT_TRY(flat_create_on(x.device, dim, metric, quant, &x.h));
     else COLTT_TRY(hnsw_create_on(x.device, dim, metric, quant, cfg, &x.h));
     COLTT_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
@@ -429,16 +429,16 @@ static int group_search(Group* g, const float* queries, const float* const* d_qu
     if (bad) return fail(COLTT_E_DEVICE, "group_search: %s", why.c_str());
     if (ge != 0) return fail(COLTT_E_DEVICE, "group_search: ncclGroupEnd: %s", r->GetErrorString(ge));
     Member& x0 = *g->m[0];
-    COLTT_TRY(use_device(x0.device));
+    COLTT_DEVICE(x0.device);
     COLTT_HIP(hipMemcpyAsync(g->h_stage, x0.d_gather.p, (size_t)g->world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.stream));
-    for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
   } else {
     for (size_t j = 0; j < nm; j++) {
       Member& x = *g->m[j];
-      COLTT_TRY(use_device(x.device));
+      COLTT_DEVICE(x.device);
       COLTT_HIP(hipMemcpyAsync(g->h_stage + (size_t)x.rank * per, x.d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.stream));
     }
-    for (auto& xp : g->m) { Member& x = *xp; COLTT_TRY(use_device(x.device)); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
   }
   return coltt_group_merge_host(g->h_stage, g->world, nq, k, nearest, out_ids, out_scores, out_counts);
 }

@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "exact.hpp"
 #include "hnsw_dev.hpp"
+#include "hnsw_walk2.hpp"
 #include "prep.hpp"
 
 using namespace coltt;
@@ -93,6 +94,72 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     }
   }
   if constexpr (VISG) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
+}
+
+
+// Hnsw.Search for large ef (HBM visited map): the level-0 walk of hnsw_walk2.hpp — delta result set, LDS Bloom filter in front
+// of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
+template <int METRIC, int QUANT, int PROFILE, int OPT>
+__global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
+                                                         const float* __restrict__ q_eff, const float* __restrict__ qnorms,
+                                                         uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t bloom_words,
+                                                         uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                         unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
+                                                         size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  WaveCtx w;
+  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  w.qs = reinterpret_cast<float*>(smem);
+  w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
+  w.vis = nullptr;
+  w.bloom = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
+  w.bloom_words = bloom_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(bloom_words | 0x80000000u);
+  w.ef_pad = ef_pad; w.hcap = 0; w.hcap_mask = 0;
+  w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
+  for (;;) {
+    const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
+    const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
+    if (qi >= nq) break;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
+#ifdef COLTT_PHASE_TIMING
+    for (int i_ = 0; i_ < 8; i_++) w.pt[i_] = 0;
+    w.t_last = __builtin_amdgcn_s_memtime();
+#endif
+    wave_sync();
+    for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    w.qnorm = qnorms[qi];
+    wave_sync();
+    uint32_t cur = (uint32_t)entry;
+    float curd = eval_pair<METRIC, QUANT, PROFILE>(g, w, cur, lane & 1);  // hnsw.go:253
+    curd = __shfl(curd, 0, 64);
+    w.n_dist += 1;
+    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROFILE>(g, w, cur, curd, l, lane);  // :254-256
+    COLTT_PT(w, 5)
+    w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    uint32_t len;
+    search_level2<METRIC, QUANT, PROFILE, OPT>(g, w, cur, curd, ef, lane, len);  // :258-259
+    const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
+    for (uint32_t i = lane; i < n; i += 64) {
+      const unsigned long long e = w.res0[i];
+      const uint32_t slot = (uint32_t)e >> 1;
+      out_ids[(size_t)qi * k + i] = g.ids ? g.ids[slot] : (uint64_t)slot;
+      out_scores[(size_t)qi * k + i] = __uint_as_float((uint32_t)(e >> 32));
+    }
+    if (lane == 0) {
+      out_counts[qi] = n;
+      atomicAdd(&stats[0], (unsigned long long)w.n_dist);
+      atomicAdd(&stats[1], (unsigned long long)w.n_exp);
+      atomicAdd(&stats[2], (unsigned long long)w.n_hops);
+      if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
+#ifdef COLTT_PHASE_TIMING
+      COLTT_PT(w, 6)
+      for (int i_ = 0; i_ < 8; i_++) atomicAdd(&stats[8 + i_], w.pt[i_]);
+#endif
+    }
+  }
+  if (lane == 0) vis_epoch[blockIdx.x] = w.epoch;
 }
 
 
@@ -231,6 +298,7 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       const uint32_t r0 = (uint32_t)__shfl((int)rt, 0, 64);
       if ((uint32_t)lane < m) {
         row[rank] = myslot; drow[rank] = myd;
+        if (l == 0 && g.adj0_n) g.adj0_n[(size_t)vi * g.mMax0 + rank] = g.norms[myslot];
         uint32_t rid = l == 0 ? myslot : (uint32_t)cap_slots + g.upper_off[myslot] + (uint32_t)(l - 1);
         uint32_t r = r0 + lane;
         uint32_t old = atomicExch(&head[rid], r);
@@ -296,6 +364,19 @@ __global__ void hnsw_link_kernel(GraphView g, uint64_t cap_slots, const BuildReq
     s[j] = si; d[j] = di;
   }
   for (uint32_t i = 0; i < W; i++) { row[i] = i < n ? s[i] : NBR_NONE; drow[i] = i < n ? d[i] : 0.f; }
+  if (lvl0 && g.adj0_n) {
+    float* nrow = g.adj0_n + (size_t)rid * g.mMax0;
+    for (uint32_t i = 0; i < W; i++) nrow[i] = i < n ? g.norms[s[i]] : 0.f;
+  }
+}
+
+// adj0_n[slot][j] = norms[adj0[slot][j]] for the level-0 rows of slots [first, first + n): after a bulk install of the topology
+__global__ void adj_norms_kernel(GraphView g, uint64_t first, uint64_t n) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * g.mMax0) return;
+  const uint64_t i = first * g.mMax0 + t;
+  const uint32_t nb = g.adj0[i];
+  g.adj0_n[i] = nb != NBR_NONE ? g.norms[nb] : 0.f;
 }
 
 __global__ void fill_u32_kernel(uint32_t* p, size_t n, uint32_t v) {
@@ -332,7 +413,7 @@ struct Hnsw : Object {
   uint64_t n = 0 /*slots*/, live = 0, cap = 0, n_upper = 0, ucap = 0;
   int32_t entry = -1, entry_level = 0;
   bool any_deleted = false;
-  DevBuf rows, norms, ids, adj0, adj0_d, upper_off, adjU, adjU_d, del_bits;
+  DevBuf rows, norms, ids, adj0, adj0_d, adj0_n, upper_off, adjU, adjU_d, del_bits;
   bool dense = true; uint64_t dense_base = 0;
   std::unordered_map<uint64_t, uint32_t> id2slot;
   std::vector<uint64_t> h_ids;       // !dense
@@ -358,6 +439,7 @@ struct Hnsw : Object {
     g.rows = rows.as<uint8_t>(); g.stride = stride; g.norms = norms.as<float>();
     g.ids = dense ? nullptr : ids.as<uint64_t>();
     g.adj0 = adj0.as<uint32_t>(); g.adj0_d = adj0_d.as<float>(); g.upper_off = upper_off.as<uint32_t>();
+    g.adj0_n = metric == COLTT_COSINE ? adj0_n.as<float>() : nullptr;
     g.adjU = adjU.as<uint32_t>(); g.adjU_d = adjU_d.as<float>();
     g.del_bits = any_deleted ? del_bits.as<uint32_t>() : nullptr;
     g.mMax = (uint32_t)cfg.m_max; g.mMax0 = (uint32_t)cfg.m_max0; g.dim = (int)dim;
@@ -371,6 +453,7 @@ struct Hnsw : Object {
       if (!dense) COLTT_TRY(ids.reserve(nc * 8, true, stream));
       COLTT_TRY(adj0.reserve(nc * cfg.m_max0 * 4, true, stream));
       COLTT_TRY(adj0_d.reserve(nc * cfg.m_max0 * 4, true, stream));
+      if (metric == COLTT_COSINE) COLTT_TRY(adj0_n.reserve(nc * cfg.m_max0 * 4, true, stream));
       COLTT_TRY(upper_off.reserve(nc * 4, true, stream));
       size_t old_words = (cap + 31) / 32, new_words = (nc + 31) / 32;
       COLTT_TRY(del_bits.reserve(new_words * 4, true, stream));
@@ -418,7 +501,7 @@ int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
 
 uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; };
+struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; int w2 = -1; uint32_t bloom_words = 0; };  // w2: hnsw_walk2.hpp variant (OPT bits | 8 = deep profile), -1 = hnsw_dev.hpp:search_level
 
 #ifndef COLTT_VISG_MIN_EF
 #define COLTT_VISG_MIN_EF 128
@@ -506,7 +589,23 @@ bool wants_visg(uint32_t ef) {
   return pol < 0 ? ef > COLTT_VISG_MIN_EF : pol != 0;
 }
 
-SearchGeom search_geom(Hnsw* x, uint32_t ef) {
+// Which level-0 walk serves the HBM-visited searches.  COLTT_WALK2=off: hnsw_dev.hpp:search_level (the round-2 kernel);
+// COLTT_WALK2=<n>: hnsw_walk2.hpp with OPT = n & 7 (1 Bloom, 2 delta result set, 4 adjacency-carried norms), n & 8 = the deep
+// profile (one wave per SIMD, whole 2-byte row in flight).  Measurement and test knob, read at every call.
+#ifndef COLTT_WALK2_DEFAULT
+#define COLTT_WALK2_DEFAULT 7
+#endif
+int walk2_policy() {
+  const char* e = getenv("COLTT_WALK2");
+  if (!e || !*e) return COLTT_WALK2_DEFAULT;
+  if (!strcmp(e, "off")) return -1;
+  return atoi(e) & 15;
+}
+
+// resident waves per CU of the walk2 profiles: see waves_per_cu_cap
+size_t waves_per_cu_cap(int quant);
+
+SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false) {
   SearchGeom s;
   s.ef = ef;
   s.ef_pad = (ef + 63) & ~63u;
@@ -519,6 +618,20 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef) {
   s.visg = wants_visg(ef) && x->vis_stride != 0 && x->vis_regions > 0;
   if (s.visg) { s.hcap = 64; s.lds = fixed; s.max_grid = x->vis_regions; }
   else { s.lds = fixed + (size_t)s.hcap * 4; s.max_grid = 0xffffffffu; }
+  if (s.visg && for_search && x->cfg.m_max0 <= 1024) {
+    s.w2 = walk2_policy();
+    if (s.w2 >= 0 && (s.w2 & 1)) {
+      // Bloom filter: the largest power of two that keeps the profile's resident waves (>= 2 KiB, <= 32 KiB), else none
+      const size_t waves = (s.w2 & 8) ? 4 : waves_per_cu_cap(x->quant);
+      const size_t budget = (160 * 1024) / waves;
+      size_t kb = 32;
+      if (const char* e = getenv("COLTT_BLOOM_KB")) { if (*e) kb = (size_t)std::max(1, std::min(64, atoi(e))); }
+      else while (kb >= 2 && fixed + kb * 1024 > budget) kb >>= 1;
+      size_t p2 = 1; while (p2 * 2 <= kb) p2 *= 2;   // power of two
+      if (kb >= 2 && fixed + p2 * 1024 <= 160 * 1024) { s.bloom_words = (uint32_t)(p2 * 256); s.lds = fixed + p2 * 1024; }
+      else s.w2 &= ~1;
+    }
+  }
   return s;
 }
 
@@ -532,7 +645,45 @@ size_t waves_per_cu_cap(int quant) {
 }
 
 uint32_t resident_waves(const SearchGeom& sg, int quant) {
-  return 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(quant), (160 * 1024) / sg.lds));
+  const size_t cap = (sg.w2 >= 0 && (sg.w2 & 8)) ? 4 : waves_per_cu_cap(quant);
+  return 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(cap, (160 * 1024) / sg.lds));
+}
+
+// hnsw_walk2.hpp kernels.  The default build carries the shipped variant (and its Bloom-less twin for geometries whose LDS
+// has no room for the filter); -DCOLTT_WALK_EXPERIMENTS adds every OPT x profile combination for A/B runs (tools/walk_sweep.py).
+template <int METRIC, int QUANT>
+int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
+                   uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
+  typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*,
+                         uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
+  kern_t kern = nullptr;
+#define COLTT_W2(V, PROF, OPT) case V: kern = hnsw_search2_kernel<METRIC, QUANT, PROF, OPT>; break;
+#ifdef COLTT_WALK_EXPERIMENTS
+  if constexpr (METRIC == M_COS && QUANT != Q_F8) {
+    switch (sg.w2) {
+      COLTT_W2(0, PROF_SEARCH_HBM, 0) COLTT_W2(1, PROF_SEARCH_HBM, 1) COLTT_W2(2, PROF_SEARCH_HBM, 2) COLTT_W2(3, PROF_SEARCH_HBM, 3)
+      COLTT_W2(4, PROF_SEARCH_HBM, 4) COLTT_W2(5, PROF_SEARCH_HBM, 5) COLTT_W2(6, PROF_SEARCH_HBM, 6) COLTT_W2(7, PROF_SEARCH_HBM, 7)
+      COLTT_W2(8, PROF_SEARCH_HBM_DEEP, 0) COLTT_W2(9, PROF_SEARCH_HBM_DEEP, 1) COLTT_W2(10, PROF_SEARCH_HBM_DEEP, 2) COLTT_W2(11, PROF_SEARCH_HBM_DEEP, 3)
+      COLTT_W2(12, PROF_SEARCH_HBM_DEEP, 4) COLTT_W2(13, PROF_SEARCH_HBM_DEEP, 5) COLTT_W2(14, PROF_SEARCH_HBM_DEEP, 6) COLTT_W2(15, PROF_SEARCH_HBM_DEEP, 7)
+      default: break;
+    }
+  } else
+#endif
+  {
+    switch (sg.w2) {
+      COLTT_W2(6, PROF_SEARCH_HBM, 6) COLTT_W2(7, PROF_SEARCH_HBM, 7)
+      default: break;
+    }
+  }
+#undef COLTT_W2
+  if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
+                                        k, sg.ef, sg.ef_pad, sg.bloom_words, counter, oi, os, oc, stats,
+                                        x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
+                                        x->w_vepoch.as<uint32_t>() + region_base);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
 }
 
 template <int METRIC, int QUANT>
@@ -593,13 +744,13 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
   if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: ef=%u > 4096", ef);
   if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
-  SearchGeom sg = search_geom(x, ef);
+  SearchGeom sg = search_geom(x, ef, true);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
   // opt-in staged kernel.  Its LDS hash must never need the reset path, so it gets the largest table that fits beside the staging
   // area (one workgroup per CU); if even that is too small for this ef the single-wave kernel serves the call.
   bool mw = nq <= mw_max_nq() && !force_single_wave;
   if (mw) {
-    SearchGeom m = sg;
+    SearchGeom m = sg; m.w2 = -1; m.bloom_words = 0;
     // LDS: query + result set + exchange words + the staging area (32 rows) + the visited hash
     const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * m.ef_pad * 8 + sizeof(MwExchange) + (size_t)MW_ROWS * x->stride;
     if (x->stride > MW_MAX_STRIDE || x->cfg.m_max0 > 1024) mw = false;               // rows too long to stage 32 at a time
@@ -630,6 +781,7 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   int rc;
 #define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
 #define COLTT_LS(Q) rc = mw ? (x->metric == COLTT_COSINE ? launch_search_mw<M_COS, Q>(COLTT_LS_ARGS) : launch_search_mw<M_L2, Q>(COLTT_LS_ARGS)) \
+                     : sg.w2 >= 0 ? (x->metric == COLTT_COSINE ? launch_search2<M_COS, Q>(COLTT_LS_ARGS) : launch_search2<M_L2, Q>(COLTT_LS_ARGS)) \
                             : (x->metric == COLTT_COSINE ? launch_search<M_COS, Q>(COLTT_LS_ARGS) : launch_search<M_L2, Q>(COLTT_LS_ARGS))
   COLTT_DISPATCH_QUANT(x->quant, COLTT_LS)
 #undef COLTT_LS
@@ -677,12 +829,13 @@ __global__ void hnsw_unlink_kernel(GraphView g, const uint32_t* __restrict__ nbs
   uint32_t W;
   uint32_t* row = const_cast<uint32_t*>(adj_row(g, nbs[t], lvl[t], W));
   float* drow = lvl[t] == 0 ? g.adj0_d + (size_t)nbs[t] * g.mMax0 : g.adjU_d + ((size_t)g.upper_off[nbs[t]] + (uint32_t)(lvl[t] - 1)) * g.mMax;
+  float* nrow = (lvl[t] == 0 && g.adj0_n) ? g.adj0_n + (size_t)nbs[t] * g.mMax0 : nullptr;
   uint32_t m = 0;
   for (uint32_t i = 0; i < W && row[i] != NBR_NONE; i++) {
     uint32_t sl = row[i]; float dd = drow[i];
-    if (!is_deleted(g, sl)) { row[m] = sl; drow[m] = dd; m++; }
+    if (!is_deleted(g, sl)) { row[m] = sl; drow[m] = dd; if (nrow) nrow[m] = nrow[i]; m++; }
   }
-  for (; m < W; m++) { row[m] = NBR_NONE; drow[m] = 0.f; }
+  for (; m < W; m++) { row[m] = NBR_NONE; drow[m] = 0.f; if (nrow) nrow[m] = 0.f; }
 }
 
 int hnsw_undense(Hnsw* x) {
@@ -775,6 +928,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     if (!x->dense) COLTT_HIP(hipMemcpyAsync(x->ids.as<uint64_t>() + base, nid.data(), (size_t)b * 8, hipMemcpyHostToDevice, x->stream));
     COLTT_HIP(hipMemsetAsync(x->adj0.as<uint32_t>() + base * x->cfg.m_max0, 0xff, (size_t)b * x->cfg.m_max0 * 4, x->stream));
     COLTT_HIP(hipMemsetAsync(x->adj0_d.as<float>() + base * x->cfg.m_max0, 0, (size_t)b * x->cfg.m_max0 * 4, x->stream));
+    if (x->metric == COLTT_COSINE) COLTT_HIP(hipMemsetAsync(x->adj0_n.as<float>() + base * x->cfg.m_max0, 0, (size_t)b * x->cfg.m_max0 * 4, x->stream));
     if (up) {
       COLTT_HIP(hipMemsetAsync(x->adjU.as<uint32_t>() + x->n_upper * x->cfg.m_max, 0xff, (size_t)up * x->cfg.m_max * 4, x->stream));
       COLTT_HIP(hipMemsetAsync(x->adjU_d.as<float>() + x->n_upper * x->cfg.m_max, 0, (size_t)up * x->cfg.m_max * 4, x->stream));
@@ -825,6 +979,15 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
       if (lv[j] > x->entry_level) { x->entry = (int32_t)(base + j); x->entry_level = lv[j]; }
     x->n += b; x->live += b; x->n_upper += up; i += b;
   }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  return COLTT_OK;
+}
+
+// the derived neighbour-norm rows of every slot (bulk installs; Insert / Remove maintain them incrementally in their kernels)
+int fill_adj_norms(Hnsw* x) {
+  if (x->metric != COLTT_COSINE || x->n == 0) return COLTT_OK;
+  adj_norms_kernel<<<ceil_div(x->n * x->cfg.m_max0, 256), 256, 0, x->stream>>>(x->view(), 0, x->n);
+  COLTT_HIP(hipGetLastError());
   COLTT_HIP(hipStreamSynchronize(x->stream));
   return COLTT_OK;
 }
@@ -951,7 +1114,7 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
-  if (device < 0) { COLTT_TRY(ensure_device()); device = default_device(); } else COLTT_TRY(use_device(device));
+  COLTT_DEVICE(device); device = coltt_dev_scope_.device();
   x->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
   *out = Registry::get().add(x);
@@ -999,7 +1162,7 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_bulk_load: unknown handle");
   if (n && (!levels || !vectors || !row_offsets)) return fail(COLTT_E_INVALID, "hnsw_bulk_load: NULL input");
   WriteLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   COLTT_TRY(graph_install(x.get(), x->cfg, n, ids, levels, deleted, row_offsets, nbr, nbr_dist, entry_slot));
   auto upload_vectors = [&]() -> int {
     // vectors in chunks through a staging buffer: Normalize (cosine) + Lower, as Insert does (hnsw.go:105-107)
@@ -1013,7 +1176,7 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   return COLTT_OK;
 }
 
@@ -1054,7 +1217,7 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_load: unknown handle");
   if (!buf && len) return fail(COLTT_E_INVALID, "hnsw_load: NULL buffer");
   WriteLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   BER r{buf, len};
   coltt_hnsw_cfg c = x->cfg;  // committed by graph_install only after the whole stream has been parsed and validated
   if (header) {  // hnswConfig.load (hnsw_config.go:205-245), dim, distIdx (hnsw_commit.go:165-183)
@@ -1135,7 +1298,7 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   if (out_n) *out_n = n;
   for (uint64_t i = 0; i < n && i < cap_n; i++) {
     if (out_ids) out_ids[i] = ids[i];
@@ -1145,14 +1308,22 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
   return COLTT_OK;
 }
 
-int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens, uint8_t* out,
-                      uint64_t cap, uint64_t* out_len) {
+int coltt_hnsw_entry_level(coltt_handle_t h, int32_t* out_level) {
+  auto x = lookup<Hnsw>(h);
+  if (!x || !out_level) return fail(COLTT_E_NOT_FOUND, "hnsw_entry_level: unknown handle");
+  ReadLock g(x->rw);
+  *out_level = x->entry >= 0 ? x->entry_level : -1;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens, uint64_t n_meta,
+                      uint8_t* out, uint64_t cap, uint64_t* out_len) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_commit: unknown handle");
   if (!out_len) return fail(COLTT_E_INVALID, "hnsw_commit: out_len is NULL");
   if (x->quant != COLTT_Q_NONE) return fail(COLTT_E_UNSUPPORTED, "hnsw_commit: the reference stream stores f32 vectors; quantised indexes are not committable");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   BEW w{out, out ? cap : 0};
   if (header) {  // hnswConfig.save (hnsw_config.go:179-203) + dim + distIdx (hnsw_commit.go:70-80)
     w.u32((uint32_t)x->cfg.algo); w.f32(x->cfg.level_multiplier); w.u32((uint32_t)x->cfg.ef); w.u32((uint32_t)x->cfg.ef_construction);
@@ -1180,7 +1351,7 @@ int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_b
     for (uint32_t s : sh) {
       w.u64(id_of(s)); w.u32((uint32_t)x->h_levels[s]);
       if (out) for (uint32_t e = 0; e < x->dim; e++) w.f32(all[(size_t)s * x->dim + e]); else w.n += (uint64_t)x->dim * 4;
-      if (meta_blobs && meta_blobs[s] && meta_lens && meta_lens[s] >= 2) w.put(meta_blobs[s], meta_lens[s]); else w.u16(0);
+      if (meta_blobs && meta_lens && s < n_meta && meta_blobs[s] && meta_lens[s] >= 2) w.put(meta_blobs[s], meta_lens[s]); else w.u16(0);
     }
   }
   // section 2: edges, highest level first, tombstoned neighbours skipped (hnsw_commit.go:133-157)
@@ -1211,7 +1382,7 @@ int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "hnsw_search: NULL buffer");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   CtxLease<HCtx> ctx(x->pool);
   if (!ctx.c) return COLTT_E_DEVICE;
   return search_common(x.get(), ctx.c, queries, false, nq, k, ef_override, out_ids, out_scores, out_counts, stats);
@@ -1223,7 +1394,7 @@ int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_search_device: unknown handle");
   if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "hnsw_search_device: NULL buffer");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   CtxLease<HCtx> ctx(x->pool);
   if (!ctx.c) return COLTT_E_DEVICE;
   return search_common(x.get(), ctx.c, d_queries, true, nq, k, ef_override, d_out_ids, d_out_scores, d_out_counts, stats);
@@ -1235,7 +1406,7 @@ int coltt_hnsw_insert(coltt_handle_t h, uint64_t id, const float* vec, int32_t l
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert: unknown handle");
   if (!vec) return fail(COLTT_E_INVALID, "hnsw_insert: NULL vector");
   WriteLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   COLTT_TRY(x->w_raw.reserve((size_t)x->dim * 4));
   COLTT_HIP(hipMemcpyAsync(x->w_raw.p, vec, (size_t)x->dim * 4, hipMemcpyHostToDevice, x->stream));
   return insert_core(x.get(), &id, 0, x->w_raw.as<float>(), &level, 1, 1);
@@ -1247,7 +1418,7 @@ int coltt_hnsw_insert_batch_device(coltt_handle_t h, const uint64_t* ids, uint64
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_insert_batch_device: unknown handle");
   if (n && (!d_vecs || !levels)) return fail(COLTT_E_INVALID, "hnsw_insert_batch_device: NULL input");
   WriteLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   return insert_core(x.get(), ids, first_id, d_vecs, levels, n, batch);
 }
 
@@ -1255,7 +1426,7 @@ int coltt_hnsw_remove(coltt_handle_t h, uint64_t id) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_remove: unknown handle");
   WriteLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   uint32_t vi;
   if (x->dense) {
     if (id < x->dense_base || id >= x->dense_base + x->n) return fail(COLTT_E_NOT_FOUND, "Item not found");
@@ -1319,9 +1490,25 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export: unknown handle");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   const uint64_t n = x->n;
   const uint32_t W0 = (uint32_t)x->cfg.m_max0, WU = (uint32_t)x->cfg.m_max;
+  const bool filling = ids || levels || deleted || row_offsets || nbr || nbr_dist;
+  if (filling) {
+    // the caller sized its arrays from an earlier call; an Insert in between must not turn into a write past their end
+    if (!n_slots || !n_rows || !n_edges) return fail(COLTT_E_INVALID, "hnsw_export: array capacities (n_slots, n_rows, n_edges) are required when arrays are passed");
+    uint64_t need_rows = 0;
+    for (uint64_t i = 0; i < n; i++) need_rows += (uint64_t)x->h_levels[i] + 1;
+    const bool slots_short = (ids || levels || deleted) && *n_slots < n;
+    const bool rows_short = row_offsets && *n_rows < need_rows;
+    if (slots_short || rows_short) {
+      const uint64_t cs = *n_slots, cr = *n_rows;
+      *n_slots = n; *n_rows = need_rows;
+      return fail(COLTT_E_INVALID, "hnsw_export: the index grew past the caller's arrays (%llu slots / %llu rows offered, %llu / %llu needed)",
+                  (unsigned long long)cs, (unsigned long long)cr, (unsigned long long)n, (unsigned long long)need_rows);
+    }
+  }
+  const uint64_t cap_edges = (filling && n_edges) ? *n_edges : 0;
   std::vector<uint32_t> a0((size_t)n * W0), aU((size_t)x->n_upper * WU);
   std::vector<float> d0, dU;
   if (n) COLTT_HIP(hipMemcpy(a0.data(), x->adj0.p, a0.size() * 4, hipMemcpyDeviceToHost));
@@ -1342,8 +1529,10 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
       const uint32_t* r = l == 0 ? &a0[(size_t)i * W0] : &aU[((size_t)x->h_upper_off[i] + l - 1) * WU];
       const float* dr = nbr_dist ? (l == 0 ? &d0[(size_t)i * W0] : &dU[((size_t)x->h_upper_off[i] + l - 1) * WU]) : nullptr;
       for (uint32_t j = 0; j < W && r[j] != NBR_NONE; j++) {
-        if (nbr) nbr[edges] = (int32_t)r[j];
-        if (nbr_dist) nbr_dist[edges] = dr[j];
+        if (edges < cap_edges) {
+          if (nbr) nbr[edges] = (int32_t)r[j];
+          if (nbr_dist) nbr_dist[edges] = dr[j];
+        }
         edges++;
       }
       rows++;
@@ -1354,6 +1543,9 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
   if (n_rows) *n_rows = rows;
   if (n_edges) *n_edges = edges;
   if (entry_slot) *entry_slot = x->entry;
+  if ((nbr || nbr_dist) && edges > cap_edges)
+    return fail(COLTT_E_INVALID, "hnsw_export: the index grew past the caller's edge arrays (%llu offered, %llu needed)",
+                (unsigned long long)cap_edges, (unsigned long long)edges);
   return COLTT_OK;
 }
 
@@ -1362,7 +1554,7 @@ int coltt_hnsw_export_raw(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_upper
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_export_raw: unknown handle");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   if (n_slots) *n_slots = x->n;
   if (n_upper_rows) *n_upper_rows = x->n_upper;
   if (entry_slot) *entry_slot = x->entry;
@@ -1379,7 +1571,7 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
   if (n == 0) return COLTT_OK;
   ReadLock g(x->rw);
   if (!out_rows || first_slot + n > x->n) return fail(COLTT_E_INVALID, "hnsw_fetch_rows: range outside [0,%llu)", (unsigned long long)x->n);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   const size_t rb = (size_t)x->dim * quant_bytes(x->quant);
   COLTT_HIP(hipMemcpy2D(out_rows, rb, x->rows.as<uint8_t>() + first_slot * x->stride, x->stride, rb, n, hipMemcpyDeviceToHost));
   return COLTT_OK;
@@ -1389,7 +1581,7 @@ int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_le
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_get: unknown handle");
   ReadLock g(x->rw);
-  COLTT_TRY(use_device(x->device));
+  COLTT_DEVICE(x->device);
   uint64_t slot;
   if (x->dense) {
     if (id < x->dense_base || id >= x->dense_base + x->n) return fail(COLTT_E_NOT_FOUND, "Item not found");

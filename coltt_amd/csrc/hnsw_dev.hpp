@@ -32,6 +32,8 @@ constexpr uint32_t NBR_NONE = 0xffffffffu;
 struct GraphView {
   const uint8_t* rows; size_t stride; const float* norms; const uint64_t* ids;
   uint32_t* adj0; float* adj0_d;      // [cap][mMax0]   level-0 rows, ascending slot, padded with NBR_NONE
+  float* adj0_n;                      // [cap][mMax0]   norms[adj0[..]] — cosine only, else null: the neighbours' ||row||^2 ride with the
+                                      //                adjacency row instead of one 4-byte gather (= one cache line) per evaluation
   const uint32_t* upper_off;          // [cap]          first upper row of a slot (levels 1..L consecutive)
   uint32_t* adjU; float* adjU_d;      // [ucap][mMax]
   const uint32_t* del_bits;           // tombstones (hnswVertex.deleted, hnsw_vertex.go:70-76) or null when none
@@ -46,6 +48,7 @@ struct WaveCtx {
   // counters (wave-uniform)
   uint32_t n_dist, n_exp, n_hops, n_resets;
   uint8_t* visg; size_t vis_bytes; uint32_t epoch;  // VISG: this workgroup's byte-per-slot region, its size, current epoch
+  uint32_t* bloom; uint32_t bloom_words, bloom_shift;  // hnsw_walk2.hpp: LDS Bloom filter in front of the byte map (words = 2^(32-shift))
 #ifdef COLTT_PHASE_TIMING
   unsigned long long pt[8], t_last;  // shader-clock ticks per traversal phase (diagnostic build only)
 #endif
@@ -122,8 +125,10 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
 // spills, 13.15 -> 11.88 ms per 10 k queries at 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under
 // 256.  Measured on MI355X, 2 M x 768, ef 128 unless noted: f32 U = 16 19.76 ms, 24 19.64, 32 21.58; f32 ef 256 (HBM visited)
 // U = 16 160 k q/s, 24 197 k; f16 U = 24 13.15 ms, 32 12.53, 48 11.88; f16 ef 256 (HBM visited) U = 24 421 k q/s, 48 364 k.
-enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_MW = 3 };
+enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_MW = 3, PROF_SEARCH_HBM_DEEP = 4 };
 template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst_depth() {
+  // large-ef walk at ONE wave per SIMD (hnsw_walk2.hpp, deep profile): registers are free, a whole 2-byte row / a third of an f32 row in flight
+  if (PROFILE == PROF_SEARCH_HBM_DEEP) return QUANT == Q_NONE ? 32 : 48;
   // multi-wave (latency) mode: 8 rows per wave, one workgroup per CU — registers are free, keep a third / a whole row in flight
   if (PROFILE == PROF_SEARCH_MW) return QUANT == Q_NONE ? 32 : 48;
   if (QUANT == Q_NONE) return PROFILE == PROF_SEARCH_HBM ? 24 : 16;

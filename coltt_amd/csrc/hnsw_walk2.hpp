@@ -1,0 +1,382 @@
+// hnsw_walk2.hpp — Hnsw.searchLevel at level 0 for LARGE ef (the recall >= 0.98 operating points: ef 256 ... 4096).
+//
+// Same closed form of core/vectorindex/hnsw.go:345-389 as hnsw_dev.hpp:search_level (stale lowerBound per popped candidate, canonical
+// neighbour order, ties by (distance, slot), the ef smallest kept) and the same exact-order distances — ids, score bits and the
+// traversal counters stay equal to the oracle's — but the three things that made the large-ef walk slow are restructured:
+//
+//  W2_DELTA  result set = a SORTED main array in LDS + an UNSORTED delta of <= 64 entries held in registers (one per lane).
+//            An admission is a register move; the eviction of the largest member compares the main array's tail (one LDS read per
+//            neighbour chunk) with the delta maximum (DPP reductions); the delta is merged into the main array only when it is full —
+//            one pass over the array per 64 admissions instead of a binary search + partial shift per admission.  The set is the
+//            same set at every step, so pop order, lowerBound and the final order are unchanged.
+//  W2_BLOOM  a blocked Bloom filter in LDS (2 bits in one 32-bit word, one ds_or_rtn per test) in front of the HBM byte-per-slot
+//            visited map: a negative answer is definite ("never tested in this traversal"), so only positives pay the dependent
+//            HBM probe; every fresh vertex is still recorded in the byte map, which stays the exact set.
+//  W2_ADJN   the neighbours' ||row||^2 (cosine) come with the adjacency row (GraphView::adj0_n) instead of one 4-byte gather per
+//            evaluation — a gather that costs a whole cache line of HBM traffic each.
+//
+// The wave must be the only one in its workgroup (wave_sync is a wave-level LDS fence).  VISG (HBM byte map) only.
+#pragma once
+#include "hnsw_dev.hpp"
+
+namespace coltt {
+namespace dev {
+
+enum { W2_BLOOM = 1, W2_DELTA = 2, W2_ADJN = 4 };
+
+// ---- wave64 reductions through DPP (no LDS crossbar): quad_perm, row_shr, row_bcast — the result lands in lane 63 -------------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_keep(uint32_t v) {  // lanes without a source keep their value
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = umin32(v, dpp_keep<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
+  v = umin32(v, dpp_keep<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
+  v = umin32(v, dpp_keep<0x114, 0xf>(v));   // row_shr:4
+  v = umin32(v, dpp_keep<0x118, 0xf>(v));   // row_shr:8   -> lane 15 of every row holds the row's minimum
+  v = umin32(v, dpp_keep<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3
+  v = umin32(v, dpp_keep<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = umax32(v, dpp_keep<0xB1, 0xf>(v));
+  v = umax32(v, dpp_keep<0x4E, 0xf>(v));
+  v = umax32(v, dpp_keep<0x114, 0xf>(v));
+  v = umax32(v, dpp_keep<0x118, 0xf>(v));
+  v = umax32(v, dpp_keep<0x142, 0xa>(v));
+  v = umax32(v, dpp_keep<0x143, 0xc>(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// lane holding the smallest / largest 64-bit key (hi:lo) among the lanes with `valid` (wave-uniform; -1 when there is none).
+// Keys are distinct.  The common case — one lane holds the extreme distance — costs one 32-bit reduction and a ballot.
+__device__ __forceinline__ int wave_argmin_key(bool valid, uint32_t hi, uint32_t lo, unsigned long long& key) {
+  if (!__ballot(valid)) { key = ~0ull; return -1; }
+  const uint32_t mh = wave_min_u32(valid ? hi : 0xffffffffu);
+  const bool tie = valid && hi == mh;
+  const unsigned long long t = __ballot(tie);
+  int L; uint32_t ml;
+  if (__popcll(t) == 1) { L = __builtin_ctzll(t); ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, L); }
+  else { ml = wave_min_u32(tie ? lo : 0xffffffffu); L = __builtin_ctzll(__ballot(tie && lo == ml)); }
+  key = ((unsigned long long)mh << 32) | ml;
+  return L;
+}
+__device__ __forceinline__ int wave_argmax_key(bool valid, uint32_t hi, uint32_t lo, unsigned long long& key) {
+  if (!__ballot(valid)) { key = 0ull; return -1; }
+  const uint32_t mh = wave_max_u32(valid ? hi : 0u);
+  const bool tie = valid && hi == mh;
+  const unsigned long long t = __ballot(tie);
+  int L; uint32_t ml;
+  if (__popcll(t) == 1) { L = __builtin_ctzll(t); ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, L); }
+  else { ml = wave_max_u32(tie ? lo : 0u); L = __builtin_ctzll(__ballot(tie && lo == ml)); }
+  key = ((unsigned long long)mh << 32) | ml;
+  return L;
+}
+
+template <int METRIC, int QUANT, int PROFILE>
+__device__ __forceinline__ float eval_pair_n(const GraphView& g, const WaveCtx& w, uint32_t slot, int half, float rn) {
+  constexpr int U = burst_depth<QUANT, PROFILE>();
+  return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+}
+
+// The delta: one (hi, lo) key per lane, lanes [0, n) valid, bit 0 of lo = expanded; `mx` = the largest key with bit 0 cleared
+// (0 when n == 0) and `mx_lane` its lane.  All members wave-uniform except hi / lo.
+struct Delta {
+  uint32_t hi, lo;
+  uint32_t n;
+  unsigned long long mx; int mx_lane;
+  __device__ __forceinline__ void refresh_max(int lane) { mx_lane = wave_argmax_key((uint32_t)lane < n, hi, lo & ~1u, mx); }
+};
+
+// Merge the delta into the sorted main array res[0, len), in place (len + delta.n <= ef_pad).  scan_lo: see search_level2.
+__device__ __forceinline__ void delta_flush(unsigned long long* res, uint32_t& len, Delta& dl, uint32_t& scan_lo, int lane) {
+  if (dl.n == 0) return;
+  const bool valid = (uint32_t)lane < dl.n;
+  const unsigned long long key = ((unsigned long long)dl.hi << 32) | dl.lo;
+  uint32_t pos = 0xffffffffu;
+  if (valid) {  // insertion point in the main array (all delta keys at once; keys are distinct, bit 0 never decides an order)
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (res[mid] < key) lo = mid + 1; else hi = mid; }
+    pos = lo;
+  }
+  uint32_t r = 0;  // rank among the delta keys
+  for (uint32_t j = 0; j < dl.n; j++) {
+    const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)dl.hi, (int)j), kl = (uint32_t)__builtin_amdgcn_readlane((int)dl.lo, (int)j);
+    r += (kh < dl.hi || (kh == dl.hi && kl < dl.lo)) ? 1u : 0u;
+  }
+  const uint32_t minpos = wave_min_u32(pos);
+  scan_lo = minpos < scan_lo ? minpos : scan_lo;  // flushed keys may be unexpanded
+  wave_sync();
+  if (len) {
+    // member i moves up by #{delta keys whose insertion point is <= i}; chunks in descending order, targets lie <= 64 above, i.e.
+    // in territory that has already been moved; members before the smallest insertion point stay
+    for (int base = (int)((len - 1) & ~63u); base >= (int)(minpos & ~63u); base -= 64) {
+      const uint32_t i = (uint32_t)base + lane;
+      const unsigned long long e = i < len ? res[i] : ~0ull;
+      uint32_t shift = __popcll(__ballot(valid && pos < (uint32_t)base));
+      unsigned long long im = __ballot(valid && pos >= (uint32_t)base && pos < (uint32_t)base + 64u);
+      while (im) {
+        const int j = __builtin_ctzll(im); im &= im - 1;
+        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)pos, j);
+        shift += (pj <= i) ? 1u : 0u;
+      }
+      wave_sync();  // every lane holds its member before any lane overwrites one
+      if (i < len && shift) res[i + shift] = e;
+    }
+  }
+  wave_sync();
+  if (valid) res[pos + r] = key;
+  len += dl.n;
+  dl.n = 0; dl.hi = dl.lo = 0xffffffffu; dl.mx = 0ull; dl.mx_lane = -1;
+  wave_sync();
+}
+
+// Drop the `e` largest members of main ∪ delta ("keep the ef smallest").
+__device__ __forceinline__ void evict_largest(const unsigned long long* res, uint32_t& len, Delta& dl, uint32_t e, int lane) {
+  // the main array's tail in registers: lane t holds res[tb + t]; at most 32 members leave per call
+  const uint32_t tb = len > 64u ? len - 64u : 0u;
+  const unsigned long long treg = tb + (uint32_t)lane < len ? res[tb + lane] : 0ull;
+  for (uint32_t t = 0; t < e; t++) {
+    const unsigned long long mt = len ? (readlane_u64(treg, (int)(len - 1u - tb)) & ~1ull) : 0ull;
+    if (dl.n && (!len || dl.mx > mt)) {  // the largest member sits in the delta: the last delta entry takes its lane
+      const int last = (int)dl.n - 1;
+      const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)dl.hi, last), vl = (uint32_t)__builtin_amdgcn_readlane((int)dl.lo, last);
+      if (lane == dl.mx_lane) { dl.hi = vh; dl.lo = vl; }
+      if (lane == last) { dl.hi = 0xffffffffu; dl.lo = 0xffffffffu; }
+      dl.n--;
+      dl.refresh_max(lane);
+    } else len--;
+  }
+}
+
+// searchLevel (hnsw.go:345-389) on level 0.  On return res[0, len) holds the result set ascending by (d, slot).
+template <int METRIC, int QUANT, int PROFILE, int OPT>
+__device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef, int lane_in,
+                                              uint32_t& out_len) {
+  constexpr bool BLOOM = (OPT & W2_BLOOM) != 0, DELTA = (OPT & W2_DELTA) != 0, ADJN = (OPT & W2_ADJN) != 0 && METRIC == M_COS;
+#ifdef COLTT_NO_ADJ_PREFETCH
+  constexpr bool PREF = false;
+#else
+  constexpr bool PREF = QUANT != Q_NONE;  // see hnsw_dev.hpp: the adjacency prefetch pays for 2-/1-byte rows only
+#endif
+  int lane = lane_in;
+  unsigned long long* const res = w.res0;
+  if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
+    for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
+    __threadfence();
+    w.epoch = 1;
+  }
+  if constexpr (BLOOM) {
+    for (uint32_t i = (uint32_t)lane * 4; i < w.bloom_words; i += 256) *reinterpret_cast<u32x4v*>(w.bloom + i) = u32x4v{0, 0, 0, 0};
+  }
+  if (lane == 0) res[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
+  wave_sync();
+  if (lane == 0) {
+    __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (BLOOM) {
+      const uint32_t h = ep * 0x9E3779B1u;
+      w.bloom[h >> w.bloom_shift] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+    }
+  }
+  uint32_t len = 1;
+  uint32_t scan_lo = 0;   // every main-array member before this index is expanded (pop scans start at its 64-entry chunk)
+  Delta dl; dl.hi = dl.lo = 0xffffffffu; dl.n = 0; dl.mx = 0ull; dl.mx_lane = -1;
+  uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE; float pre_nn = 0.f;
+  const uint32_t width = g.mMax0;
+  wave_sync();
+  for (uint32_t iters = 0;; iters++) {
+    if (iters > (1u << 22)) { w.err |= 2u; break; }
+    lane = opaque_lane(lane_in);
+    const int half = lane & 1, p = lane >> 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // ---- pop: the smallest unexpanded member of main ∪ delta (cj = the unexpanded main member after the first one)
+    int ci = -1, cj = -1;
+    for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
+      const uint32_t i = base + lane;
+      const bool un = i < len && !(res[i] & 1ull);
+      unsigned long long m = __ballot(un);
+      if (m) {
+        ci = (int)base + __builtin_ctzll(m);
+        m &= m - 1;
+        if (m) cj = (int)base + __builtin_ctzll(m);
+        break;
+      }
+    }
+    const unsigned long long kci = ci >= 0 ? res[ci] : ~0ull;
+    unsigned long long kd = ~0ull; int dlane = -1;
+    bool d_un = false;
+    if constexpr (DELTA) {
+      d_un = (uint32_t)lane < dl.n && !(dl.lo & 1u);
+      dlane = wave_argmin_key(d_un, dl.hi, dl.lo, kd);
+    }
+    if (ci < 0 && dlane < 0) break;
+    const bool from_delta = kd < kci;
+    const unsigned long long ce = from_delta ? kd : kci;
+    unsigned long long runner_key = ~0ull;
+    if constexpr (PREF) {
+      if (from_delta) {
+        unsigned long long kd2; (void)wave_argmin_key(d_un && lane != dlane, dl.hi, dl.lo, kd2);
+        runner_key = kci < kd2 ? kci : kd2;
+      } else {
+        const unsigned long long kcj = cj >= 0 ? res[cj] : ~0ull;
+        runner_key = kcj < kd ? kcj : kd;
+      }
+    }
+    COLTT_PT(w, 0)  // pop
+    // lowerBound: the distance of the largest member, sampled once per pop (hnsw.go:357)
+    unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
+    if constexpr (DELTA) worst = dl.mx > worst ? dl.mx : worst;
+    const float lower_bound = __uint_as_float((uint32_t)(worst >> 32));
+    wave_sync();
+    if (from_delta) { if (lane == dlane) dl.lo |= 1u; }
+    else { if (lane == 0) res[ci] = ce | 1ull; scan_lo = (uint32_t)ci + 1; }
+    const uint32_t cslot = (uint32_t)ce >> 1;
+    uint32_t free_slots = ef - (len + dl.n);  // the set never exceeds ef
+    w.n_exp++;
+    wave_sync();
+    const uint32_t* row = g.adj0 + (size_t)cslot * width;
+    const float* nrow = ADJN ? g.adj0_n + (size_t)cslot * width : nullptr;
+    const bool use_pre = pre_slot == cslot;
+    const uint32_t pre_now = pre_nb; const float pre_nn_now = pre_nn;
+    pre_slot = NBR_NONE;
+    unsigned long long best_new = ~0ull;
+#define COLTT_PREFETCH_NEXT2()                                                                       \
+    if constexpr (PREF) {                                                                            \
+      const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
+      if (nk_ != ~0ull) {                                                                            \
+        pre_slot = (uint32_t)nk_ >> 1;                                                               \
+        pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;             \
+        if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \
+      }                                                                                              \
+    }
+    for (uint32_t c0 = 0; c0 < width; c0 += 32) {
+      const uint32_t idx = c0 + p;
+      const bool pre_hit = use_pre && c0 == 0;
+      const uint32_t nb = idx < width ? (pre_hit ? pre_now : row[idx]) : NBR_NONE;
+      float nrm = 0.f;
+      if constexpr (ADJN) nrm = idx < width ? (pre_hit ? pre_nn_now : nrow[idx]) : 0.f;
+      const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+#ifdef COLTT_PHASE_TIMING
+      if (__ballot(valid) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the adjacency values to have arrived
+#endif
+      COLTT_PT(w, 1)  // adjacency row
+      int fresh_i = 0;
+      if (valid && half == 0) {
+        // Test-and-set.  No two lanes hold the same slot (a row lists a neighbour once), so load + store on the byte map is
+        // race-free; agent-scope atomics are served by L2, never by a stale L1 line.
+        bool maybe = true;
+        if constexpr (BLOOM) {
+          const uint32_t h = nb * 0x9E3779B1u;
+          const uint32_t bits = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+          const uint32_t old = atomicOr(&w.bloom[h >> w.bloom_shift], bits);
+          maybe = (old & bits) == bits;
+        }
+        if (maybe) {
+          const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
+        } else fresh_i = 1;
+        if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);  // even lane's verdict to its pair: quad_perm [0,0,2,2]
+      const bool fresh = fresh_i != 0;
+      const unsigned long long E = __ballot(fresh && half == 0);
+      const uint32_t nfresh = __popcll(E);
+      COLTT_PT(w, 2)  // visited test-and-set
+      const bool last_chunk = c0 + 32 >= width;
+      if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT2() } continue; }
+      w.n_dist += nfresh;
+      float d = 0.f;
+      if (fresh) {
+        if constexpr (ADJN) d = eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
+        else d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+      }
+      const uint32_t rank = __popcll(E & lt_mask);
+      const bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
+#ifdef COLTT_PHASE_TIMING
+      if (__ballot(adm) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the distances
+#endif
+      COLTT_PT(w, 3)  // row reads + distances
+      free_slots = free_slots > nfresh ? free_slots - nfresh : 0;
+      const unsigned long long A = __ballot(adm);
+      const uint32_t m = __popcll(A);
+      const uint32_t khi = __float_as_uint(d), klo = nb << 1;
+      const unsigned long long mykey = adm ? (((unsigned long long)khi << 32) | klo) : ~0ull;
+      if constexpr (DELTA) {
+        if (m) {
+          if constexpr (PREF) { unsigned long long mn; (void)wave_argmin_key(adm, khi, klo, mn); best_new = mn < best_new ? mn : best_new; }
+        }
+        if (last_chunk) { COLTT_PREFETCH_NEXT2() }
+        if (m == 0) continue;
+        if (dl.n + m > 64u) delta_flush(res, len, dl, scan_lo, lane);
+        {
+          unsigned long long am = A; uint32_t t = dl.n;
+          while (am) {
+            const int j = __builtin_ctzll(am); am &= am - 1;
+            const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j), vl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+            if ((uint32_t)lane == t) { dl.hi = vh; dl.lo = vl; }
+            t++;
+          }
+          dl.n += m;
+        }
+        dl.refresh_max(lane);
+        const uint32_t total = len + dl.n;
+        if (total > ef) evict_largest(res, len, dl, total - ef, lane);
+        COLTT_PT(w, 4)  // admission + eviction (+ the occasional flush)
+      } else {
+        uint32_t myrank = 0;  // rank of my key among the admitted ones (readlane broadcasts: no LDS round trips)
+        {
+          unsigned long long am = A;
+          while (am) {
+            const int j = __builtin_ctzll(am); am &= am - 1;
+            const unsigned long long kj = readlane_u64(mykey, j);
+            myrank += (kj < mykey) ? 1u : 0u;
+          }
+        }
+        if (m) {  // the smallest admitted key is the one of rank 0
+          const unsigned long long z = __ballot(adm && myrank == 0);
+          const unsigned long long mn = readlane_u64(mykey, __builtin_ctzll(z));
+          best_new = mn < best_new ? mn : best_new;
+        }
+        if (last_chunk) { COLTT_PREFETCH_NEXT2() }
+        if (m == 0) continue;
+        // in-place merge from the tail down to the chunk of the smallest new key (hnsw_dev.hpp:search_level)
+        uint32_t mypos = 0xffffffffu;
+        if (adm) {
+          uint32_t lo = 0, hi = len;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (res[mid] < mykey) lo = mid + 1; else hi = mid; }
+          mypos = lo;
+        }
+        const uint32_t minpos = (uint32_t)__builtin_amdgcn_readlane((int)mypos, __builtin_ctzll(__ballot(adm && myrank == 0)));
+        scan_lo = minpos < scan_lo ? minpos : scan_lo;
+        wave_sync();
+        if (len) {
+          for (int base = (int)((len - 1) & ~63u); base >= (int)(minpos & ~63u); base -= 64) {
+            const uint32_t i = (uint32_t)base + lane;
+            const unsigned long long e = i < len ? res[i] : ~0ull;
+            uint32_t shift = 0;
+            unsigned long long am = A;
+            while (am) {
+              const int j = __builtin_ctzll(am); am &= am - 1;
+              const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)mypos, j);
+              shift += (pj <= i) ? 1u : 0u;
+            }
+            wave_sync();
+            const uint32_t np = i + shift;
+            if (i < len && shift && np < ef) res[np] = e;
+          }
+        }
+        wave_sync();
+        { const uint32_t np = mypos + myrank; if (adm && np < ef) res[np] = mykey; }
+        len = len + m < ef ? len + m : ef;
+        wave_sync();
+        COLTT_PT(w, 4)  // merge
+      }
+    }
+  }
+#undef COLTT_PREFETCH_NEXT2
+  if constexpr (DELTA) delta_flush(res, len, dl, scan_lo, lane);
+  out_len = len;
+}
+
+}  // namespace dev
+}  // namespace coltt

@@ -175,7 +175,7 @@ int coltt_distance_pairs(int metric, int order, const float* a, const float* b, 
   if (!a || !b || !out || dim == 0) return fail(COLTT_E_INVALID, "distance_pairs: NULL/empty input");
   if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "distance_pairs: bad metric");
   if (order < 0 || order > 2) return fail(COLTT_E_INVALID, "distance_pairs: order must be 0 (avx), 1 (sse) or 2 (native)");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; float *da, *db, *dout;
   size_t bytes = n * dim * 4;
   // rows are padded by 16 floats so the 16-byte vector loads of the last row stay in bounds
@@ -198,7 +198,7 @@ int coltt_distance_pairs(int metric, int order, const float* a, const float* b, 
 int coltt_normalize(const float* in, size_t n, uint32_t dim, float* out) {
   if (n == 0) return COLTT_OK;
   if (!in || !out || dim == 0) return fail(COLTT_E_INVALID, "normalize: NULL/empty input");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; float *di, *dout;
   COLTT_TRY(st.alloc((void**)&di, n * dim * 4)); COLTT_TRY(st.alloc((void**)&dout, n * dim * 4));
   COLTT_HIP(hipMemcpy(di, in, n * dim * 4, hipMemcpyHostToDevice));
@@ -212,7 +212,7 @@ int coltt_quant_lower(int quant, const float* in, size_t n, void* out_codes) {
   if (n == 0) return COLTT_OK;
   if (!in || !out_codes) return fail(COLTT_E_INVALID, "quant_lower: NULL input");
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; float* di; uint8_t* dout;
   size_t ob = n * quant_bytes(quant);
   COLTT_TRY(st.alloc((void**)&di, n * 4)); COLTT_TRY(st.alloc((void**)&dout, ob));
@@ -227,7 +227,7 @@ int coltt_quant_raise(int quant, const void* codes, size_t n, float* out) {
   if (n == 0) return COLTT_OK;
   if (!codes || !out) return fail(COLTT_E_INVALID, "quant_raise: NULL input");
   if (quant < COLTT_Q_NONE || quant > COLTT_Q_BF16) return fail(COLTT_E_UNSUPPORTED, "not support quantization type");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; uint8_t* di; float* dout;
   size_t ib = n * quant_bytes(quant);
   COLTT_TRY(st.alloc((void**)&di, ib)); COLTT_TRY(st.alloc((void**)&dout, n * 4));
@@ -241,7 +241,7 @@ int coltt_quant_raise(int quant, const void* codes, size_t n, float* out) {
 int coltt_shard_vertex(const uint64_t* ids, size_t n, uint64_t shard_count, uint64_t* out) {
   if (n == 0) return COLTT_OK;
   if (!ids || !out || shard_count == 0) return fail(COLTT_E_INVALID, "shard_vertex: NULL input or zero shard count");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; uint64_t *di, *dout;
   COLTT_TRY(st.alloc((void**)&di, n * 8)); COLTT_TRY(st.alloc((void**)&dout, n * 8));
   COLTT_HIP(hipMemcpy(di, ids, n * 8, hipMemcpyHostToDevice));
@@ -255,7 +255,7 @@ int coltt_pq_float_scan(int kind, const float* query, const float* rows, size_t 
   if (n == 0) return COLTT_OK;
   if (!query || !rows || !out || dim == 0) return fail(COLTT_E_INVALID, "pq_float_scan: NULL/empty input");
   if (kind < 0 || kind > 3) return fail(COLTT_E_INVALID, "pq_float_scan: kind must be 0..3");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; float *dq, *dr, *dout;
   COLTT_TRY(st.alloc((void**)&dq, dim * 4)); COLTT_TRY(st.alloc((void**)&dr, n * dim * 4)); COLTT_TRY(st.alloc((void**)&dout, n * 4));
   COLTT_HIP(hipMemcpy(dq, query, dim * 4, hipMemcpyHostToDevice));
@@ -274,7 +274,7 @@ int coltt_pq_bit_scan(int kind, const uint64_t* query, const uint64_t* rows, siz
   if (n == 0) return COLTT_OK;
   if (!query || !rows || !out || words == 0) return fail(COLTT_E_INVALID, "pq_bit_scan: NULL/empty input");
   if (kind != 0 && kind != 1) return fail(COLTT_E_INVALID, "pq_bit_scan: kind must be 0 (hamming) or 1 (jaccard)");
-  COLTT_TRY(ensure_device());
+  COLTT_DEVICE(-1);
   Stage st; uint64_t *dq, *dr; float* dout;
   COLTT_TRY(st.alloc((void**)&dq, words * 8)); COLTT_TRY(st.alloc((void**)&dr, n * words * 8)); COLTT_TRY(st.alloc((void**)&dout, n * 4));
   COLTT_HIP(hipMemcpy(dq, query, words * 8, hipMemcpyHostToDevice));

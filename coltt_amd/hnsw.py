@@ -140,9 +140,9 @@ class Hnsw:
     # -- Hnsw.Commit / Hnsw.Load (core/vectorindex/hnsw_commit.go:69-278)
     def Commit(self, header=True):
         n = C.c_uint64(0)
-        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, None, C.c_uint64(0), C.byref(n)))
+        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, C.c_uint64(0), None, C.c_uint64(0), C.byref(n)))
         buf = np.empty(n.value, np.uint8)
-        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, L.vp(buf), C.c_uint64(n.value), C.byref(n)))
+        L.check(L.lib().coltt_hnsw_commit(self.h, int(header), None, None, C.c_uint64(0), L.vp(buf), C.c_uint64(n.value), C.byref(n)))
         return buf.tobytes()
 
     def Load(self, data, header=True):

@@ -2,6 +2,7 @@ package colttgpu
 
 import (
 	"fmt"
+	"sync"
 	"time"
 )
 
@@ -29,6 +30,7 @@ type Batcher struct {
 	MaxWait  time.Duration
 	in       chan *pending
 	quit     chan struct{}
+	closeOne sync.Once
 }
 
 type pending struct {
@@ -51,7 +53,11 @@ func NewBatcher(dim int, backend Backend, maxBatch int, maxWait time.Duration) *
 	return b
 }
 
-func (b *Batcher) Close() { close(b.quit) }
+// Close stops the collector.  Queries still queued (or racing with Close) are answered with "batcher closed": no caller is left
+// blocked on its done channel.  Safe to call more than once.
+func (b *Batcher) Close() { b.closeOne.Do(func() { close(b.quit) }) }
+
+var errClosed = fmt.Errorf("batcher closed")
 
 // HnswBackend / FlatBackend: the two searches that need batching (BASELINE.json configs 2-5)
 func HnswBackend(h Handle, dim uint32, ef uint32) Backend {
@@ -77,10 +83,20 @@ func (b *Batcher) Search(q []float32, k uint) ([]BatchItem, error) {
 	select {
 	case b.in <- p:
 	case <-b.quit:
-		return nil, fmt.Errorf("batcher closed")
+		return nil, errClosed
 	}
-	r := <-p.done
-	return r.items, r.err
+	select {
+	case r := <-p.done:
+		return r.items, r.err
+	case <-b.quit:
+		// the collector may still answer (it drains on quit) — prefer its answer, never block
+		select {
+		case r := <-p.done:
+			return r.items, r.err
+		default:
+			return nil, errClosed
+		}
+	}
 }
 
 func (b *Batcher) loop() {
@@ -89,10 +105,12 @@ func (b *Batcher) loop() {
 		select {
 		case first = <-b.in:
 		case <-b.quit:
+			b.drain(nil)
 			return
 		}
 		batch := []*pending{first}
 		timer := time.NewTimer(b.MaxWait)
+		closed := false
 	collect:
 		for len(batch) < b.MaxBatch {
 			select {
@@ -100,10 +118,32 @@ func (b *Batcher) loop() {
 				batch = append(batch, p)
 			case <-timer.C:
 				break collect
+			case <-b.quit:
+				closed = true
+				break collect
 			}
 		}
 		timer.Stop()
+		if closed {
+			b.drain(batch)
+			return
+		}
 		b.flush(batch)
+	}
+}
+
+// drain answers the batch in hand and everything still queued with errClosed (done has capacity 1: never blocks)
+func (b *Batcher) drain(batch []*pending) {
+	for _, p := range batch {
+		p.done <- batchResult{nil, errClosed}
+	}
+	for {
+		select {
+		case p := <-b.in:
+			p.done <- batchResult{nil, errClosed}
+		default:
+			return
+		}
 	}
 }
 

@@ -156,27 +156,43 @@ func HnswGet(h Handle, dim uint32, id uint64) ([]float32, int, error) {
 	return v, int(lv), err
 }
 
+// HnswEntryLevel: level of the entrypoint (-1 = empty index); host-side only, no device traffic (what BytesSize needs).
+func HnswEntryLevel(h Handle) (int, error) {
+	var lv C.int32_t
+	err := call(func() C.int { return C.coltt_hnsw_entry_level(h, &lv) })
+	return int(lv), err
+}
+
 // HnswSlots: ids of every slot in slot order and the deleted flags (what Commit walks).
-func HnswSlots(h Handle) (ids []uint64, deleted []byte, entryLevel int, err error) {
-	var ns, nr, ne C.uint64_t
-	var ent C.int32_t
-	if err = call(func() C.int { return C.coltt_hnsw_export(h, &ns, &nr, &ne, nil, nil, nil, nil, nil, nil, &ent) }); err != nil {
-		return
-	}
-	ids = make([]uint64, int(ns))
-	deleted = make([]byte, int(ns))
-	lv := make([]int32, int(ns))
-	if ns > 0 {
+// The size query and the fill are two cgo calls; an Insert may land between them.  The library treats the counts passed to
+// the second call as the CAPACITIES of the slices and refuses (COLTT_E_INVALID, needed sizes returned) instead of writing past
+// them, so the loop simply re-sizes and retries.
+func HnswSlots(h Handle) (ids []uint64, deleted []byte, err error) {
+	for attempt := 0; attempt < 8; attempt++ {
+		var ns, nr, ne C.uint64_t
+		var ent C.int32_t
+		if err = call(func() C.int { return C.coltt_hnsw_export(h, &ns, &nr, &ne, nil, nil, nil, nil, nil, nil, &ent) }); err != nil {
+			return
+		}
+		if ns == 0 {
+			return nil, nil, nil
+		}
+		capSlots := ns
+		ids = make([]uint64, int(capSlots))
+		deleted = make([]byte, int(capSlots))
+		rc := C.int(0)
 		err = call(func() C.int {
-			return C.coltt_hnsw_export(h, &ns, &nr, &ne, uptr(ids), (*C.int32_t)(unsafe.Pointer(&lv[0])), bptr(deleted), nil, nil, nil, &ent)
+			rc = C.coltt_hnsw_export(h, &ns, &nr, &ne, uptr(ids), nil, bptr(deleted), nil, nil, nil, &ent)
+			return rc
 		})
+		if err == nil {
+			return ids[:int(ns)], deleted[:int(ns)], nil // ns <= capSlots: Remove never shrinks the slot count
+		}
+		if rc != C.COLTT_E_INVALID || ns <= capSlots {
+			return nil, nil, err
+		}
 	}
-	if err == nil && ent >= 0 {
-		entryLevel = int(lv[int(ent)])
-	} else {
-		entryLevel = -1
-	}
-	return
+	return nil, nil, errors.New("hnsw export: the index kept growing during 8 attempts")
 }
 
 // HnswCommit: Hnsw.Commit stream (hnsw_commit.go:69-162); metaBlobs[slot] = that vertex's Metadata in stream encoding
@@ -214,12 +230,23 @@ func HnswCommit(h Handle, header bool, metaBlobs [][]byte) ([]byte, error) {
 		hd = 1
 	}
 	var need C.uint64_t
-	if err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, nil, 0, &need) }); err != nil {
+	if err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, C.uint64_t(n), nil, 0, &need) }); err != nil {
 		return nil, err
 	}
-	out := make([]byte, int(need))
-	err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, bptr(out), need, &need) })
-	return out[:int(need)], err
+	// slots past n (vertices inserted since the caller built metaBlobs) are written with empty metadata by the library; a
+	// stream that outgrew the buffer between the two calls comes back as "buffer too small" and is retried with the new size
+	for attempt := 0; attempt < 8; attempt++ {
+		capB := need
+		out := make([]byte, int(capB))
+		err := call(func() C.int { return C.coltt_hnsw_commit(h, hd, cptr, clen, C.uint64_t(n), bptr(out), capB, &need) })
+		if err == nil {
+			return out[:int(need)], nil
+		}
+		if need <= capB {
+			return nil, err
+		}
+	}
+	return nil, errors.New("hnsw commit: the index kept growing during 8 attempts")
 }
 
 // HnswLoad: Hnsw.Load (hnsw_commit.go:164-278) straight into HBM; returns each vertex's id and the position of its

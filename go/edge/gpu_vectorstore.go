@@ -117,10 +117,26 @@ func (s *gpuVecSpace) ChangedVertex(updateId string, commitId uint64, data ENode
 	}
 	sh := s.shard(commitId)
 	s.metaMu[sh].Lock() // metadata first: a concurrent search must never return the id without it
+	prev, had := s.meta[sh][commitId]
 	s.meta[sh][commitId] = data.Metadata
 	s.metaMu[sh].Unlock()
 	// Normalize (cosine) + Lower happen in the library, on the device
-	return colttgpu.FlatUpsert(s.h, s.Dim(), []uint64{commitId}, data.Vector)
+	if err := colttgpu.FlatUpsert(s.h, s.Dim(), []uint64{commitId}, data.Vector); err != nil {
+		// the row was not stored: take the metadata and the inverted-index entry back out (or restore the previous ones)
+		s.metaMu[sh].Lock()
+		if had {
+			s.meta[sh][commitId] = prev
+		} else {
+			delete(s.meta[sh], commitId)
+		}
+		s.metaMu[sh].Unlock()
+		_ = s.invertedIndex.Remove(commitId, data.Metadata)
+		if had {
+			_ = s.invertedIndex.Add(commitId, prev)
+		}
+		return err
+	}
+	return nil
 }
 
 // RemoveVertex — none_vectorstore.go:105-127

@@ -218,6 +218,7 @@ type Hnsw struct {
 	bytesSize uint64 // sum of vector + metadata bytes of live vertices (hnsw_vertex.go:123-127), Go side
 	meta      [metaShards]map[uint64]Metadata
 	metaMu    [metaShards]sync.RWMutex
+	commitMu  sync.RWMutex // Insert / Remove hold it shared, Commit exclusive: a snapshot never interleaves with a mutation
 	err       error // creation error, surfaced by the first call (NewHnsw has no error result in the reference)
 }
 
@@ -305,6 +306,8 @@ func (xx *Hnsw) Insert(id uint64, value edge.Vector, metadata Metadata, vertexLe
 	if xx.err != nil {
 		return xx.err
 	}
+	xx.commitMu.RLock()
+	defer xx.commitMu.RUnlock()
 	s := xx.shard(id)
 	// the metadata is in place BEFORE the id becomes searchable (a concurrent Search must never see the id without it);
 	// on failure it is taken out again unless the id already existed
@@ -350,6 +353,8 @@ func (xx *Hnsw) GetVertex(id uint64) (*hnswVertex, error) {
 
 // Remove(id) — hnsw.go:191-241
 func (xx *Hnsw) Remove(id uint64) error {
+	xx.commitMu.RLock()
+	defer xx.commitMu.RUnlock()
 	if err := colttgpu.HnswRemove(xx.h, id); err != nil {
 		return mapErr(err)
 	}
@@ -403,7 +408,7 @@ func (xx *Hnsw) RandomLevel() int {
 // reference reports; the HBM footprint is Len() * (row stride + 2 * 4 * mMax0) + upper rows)
 func (xx *Hnsw) BytesSize() uint64 {
 	maxLevel := 10
-	if _, _, lv, err := colttgpu.HnswSlots(xx.h); err == nil && lv >= 0 {
+	if lv, err := colttgpu.HnswEntryLevel(xx.h); err == nil && lv >= 0 { // host-side field of the index: no adjacency is copied
 		maxLevel = lv
 	}
 	const edgeB, mutB = 12.0, 24.0
@@ -416,7 +421,11 @@ func (xx *Hnsw) BytesSize() uint64 {
 
 // Commit(w, header) — hnsw_commit.go:69-162: the reference's big-endian stream, produced by the library from the HBM layout.
 func (xx *Hnsw) Commit(w io.Writer, header bool) error {
-	ids, deleted, _, err := colttgpu.HnswSlots(xx.h)
+	// Snapshot against mutations: the reference's Commit walks the live maps without a lock; here the slot list, the metadata
+	// blobs and the stream are produced under commitMu so an Insert / Remove cannot interleave (they take it shared).
+	xx.commitMu.Lock()
+	defer xx.commitMu.Unlock()
+	ids, deleted, err := colttgpu.HnswSlots(xx.h)
 	if err != nil {
 		return err
 	}

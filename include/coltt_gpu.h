@@ -184,7 +184,10 @@ int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
 int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
                              uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats);
 /* graph export in the bulk_load layout (what Hnsw.Commit serialises, hnsw_commit.go:69-162).
- * Call with NULL arrays to get sizes. */
+ * Call with NULL arrays to get sizes.  With any array non-NULL, *n_slots / *n_rows / *n_edges are IN-OUT: on entry the
+ * capacities of the caller's arrays (slots: ids, levels, deleted; rows + 1: row_offsets; edges: nbr, nbr_dist) — normally the
+ * sizes the first call returned — and if an Insert has grown the index past them in between, nothing is written, the needed
+ * sizes are returned and the call fails with COLTT_E_INVALID (retry with larger arrays). */
 int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uint64_t* n_edges, uint64_t* ids,
                       int32_t* levels, uint8_t* deleted, int64_t* row_offsets, int32_t* nbr, float* nbr_dist,
                       int32_t* entry_slot);
@@ -192,10 +195,13 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
  * (hnsw_config.go:179-203), u32 dim, u8 distIdx], u64 entrypoint id, 16 FNV shards of {u64 id, i32 level, dim x f32,
  * metadata}, then per vertex {u64 id, per level (top down) u32 n, n x (u64 neighbour id, f32 distance)}; removed
  * vertices and edges to them are skipped.  meta_blobs[slot]/meta_lens[slot] = the vertex's Metadata already in stream
- * encoding (metadata.go:31-74: u16 pairs, {u8 keylen, key, u16 vallen, msgpack}); NULL => empty maps.
+ * encoding (metadata.go:31-74: u16 pairs, {u8 keylen, key, u16 vallen, msgpack}); NULL => empty maps.  n_meta = the length
+ * of both arrays: slots >= n_meta (vertices inserted after the caller sized them) get empty metadata, never an out-of-bounds read.
  * out == NULL => only *out_len is computed. */
-int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens,
+int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens, uint64_t n_meta,
                       uint8_t* out, uint64_t cap, uint64_t* out_len);
+/* level of the entrypoint (what Hnsw.BytesSize needs, hnsw.go:476-490), -1 for an empty index: no device traffic */
+int coltt_hnsw_entry_level(coltt_handle_t h, int32_t* out_level);
 /* Hnsw.Load(r, header) (hnsw_commit.go:164-278) straight into the HBM layout: vectors are byte-swapped on the device
  * and NOT re-normalised (as in the reference).  Slots follow stream order.  out_ids / out_meta_off / out_meta_len
  * (capacity cap_n, may be NULL) receive each vertex's id and the position of its metadata blob inside buf, so the

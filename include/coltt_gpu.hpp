@@ -173,9 +173,9 @@ class Hnsw {
   // Commit(w, header) / Load(r, header) (hnsw_commit.go:69-278): the reference's big-endian stream (metadata: empty maps)
   std::vector<uint8_t> Commit(bool header = true) const {
     uint64_t n = 0;
-    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, nullptr, 0, &n));
+    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, 0, nullptr, 0, &n));
     std::vector<uint8_t> out(n);
-    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, out.data(), out.size(), &n));
+    check(coltt_hnsw_commit(h_, header, nullptr, nullptr, 0, out.data(), out.size(), &n));
     return out;
   }
   uint64_t Load(const std::vector<uint8_t>& data, bool header = true) {
