@@ -94,7 +94,13 @@ int coltt_device_count(void) {
 }
 
 const char* coltt_last_error(void) { return g_last_error.c_str(); }
-const char* coltt_version(void) { return "coltt_gpu 0.1 (gfx950)"; }
+const char* coltt_version(void) {
+#ifdef COLTT_EXPERIMENTS
+  return "coltt_gpu 0.3 (gfx950) +experiments";   // superseded kernel generations compiled in (tools/experiments/)
+#else
+  return "coltt_gpu 0.3 (gfx950)";
+#endif
+}
 
 }  // extern "C"
 

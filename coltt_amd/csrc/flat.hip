@@ -16,9 +16,12 @@
 #include "common.hpp"
 #include "exact.hpp"
 #include "prep.hpp"
-#include "flat_mfma.hpp"
-#include "flat_mfma2.hpp"
-#include "flat_mfma4.hpp"
+#include "flat_mfma3.hpp"
+#ifdef COLTT_EXPERIMENTS   // superseded kernel generations, A/B only (tools/flat_ab.py, COLTT_MFMA_GEN)
+#include "../../tools/experiments/flat_mfma_gen1.hpp"
+#include "../../tools/experiments/flat_mfma_gen2.hpp"
+#include "../../tools/experiments/flat_mfma_gen4.hpp"
+#endif
 #include "select.hpp"
 
 using namespace coltt;
@@ -183,7 +186,9 @@ struct Flat : Object {
   std::atomic<float> last_ms{0.f};   // kernel time of the most recently finished search call
   CtxPool<FCtx> pool;
   DevBuf w_raw, w_slots;             // ingest staging
-  DevBuf d_maxn; float max_norm = 0.f;  // running upper bound of ||row||^2 (bits, atomicMax on the device): scales the Euclidean matrix-core margin
+  DevBuf d_maxn; uint32_t norm_bits[2] = {0u, 0u};  // running bounds of ||row||^2 over everything ever stored: [0] max (bits), [1] max of the complemented bits = min
+  float max_norm() const { return __builtin_bit_cast(float, norm_bits[0]); }   // scales the Euclidean matrix-core margin
+  float min_norm() const { return __builtin_bit_cast(float, ~norm_bits[1]); }   // NaN bits while the store is empty
   std::atomic<uint64_t> mfma_groups{0}, mfma_fallbacks{0};  // groups served by the MFMA path / sent back to the exact path
   ~Flat() override {
     (void)hipSetDevice(device);
@@ -228,7 +233,7 @@ int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_
                                f->rows.as<uint8_t>(), f->stride);
   row_norms_kernel<QUANT><<<ceil_div(n * 2, 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, d_slots,
                                                                        slot_base, n, (int)f->dim, f->norms.as<float>(), f->d_maxn.as<uint32_t>());
-  COLTT_HIP(hipMemcpyAsync(&f->max_norm, f->d_maxn.p, 4, hipMemcpyDeviceToHost, f->stream));  // complete at the caller's stream sync
+  COLTT_HIP(hipMemcpyAsync(f->norm_bits, f->d_maxn.p, 8, hipMemcpyDeviceToHost, f->stream));  // complete at the caller's stream sync
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -321,16 +326,21 @@ int search_group_exact(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neare
   return COLTT_OK;
 }
 
-// COLTT_MFMA_GEN=1 selects the first-generation kernel (register-staged 128-row tiles) for A/B measurements; default is the
-// LDS-DMA ring (flat_mfma2.hpp).
+// The FLAT matrix-core kernel is flat_mfma3.hpp (split LDS-DMA rings).  A -DCOLTT_EXPERIMENTS build also carries generations 1, 2
+// and 4 (tools/experiments/), selectable with COLTT_MFMA_GEN for A/B measurements; the default library has exactly one.
 static int mfma_generation() {
+#ifdef COLTT_EXPERIMENTS
   static const int v = [] { const char* e = getenv("COLTT_MFMA_GEN"); return e && *e ? atoi(e) : 3; }();
   return v;
+#else
+  return 3;
+#endif
 }
 
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                        unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim) {
+#ifdef COLTT_EXPERIMENTS
   if (mfma_generation() >= 4 && !(seed && BN == 256)) {   // (the batch-256 seed instance would spill: it stays on generation 3)
     auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma4_kernel<BN, AF32, true, M_COS> : flat_mfma4_kernel<BN, AF32, false, M_COS>)
                                           : (seed ? flat_mfma4_kernel<BN, AF32, true, M_L2> : flat_mfma4_kernel<BN, AF32, false, M_L2>);
@@ -343,7 +353,31 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
   }
-  if (mfma_generation() >= 3) {
+  if (mfma_generation() == 2) {
+    // seed = the first, unfiltered segment (every score passes, e - b <= cap): candidates are written in place, no atomics
+    auto kern = seed ? flat_mfma2_kernel<BN, AF32, true> : flat_mfma2_kernel<BN, AF32, false>;
+    const size_t lds = M2Geom<BN, AF32>::LDS;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+                                          nearest, cand, cnt, cap);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
+  if (mfma_generation() == 1) {
+    auto kern = flat_mfma_cos_kernel<BN, AF32>;
+    const size_t lds = mfma_lds_bytes<BN>();
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
+    kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+                                        nearest, cand, cnt, cap);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
+#endif
+  {
 #ifdef COLTT_M3_BM
     constexpr int BM = (!AF32 && BN == 256) ? COLTT_M3_BM : M2_BM;
 #else
@@ -360,27 +394,6 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
   }
-  if (mfma_generation() != 1) {
-    // seed = the first, unfiltered segment (every score passes, e - b <= cap): candidates are written in place, no atomics
-    auto kern = seed ? flat_mfma2_kernel<BN, AF32, true> : flat_mfma2_kernel<BN, AF32, false>;
-    const size_t lds = M2Geom<BN, AF32>::LDS;
-    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
-                                          nearest, cand, cnt, cap);
-    COLTT_HIP(hipGetLastError());
-    return COLTT_OK;
-  }
-  auto kern = flat_mfma_cos_kernel<BN, AF32>;
-  const size_t lds = mfma_lds_bytes<BN>();
-  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
-  uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
-  kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
-                                      nearest, cand, cnt, cap);
-  COLTT_HIP(hipGetLastError());
-  return COLTT_OK;
 }
 
 template <int BN>
@@ -420,7 +433,7 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
     if (f->metric == COLTT_COSINE)
       flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     else  // Euclidean: |s~^2 - s^2| <= eps * (||q||^2 + ||r||^2), eps = dot error (+ f16 rounding of f32 rows) + f32 rounding of the norms / the exact sum
-      flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, 2.0f * l2_eps(f), ovf, qn, f->max_norm);
+      flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, 2.0f * l2_eps(f), ovf, qn, f->max_norm());
     std::swap(cur, oth);
     return COLTT_OK;
   };
@@ -455,14 +468,20 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // matrix-core candidates: cosine with every kernel generation; Euclidean (s~^2 = ||q||^2 + ||r||^2 - 2 dot, exact re-score) with
   // the third-generation kernel, as long as every stored norm is finite (max_norm bounds the margin)
   // (f32 rows are rounded to binary16 for candidate generation: ||row||^2 <= 4e9 keeps every element inside its range)
-  const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && f->max_norm == f->max_norm &&
-                     f->max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
+  const float max_norm = f->max_norm(), min_norm = f->min_norm();
+  const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && max_norm == max_norm &&
+                     max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
+  // Cosine: the candidate margin (flat_mfma.hpp: MF_MARGIN / MF_MARGIN_F32) is proved for rows of norm ~1 — f32 rows are rounded to
+  // binary16 on their way into the fragments, which is a RELATIVE perturbation only while the elements stay in binary16's normal
+  // range.  Upserts normalise (none_vectorstore.go:63-65), but a loaded stream is stored as it is (vectorstore load paths do not
+  // re-normalise), so a store that ever held a row with ||row||^2 outside [1/4, 4] answers through the exact scan.
+  const bool cos_ok = f->metric == COLTT_COSINE && min_norm >= 0.25f && max_norm <= 4.0f;
   // K need not be a multiple of the 32-column step with the DMA kernels: the query tile is zero-padded and the rows' overhang
   // (padding, head of the next row — all finite as long as no stored norm ever was non-finite; Flat::reserve zeroes the rest)
   // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
-  const bool finite_rows = f->max_norm == f->max_norm && f->max_norm < 3.0e38f;
+  const bool finite_rows = max_norm == max_norm && max_norm < 3.0e38f;
   const bool k_ok = f->dim % MF_BK == 0 || (mfma_generation() >= 2 && finite_rows);
-  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (f->metric == COLTT_COSINE || l2_ok) &&
+  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (cos_ok || l2_ok) &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 128 && f->dim <= 4096 && total > 0;
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
@@ -836,7 +855,7 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
       uint8_t* R = f->rows.as<uint8_t>();
 #define COLTT_BE(Q) do { be_codes_kernel<Q><<<grid, 256, 0, f->stream>>>(d_chunk.as<uint8_t>(), d_offs.as<uint64_t>(), m, (int)f->dim, R, f->stride, b); \
         row_norms_kernel<Q><<<ceil_div(m * 2, 256), 256, 0, f->stream>>>(R, f->stride, nullptr, b, m, (int)f->dim, f->norms.as<float>(), f->d_maxn.as<uint32_t>()); \
-        (void)hipMemcpyAsync(&f->max_norm, f->d_maxn.p, 4, hipMemcpyDeviceToHost, f->stream); } while (0)
+        (void)hipMemcpyAsync(f->norm_bits, f->d_maxn.p, 8, hipMemcpyDeviceToHost, f->stream); } while (0)
       COLTT_DISPATCH_QUANT(f->quant, COLTT_BE)
 #undef COLTT_BE
       COLTT_HIP(hipGetLastError());

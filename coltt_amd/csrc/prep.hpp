@@ -90,7 +90,9 @@ __global__ void row_norms_kernel(const uint8_t* __restrict__ rows, size_t stride
     norms[slot] = s;
     // running upper bound of ||row||^2 over everything ever stored (bit pattern order == value order for s >= 0; NaN sorts
     // above +inf, so a store that ever held a non-finite row keeps its matrix-core Euclidean path switched off)
-    if (max_bits) atomicMax(max_bits, __float_as_uint(s));
+    // max_bits[1] = max of the COMPLEMENTED bits = the running lower bound (zero-initialised like the upper one): the cosine
+    // matrix-core path needs every stored norm near 1 (flat.hip: search_prepared)
+    if (max_bits) { atomicMax(max_bits, __float_as_uint(s)); atomicMax(max_bits + 1, ~__float_as_uint(s)); }
   }
 }
 

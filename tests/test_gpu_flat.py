@@ -203,6 +203,8 @@ def test_flat_mfma_many_tiles_per_workgroup_smallest_dim(gpu, metric, quant, gen
     epilogue).  Ragged batch, batch 256 and a last tile of 64 rows; both kernel generations; == exact mode bit for bit.
     (dim 96 / 64 / 32 are served by the exact scan: `Stats()` shows no matrix-core group.)"""
     import subprocess, sys, os, json
+    if gen != "3" and b"+experiments" not in gpu.lib().coltt_version():
+        pytest.skip("generation 4 lives in tools/experiments/: only a -DCOLTT_EXPERIMENTS build carries it")
     # the generation is read once per process: run the comparison in a child so both generations are really exercised
     code = f"""
 import numpy as np, json, sys

@@ -110,7 +110,7 @@ def test_neighbour_norm_rows_follow_insert_remove_and_load(gpu, walk):
     blob = g32.Commit()
     g2 = gpu.Hnsw(d, O.COSINE)
     assert g2.Load(blob) == 1200
-    _check(g2, Q, O.Q_NONE, O.COSINE, (300,))
+    _check(g2, Q, O.Q_NONE, O.COSINE, (300,), id_of=g2.Export()["ids"])   # slots follow the stream's shard order
     # bulk load of an oracle-built graph
     oh = O.Hnsw(d, O.COSINE); oh.insert_many(ids[:900], X[:900], lv[:900])
     g3 = gpu.Hnsw(d, O.COSINE); g3.BulkLoad(oh.export(with_vectors=False), X[:900])

@@ -1,3 +1,4 @@
+// EXPERIMENT, not part of the default library (-DCOLTT_EXPERIMENTS; COLTT_MFMA_GEN=4 selects it): bit-identical to generation 3, 4.93 ms at C3 (gen 3: 4.8).
 // flat_mfma4.hpp — fourth generation of the batched FLAT candidate GEMM: flat_mfma3.hpp's split DMA rings with the fragment
 // reads SOFTWARE-PIPELINED one K step ahead of the matrix cores.
 //
@@ -21,7 +22,7 @@
 // Everything else (256 x BN tile, 4 x 2 waves, XOR-swizzled lane-linear DMA image, saddr-form DMA, seed segment in place, one
 // atomic per half block) is flat_mfma3.hpp's.  The raw-norm parity buffers require dim >= 128 (flat.hip checks).
 #pragma once
-#include "flat_mfma3.hpp"
+#include "../../coltt_amd/csrc/flat_mfma3.hpp"
 
 namespace coltt {
 namespace dev {

@@ -84,8 +84,11 @@ void both(const uint8_t* table, uint64_t nrows, uint32_t row_bytes, int w, uint3
   fflush(stdout);
 }
 
-int main(int argc, char** argv) {
-  const double gib = argc > 1 ? atof(argv[1]) : 15.0;
+// also callable from a process that already holds a HIP runtime (python -c "import torch, ctypes; ctypes.CDLL('./gather.so').gather_run(...)")
+extern "C" int gather_run(double gib, int quick);
+int main(int argc, char** argv) { return gather_run(argc > 1 ? atof(argv[1]) : 15.0, argc > 2 ? atoi(argv[2]) : 0); }
+
+extern "C" int gather_run(double gib, int quick) {
   const uint64_t bytes = (uint64_t)(gib * (1ull << 30));
   uint8_t* table; uint32_t* sink;
   CK(hipMalloc(&table, bytes)); CK(hipMalloc(&sink, 1 << 20));
@@ -96,6 +99,13 @@ int main(int argc, char** argv) {
     const uint64_t nrows = bytes / rb;
     const int ws[3] = {4, 8, 16};
     for (int w : ws) {
+      if (quick) {  // the two shapes that matter, one occupancy
+        if (w != 8) continue;
+        both<2, 24>(table, nrows, rb, w, sink, gib);
+        both<4, 12>(table, nrows, rb, w, sink, gib);
+        both<8, 12>(table, nrows, rb, w, sink, gib);
+        continue;
+      }
       both<2, 12>(table, nrows, rb, w, sink, gib);
       both<2, 24>(table, nrows, rb, w, sink, gib);
       both<2, 48>(table, nrows, rb, w, sink, gib);
@@ -108,5 +118,6 @@ int main(int argc, char** argv) {
       both<64, 3>(table, nrows, rb, w, sink, gib);
     }
   }
+  CK(hipFree(table)); CK(hipFree(sink));
   return 0;
 }
