@@ -195,6 +195,52 @@ def recall_curve(G, torch, fl, h, q, rq, k, efs):
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline legs
+def host_cpu_provenance(O, threads_used=None):
+    """What the host really gives this process: affinity mask, cgroup CPU quota, SMT / socket topology, NUMA nodes, and which CPUs
+    the pinned drivers use under each policy.  A sweep that peaks far below the CPU count is usually the cgroup quota (cpu.max):
+    more runnable threads than quota only buys throttling."""
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    aff = sorted(os.sched_getaffinity(0))
+    info = {"online_cpus": os.cpu_count(), "affinity_mask_size": len(aff), "affinity_first_last": [aff[0], aff[-1]] if aff else None,
+            "cgroup_cpu_max": rd("/sys/fs/cgroup/cpu.max"), "cgroup_cpuset_effective": rd("/sys/fs/cgroup/cpuset.cpus.effective"),
+            "cgroup_v1_cfs_quota_us": rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), "cgroup_v1_cfs_period_us": rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us"),
+            "numa_nodes_online": rd("/sys/devices/system/node/online"), "loadavg": rd("/proc/loadavg")}
+    q = info["cgroup_cpu_max"]
+    if q and q.split()[0] != "max":
+        try:
+            info["cgroup_quota_cpus"] = float(q.split()[0]) / float(q.split()[1])
+        except (ValueError, IndexError, ZeroDivisionError):
+            pass
+    sib = {}; pkg = {}
+    for c in aff:
+        t = rd(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list")
+        if t: sib[c] = t
+        k = rd(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id")
+        if k is not None: pkg[c] = k
+    info["physical_cores_in_mask"] = len(set(sib.values())) if sib else None
+    info["smt_threads_per_core"] = (len(aff) / len(set(sib.values()))) if sib else None
+    info["sockets_in_mask"] = len(set(pkg.values())) if pkg else None
+    info["thread_siblings_of_cpu0"] = sib.get(aff[0]) if aff else None
+    model = None
+    ci = rd("/proc/cpuinfo")
+    if ci:
+        for line in ci.splitlines():
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    info["cpu_model"] = model
+    if threads_used:
+        info["pin_policy"] = "spread: thread t of T on allowed[t * n / T] (oracle/coltt_oracle.cpp: pinned_cpu)"
+        info["pin_map_spread"] = O.pin_map(min(threads_used, 64), 2)
+        info["pin_map_dense"] = O.pin_map(min(threads_used, 64), 1)
+        info["threads_in_pin_map"] = threads_used
+    return info
+
+
 def thread_counts(threads):
     """1 (latency), 16 (the reference's highCpu width), then doubling up to every allowed CPU: the box decides which is best"""
     c = {1, min(16, threads), threads}
@@ -229,6 +275,8 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None
         q_host = q_dev.cpu().numpy()
         common = dict(upper_off=g["upper_off"], adjU=g["adjU"], dim=dim, metric=O.COSINE, entry=int(g["entry"]), entry_level=int(g["entry_level"]), k=k, ef=ef)
 
+        O.set_pin_policy(2)   # spread the pinned threads over sockets / CCDs (dense packing is timed once below, at the best count)
+
         def run(qs, th):
             return O.csr_search(rows.a, quant, adj0.a, queries=qs, threads=th, pin=True, **common)
         r1 = run(q_host[:8], 1); lat = r1[4] / 8                       # single-thread latency
@@ -241,6 +289,8 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None
         best_th = max(legs, key=lambda t: legs[t]["queries_per_s"])
         best = legs[best_th]
         sample = best["sample"]; res = best["res"]
+        O.set_pin_policy(1); dense = run(q_host[:sample], best_th); O.set_pin_policy(2)
+        dense_qps = sample / dense[4]
         stream = {str(t): O.membw(rows.a, t) for t in sorted({min(16, threads), best_th, threads})}
         bpq = hnsw_bytes_per_query(res[3]["n_dist"] / sample, res[3]["n_exp"] / sample, dim, quant, m)
         st = h.SearchDevice(q_dev.data_ptr(), sample, k, *out.ptrs(), ef=ef)   # parity of the sample: GPU == oracle
@@ -252,7 +302,8 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None
                 "sample": f"{sample} of the step's queries on the full {g['n']}x{dim} index ({QNAME[quant]}{'' if quant == 0 else ', both operands decoded per pair as the reference does'}), "
                           f"oracle contiguous variant, BEST of {sorted(legs)} native threads (pinned 1:1 to the allowed CPUs, 1 query per thread) = {best_th}; rows and level-0 adjacency in "
                           f"NUMA-interleaved memory ({O.lib().orc_numa_nodes()} node(s), mbind={'ok' if rows.flags & 1 else 'refused -> parallel first touch'}, THP advised={bool(rows.flags & 2)})",
-                "queries_per_s_by_threads": qps, "single_thread_latency_ms": lat * 1e3,
+                "queries_per_s_by_threads": qps, "queries_per_s_dense_pinning_at_best": dense_qps, "host": host_cpu_provenance(O, best_th),
+                "single_thread_latency_ms": lat * 1e3,
                 "parallel_efficiency": {str(t): v["queries_per_s"] / (t * legs[1]["queries_per_s"]) for t, v in legs.items()},
                 "dram_GBps_at_best": best["queries_per_s"] * bpq / 1e9, "dram_stream_read_GBps_by_threads": stream,
                 "gpu_equals_oracle_on_sample": same, "counters_equal": same_counters}
@@ -273,6 +324,7 @@ def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=Non
             fl.FetchRows(b, min(step, n_rows - b), out=rows.a[b:b + step])
         q = q_dev.cpu().numpy()
         bytes_per_query = n_rows * dim * QBYTES[quant]
+        O.set_pin_policy(2)   # spread pinning (see host_cpu_provenance)
         stream = {str(t): O.membw(rows.a, t) for t in sorted({min(16, threads), min(64, threads), threads})}
         r1 = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:1], k, nearest=True, shape=0, split=1, threads=1)
         lat = r1[3]
@@ -302,7 +354,8 @@ def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=Non
                "sample": f"{nqa} queries over {n_rows}x{dim} {QNAME[quant]} rows copied out of HBM (NUMA-interleaved), contiguous variant, reference arithmetic "
                          f"(Normalize, Lower, decode both operands per pair, AVX-order distance, bounded queue), native pinned threads, best thread count of the sweep",
                "by_threads": legs, "bytes_per_query": bytes_per_query, "dram_stream_read_GBps_by_threads": stream,
-               "parallel_efficiency_at_best": best_q / (best_th / lat), "reference_shaped_equals_contiguous": same_shape}
+               "parallel_efficiency_at_best": best_q / (best_th / lat), "reference_shaped_equals_contiguous": same_shape,
+               "host": host_cpu_provenance(O, best_th)}
         if quant != 0:
             rd = O.flat_scan(rows.a, quant, dim, O.COSINE, q[:nqa], k, nearest=True, shape=1, split=1, threads=best_th)
             res["decode_once_variant_queries_per_s"] = nqa / rd[3]

@@ -13,9 +13,14 @@
 // single-process group sit on ONE device (tests on a 1-GPU box) RCCL refuses duplicate devices and the records travel
 // through pinned host memory instead — that is a transport choice, the merge is on the host either way.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 #include "common.hpp"
@@ -74,6 +79,111 @@ __global__ void pack_topk_kernel(const uint64_t* __restrict__ ids, const float* 
   out[i] = Rec{v ? ids[i] : 0ull, v ? sc[i] : 0.f, v ? 1u : 0u};
 }
 
+// ---- all-gather between the processes of one box through POSIX shared memory -------------------------------------------------
+// Transport of COLTT_EXCHANGE_SHM groups (several processes, possibly on ONE device, where RCCL refuses to run).  One segment
+// per group: a header of process-shared atomics + world slots of `cap` bytes.  A gather of generation g:
+//   wait consumed >= g * world      (every rank has read generation g - 1: the slots may be overwritten)
+//   copy my slots, len[rank] = bytes, written += n_local (release)
+//   wait written >= (g + 1) * world (acquire), copy every slot out, consumed += n_local
+// The counters only grow, so the barrier needs no reset and a late process can never confuse two generations.
+struct ShmHdr {
+  std::atomic<uint32_t> magic;      // set last by the creating process
+  uint32_t world;
+  uint64_t cap;                     // bytes per rank slot
+  std::atomic<uint64_t> attached, written, consumed;
+  std::atomic<uint32_t> failed;     // a process that gives up (timeout, size mismatch) releases the others
+  uint64_t len[64];                 // bytes written by each rank in the current generation
+};
+constexpr uint32_t SHM_MAGIC = 0xC0177511u;
+constexpr size_t SHM_HDR_BYTES = 4096;
+static_assert(sizeof(ShmHdr) <= SHM_HDR_BYTES, "ShmHdr");
+
+struct ShmExchange : Object {
+  std::string name; int fd = -1; ShmHdr* hdr = nullptr; uint8_t* data = nullptr; size_t map_bytes = 0;
+  int world = 0, n_local = 0, rank_base = 0; uint64_t cap = 0, gen = 0; bool creator = false, unlinked = false;
+  double timeout_s = 120.0;
+  ~ShmExchange() override {
+    if (hdr) (void)munmap(hdr, map_bytes);
+    if (fd >= 0) (void)close(fd);
+    if (creator && !unlinked && !name.empty()) (void)shm_unlink(name.c_str());
+  }
+  template <class P> bool wait_for(P&& pred) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+      if (pred()) return true;
+      if (hdr && hdr->failed.load(std::memory_order_acquire)) return false;
+      if (spin < 2000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if ((spin & 255u) == 255u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+    }
+  }
+};
+
+int shm_open_exchange(const uint8_t* unique_id, int world, int n_local, int rank_base, uint64_t bytes_per_rank, std::shared_ptr<ShmExchange>& out) {
+  if (!unique_id) return fail(COLTT_E_INVALID, "shm exchange: unique_id is NULL");
+  if (world <= 0 || world > 64 || n_local <= 0 || rank_base < 0 || rank_base + n_local > world) return fail(COLTT_E_INVALID, "shm exchange: ranks [%d,%d) outside world %d (<= 64)", rank_base, rank_base + n_local, world);
+  if (bytes_per_rank == 0) return fail(COLTT_E_INVALID, "shm exchange: bytes_per_rank is 0");
+  auto x = std::make_shared<ShmExchange>();
+  if (const char* e = getenv("COLTT_SHM_TIMEOUT_S")) { if (*e) x->timeout_s = std::max(0.1, atof(e)); }
+  char nm[64]; int k = snprintf(nm, sizeof(nm), "/coltt_");
+  for (int i = 0; i < 16; i++) k += snprintf(nm + k, sizeof(nm) - (size_t)k, "%02x", unique_id[i]);
+  x->name = nm; x->world = world; x->n_local = n_local; x->rank_base = rank_base;
+  x->cap = (bytes_per_rank + 63) & ~63ull;
+  x->map_bytes = SHM_HDR_BYTES + (size_t)world * x->cap;
+  x->fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (x->fd >= 0) {
+    x->creator = true;
+    if (ftruncate(x->fd, (off_t)x->map_bytes) != 0) return fail(COLTT_E_NOMEM, "shm exchange: ftruncate(%zu): %s", x->map_bytes, strerror(errno));
+  } else if (errno == EEXIST) {
+    x->fd = shm_open(nm, O_RDWR, 0600);
+    if (x->fd < 0) return fail(COLTT_E_DEVICE, "shm exchange: shm_open(%s): %s", nm, strerror(errno));
+    // the creator may not have sized the segment yet
+    if (!x->wait_for([&] { struct stat st; return fstat(x->fd, &st) == 0 && (size_t)st.st_size >= x->map_bytes; }))
+      return fail(COLTT_E_DEVICE, "shm exchange: %s never reached %zu bytes (do all processes pass the same world / bytes_per_rank?)", nm, x->map_bytes);
+  } else return fail(COLTT_E_DEVICE, "shm exchange: shm_open(%s): %s", nm, strerror(errno));
+  void* m = mmap(nullptr, x->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+  if (m == MAP_FAILED) return fail(COLTT_E_NOMEM, "shm exchange: mmap(%zu): %s", x->map_bytes, strerror(errno));
+  x->hdr = static_cast<ShmHdr*>(m); x->data = static_cast<uint8_t*>(m) + SHM_HDR_BYTES;
+  if (x->creator) {   // a fresh segment is zero-filled: counters start at 0
+    x->hdr->world = (uint32_t)world; x->hdr->cap = x->cap;
+    x->hdr->magic.store(SHM_MAGIC, std::memory_order_release);
+  } else {
+    if (!x->wait_for([&] { return x->hdr->magic.load(std::memory_order_acquire) == SHM_MAGIC; })) return fail(COLTT_E_DEVICE, "shm exchange: %s was never initialised by its creator", nm);
+    if (x->hdr->world != (uint32_t)world || x->hdr->cap != x->cap)
+      return fail(COLTT_E_INVALID, "shm exchange: this process asks for world %d / %llu B per rank, the segment was made for %u / %llu", world,
+                  (unsigned long long)x->cap, x->hdr->world, (unsigned long long)x->hdr->cap);
+  }
+  x->hdr->attached.fetch_add((uint64_t)n_local, std::memory_order_acq_rel);
+  if (!x->wait_for([&] { return x->hdr->attached.load(std::memory_order_acquire) >= (uint64_t)world; })) {
+    x->hdr->failed.store(1, std::memory_order_release);
+    return fail(COLTT_E_DEVICE, "shm exchange: only %llu of %d ranks attached to %s within %.0f s", (unsigned long long)x->hdr->attached.load(), world, nm, x->timeout_s);
+  }
+  if (x->creator) { (void)shm_unlink(nm); x->unlinked = true; }   // everybody holds a mapping: the name can go (nothing leaks if a process dies later)
+  out = x;
+  return COLTT_OK;
+}
+
+int shm_allgather(ShmExchange* x, const void* local, uint64_t bytes, void* out) {
+  if (bytes > x->cap) return fail(COLTT_E_INVALID, "shm allgather: %llu bytes per rank > the segment's %llu", (unsigned long long)bytes, (unsigned long long)x->cap);
+  ShmHdr* h = x->hdr;
+  const uint64_t g = x->gen, W = (uint64_t)x->world;
+  auto give_up = [&](const char* what) { h->failed.store(1, std::memory_order_release); return fail(COLTT_E_DEVICE, "shm allgather (generation %llu): %s", (unsigned long long)g, what); };
+  if (!x->wait_for([&] { return h->consumed.load(std::memory_order_acquire) >= g * W; })) return give_up("a peer never finished reading the previous generation");
+  for (int i = 0; i < x->n_local; i++) {
+    const int r = x->rank_base + i;
+    if (bytes) std::memcpy(x->data + (size_t)r * x->cap, static_cast<const uint8_t*>(local) + (size_t)i * bytes, bytes);
+    h->len[r] = bytes;
+  }
+  h->written.fetch_add((uint64_t)x->n_local, std::memory_order_acq_rel);
+  if (!x->wait_for([&] { return h->written.load(std::memory_order_acquire) >= (g + 1) * W; })) return give_up("a peer never arrived (did every process make the same call?)");
+  for (int r = 0; r < x->world; r++) {
+    if (h->len[r] != bytes) return give_up("ranks disagree on the size of their contribution");
+    if (bytes) std::memcpy(static_cast<uint8_t*>(out) + (size_t)r * bytes, x->data + (size_t)r * x->cap, bytes);
+  }
+  h->consumed.fetch_add((uint64_t)x->n_local, std::memory_order_acq_rel);
+  x->gen++;
+  return COLTT_OK;
+}
+
 struct Member {
   int device = 0, rank = 0;
   coltt_handle_t h = 0;
@@ -88,6 +198,8 @@ struct Group : Object {
   std::vector<std::unique_ptr<Member>> m;  // DevBuf is neither copyable nor movable
   std::mutex call_mu;  // one group call at a time (members' own locks still protect them against direct use)
   Rec* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host staging for the gathered records
+  std::shared_ptr<ShmExchange> shm;                  // COLTT_EXCHANGE_SHM
+  std::vector<Rec> h_local, h_chunk_in, h_chunk_out; // SHM: this process's packed answers / one chunk of queries in flight
   ~Group() override {
     Rccl* r = rccl();
     for (auto& xp : m) {
@@ -176,11 +288,37 @@ extern "C" {
 int coltt_group_unique_id(uint8_t* out) {
   if (!out) return fail(COLTT_E_INVALID, "group_unique_id: NULL out");
   Rccl* r = rccl();
-  if (!r) return fail(COLTT_E_UNSUPPORTED, "group_unique_id: librccl is not loadable in this process");
+  if (!r || coltt_device_count() <= 0) {
+    // no RCCL (or no device) in this process: an id for the shared-memory exchange only — random bytes name the segment
+    FILE* f = fopen("/dev/urandom", "rb");
+    const size_t got = f ? fread(out, 1, COLTT_UNIQUE_ID_BYTES, f) : 0;
+    if (f) fclose(f);
+    if (got != COLTT_UNIQUE_ID_BYTES) return fail(COLTT_E_DEVICE, "group_unique_id: neither librccl nor /dev/urandom is available");
+    return COLTT_OK;
+  }
   COLTT_DEVICE(-1);
   NcclId id;
   COLTT_NCCL(r, r->GetUniqueId(&id));
   std::memcpy(out, id.internal, COLTT_UNIQUE_ID_BYTES);
+  return COLTT_OK;
+}
+
+int coltt_shm_open(const uint8_t* unique_id, int world, int n_local, int rank_base, uint64_t bytes_per_rank, coltt_handle_t* out) {
+  if (!out) return fail(COLTT_E_INVALID, "shm_open: out is NULL");
+  std::shared_ptr<ShmExchange> x;
+  COLTT_TRY(shm_open_exchange(unique_id, world, n_local, rank_base, bytes_per_rank, x));
+  *out = Registry::get().add(x);
+  return COLTT_OK;
+}
+int coltt_shm_allgather(coltt_handle_t h, const void* local, uint64_t bytes, void* out) {
+  auto x = lookup<ShmExchange>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "shm_allgather: unknown handle");
+  if (bytes && (!local || !out)) return fail(COLTT_E_INVALID, "shm_allgather: NULL buffer");
+  WriteLock g(x->rw);   // one collective at a time per process
+  return shm_allgather(x.get(), local, bytes, out);
+}
+int coltt_shm_close(coltt_handle_t h) {
+  if (!Registry::get().erase(h)) return fail(COLTT_E_NOT_FOUND, "shm_close: unknown handle");
   return COLTT_OK;
 }
 
@@ -190,12 +328,13 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
   coltt_group_opts o{}; if (opts) o = *opts;
   if (o.kind != COLTT_GROUP_FLAT && o.kind != COLTT_GROUP_HNSW) return fail(COLTT_E_INVALID, "group_create: bad kind %d", o.kind);
   if (o.layout != COLTT_LAYOUT_SHARD && o.layout != COLTT_LAYOUT_REPLICA) return fail(COLTT_E_INVALID, "group_create: bad layout %d", o.layout);
-  if (o.exchange < COLTT_EXCHANGE_AUTO || o.exchange > COLTT_EXCHANGE_HOST) return fail(COLTT_E_INVALID, "group_create: bad exchange %d", o.exchange);
+  if (o.exchange < COLTT_EXCHANGE_AUTO || o.exchange > COLTT_EXCHANGE_SHM) return fail(COLTT_E_INVALID, "group_create: bad exchange %d", o.exchange);
   const int world = o.world_size > 0 ? o.world_size : n_devices;
   if (o.rank_base < 0 || o.rank_base + n_devices > world) return fail(COLTT_E_INVALID, "group_create: ranks [%d,%d) outside world %d", o.rank_base, o.rank_base + n_devices, world);
   const bool multi_process = world > n_devices;
   if (multi_process && o.layout != COLTT_LAYOUT_SHARD) return fail(COLTT_E_INVALID, "group_create: a replica group is per process (replicas exchange nothing)");
-  if (multi_process && !o.unique_id) return fail(COLTT_E_INVALID, "group_create: world_size > n_devices needs the shared unique_id (coltt_group_unique_id on one process)");
+  if ((multi_process || o.exchange == COLTT_EXCHANGE_SHM) && !o.unique_id) return fail(COLTT_E_INVALID, "group_create: world_size > n_devices (and every shared-memory group) needs the shared unique_id (coltt_group_unique_id on one process)");
+  if (o.exchange == COLTT_EXCHANGE_SHM && o.layout != COLTT_LAYOUT_SHARD) return fail(COLTT_E_INVALID, "group_create: replicas exchange nothing");
   int n_dev = coltt_device_count();
   bool distinct = true;
   for (int i = 0; i < n_devices; i++) {
@@ -215,7 +354,15 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
   }
   // exchange transport
   g->exchange = COLTT_EXCHANGE_HOST;
-  if (o.layout == COLTT_LAYOUT_SHARD && o.exchange != COLTT_EXCHANGE_HOST) {
+  if (o.exchange == COLTT_EXCHANGE_SHM) {
+    // processes of one box (also: several ranks on ONE device, where a RCCL communicator cannot be formed): the same packed records
+    // travel through a POSIX shared-memory segment; a batch larger than the segment is exchanged in chunks of queries
+    uint64_t mb = 32;
+    if (const char* e = getenv("COLTT_SHM_MB")) { if (*e) mb = (uint64_t)std::max(1L, atol(e)); }
+    const uint64_t per_rank = std::max<uint64_t>(4096, (mb << 20) / (uint64_t)world);
+    COLTT_TRY(shm_open_exchange(o.unique_id, world, n_devices, o.rank_base, per_rank, g->shm));
+    g->exchange = COLTT_EXCHANGE_SHM;
+  } else if (o.layout == COLTT_LAYOUT_SHARD && o.exchange != COLTT_EXCHANGE_HOST) {
     Rccl* r = rccl();
     const bool can = r && (distinct || n_devices == 1);
     if (!can && (o.exchange == COLTT_EXCHANGE_RCCL || multi_process))
@@ -241,7 +388,7 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
       }
       g->exchange = COLTT_EXCHANGE_RCCL;
     }
-  } else if (multi_process) return fail(COLTT_E_UNSUPPORTED, "group_create: shards in several processes can only exchange through RCCL");
+  } else if (multi_process) return fail(COLTT_E_UNSUPPORTED, "group_create: shards in several processes exchange through RCCL or shared memory (COLTT_EXCHANGE_SHM), not through one process's host buffer");
   g->device = devices[0];
   *out = Registry::get().add(g);
   return COLTT_OK;
@@ -415,6 +562,26 @@ static int group_search(Group* g, const float* queries, const float* const* d_qu
     return COLTT_OK;
   }));
   // ---- ... ONE all-gather of the packed per-shard top-k (RCCL over xGMI), then the host-side final merge
+  if (g->exchange == COLTT_EXCHANGE_SHM) {
+    // the local members' records come to the host, then travel rank-major through the shared segment, a chunk of queries at a
+    // time when the batch is larger than a slot; every process merges every chunk itself (an all-gather, like the RCCL path)
+    g->h_local.resize(nm * per);
+    for (size_t j = 0; j < nm; j++) {
+      Member& x = *g->m[j];
+      COLTT_DEVICE(x.device);
+      COLTT_HIP(hipMemcpyAsync(g->h_local.data() + j * per, x.d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.stream));
+    }
+    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+    const size_t q_chunk = std::max<size_t>(1, (size_t)(g->shm->cap / ((size_t)k * sizeof(Rec))));
+    for (size_t q0 = 0; q0 < nq; q0 += q_chunk) {
+      const size_t qn = std::min(q_chunk, nq - q0), cper = qn * (size_t)k;
+      g->h_chunk_in.resize(nm * cper); g->h_chunk_out.resize((size_t)g->world * cper);
+      for (size_t j = 0; j < nm; j++) std::memcpy(g->h_chunk_in.data() + j * cper, g->h_local.data() + j * per + q0 * k, cper * sizeof(Rec));
+      COLTT_TRY(shm_allgather(g->shm.get(), g->h_chunk_in.data(), cper * sizeof(Rec), g->h_chunk_out.data()));
+      COLTT_TRY(coltt_group_merge_host(g->h_chunk_out.data(), g->world, qn, k, nearest, out_ids + q0 * k, out_scores + q0 * k, out_counts + q0));
+    }
+    return COLTT_OK;
+  }
   COLTT_TRY(g->stage((size_t)g->world * per * sizeof(Rec)));
   if (g->exchange == COLTT_EXCHANGE_RCCL) {
     Rccl* r = rccl();

@@ -119,19 +119,24 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
   for (uint32_t i = lane; i < w.hcap; i += 64) w.vis[i] = VIS_EMPTY;
 }
 
-// Burst depth of the row loads (exact.hpp: pair_distance), per kernel profile.  What buys HBM bandwidth here is bytes in
-// flight per CU = waves x bursts, and registers decide both: the LDS-visited search kernel runs 1 wave per SIMD anyway (LDS
-// bound), so its 2-byte path keeps a WHOLE 768-dim row in flight (U = 48: 2 x 24 x 16 B per lane, ~350 registers with AGPR
-// spills, 13.15 -> 11.88 ms per 10 k queries at 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under
-// 256.  Measured on MI355X, 2 M x 768, ef 128 unless noted: f32 U = 16 19.76 ms, 24 19.64, 32 21.58; f32 ef 256 (HBM visited)
-// U = 16 160 k q/s, 24 197 k; f16 U = 24 13.15 ms, 32 12.53, 48 11.88; f16 ef 256 (HBM visited) U = 24 421 k q/s, 48 364 k.
+// Burst depth of the row loads (exact.hpp: pair_distance), per kernel profile.  What buys HBM bandwidth is bytes in flight per CU =
+// waves x bursts — but a lane pair completes a 128-byte line with FOUR consecutive loads, so every burst keeps U/4 lines per row x
+// up to 32 rows x the resident waves alive in the CU's 32 KB vector L1, and 32 translations per load in its UTCL1.  Past that the
+// lines are evicted between their quarters and re-fetched from L2.  tools/micro/rowscan.hip measures this very code over random rows
+// of a 15 / 31 GB table without the walk around it (profiles/r03_rowscan_*.jsonl, TB/s at 4 waves per CU, 32 / 20 active pairs):
+//   f32 rows  U = 8: 6.44 / 5.73   12: 6.35 / 6.38   16: 4.79 / 6.23   24: 3.48 / 3.69      (8 waves per CU: at most 5.3)
+//   f16 rows  U = 12: 5.53 / 3.91  16: 6.02 / 4.46   24: 6.20 / 5.44   32: 6.17 / 5.87     (8 waves per CU, U = 24: 6.06 / 6.01)
+// and on the 10 M x 768 f32 walk itself (ms per 10 k queries, ef 128 / 256 / 1024): U = 16 (round 2; 24 in the HBM-visited kernel)
+// 22.81 / 47.37 / 174.6, U = 12 22.06 / 43.89 / 165.6, U = 8 23.75 / 46.83 / 176.2.  Hence 12 for f32 rows in every profile.
+// 2-byte rows: the LDS-visited kernel runs 1 wave per SIMD and keeps a WHOLE 768-dim row in flight (U = 48, 13.15 -> 11.88 ms at
+// 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under 256 registers (U = 24).
 enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_MW = 3, PROF_SEARCH_HBM_DEEP = 4 };
+#ifndef COLTT_U_F32      // measurement knob: burst depth of f32 rows, all profiles
+#define COLTT_U_F32 12
+#endif
 template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst_depth() {
-  // large-ef walk at ONE wave per SIMD (hnsw_walk2.hpp, deep profile): registers are free, a whole 2-byte row / a third of an f32 row in flight
-  if (PROFILE == PROF_SEARCH_HBM_DEEP) return QUANT == Q_NONE ? 32 : 48;
-  // multi-wave (latency) mode: 8 rows per wave, one workgroup per CU — registers are free, keep a third / a whole row in flight
-  if (PROFILE == PROF_SEARCH_MW) return QUANT == Q_NONE ? 32 : 48;
-  if (QUANT == Q_NONE) return PROFILE == PROF_SEARCH_HBM ? 24 : 16;
+  if (QUANT == Q_NONE) return COLTT_U_F32;
+  if (PROFILE == PROF_SEARCH_HBM_DEEP || PROFILE == PROF_SEARCH_MW) return 48;   // one wave per SIMD: a whole 2-byte row in flight
   return PROFILE == PROF_SEARCH_LDS ? 48 : 24;
 }
 template <int METRIC, int QUANT, int PROFILE>

@@ -10,7 +10,7 @@ from .hnsw import HnswCfg
 
 GROUP_FLAT, GROUP_HNSW = 0, 1
 LAYOUT_SHARD, LAYOUT_REPLICA = 0, 1
-EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1, 2
+EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_HOST, EXCHANGE_SHM = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
 
@@ -20,7 +20,8 @@ class GroupOpts(C.Structure):
 
 
 def unique_id():
-    """128 opaque bytes (ncclGetUniqueId) one process creates and hands to every process of a multi-process group."""
+    """128 opaque bytes (ncclGetUniqueId; random bytes when librccl / a device is absent — enough for the shared-memory exchange)
+    one process creates and hands to every process of a multi-process group."""
     b = (C.c_uint8 * UNIQUE_ID_BYTES)()
     L.check(L.lib().coltt_group_unique_id(b))
     return bytes(b)
@@ -43,6 +44,38 @@ def merge_host(recs, world, nq, k, nearest=True):
 
 
 REC_DTYPE = np.dtype([("id", np.uint64), ("score", np.float32), ("valid", np.uint32)])
+
+
+class ShmExchange:
+    """coltt_shm_*: all-gather between the processes of one box through POSIX shared memory (host-only) — the transport of
+    EXCHANGE_SHM groups.  Every process passes the same uid / world / bytes_per_rank and hosts ranks rank_base .. +n_local-1."""
+
+    def __init__(self, uid, world, n_local, rank_base, bytes_per_rank):
+        self.world, self.n_local = int(world), int(n_local)
+        u = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_uint64(0)
+        L.check(L.lib().coltt_shm_open(u, int(world), int(n_local), int(rank_base), C.c_uint64(int(bytes_per_rank)), C.byref(h)))
+        self.h = h
+
+    def allgather(self, local):
+        """local: array whose first axis is n_local -> array [world, ...] (rank-major), same dtype"""
+        a = np.ascontiguousarray(local)
+        assert a.shape[0] == self.n_local
+        per = a.nbytes // self.n_local
+        out = np.empty((self.world,) + a.shape[1:], a.dtype)
+        L.check(L.lib().coltt_shm_allgather(self.h, L.vp(a), C.c_uint64(per), L.vp(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            L.lib().coltt_shm_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Group:
@@ -71,7 +104,7 @@ class Group:
     def info(self):
         a, b, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         L.check(L.lib().coltt_group_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return {"n_local": a.value, "world": b.value, "exchange": {1: "rccl", 2: "host"}.get(c.value, c.value), "rank_base": d.value}
+        return {"n_local": a.value, "world": b.value, "exchange": {1: "rccl", 2: "host", 3: "shm"}.get(c.value, c.value), "rank_base": d.value}
 
     def member(self, i):
         m = C.c_uint64(0)

@@ -232,17 +232,27 @@ int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms);
  * (RCCL refuses a device twice) moves the records through pinned host memory instead; the merge is on the host either way. */
 enum { COLTT_GROUP_FLAT = 0, COLTT_GROUP_HNSW = 1 };
 enum { COLTT_LAYOUT_SHARD = 0, COLTT_LAYOUT_REPLICA = 1 };
-enum { COLTT_EXCHANGE_AUTO = 0, COLTT_EXCHANGE_RCCL = 1, COLTT_EXCHANGE_HOST = 2 };
+enum { COLTT_EXCHANGE_AUTO = 0, COLTT_EXCHANGE_RCCL = 1, COLTT_EXCHANGE_HOST = 2,
+       COLTT_EXCHANGE_SHM = 3 /* processes of ONE box: POSIX shared memory + a process-shared barrier (coltt_shm_*) */ };
 #define COLTT_UNIQUE_ID_BYTES 128
 typedef struct coltt_group_opts {
   int32_t kind;               /* COLTT_GROUP_FLAT (edge vectorspace) | COLTT_GROUP_HNSW (core vectorindex)                  */
   int32_t layout;             /* COLTT_LAYOUT_SHARD | COLTT_LAYOUT_REPLICA                                                  */
-  int32_t exchange;           /* COLTT_EXCHANGE_AUTO | _RCCL (fail if unavailable) | _HOST                                  */
+  int32_t exchange;           /* COLTT_EXCHANGE_AUTO | _RCCL (fail if unavailable) | _HOST (one process) | _SHM (processes of a box) */
   int32_t world_size;         /* shards in the whole collection; 0 => n_devices (single process)                            */
   int32_t rank_base;          /* shard number of devices[0]; this process hosts shards rank_base .. rank_base+n_devices-1   */
   const uint8_t* unique_id;   /* COLTT_UNIQUE_ID_BYTES from coltt_group_unique_id(), the same in every process; NULL if one */
 } coltt_group_opts;
-int coltt_group_unique_id(uint8_t* out /*[COLTT_UNIQUE_ID_BYTES]*/);
+int coltt_group_unique_id(uint8_t* out /*[COLTT_UNIQUE_ID_BYTES]*/);   /* ncclGetUniqueId, or random bytes when librccl is absent (SHM only) */
+/* All-gather between the processes of one box through POSIX shared memory (host-only: no device call) — the transport of
+ * COLTT_EXCHANGE_SHM groups, same packed records and same merge as the RCCL path; exported so the multi-process rendezvous,
+ * barrier and chunking can be exercised without a GPU.  Every process passes the same unique_id, world and bytes_per_rank; it
+ * hosts ranks rank_base .. rank_base + n_local - 1.  open() returns once all `world` ranks have attached (timeout:
+ * COLTT_SHM_TIMEOUT_S, default 120 s).  allgather: local = n_local x bytes, out = world x bytes (rank-major), bytes <= bytes_per_rank
+ * and equal in every process; collective — every process must make the same sequence of calls. */
+int coltt_shm_open(const uint8_t* unique_id, int world, int n_local, int rank_base, uint64_t bytes_per_rank, coltt_handle_t* out);
+int coltt_shm_allgather(coltt_handle_t h, const void* local, uint64_t bytes, void* out);
+int coltt_shm_close(coltt_handle_t h);
 int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg,
                        const coltt_group_opts* opts, coltt_handle_t* out);
 int coltt_group_destroy(coltt_handle_t h);

@@ -1385,17 +1385,27 @@ static std::vector<int> allowed_cpus() {
   if (r.empty()) { unsigned n = std::thread::hardware_concurrency(); for (unsigned c = 0; c < (n ? n : 1); c++) r.push_back((int)c); }
   return r;
 }
-static void pin_self(const std::vector<int>& cpus, int t) {
-  cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpus[(size_t)t % cpus.size()], &set);
+// pin policy 1: thread t -> the t-th allowed CPU (dense: the first cores of the first socket, SMT siblings last on Linux's usual
+// numbering); policy 2: SPREAD — thread t of T -> allowed[t * n / T]: evenly over sockets / CCDs / memory channels, which is what
+// a T-thread run on an n-CPU host should get before it is called "the host's best".
+static int pinned_cpu(const std::vector<int>& cpus, int t, int n_threads, int pin) {
+  const size_t n = cpus.size();
+  if (pin == 2 && n_threads > 0 && (size_t)n_threads < n) return cpus[((size_t)t * n) / (size_t)n_threads % n];
+  return cpus[(size_t)t % n];
+}
+static void pin_self(const std::vector<int>& cpus, int t, int n_threads, int pin) {
+  cpu_set_t set; CPU_ZERO(&set); CPU_SET(pinned_cpu(cpus, t, n_threads, pin), &set);
   (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
 }
+static std::atomic<int> g_pin_policy{1};   // what "pin != 0" means for the drivers below: 1 dense, 2 spread (orc_set_pin_policy)
 template <class F> static double run_threads(int n_threads, int pin, F&& body) {
+  if (pin) pin = g_pin_policy.load();
   const std::vector<int> cpus = allowed_cpus();
   std::atomic<int> ready{0}; std::atomic<bool> go{false};
   std::vector<std::thread> th;
   for (int t = 0; t < n_threads; t++)
     th.emplace_back([&, t]() {
-      if (pin) pin_self(cpus, t);
+      if (pin) pin_self(cpus, t, n_threads, pin);
       ready.fetch_add(1);
       while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
       body(t);
@@ -1410,6 +1420,14 @@ template <class F> static double run_threads(int n_threads, int pin, F&& body) {
 extern "C" {
 
 int orc_cpu_count(void) { return (int)allowed_cpus().size(); }
+// the CPU ids a run of n_threads pinned threads uses under `pin` policy (provenance of the cpu_baseline legs)
+void orc_set_pin_policy(int policy) { g_pin_policy.store(policy == 2 ? 2 : 1); }
+int orc_pin_map(int n_threads, int pin, int* out, int cap) {
+  const std::vector<int> cpus = allowed_cpus();
+  int k = 0;
+  for (int t = 0; t < n_threads && k < cap; t++) out[k++] = pinned_cpu(cpus, t, n_threads, pin);
+  return k;
+}
 int orc_numa_nodes(void) {  // highest online node + 1 (from sysfs; 1 when unknown)
   FILE* f = fopen("/sys/devices/system/node/online", "r");
   if (!f) return 1;

@@ -403,6 +403,17 @@ def cpu_count():
     return int(lib().orc_cpu_count())
 
 
+def set_pin_policy(policy):
+    """1 = dense (thread t on the t-th allowed CPU), 2 = spread (thread t of T on allowed[t * n / T]); applies to every pinned driver"""
+    lib().orc_set_pin_policy(int(policy))
+
+
+def pin_map(threads, policy):
+    out = (C.c_int * max(1, threads))()
+    k = lib().orc_pin_map(int(threads), int(policy), out, int(threads))
+    return [int(out[i]) for i in range(k)]
+
+
 class NumaArray:
     """numpy view of a page-interleaved anonymous mapping (orc_numa_alloc): mbind(MPOL_INTERLEAVE) when the kernel accepts
     it, transparent huge pages advised, first touch by `threads` pinned threads.  .flags: bit0 mbind ok, bit1 THP advised."""

@@ -62,19 +62,28 @@ void run(const uint8_t* table, uint64_t bytes, int dim, int w, uint32_t active, 
 
 int main(int argc, char** argv) {
   const double gib = argc > 1 ? atof(argv[1]) : 15.0;
+  const int which = argc > 2 ? atoi(argv[2]) : 3;   // 1 f16, 2 f32, 3 both
   const uint64_t bytes = (uint64_t)(gib * (1ull << 30));
   uint8_t* table; uint32_t* sink;
   CK(hipMalloc(&table, bytes)); CK(hipMalloc(&sink, 1 << 20));
   CK(hipMemset(table, 0x3c, bytes)); CK(hipMemset(sink, 0, 1 << 20));   // 0x3c3c = 1.06 as binary16, a small normal as f32
   CK(hipDeviceSynchronize());
   const int dim = 768;
-  for (int w : {4, 8}) {
-    run<Q_F16, 24>(table, bytes, dim, w, 32, sink, gib);
-    run<Q_F16, 48>(table, bytes, dim, w, 32, sink, gib);
-    run<Q_F16, 24>(table, bytes, dim, w, 20, sink, gib);
-    run<Q_NONE, 16>(table, bytes, dim, w, 32, sink, gib);
-    run<Q_NONE, 24>(table, bytes, dim, w, 32, sink, gib);
-    run<Q_NONE, 16>(table, bytes, dim, w, 20, sink, gib);
+  for (uint32_t act : {32u, 20u}) {
+    for (int w : {4, 6, 8, 12}) {
+      if (which & 1) {
+        run<Q_F16, 12>(table, bytes, dim, w, act, sink, gib);
+        run<Q_F16, 16>(table, bytes, dim, w, act, sink, gib);
+        run<Q_F16, 24>(table, bytes, dim, w, act, sink, gib);
+        run<Q_F16, 32>(table, bytes, dim, w, act, sink, gib);
+      }
+      if (which & 2) {
+        run<Q_NONE, 8>(table, bytes, dim, w, act, sink, gib);
+        run<Q_NONE, 12>(table, bytes, dim, w, act, sink, gib);
+        run<Q_NONE, 16>(table, bytes, dim, w, act, sink, gib);
+        run<Q_NONE, 24>(table, bytes, dim, w, act, sink, gib);
+      }
+    }
   }
   return 0;
 }
