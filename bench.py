@@ -415,7 +415,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
            "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bpq},
            "roofline": {"bound": "hbm", "achieved": bpq * nq / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bpq * nq / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[0],
-                        "traffic_source": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[1], "kernel": "hnsw_search_kernel (HBM-visited, 2-byte rows)",
+                        "traffic_source": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[1], "kernel": "hnsw_search2_kernel (hnsw_walk2.hpp: HBM visited map behind an LDS Bloom filter, delta result set, 2-byte rows)",
                         "avg_launch_ms": launch_s * 1e3},
            "cpu_baseline": cpu}
     if cpu and "value" in cpu:
@@ -459,33 +459,47 @@ def leg_published_hnsw_point(G, torch, dev, O, args, k):
 
 def leg_filtered(G, torch, dev, O, args, dim, k):
     """SURVEY §8 f3, reported separately: FilterableVertexSearch (edge/none_vectorstore.go:182-253) — the inverted index hands over
-    an ascending id list (roaring ToArray), the library translates ids to slots on the host and runs the exact-order GATHER scan
-    over those rows only.  1 M x 768 f32, every 10th id a candidate, one query per call (what the reference's RPC does) and 16."""
+    an ascending id list (roaring ToArray), the library translates ids to slots on the host and scans those rows only: one query
+    per call (the reference's RPC shape) through the exact-order GATHER scan, batches through the matrix cores' gather mode
+    (flat_mfma3.hpp: candidates from the gathered rows + exact re-score; answers equal exact mode's, checked here).
+    1 M x 768 f32; every 10th id a candidate (100 k rows, 30 KB apart), and every id (1 M candidates)."""
     n = 1_000_000
     ds = Dataset(torch, dev, dim, "normal")
     fl = fill_flat(G, torch, dev, ds, n, dim, 0, args.seed + 505)
-    cand = np.arange(0, n, 10, dtype=np.uint64)
     qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 17)
-    q = ds.rows(16, qgen).cpu().numpy()
-    out = {}
-    for nq in (1, 16):
-        fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST)
-        t = []
-        for _ in range(5):
-            t0 = time.perf_counter(); r = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST); t.append(time.perf_counter() - t0)
-        ms = fl.last_kernel_ms()
-        out[f"batch_{nq}"] = {"call_ms": float(np.median(t)) * 1e3, "kernels_ms": ms, "queries_per_s": nq / float(np.median(t)),
-                               "gathered_GBps": len(cand) * dim * 4 / (ms / 1e3) / 1e9}
-    res = {"workload": f"edge FLAT FilterableVertexSearch, {n}x{dim} float32, {len(cand)} candidate ids (every 10th), cosine, k={k}, exact-order gather scan",
-           "candidates": int(len(cand)), **out,
-           "note": "call_ms includes the host id -> slot translation and the H2D copy of the slot list; the rows of a gather scan are not contiguous (3 KB each)"}
+    q = ds.rows(64, qgen).cpu().numpy()
+    res = {"workload": f"edge FLAT FilterableVertexSearch, {n}x{dim} float32, cosine, k={k}", "lists": {}}
+    r_first = None
+    for lname, cand in (("every_10th", np.arange(0, n, 10, dtype=np.uint64)), ("all_ids", np.arange(n, dtype=np.uint64))):
+        out = {}
+        for nq in (1, 16, 64):
+            ex = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST, G.MODE_EXACT)
+            for mode, mname in ((G.MODE_EXACT, "exact"), (G.MODE_MFMA, "mfma")):
+                if mode == G.MODE_MFMA and nq == 1:
+                    continue
+                if mode == G.MODE_EXACT and nq == 64 and len(cand) > 200_000:
+                    continue   # 4 exact passes over 3 GB: not what a batch is served by
+                r = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST, mode)
+                t = []; ms = []
+                for _ in range(5):
+                    t0 = time.perf_counter(); r = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST, mode); t.append(time.perf_counter() - t0)
+                    ms.append(fl.last_kernel_ms())
+                km = float(np.median(ms))
+                out[f"batch_{nq}_{mname}"] = {"call_ms": float(np.median(t)) * 1e3, "kernels_ms": km, "queries_per_s": nq / float(np.median(t)),
+                                             "gathered_GBps": len(cand) * dim * 4 / (km / 1e3) / 1e9, "frac_of_hbm_peak": len(cand) * dim * 4 / (km / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                             "equals_exact_mode": bool(np.array_equal(r[0], ex[0]) and np.array_equal(r[1].view(np.uint32), ex[1].view(np.uint32)))}
+                if r_first is None:
+                    r_first = r
+        res["lists"][lname] = {"candidates": int(len(cand)), **out}
+    res["note"] = ("call_ms includes the host id -> slot translation and the H2D copy of the slot list; kernels_ms = hipEvent pair around the scan / pick / re-score / "
+                   "select kernels; gathered_GBps = candidate rows x row bytes / kernels_ms (one pass over the candidates, whatever the batch)")
     if O is not None:
         try:
             rows = fl.FetchRows(0, n)
             sub = np.ascontiguousarray(rows[::10])
             sl, sc, cn, w = O.flat_scan(sub, 0, dim, O.COSINE, q[:1], k, nearest=True, shape=0, split=1, threads=1)
             res["cpu_baseline"] = {"ms_per_query_1_thread_contiguous_candidates": w * 1e3,
-                                   "gpu_equals_oracle": bool(np.array_equal(r[0][0] if len(r[0]) == 1 else fl.FilterableVertexSearch(cand, q[:1], k, G.SELECT_NEAREST)[0][0], (sl[0] * 10).astype(np.uint64)))}
+                                   "gpu_equals_oracle": bool(np.array_equal(r_first[0][0], (sl[0] * 10).astype(np.uint64)) and np.array_equal(r_first[1][0].view(np.uint32), sc[0].view(np.uint32)))}
         except Exception as e:
             res["cpu_baseline"] = {"error": str(e)}
     fl.close()
@@ -557,9 +571,27 @@ def leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k):
         e = min(n_total, b + (1 << 24))
         G.check(L.coltt_shard_vertex(G.vp(all_ids[b:e]), C.c_size_t(e - b), C.c_uint64(world), G.vp(sh[b:e])))
     my_ids = np.ascontiguousarray(all_ids[sh == rank]); del all_ids, sh
-    grp = GG.Group([local], dim, G.COSINE, args.quant, kind=GG.GROUP_HNSW, layout=GG.LAYOUT_SHARD,
-                   cfg=G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc),
-                   exchange=GG.EXCHANGE_RCCL if world > 1 else GG.EXCHANGE_AUTO, world_size=world, rank_base=rank, uid=uid)
+    def make(exchange, uid_):
+        return GG.Group([local], dim, G.COSINE, args.quant, kind=GG.GROUP_HNSW, layout=GG.LAYOUT_SHARD,
+                        cfg=G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc),
+                        exchange=exchange, world_size=world, rank_base=rank, uid=uid_)
+    want = {"rccl": GG.EXCHANGE_RCCL, "shm": GG.EXCHANGE_SHM}.get(os.environ.get("COLTT_BENCH_EXCHANGE", "rccl"), GG.EXCHANGE_RCCL)
+    grp, err = None, None
+    try:
+        grp = make(want if world > 1 else GG.EXCHANGE_AUTO, uid)
+    except Exception as e:   # e.g. RCCL refuses the bootstrap (two ranks on one device, no librccl): every rank must take the same decision
+        err = str(e)
+    if world > 1:
+        bad = torch.tensor([0 if grp is not None else 1], dtype=torch.int32, device=cdev)
+        dist.all_reduce(bad)
+        if int(bad.item()) > 0:   # somebody could not form the RCCL group: all ranks fall back to the shared-memory exchange (one box)
+            if grp is not None:
+                grp.close()
+            box = [GG.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            grp = make(GG.EXCHANGE_SHM, box[0])
+    elif grp is None:
+        raise RuntimeError(err)
     member = G.Hnsw.from_handle(grp.member(0), dim, G.COSINE, args.quant)
     ds = Dataset(torch, dev, dim, args.dataset)
     _, build_s = build_index(G, torch, dev, ds, len(my_ids), dim, args, args.seed + 7919 * (rank + 1), args.quant, ids=my_ids, h=member)
@@ -731,7 +763,9 @@ def main():
             "config": {"workload": f"core/vectorindex HNSW M={args.m} efSearch={args.ef} efConstruction={args.efc}, "
                                    f"{n_total}x{dim} {QNAME[args.quant]}, cosine, k={k}, {nq} queries/step/rank, "
                                    f"mode={'shard (ShardVertex) + RCCL all-gather of per-shard top-k + host merge' if shard else ('replica' if world > 1 else 'single')}",
-                       "n": n_total, "dim": dim, "queries_per_step": nq, "ef": args.ef, "build_batch": args.build_batch},
+                       "n": n_total, "dim": dim, "queries_per_step": nq, "ef": args.ef, "build_batch": args.build_batch,
+                       "query_batches_cycled": min(2, args.steps + args.warmup),
+                       "query_batches_note": "the timed steps alternate between two resident query batches; a step touches ~124 GB of rows, far past the 256 MiB Infinity Cache and the 32 MiB of L2, so nothing of one step survives into the next"},
             "recall_at_10": recall[str(args.ef)] if isinstance(recall, dict) else recall,
             "recall_vs_ef": recall if isinstance(recall, dict) else None,
             "qps_vs_ef": qps_vs_ef,

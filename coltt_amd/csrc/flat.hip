@@ -282,10 +282,9 @@ int prep_queries(Flat* f, FCtx* c, const float* d_qraw, size_t nq) {
   COLTT_TRY(c->w_qeff.reserve(nq * f->dim * 4));
   COLTT_TRY(c->w_qn.reserve(nq * 4));
   int norm = f->metric == COLTT_COSINE;
-#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)f->dim, norm, c->w_qeff.as<float>())
+#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)f->dim, norm, c->w_qeff.as<float>(), c->w_qn.as<float>())
   COLTT_DISPATCH_QUANT(f->quant, COLTT_PQ)
 #undef COLTT_PQ
-  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, c->stream>>>(c->w_qeff.as<float>(), nq, (int)f->dim, c->w_qn.as<float>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -339,7 +338,19 @@ static int mfma_generation() {
 
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                       unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim) {
+                       unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim, const uint32_t* d_gather) {
+  if (d_gather) {   // rows[gather[pos]] for pos in [b, e): FilterableVertexSearch through the matrix cores (flat_mfma3.hpp, GATHER)
+    auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_COS, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_COS, true>)
+                                          : (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_L2, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_L2, true>);
+    const size_t lds = M3Geom<BN, AF32, M2_BM, true>::LDS;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
+    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+                                          nearest, cand, cnt, cap, d_gather);
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
 #ifdef COLTT_EXPERIMENTS
   if (mfma_generation() >= 4 && !(seed && BN == 256)) {   // (the batch-256 seed instance would spill: it stays on generation 3)
     auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma4_kernel<BN, AF32, true, M_COS> : flat_mfma4_kernel<BN, AF32, false, M_COS>)
@@ -390,7 +401,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     const uint64_t tiles = (e - b + BM - 1) / BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
     kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
-                                          nearest, cand, cnt, cap);
+                                          nearest, cand, cnt, cap, nullptr);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
   }
@@ -398,9 +409,9 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
 
 template <int BN>
 int launch_mfma_scan(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
-                     unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim) {
-  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim);
-  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim);
+                     unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim, const uint32_t* d_gather) {
+  if (f->quant == COLTT_Q_NONE) return launch_mfma_scan_t<BN, true>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim, d_gather);
+  return launch_mfma_scan_t<BN, false>(f, c, b, e, q16, qn, g, thr, nearest, cand, cnt, cap, seed, kdim, d_gather);
 }
 
 // relative error bound of the Euclidean candidate value s~^2 against the exact s^2, in units of (||q||^2 + ||r||^2): D * 2^-24 from
@@ -412,7 +423,7 @@ float l2_eps(const Flat* f) {
 }
 
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
-int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
+int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
                       uint32_t* d_out_cnt, uint32_t cap, uint32_t* ovf) {
   uint32_t* cnt = c->w_cnt.as<uint32_t>();
   uint32_t* thr = cnt + 256;
@@ -427,9 +438,9 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * dimp, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, dimp, q16, cnt, thr, ovf, nearest);
   auto scan = [&](uint64_t b, uint64_t e) -> int {
     const bool seed = b == 0 && e - b <= cap;
-    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
-    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
-    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp));
+    if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp, d_gather));
+    else if (BN == 128) COLTT_TRY(launch_mfma_scan<128>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp, d_gather));
+    else COLTT_TRY(launch_mfma_scan<256>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp, d_gather));
     if (f->metric == COLTT_COSINE)
       flat_pick_kernel<<<g, 256, 0, c->stream>>>(cur, oth, cnt, thr, cap, k, nearest, f->quant == COLTT_Q_NONE ? MF_MARGIN_F32 : MF_MARGIN, ovf);
     else  // Euclidean: |s~^2 - s^2| <= eps * (||q||^2 + ||r||^2), eps = dot error (+ f16 rounding of f32 rows) + f32 rounding of the norms / the exact sum
@@ -481,7 +492,9 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
   const bool finite_rows = max_norm == max_norm && max_norm < 3.0e38f;
   const bool k_ok = f->dim % MF_BK == 0 || (mfma_generation() >= 2 && finite_rows);
-  const bool mfma = mode == COLTT_MODE_MFMA && !d_gather && (cos_ok || l2_ok) &&
+  // (a filtered search — d_gather: positions of a slot list — takes the matrix cores too, through the kernel's gather mode; the
+  //  superseded experiment generations have none)
+  const bool mfma = mode == COLTT_MODE_MFMA && (!d_gather || mfma_generation() == 3) && (cos_ok || l2_ok) &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 128 && f->dim <= 4096 && total > 0;
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
@@ -493,7 +506,7 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   if (mfma) {
     for (size_t q0 = 0, gi = 0; q0 < nq; q0 += gq, gi++) {
       int g = (int)std::min<size_t>(gq, nq - q0);
-      COLTT_TRY(search_group_mfma(f, c, q0, g, k, nearest, total, d_out_ids, d_out_sc, d_out_cnt, cap, d_ovf + gi));
+      COLTT_TRY(search_group_mfma(f, c, q0, g, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap, d_ovf + gi));
       f->mfma_groups.fetch_add(1);
     }
     COLTT_HIP(hipEventRecord(c->ev1, c->stream));
@@ -507,7 +520,7 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
       f->mfma_fallbacks.fetch_add(1);
       const size_t q0 = gi * gq; const int g = (int)std::min<size_t>(gq, nq - q0);
       for (size_t s = 0; s < (size_t)g; s += scan_qb(f))
-        COLTT_TRY(search_group_exact(f, c, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, nullptr, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+        COLTT_TRY(search_group_exact(f, c, q0 + s, (int)std::min<size_t>(scan_qb(f), g - s), k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
     }
     if (any) COLTT_HIP(hipEventRecord(c->ev1, c->stream));
     COLTT_HIP(hipGetLastError());
@@ -775,6 +788,12 @@ int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq
 int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,
                           const uint64_t* cand_ids, size_t n_cand, uint64_t* out_ids, float* out_scores,
                           uint32_t* out_counts) {
+  return coltt_flat_search_ids_mode(h, queries, nq, k, select, COLTT_MODE_EXACT, cand_ids, n_cand, out_ids, out_scores, out_counts);
+}
+
+int coltt_flat_search_ids_mode(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,
+                               const uint64_t* cand_ids, size_t n_cand, uint64_t* out_ids, float* out_scores,
+                               uint32_t* out_counts) {
   auto f = lookup<Flat>(h);
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_search_ids: unknown handle");
   if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "flat_search_ids: NULL buffer");
@@ -796,7 +815,7 @@ int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uin
   if (!ctx.c) return COLTT_E_DEVICE;
   COLTT_TRY(ctx.c->w_gather.reserve(std::max<size_t>(slots.size(), 1) * 4));
   if (!slots.empty()) COLTT_HIP(hipMemcpyAsync(ctx.c->w_gather.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice, ctx.c->stream));
-  return flat_search_common(f.get(), ctx.c, queries, false, nq, k, select, COLTT_MODE_EXACT, ctx.c->w_gather.as<uint32_t>(), slots.size(),
+  return flat_search_common(f.get(), ctx.c, queries, false, nq, k, select, mode, ctx.c->w_gather.as<uint32_t>(), slots.size(),
                             out_ids, out_scores, out_counts, false);
 }
 

@@ -96,7 +96,8 @@ __device__ __forceinline__ QCol m2_query_col_l2(int qidx, int nq, const float* _
 template <bool SEED, int METRIC = M_COS>
 __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&ir)[4], bool bad, const QCol& qc, int nearest, int nq,
                                               uint64_t rbase, uint64_t begin, uint64_t end, unsigned long long* __restrict__ cand,
-                                              uint32_t* __restrict__ cnt, uint32_t cap, float* ep) {
+                                              uint32_t* __restrict__ cnt, uint32_t cap, float* ep,
+                                              const uint32_t* __restrict__ gather = nullptr) {  // gather: row numbers are positions of a slot list
   float t[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
@@ -108,7 +109,7 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
       for (int r = 0; r < 16; r++) {
         const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
         const float s = value(t[r]);
-        if (gr < end) cand[(size_t)qc.qidx * cap + (uint32_t)(gr - begin)] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
+        if (gr < end) cand[(size_t)qc.qidx * cap + (uint32_t)(gr - begin)] = ((unsigned long long)score_key(s) << 32) | (gather ? gather[gr] : (uint32_t)gr);
       }
       if (rbase == begin) cnt[qc.qidx] = (uint32_t)(end - begin);
     }
@@ -154,7 +155,7 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
         const int r = h * 8 + r8;
         const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
         const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
-        if (idx < cap) cand[(size_t)qc.qidx * cap + idx] = ((unsigned long long)score_key(s) << 32) | (uint32_t)gr;
+        if (idx < cap) cand[(size_t)qc.qidx * cap + idx] = ((unsigned long long)score_key(s) << 32) | (gather ? gather[gr] : (uint32_t)gr);
         idx++;
       }
     }

@@ -38,13 +38,16 @@ __device__ __forceinline__ void m3_dma4s(uint32_t voffset, const void* sbase, ui
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voffset), "s"(sbu), "s"(lds_base) : "memory");
 }
 
-template <int BN, bool AF32, int BM = M2_BM> struct M3Geom {
+// GATHER: the rows of a tile are rows[gather[pos]] for consecutive positions pos (FilterableVertexSearch, edge/none_vectorstore.go:182-253):
+// every wave keeps the slot numbers of its 64 tile rows for three tiles in LDS (IDS bytes, see flat_mfma3_kernel).
+template <int BN, bool AF32, int BM = M2_BM, bool GATHER = false> struct M3Geom {
   static constexpr int A_ROWB = M2_BK * (AF32 ? 4 : 2);
   static constexpr int A_STAGE = BM * A_ROWB;                      // 16 KiB | 32 KiB (24 | 48 at BM = 384)
   static constexpr int B_STAGE = BN * M2_BK * 2;                   // 4 / 8 / 16 KiB
   static constexpr int TNORM = BM + 64;                            // floats per tile-parity buffer of raw ||row||^2
   static constexpr int NN_I = BM / 256 + (BM % 256 ? 1 : 0);       // raw-norm DMA instructions per query-loader wave per stage
-  static constexpr int FIXED = 2 * TNORM * 4 + M2_NT * 32;
+  static constexpr int IDS = GATHER ? 8 * 3 * 64 * 4 : 0;          // [8 waves][3 tiles][64 rows] u32
+  static constexpr int FIXED = 2 * TNORM * 4 + M2_NT * 32 + IDS;
   static constexpr bool TUNED = !AF32 && BN == 256;              // measurement overrides apply to the batch-256 f16 shape only
 #ifdef COLTT_M3_NSB
   static constexpr int NSB = TUNED ? COLTT_M3_NSB : 3;
@@ -62,15 +65,17 @@ template <int BN, bool AF32, int BM = M2_BM> struct M3Geom {
   static constexpr int A_BYTES = NSA * A_STAGE, B_BYTES = NSB * B_STAGE;
   static constexpr size_t LDS = (size_t)A_BYTES + B_BYTES + FIXED;
   static_assert(NSA >= 2 && NSB >= 2 && LDS <= 160 * 1024, "ring does not fit");
+  static_assert(!GATHER || BM == 256, "gather mode: 64 tile rows per loader wave");
   static_assert((NSA - 2) * NA_I < 64 && (NSB - 2) * (NB_I + NN_I) < 64, "vmcnt range");
 };
 
-template <int BN, bool AF32, bool SEED, int BM = M2_BM, int METRIC = M_COS>
+template <int BN, bool AF32, bool SEED, int BM = M2_BM, int METRIC = M_COS, bool GATHER = false>
 __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, uint64_t begin, uint64_t end,
     const _Float16* __restrict__ q16, const float* __restrict__ qnorms, int nq, int dim, const uint32_t* __restrict__ thr,
-    int nearest, unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap) {
-  typedef M3Geom<BN, AF32, BM> G;
+    int nearest, unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
+    const uint32_t* __restrict__ gather = nullptr) {
+  typedef M3Geom<BN, AF32, BM, GATHER> G;
   constexpr int WN = 2;
   constexpr int WROWS = BM / 4;            // rows per wave row (4 x 2 wave grid)
   constexpr int TM = WROWS / 32, TN = BN / WN / 32;
@@ -84,6 +89,9 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
   uint8_t* const ringB = smem + G::A_BYTES;                                      // [NSB][BN queries][64]
   float* const tnorm = reinterpret_cast<float*>(smem + G::A_BYTES + G::B_BYTES); // [2][M2_TNORM] raw ||row||^2
   float* const ep = reinterpret_cast<float*>(smem + G::A_BYTES + G::B_BYTES + 2 * G::TNORM * 4) + tid * 8;
+  // GATHER: slot numbers of this wave's 64 tile rows (tile rows lw*64 .. lw*64+63: the rows a row loader fetches, the norms a query
+  // loader refreshes), for three consecutive tiles of this workgroup
+  uint32_t* const idbuf = reinterpret_cast<uint32_t*>(smem + G::A_BYTES + G::B_BYTES + 2 * G::TNORM * 4 + M2_NT * 32) + wave * (3 * 64);
   const int nk = dim / M2_BK;
   const uint64_t ntiles = (end - begin + BM - 1) / BM;
   if ((uint64_t)blockIdx.x >= ntiles) return;
@@ -113,14 +121,49 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
   const uint32_t nvoff = (uint32_t)lane * 4;
   uint64_t ld_tile = blockIdx.x; int ld_ks = 0; uint32_t ld_g = 0, ld_par = 0;
   const uint64_t last_tile = blockIdx.x + ((ntiles - 1 - blockIdx.x) / gridDim.x) * gridDim.x;
+  // ---- GATHER: per-lane 64-bit source addresses.  Tile n (n-th tile of this workgroup) has its slot numbers in idbuf[n % 3]:
+  // tiles 0-2 are fetched synchronously below (the prologue may already cross into them), tile n + 2 is requested — an LDS-DMA, no
+  // register result that would have to be waited for — when the loader switches to tile n, i.e. >= 2 nk stages before it is read:
+  // every wave waits for all but its last few DMAs at every K step, so the request has long landed by then.
+  uint32_t ld_n = 0;                 // index of the loader's tile among this workgroup's tiles
+  const uint8_t* gbase[GATHER ? G::NA_I : 1];
+  const float* gnorm = nullptr;
+  auto tile_of = [&](uint32_t n) { const uint64_t t = blockIdx.x + (uint64_t)n * gridDim.x; return t < ntiles ? t : last_tile; };
+  auto ids_pos = [&](uint32_t n) {   // position (in the gather list) of tile row lw*64 + lane of this workgroup's n-th tile, clamped
+    const uint64_t pos = begin + tile_of(n) * BM + (uint64_t)(lw * 64 + lane);
+    return pos < end ? pos : end - 1;
+  };
+  auto take_ids = [&](uint32_t n) {  // addresses of the loader's rows / norms for tile n from idbuf (LDS)
+    const uint32_t* ib = idbuf + (n % 3) * 64;
+    if (row_loader) {
+      const int lr = lane / A_CPR, p = lane % A_CPR;
+#pragma unroll
+      for (int i = 0; i < G::NA_I; i++) {
+        const uint32_t slot = ib[i * A_RPI + lr];
+        const uint32_t chunk = AF32 ? (uint32_t)((p ^ (((lr >> 1) & 7) | ((i & 1) ? 4 : 0))) * 16) : (uint32_t)((p ^ ((lr >> 2) & 3)) * 16);
+        gbase[i] = rows + (size_t)slot * stride + chunk;
+      }
+    } else gnorm = norms + ib[lane];
+  };
+  if constexpr (GATHER) {
+#pragma unroll
+    for (uint32_t n = 0; n < 3; n++) idbuf[n * 64 + lane] = gather[ids_pos(n)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    take_ids(0);
+  }
   auto issue_stage = [&]() {   // my kind's share of the stage the loader points at, then advance
 #ifndef COLTT_M2_NO_DMA
     const uint64_t row0 = begin + ld_tile * BM;
     if (row_loader) {
       const uint32_t slot = lds0 + (ld_g % NSA) * G::A_STAGE + (uint32_t)(lw * G::NA_I * 1024);
-      const uint8_t* sb = rows + (row0 + (uint64_t)(lw * G::NA_I * A_RPI)) * stride + (size_t)ld_ks * G::A_ROWB;
+      if constexpr (GATHER) {
 #pragma unroll
-      for (int i = 0; i < G::NA_I; i++) m3_dma16s<M2_A_NT || AF32>((AF32 && (i & 1)) ? voff_odd : voff, sb + (size_t)i * A_RPI * stride, slot + (uint32_t)(i * 1024));
+        for (int i = 0; i < G::NA_I; i++) m2_dma16<M2_A_NT || AF32>(gbase[i] + (size_t)ld_ks * G::A_ROWB, slot + (uint32_t)(i * 1024));
+      } else {
+        const uint8_t* sb = rows + (row0 + (uint64_t)(lw * G::NA_I * A_RPI)) * stride + (size_t)ld_ks * G::A_ROWB;
+#pragma unroll
+        for (int i = 0; i < G::NA_I; i++) m3_dma16s<M2_A_NT || AF32>((AF32 && (i & 1)) ? voff_odd : voff, sb + (size_t)i * A_RPI * stride, slot + (uint32_t)(i * 1024));
+      }
     } else {
       const uint32_t slot = lds0 + G::A_BYTES + (ld_g % NSB) * G::B_STAGE + (uint32_t)(lw * G::NB_I * 1024);
       const uint8_t* sb = reinterpret_cast<const uint8_t*>(q16) + (size_t)(lw * G::NB_I * 16) * dim * 2 + (size_t)ld_ks * 64;
@@ -129,8 +172,9 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
 #pragma unroll
       for (int i = 0; i < G::NN_I; i++) {   // raw norms of the tile being loaded: this wave refreshes BM/4 of them, 64 per DMA
         const int off = i == 0 ? 0 : (BM / 4 - 64);   // the last piece ends exactly at the wave's share (pieces may overlap)
-        m3_dma4s(nvoff, norms + row0 + (uint64_t)(lw * (BM / 4) + off),
-                 lds0 + (uint32_t)(G::A_BYTES + G::B_BYTES) + ld_par * (G::TNORM * 4) + (uint32_t)((lw * (BM / 4) + off) * 4));
+        const uint32_t dst = lds0 + (uint32_t)(G::A_BYTES + G::B_BYTES) + ld_par * (G::TNORM * 4) + (uint32_t)((lw * (BM / 4) + off) * 4);
+        if constexpr (GATHER) m2_dma4(gnorm, dst);   // norms[gather[pos]]: one address per lane (BM = 256: one piece)
+        else m3_dma4s(nvoff, norms + row0 + (uint64_t)(lw * (BM / 4) + off), dst);
       }
     }
 #endif
@@ -138,6 +182,11 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
     if (++ld_ks == nk) {
       ld_ks = 0;
       if (ld_tile != last_tile) { ld_tile += gridDim.x; ld_par ^= 1u; }  // past the end: re-fetch the last tile (uniform vmcnt)
+      if constexpr (GATHER) {   // next tile: its slot numbers are in LDS; request those of the tile after the next one
+        ld_n++;
+        take_ids(ld_n);
+        m2_dma4(gather + ids_pos(ld_n + 2), lds0 + (uint32_t)(reinterpret_cast<uint8_t*>(idbuf + ((ld_n + 2) % 3) * 64) - smem));
+      }
     }
   };
   uint32_t fa[2][AF32 ? 2 : 1], fb[2];
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
       }
       const uint64_t rbase = row0 + wm * WROWS + tm * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int tn = 0; tn < TN; tn++) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep);
+      for (int tn = 0; tn < TN; tn++) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep, GATHER ? gather : nullptr);
     }
   }
   m2_wait_vmcnt<0>();

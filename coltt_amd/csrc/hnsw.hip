@@ -17,6 +17,7 @@
 #include "exact.hpp"
 #include "hnsw_dev.hpp"
 #include "hnsw_walk2.hpp"
+#include "hnsw_lat.hpp"
 #include "prep.hpp"
 
 using namespace coltt;
@@ -163,56 +164,75 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
 }
 
 
-// Hnsw.Search with a 256-thread workgroup per query (search_level_mw: rows of an expansion staged in LDS by all four waves,
-// evaluated by wave 0) — the opt-in experiment for small batches; the reference serves one query per RPC (core/core.go:633-667).
-// One workgroup per query at a time, queries pulled from a global counter.  Measured slower than one wave per query (see
-// mw_max_nq()); kept for the record and covered by the same parity tests.
-template <int METRIC, int QUANT, bool VISG>
-__global__ __launch_bounds__(256) void hnsw_search_mw_kernel(GraphView g, int32_t entry, int32_t entry_level,
-                                                            const float* __restrict__ q_eff, const float* __restrict__ qnorms,
-                                                            uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
-                                                            uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
-                                                            float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                            unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
-                                                            size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+// Hnsw.Search with a 256-thread workgroup per query (hnsw_lat.hpp): the latency path for small batches — the reference serves one
+// query per RPC (core/core.go:633-667).  One workgroup per CU, queries pulled from a global counter.  Same answers, score bits and
+// counters as the one-wave kernel (the parity tests run both).
+template <int METRIC, int QUANT>
+__global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32_t entry, int32_t entry_level,
+                                                             const float* __restrict__ q_eff, const float* __restrict__ qnorms,
+                                                             uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
+                                                             uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
+                                                             float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                             unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveCtx w;
-  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  size_t off = (lat_q_floats(g.dim) * 4 + 15) & ~(size_t)15;   // the query, residue-major (hnsw_lat.hpp: lat_n8p)
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
-  MwExchange* xs = reinterpret_cast<MwExchange*>(w.res0 + 2 * (size_t)ef_pad);
-  uint8_t* stage = reinterpret_cast<uint8_t*>(xs + 1);                                   // [32][stride] rows of the chunk being expanded
-  w.vis = reinterpret_cast<uint32_t*>(stage + (size_t)MW_ROWS * g.stride);
+  LatShared* xs = reinterpret_cast<LatShared*>(w.res0 + (size_t)ef_pad);
+  uint8_t* stage = reinterpret_cast<uint8_t*>(xs + 1);                                   // [32][stride + pad] rows of the chunk being evaluated
+  w.vis = reinterpret_cast<uint32_t*>(stage + (size_t)LAT_ROWS * (g.stride + LAT_PAD));
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
-  w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
-  if constexpr (VISG) { w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x]; }
+  w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0; w.bloom = nullptr; w.bloom_words = 0; w.bloom_shift = 0;
   for (;;) {
-    __syncthreads();   // everybody is done with the previous query's LDS state (and with ctl[2])
-    if (threadIdx.x == 0) xs->ctl[2] = atomicAdd(counter, 1u);
+    __syncthreads();   // everybody is done with the previous query's LDS state (and with ctl[1])
+    if (threadIdx.x == 0) xs->ctl[1] = atomicAdd(counter, 1u);
     __syncthreads();
-    const uint32_t qi = xs->ctl[2];
+    const uint32_t qi = xs->ctl[1];
     if (qi >= nq) break;
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
-    for (int e = threadIdx.x; e < g.dim; e += 256) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
-    w.qnorm = qnorms[qi];
-    __syncthreads();
-    uint32_t cur = (uint32_t)entry; float curd = 0.f;
-    if (wave == 0) {  // entry distance + greedy descent on the upper levels: a handful of 16-neighbour hops, one wave (hnsw.go:253-256)
-      curd = eval_pair<METRIC, QUANT, PROF_SEARCH_MW>(g, w, cur, lane & 1);
-      curd = __shfl(curd, 0, 64);
-      w.n_dist += 1;
-      for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF_SEARCH_MW>(g, w, cur, curd, l, lane);
-      w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+#ifdef COLTT_PHASE_TIMING
+    for (int i_ = 0; i_ < 8; i_++) w.pt[i_] = 0;
+    w.t_last = __builtin_amdgcn_s_memtime();
+#endif
+    {
+      const int n8 = g.dim >> 3, n8p = lat_n8p(g.dim);
+      for (int e = threadIdx.x; e < g.dim; e += 256) {
+        const float v = q_eff[(size_t)qi * g.dim + e];
+        if (e < n8 * 8) w.qs[(size_t)(e & 7) * n8p + (e >> 3)] = v; else w.qs[(size_t)8 * n8p + (e - n8 * 8)] = v;
+      }
     }
-    uint32_t len; int buf;
-    search_level_mw<METRIC, QUANT, VISG>(g, w, xs, stage, cur, curd, ef, 0, lane, wave, len, buf);
+    w.qnorm = qnorms[qi];
+    // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253): a chunk with one live row
+    if (threadIdx.x < LAT_ROWS) { xs->nb[threadIdx.x] = threadIdx.x == 0 ? (uint32_t)entry : NBR_NONE; xs->fresh[threadIdx.x] = threadIdx.x == 0 ? 1u : 0u; }
+    lat_chunk<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+    uint32_t cur = (uint32_t)entry;
+    float curd = xs->d[0];
+    w.n_dist += 1;
+    __syncthreads();   // xs->d[0] has been read by every wave before the next chunk overwrites it
+    for (int l = entry_level; l > 0; l--) greedy_level_lat<METRIC, QUANT>(g, w, xs, stage, cur, curd, l, wave, lane);  // :254-256
+#ifdef COLTT_PHASE_TIMING
+    if (wave == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); w.pt[6] += t_ - w.t_last; w.t_last = t_; }   // query load + entry + upper levels
+#endif
+    w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    uint32_t len;
+    if (wave == 0) {   // hnsw_walk2.hpp's level-0 walk on wave 0, the chunks evaluated by all four waves (hnsw_lat.hpp: LatEval)
+      if (lane == 0) xs->ctl[0] = 1u;
+      LatEval<METRIC, QUANT> ev{xs, stage};
+      search_level2<METRIC, QUANT, PROF_SEARCH_LDS, W2_DELTA, VIS_LDS, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259
+      wave_sync();
+      if (lane == 0) xs->ctl[0] = 0u;
+      lds_barrier();   // releases the companions
+    } else {
+      len = 0;
+      lat_companion<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+    }
     if (wave == 0) {
-      uint32_t n = len < k ? len : k;
-      const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
+      const uint32_t n = len < k ? len : k;
       for (uint32_t i = lane; i < n; i += 64) {
-        unsigned long long e = res[i];
-        uint32_t slot = (uint32_t)e >> 1;
+        const unsigned long long e = w.res0[i];
+        const uint32_t slot = (uint32_t)e >> 1;
         out_ids[(size_t)qi * k + i] = g.ids ? g.ids[slot] : (uint64_t)slot;
         out_scores[(size_t)qi * k + i] = __uint_as_float((uint32_t)(e >> 32));
       }
@@ -222,10 +242,12 @@ __global__ __launch_bounds__(256) void hnsw_search_mw_kernel(GraphView g, int32_
         atomicAdd(&stats[1], (unsigned long long)w.n_exp);
         atomicAdd(&stats[2], (unsigned long long)w.n_hops);
         if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
+#ifdef COLTT_PHASE_TIMING
+        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&stats[8 + i_], w.pt[i_]);
+#endif
       }
     }
   }
-  if constexpr (VISG) { if (threadIdx.x == 0) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 
@@ -491,10 +513,9 @@ int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
   COLTT_TRY(c->w_qn.reserve(nq * 4));
   int norm = x->metric == COLTT_COSINE;
   float* qe = c->w_qeff.as<float>();
-#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)x->dim, norm, qe)
+#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)x->dim, norm, qe, c->w_qn.as<float>())
   COLTT_DISPATCH_QUANT(x->quant, COLTT_PQ)
 #undef COLTT_PQ
-  query_norms_kernel<<<ceil_div(nq * 2, 256), 256, 0, c->stream>>>(qe, nq, (int)x->dim, c->w_qn.as<float>());
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -699,28 +720,28 @@ int launch_search(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_
   return COLTT_OK;
 }
 
-// multi-wave (latency) launch: one 4-wave workgroup per query in flight, at most one per CU
+// latency launch: one 4-wave workgroup per query in flight, at most one per CU
 template <int METRIC, int QUANT>
-int launch_search_mw(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
-                     uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
-  auto kern = sg.visg ? hnsw_search_mw_kernel<METRIC, QUANT, true> : hnsw_search_mw_kernel<METRIC, QUANT, false>;
+int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
+                      uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
+  (void)region_base;
+  auto kern = hnsw_search_lat_kernel<METRIC, QUANT>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats,
-                                         x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
-                                         x->w_vepoch.as<uint32_t>() + region_base);
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
-// Batches of at most COLTT_MW_MAX_NQ queries take the 256-thread staged kernel (search_level_mw).  OFF by default (0): measured
-// at 10 M x 768 f32, ef 128 it is SLOWER than one wave per query (1 query: 1.46 ms vs 1.24 ms; 128 queries: 2.02 vs 1.71 ms —
-// profiles/r02_latency.json): the single-wave walk already overlaps the next adjacency row with the distance evaluation, and the
-// workgroup barriers + the LDS round trip cost more than the wider fetch saves.  Kept as an opt-in experiment; its answers and
-// counters are bit-identical to the single-wave kernel (tests run both).
-uint32_t mw_max_nq() {
-  const char* e = getenv("COLTT_MW_MAX_NQ");
-  return e && *e ? (uint32_t)atoi(e) : 0u;
+// Batches of at most COLTT_LAT_MAX_NQ queries (default below; COLTT_MW_MAX_NQ is the round-2 name of the knob) take the
+// 256-thread latency kernel (hnsw_lat.hpp).
+#ifndef COLTT_LAT_MAX_NQ_DEFAULT
+#define COLTT_LAT_MAX_NQ_DEFAULT 0
+#endif
+uint32_t lat_max_nq() {
+  const char* e = getenv("COLTT_LAT_MAX_NQ");
+  if (!e || !*e) e = getenv("COLTT_MW_MAX_NQ");
+  return e && *e ? (uint32_t)atoi(e) : (uint32_t)COLTT_LAT_MAX_NQ_DEFAULT;
 }
 
 int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
@@ -746,21 +767,19 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
   SearchGeom sg = search_geom(x, ef, true);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
-  // opt-in staged kernel.  Its LDS hash must never need the reset path, so it gets the largest table that fits beside the staging
-  // area (one workgroup per CU); if even that is too small for this ef the single-wave kernel serves the call.
-  bool mw = nq <= mw_max_nq() && !force_single_wave;
+  // latency kernel for small batches.  Its LDS hash must never need the reset path, so it gets the largest table that fits beside the
+  // staging area (one workgroup per CU); if even that is too small for this ef the one-wave kernel serves the call.
+  bool mw = nq <= lat_max_nq() && !force_single_wave;
   if (mw) {
-    SearchGeom m = sg; m.w2 = -1; m.bloom_words = 0;
-    // LDS: query + result set + exchange words + the staging area (32 rows) + the visited hash
-    const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)2 * m.ef_pad * 8 + sizeof(MwExchange) + (size_t)MW_ROWS * x->stride;
-    if (x->stride > MW_MAX_STRIDE || x->cfg.m_max0 > 1024) mw = false;               // rows too long to stage 32 at a time
-    else if (m.visg) { m.hcap = 64; m.lds = fixed + 256; }
+    SearchGeom m = sg; m.w2 = -1; m.bloom_words = 0; m.visg = false;
+    // LDS: query + result set + exchange words + the staging area (32 padded rows) + the visited hash
+    const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (size_t)LAT_ROWS * (x->stride + LAT_PAD);
+    if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to stage 32 at a time
     else {
-      m.hcap = 16384; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;
+      m.hcap = 32768; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;
       m.lds = fixed + (size_t)m.hcap * 4;
-      if (m.lds > 160 * 1024 || (m.hcap / 4) * 3 < ef * 34u + 64u) mw = false;        // table too small to be sure: single-wave kernel
+      if (m.lds > 160 * 1024 || (m.hcap / 4) * 3 < ef * 34u + 64u) mw = false;        // table too small to be sure: one-wave kernel
     }
-    if (mw && m.lds > 160 * 1024) mw = false;
     if (mw) sg = m;
   }
   uint32_t grid = mw ? std::min<uint32_t>((uint32_t)nq, 256u) : std::min<uint32_t>((uint32_t)std::min<size_t>(nq, 0xffffffffu), resident_waves(sg, x->quant));
@@ -780,7 +799,7 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
 #define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
-#define COLTT_LS(Q) rc = mw ? (x->metric == COLTT_COSINE ? launch_search_mw<M_COS, Q>(COLTT_LS_ARGS) : launch_search_mw<M_L2, Q>(COLTT_LS_ARGS)) \
+#define COLTT_LS(Q) rc = mw ? (x->metric == COLTT_COSINE ? launch_search_lat<M_COS, Q>(COLTT_LS_ARGS) : launch_search_lat<M_L2, Q>(COLTT_LS_ARGS)) \
                      : sg.w2 >= 0 ? (x->metric == COLTT_COSINE ? launch_search2<M_COS, Q>(COLTT_LS_ARGS) : launch_search2<M_L2, Q>(COLTT_LS_ARGS)) \
                             : (x->metric == COLTT_COSINE ? launch_search<M_COS, Q>(COLTT_LS_ARGS) : launch_search<M_L2, Q>(COLTT_LS_ARGS))
   COLTT_DISPATCH_QUANT(x->quant, COLTT_LS)
@@ -803,7 +822,9 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
 #ifdef COLTT_PHASE_TIMING
   {
-    static const char* nm[8] = {"pop", "adjacency", "visited", "rows+dist", "merge", "prologue(upper levels)", "writeout", "-"};
+    static const char* nm_w[8] = {"pop", "adjacency", "visited", "rows+dist", "merge", "prologue(upper levels)", "writeout", "-"};
+    static const char* nm_l[8] = {"pop+publish", "adjacency", "visited+fetch+stage", "eval", "barrier2+admission", "-", "prologue(upper levels)", "-"};
+    const char* const* nm = mw ? nm_l : nm_w;
     double tot = 0; for (int i = 0; i < 7; i++) tot += (double)h_pt[i];
     fprintf(stderr, "[phase] nq=%zu ef=%u visg=%d:", nq, sg.ef, (int)sg.visg);
     for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_pt[i] / tot);

@@ -2,7 +2,7 @@
 //
 // One wave64 owns one query (or one vertex being inserted).  State in LDS, per wave:
 //   qs   [dim] f32         the query as the distance kernel sees it (normalised / decoded)
-//   res  [ef_pad] u64      result set, sorted ascending, merged in place (the staged multi-wave kernel keeps two buffers);
+//   res  [ef_pad] u64      result set, sorted ascending, merged in place;
 //                          entry = d_bits<<32 | slot<<1 | expanded
 //   vis  [hcap] u32        open-addressed visited set (slots), linear probing, EMPTY = 0xffffffff   (VISG = false)
 // or, VISG = true, the visited set lives in HBM: one byte per slot in a region private to the workgroup, holding the epoch of
@@ -130,13 +130,13 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
 // 22.81 / 47.37 / 174.6, U = 12 22.06 / 43.89 / 165.6, U = 8 23.75 / 46.83 / 176.2.  Hence 12 for f32 rows in every profile.
 // 2-byte rows: the LDS-visited kernel runs 1 wave per SIMD and keeps a WHOLE 768-dim row in flight (U = 48, 13.15 -> 11.88 ms at
 // 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under 256 registers (U = 24).
-enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_MW = 3, PROF_SEARCH_HBM_DEEP = 4 };
+enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_HBM_DEEP = 4 };
 #ifndef COLTT_U_F32      // measurement knob: burst depth of f32 rows, all profiles
 #define COLTT_U_F32 12
 #endif
 template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst_depth() {
   if (QUANT == Q_NONE) return COLTT_U_F32;
-  if (PROFILE == PROF_SEARCH_HBM_DEEP || PROFILE == PROF_SEARCH_MW) return 48;   // one wave per SIMD: a whole 2-byte row in flight
+  if (PROFILE == PROF_SEARCH_HBM_DEEP) return 48;   // one wave per SIMD: a whole 2-byte row in flight
   return PROFILE == PROF_SEARCH_LDS ? 48 : 24;
 }
 template <int METRIC, int QUANT, int PROFILE>
@@ -393,160 +393,6 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
   out_buf = buf;
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// searchLevel for ONE query on a 256-thread workgroup: the LATENCY path of the single-query RPC (core/core.go:633-667 serves
-// one query per call).  With one query in flight the chip is idle and an expansion is a chain of dependent round trips; the
-// longest link in the single-wave kernel is the row fetch — a lane pair streams its whole 3 KB row through 96 sequential 16-byte
-// loads (the residue chains must be summed in index order), i.e. several HBM round trips per expansion.  Here the arithmetic
-// order is untouched but the FETCH is decoupled from it: all 256 threads copy the fresh rows of the expansion into LDS with
-// every load in flight at once (32 rows x 3 KB = 96 KB, 24 x 16 B per thread: ONE round trip), then wave 0 evaluates the
-// distances out of LDS with exactly the single-wave kernel's lane-pair code (same residue chains, same order, same bits) and
-// runs the admission rule and the merge as before.  Waves 1-3 only fetch.
-// The visited set is the HBM byte map or a 8 192-entry LDS hash that is never reset here (a traversal that would need the
-// reset reports err 8 and the host re-runs the call on the single-wave kernel).
-struct MwExchange { uint32_t nb[32]; uint32_t fresh[32]; uint32_t ctl[8]; };  // ctl: 0 state (1 go, 0 done), 1 cslot, 2 query index
-
-constexpr int MW_ROWS = 32;           // neighbours staged per chunk
-constexpr int MW_MAX_STRIDE = 3200;   // bytes per row the staging area takes (32 x 3200 = 100 KB): f32 up to dim 800, 2-byte codes up to 1600
-
-template <int METRIC, int QUANT, bool VISG>
-__device__ __forceinline__ void search_level_mw(const GraphView& g, WaveCtx& w, MwExchange* xs, uint8_t* stage, uint32_t ep, float epd,
-                                                uint32_t ef, int level, int lane_in, int wave, uint32_t& out_len, int& out_buf) {
-  int lane = lane_in;
-  const int tid = wave * 64 + lane;
-  const uint32_t chunks = (uint32_t)(g.stride >> 4);   // 16-byte pieces per row (<= 200)
-  if constexpr (VISG) {
-    if (++w.epoch > 255u) {  // every wave keeps the same epoch copy; the wipe is shared by the 256 threads
-      for (size_t i = (size_t)tid * 16; i < w.vis_bytes; i += 256 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
-      __threadfence();
-      w.epoch = 1;
-    }
-  } else {
-    for (uint32_t i = tid; i < w.hcap; i += 256) w.vis[i] = VIS_EMPTY;
-  }
-  __syncthreads();
-  int buf = 0;
-  if (tid == 0) {
-    w.res0[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
-    if constexpr (VISG) __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else vis_insert(w.vis, w.hcap_mask, ep);
-  }
-  uint32_t len = 1, vis_count = 1;
-  __syncthreads();
-  for (uint32_t iters = 0;; iters++) {
-    lane = opaque_lane(lane_in);
-    const int half = lane & 1, p = lane >> 1;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    float lower_bound = 0.f; uint32_t free_slots = 0;
-    if (wave == 0) {  // ---- pop: the smallest unexpanded member
-      unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
-      int ci = -1;
-      if (iters <= (1u << 22)) {
-        for (uint32_t base = 0; base < len; base += 64) {
-          uint32_t i = base + lane;
-          bool un = i < len && !(res[i] & 1ull);
-          unsigned long long m = __ballot(un);
-          if (m) { ci = (int)base + __builtin_ctzll(m); break; }
-        }
-      } else w.err |= 2u;
-      if (!VISG && ci >= 0 && vis_count + 64 > (w.hcap >> 2) * 3) { w.err |= 8u; ci = -1; }  // would need the reset path: give up
-      if (ci >= 0) {
-        unsigned long long ce = res[ci];
-        lower_bound = __uint_as_float((uint32_t)(res[len - 1] >> 32));
-        wave_sync();
-        if (lane == 0) { res[ci] = ce | 1ull; xs->ctl[0] = 1u; xs->ctl[1] = (uint32_t)ce >> 1; }
-        free_slots = ef - len;
-        w.n_exp++;
-      } else if (lane == 0) xs->ctl[0] = 0u;
-    }
-    __syncthreads();
-    if (xs->ctl[0] == 0u) break;
-    const uint32_t cslot = xs->ctl[1];
-    uint32_t width;
-    const uint32_t* row = adj_row(g, cslot, level, width);
-    for (uint32_t c0 = 0; c0 < width; c0 += MW_ROWS) {
-      uint32_t nb = NBR_NONE; bool fresh = false; float rn = 0.f;
-      if (wave == 0) {  // ---- adjacency + visited test-and-set (wave 0, lane pair p = neighbour c0 + p)
-        const uint32_t idx = c0 + (uint32_t)p;
-        nb = idx < width ? row[idx] : NBR_NONE;
-        const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
-        int fresh_i = 0;
-        if (valid && half == 0) {
-          if constexpr (VISG) {
-            const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
-            if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
-        }
-        fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);  // even lane's verdict to its pair
-        fresh = fresh_i != 0;
-        if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = (uint32_t)fresh_i; }
-        if constexpr (METRIC == M_COS) { if (fresh) rn = g.norms[nb]; }     // flies during the staging below
-      }
-      __syncthreads();
-      {  // ---- stage: every fresh row of the chunk, global -> LDS, all loads in flight before the first store.
-         // The chunk's ids and fresh flags are pulled into registers ONCE (one LDS read per lane) and handed out as wave-uniform
-         // scalars, so the 32 loads issue back to back instead of each waiting on its own LDS round trip.
-        const uint32_t my_nb = xs->nb[lane & 31];
-        const unsigned long long fm = __ballot(xs->fresh[lane & 31] != 0u && lane < 32);
-        u32x4v tmp[MW_ROWS];
-        const bool mine = (uint32_t)tid < chunks;
-        const uint8_t* src0 = g.rows + (size_t)tid * 16;
-#pragma unroll
-        for (int j = 0; j < MW_ROWS; j++) {
-          const uint32_t nbj = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, j);
-          if (((fm >> j) & 1ull) && mine) tmp[j] = *reinterpret_cast<const u32x4v*>(src0 + (size_t)nbj * g.stride);
-        }
-#pragma unroll
-        for (int j = 0; j < MW_ROWS; j++)
-          if (((fm >> j) & 1ull) && mine) *reinterpret_cast<u32x4v*>(stage + (size_t)j * g.stride + (size_t)tid * 16) = tmp[j];
-      }
-      __syncthreads();
-      if (wave == 0) {  // ---- distances out of LDS (lane pair p, the single-wave kernel's arithmetic), admission, merge
-        unsigned long long* res = w.res0 + (size_t)buf * w.ef_pad;
-        unsigned long long E = __ballot(fresh && half == 0);
-        uint32_t nfresh = __popcll(E);
-        if (nfresh) {
-          vis_count += nfresh; w.n_dist += nfresh;
-          float d = 0.f;
-          if (fresh) d = pair_distance<METRIC, QUANT, 8>(stage + (size_t)p * g.stride, w.qs, g.dim, w.qnorm, rn, half);
-          uint32_t rank = __popcll(E & lt_mask);
-          bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
-          free_slots = free_slots > nfresh ? free_slots - nfresh : 0;
-          unsigned long long A = __ballot(adm);
-          uint32_t m = __popcll(A);
-          if (m) {
-            unsigned long long mykey = adm ? (((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)nb << 1)) : ~0ull;
-            uint32_t myrank = 0;
-            {
-              unsigned long long am = A;
-              while (am) { int j = __builtin_ctzll(am); am &= am - 1; unsigned long long kj = readlane_u64(mykey, j); myrank += (kj < mykey) ? 1u : 0u; }
-            }
-            unsigned long long* dst = w.res0 + (size_t)(buf ^ 1) * w.ef_pad;
-            uint32_t mypos = 0;
-            if (adm) { uint32_t lo = 0, hi = len; while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (res[mid] < mykey) lo = mid + 1; else hi = mid; } mypos = lo; }
-            for (uint32_t base = 0; base < len; base += 64) {
-              uint32_t i = base + lane;
-              unsigned long long e = i < len ? res[i] : ~0ull;
-              uint32_t shift = 0;
-              unsigned long long am = A;
-              while (am) { int j = __builtin_ctzll(am); am &= am - 1; unsigned long long kj = readlane_u64(mykey, j); shift += (kj < e) ? 1u : 0u; }
-              uint32_t np = i + shift;
-              if (i < len && np < ef) dst[np] = e;
-            }
-            { uint32_t np = mypos + myrank; if (adm && np < ef) dst[np] = mykey; }
-            len = len + m < ef ? len + m : ef;
-            buf ^= 1;
-          }
-        }
-      }
-      __syncthreads();   // the staging area and the exchange words are reused by the next chunk
-    }
-  }
-  out_len = len;   // meaningful on wave 0
-  out_buf = buf;
-}
 
 }  // namespace dev
 }  // namespace coltt

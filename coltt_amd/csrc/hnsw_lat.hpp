@@ -1,0 +1,247 @@
+// hnsw_lat.hpp — Hnsw.Search for ONE query on a 256-thread workgroup: the LATENCY path of the reference's RPC shape
+// (core/core.go:633-667 and edge/edge.go:610-690 serve one query per call).
+//
+// With a single query in flight the chip is idle and an expansion is a chain of dependent round trips.  In the one-wave kernel the
+// longest link is the row fetch: a lane pair streams its 3 KB row through 96 sequential 16-byte loads in bursts (the residue chains
+// must be summed in index order), several HBM round trips per expansion.  Here the FETCH is decoupled from the arithmetic order and
+// every wave computes:
+//   * wave w owns neighbours 8w .. 8w+7 of the expansion; EIGHT lanes cover one row, lane j of the group loading the 16-byte
+//     pieces j, j+8, j+16, ... — one whole 128-byte line per row per instruction, the whole row in flight at once: ONE round trip
+//     for all 32 rows (96 KB at 768 x f32);
+//   * the pieces are copied to LDS as they are and read back element-wise: lane j of the group owns residue j of the reference's
+//     8-lane AVX accumulator (pkg/distance/simd/cpp/avx.cpp:15-32,51-75) and adds q[8g+j] * r[8g+j] for g = 0, 1, 2, ... strictly in
+//     order (separate multiply and add); the eight partial sums are combined ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)) by a DPP butterfly
+//     (IEEE addition commutes, so both sides of every exchange hold the same bits), then the scalar tail and the epilogue of
+//     exact.hpp.  Same values, same order, same bits as pair_distance — the parity tests run both kernels;
+//   * wave 0 keeps what is inherently serial — pop, visited test-and-set (LDS hash), admission — by running hnsw_walk2.hpp's
+//     search_level2 with the delta result set (an admission is a register move) and this file's evaluator in place of the lane-pair
+//     distance code; the neighbours' adjacency rows are fetched WITH their vectors, so the next candidate's row is on chip.
+// Two workgroup barriers per expansion (LDS-only: loads requested ahead of time stay in flight across them).  The visited set is an LDS hash that is never reset here: a traversal that would need the
+// reset reports err 8 and the host re-runs the call on the one-wave kernel (hnsw.hip: search_common).
+#pragma once
+#include "hnsw_walk2.hpp"
+
+namespace coltt {
+namespace dev {
+
+constexpr int LAT_ROWS = 32;            // neighbours evaluated per chunk (8 per wave)
+constexpr int LAT_MAX_STRIDE = 3200;    // bytes per stored row the staging area takes: f32 up to dim 800, 2-byte codes up to 1600
+constexpr int LAT_PAD = 32;             // staging rows are padded by 8 dwords: the 8 rows of a wave land on disjoint LDS banks
+constexpr int LAT_MAX_PIECES = LAT_MAX_STRIDE / 128;   // 16-byte pieces per lane per row (25)
+
+struct LatShared {
+  uint32_t nb[LAT_ROWS];      // neighbour slots of the chunk (NBR_NONE = none)
+  uint32_t fresh[LAT_ROWS];   // 1 = evaluate
+  float d[LAT_ROWS];          // distances
+  uint32_t ctl[8];            // 0 state (1 go, 0 done), 1 query index, 2/3 greedy verdict
+  uint32_t adjn[LAT_ROWS][32] __attribute__((aligned(16)));   // level-0 adjacency rows of the chunk's fresh neighbours (mMax0 <= 32): fetched WITH
+                              // their vectors, so the next candidate's neighbour list is on chip the moment it is chosen
+};
+// The query as the residue lanes read it: qT[j * n8p + g] = q[8 g + j] (n8p = n8 rounded up to 4, + 4: every residue row starts on a
+// 16-byte boundary and the eight rows on disjoint LDS banks), followed by the scalar tail q[8 n8 .. dim).
+__device__ __host__ __forceinline__ int lat_n8p(int dim) { return (((dim >> 3) + 3) & ~3) + 4; }
+__device__ __host__ __forceinline__ size_t lat_q_floats(int dim) { return (size_t)8 * lat_n8p(dim) + 8; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt — i.e. it would wait for the adjacency rows
+// requested ahead of time, which are exactly the loads that must stay in flight across the barrier.  Nothing but LDS is handed
+// from wave to wave in this kernel.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// element e of a staged row, decoded
+template <int QUANT> __device__ __forceinline__ float lat_elem(const uint8_t* __restrict__ row, int e) {
+  if constexpr (QUANT == Q_NONE) return *reinterpret_cast<const float*>(row + (size_t)e * 4);
+  else if constexpr (QUANT == Q_F8) return __uint_as_float(f8bits_to_f32bits(row[e]));
+  else return f16bits_to_f32(*reinterpret_cast<const unsigned short*>(row + (size_t)e * 2));
+}
+
+#ifdef COLTT_PHASE_TIMING   // diagnostic build: shader-clock ticks per phase of wave 0 (slots of WaveCtx::pt)
+#define COLTT_LT(W, K) { if (wave == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); const_cast<WaveCtx&>(W).pt[K] += t_ - (W).t_last; const_cast<WaveCtx&>(W).t_last = t_; } }
+#define COLTT_LT0(W, K) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); const_cast<WaveCtx&>(W).pt[K] += t_ - (W).t_last; const_cast<WaveCtx&>(W).t_last = t_; }
+#else
+#define COLTT_LT(W, K)
+#define COLTT_LT0(W, K)
+#endif
+// Distances of the chunk's fresh neighbours (xs->nb / xs->fresh, written by wave 0 before the barrier) -> xs->d.
+// Called by all four waves; no workgroup barrier inside (a wave stages and evaluates its own 8 rows).
+// ADJ: also fetch the fresh neighbours' level-0 adjacency rows into xs->adjn (one 16-byte load per lane: 8 lanes = 32 ids).
+struct LatNoMid { __device__ __forceinline__ void operator()() const {} };
+// MID: called (by every wave) after the row loads have been ISSUED and before they are waited for — wave 0 runs the previous
+// expansion's merge there, under the shadow of the fetch.
+template <int METRIC, int QUANT, bool ADJ, class MID = LatNoMid>
+__device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane, MID&& mid = MID()) {
+  const int r = lane >> 3, j = lane & 7;            // row of this wave's eight, lane within the row
+  const int idx = wave * 8 + r;
+  const uint32_t nb = xs->nb[idx];
+  const bool fresh = xs->fresh[idx] != 0u;
+  const int lds_stride = (int)g.stride + LAT_PAD;
+  uint8_t* srow = stage + (size_t)idx * lds_stride;
+  const int pieces = (int)(g.stride >> 4);          // 16-byte pieces per row (the stride is a multiple of 16)
+  const int n8 = g.dim >> 3, n8p = lat_n8p(g.dim);
+  float rn = 0.f;
+  if (__ballot(fresh)) {
+    // ---- fetch: every piece of every fresh row of this wave in flight before the first one is stored
+    u32x4v tmp[LAT_MAX_PIECES];
+    u32x4v adj = {NBR_NONE, NBR_NONE, NBR_NONE, NBR_NONE};
+    const uint8_t* src = g.rows + (size_t)nb * g.stride;
+#pragma unroll
+    for (int t = 0; t < LAT_MAX_PIECES; t++) {
+      const int pc = t * 8 + j;
+      if (fresh && pc < pieces) tmp[t] = *reinterpret_cast<const u32x4v*>(src + (size_t)pc * 16);
+    }
+    if constexpr (ADJ) { if (fresh && (uint32_t)(j * 4) < g.mMax0) adj = *reinterpret_cast<const u32x4v*>(g.adj0 + (size_t)nb * g.mMax0 + j * 4); }
+    if constexpr (METRIC == M_COS) { if (fresh) rn = g.norms[nb]; }
+    mid();
+#pragma unroll
+    for (int t = 0; t < LAT_MAX_PIECES; t++) {
+      const int pc = t * 8 + j;
+      if (fresh && pc < pieces) *reinterpret_cast<u32x4v*>(srow + (size_t)pc * 16) = tmp[t];
+    }
+    COLTT_LT(w, 2)   // fetch issued + landed + staged
+    if constexpr (ADJ) { if (fresh) *reinterpret_cast<u32x4v*>(&xs->adjn[idx][j * 4]) = adj; }
+  } else mid();
+  wave_sync();   // the rows of this wave were staged by this wave
+  float d = 0.f;
+  if (__ballot(fresh)) {
+    // ---- evaluate out of LDS: lane j = residue j of the 8-lane accumulator, groups in increasing order.  Blocks of 16 groups:
+    // the 16 row elements and the 16 query elements (4 x ds_read_b128 of the transposed query) are requested together, then
+    // the 16 multiply / add pairs run in order.
+    float acc = 0.f;
+    const float* qT = w.qs + (size_t)j * n8p;
+    if (fresh) {
+      int gq = 0;
+      for (; gq + 16 <= n8; gq += 16) {
+        float rv[16]; f32x4 qv[4];
+#pragma unroll
+        for (int u = 0; u < 16; u++) rv[u] = lat_elem<QUANT>(srow, 8 * (gq + u) + j);
+#pragma unroll
+        for (int u = 0; u < 4; u++) qv[u] = *reinterpret_cast<const f32x4*>(qT + gq + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const float qe = qv[u >> 2][u & 3];
+          if constexpr (METRIC == M_COS) { const float p = qe * rv[u]; acc = acc + p; }
+          else { const float df = qe - rv[u]; const float p = df * df; acc = acc + p; }
+        }
+      }
+      for (; gq < n8; gq++) {
+        const float rv = lat_elem<QUANT>(srow, 8 * gq + j);
+        const float qe = qT[gq];
+        if constexpr (METRIC == M_COS) { const float p = qe * rv; acc = acc + p; }
+        else { const float df = qe - rv; const float p = df * df; acc = acc + p; }
+      }
+    }
+    // ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)): butterfly over the 8 lanes of the row (all lanes take part in the DPP moves)
+    float s = acc;
+    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
+    if (fresh) {
+      const float* qtail = w.qs + (size_t)8 * n8p;
+      for (int e = n8 * 8; e < g.dim; e++) {  // scalar tail (avx.cpp:28-31,68-72), the same in every lane of the row
+        const float rv = lat_elem<QUANT>(srow, e);
+        const float qe = qtail[e - n8 * 8];
+        if constexpr (METRIC == M_COS) s += qe * rv;
+        else { const float df = qe - rv; s += df * df; }
+      }
+      if constexpr (METRIC == M_COS) d = cos_epilogue(s, w.qnorm, rn);
+      else d = go_sqrt(s);
+    }
+  }
+  if (j == 0) xs->d[idx] = d;
+  COLTT_LT(w, 3)   // evaluation out of LDS
+}
+
+// Run one chunk through the four waves: wave 0 has written xs->nb / xs->fresh.  Two barriers; afterwards xs->d is valid.
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void lat_chunk(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane) {
+  __syncthreads();
+  lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, wave, lane);
+  __syncthreads();
+}
+
+// greedyClosestNeighbor (hnsw.go:320-343) on an upper level, all four waves.  cur / curd are meaningful on wave 0 and are
+// handed to the other waves through the exchange words (every wave follows the same hop sequence).
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w, LatShared* xs, uint8_t* stage, uint32_t& cur, float& curd,
+                                                 int level, int wave, int lane_in) {
+  for (uint32_t hops = 0;; hops++) {
+    const int lane = opaque_lane(lane_in);
+    const int p = lane >> 1;
+    uint32_t width;
+    const uint32_t* row = adj_row(g, cur, level, width);
+    unsigned long long best = ~0ull; uint32_t best_slot = NBR_NONE;
+    if (hops > (1u << 20)) { w.err |= 4u; }
+    for (uint32_t c0 = 0; c0 < width && hops <= (1u << 20); c0 += LAT_ROWS) {
+      uint32_t nb = NBR_NONE; bool valid = false;
+      if (wave == 0) {
+        const uint32_t idx = c0 + (uint32_t)p;
+        nb = idx < width ? row[idx] : NBR_NONE;
+        valid = nb != NBR_NONE && !is_deleted(g, nb);
+        if ((lane & 1) == 0) { xs->nb[p] = nb; xs->fresh[p] = valid ? 1u : 0u; }
+      }
+      lat_chunk<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+      if (wave == 0) {
+        const float d = xs->d[p];
+        w.n_dist += __popcll(__ballot(valid && (lane & 1) == 0));
+        const unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | (c0 + (uint32_t)p)) : ~0ull;
+        const unsigned long long km = wave_min_u64(key);
+        if (km < best) {
+          best = km;
+          best_slot = (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)(((uint32_t)km - c0) * 2));
+        }
+      }
+    }
+    // every wave must take the same branch: wave 0 publishes the verdict
+    if (wave == 0) {
+      w.n_hops++;
+      const float bd = __uint_as_float((uint32_t)(best >> 32));
+      const bool move = best != ~0ull && bd < curd && hops <= (1u << 20);
+      if (move) { cur = best_slot; curd = bd; }
+      if (lane == 0) { xs->ctl[2] = move ? 1u : 0u; xs->ctl[3] = cur; }
+    }
+    __syncthreads();
+    const bool move = xs->ctl[2] != 0u;
+    cur = xs->ctl[3];
+    __syncthreads();   // ctl is rewritten by the next hop
+    if (!move) break;
+  }
+}
+
+// Level 0: wave 0 runs hnsw_walk2.hpp's search_level2 — delta result set (admissions are register moves, no per-chunk merge on the
+// critical path), LDS-hash visited set, adjacency prefetch — with THIS evaluator: the chunk's neighbours are published, all four waves
+// fetch and evaluate them (lat_eval_chunk), the distances come back through LDS.  The other waves sit in lat_companion().
+// The chunk's adjacency rows come along with its vectors (xs->adjn), so the next candidate's neighbour list is on chip when it is
+// chosen (search_level2: CHUNK_ADJ); the runner-up's row is requested at pop time.
+template <int METRIC, int QUANT> struct LatEval {
+  static constexpr bool CHUNK_ADJ = true;
+  LatShared* xs; uint8_t* stage;
+  __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }
+  __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float /*nrm*/, int half, int lane) const {
+    const int p = lane >> 1;
+    if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = fresh ? 1u : 0u; }
+    COLTT_LT0(w, 0)   // walk: pop + visited + admission of the previous chunk
+    lds_barrier();
+    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, 0, lane);
+    else lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, 0, lane);
+    lds_barrier();
+    COLTT_LT0(w, 4)   // barrier 2 (the slowest wave)
+    return xs->d[p];
+  }
+};
+// waves 1-3 while wave 0 walks: one round per published chunk until wave 0 clears ctl[0]
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane) {
+  for (;;) {
+    lds_barrier();
+    if (xs->ctl[0] == 0u) break;
+    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, wave, lane);
+    else lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, wave, lane);
+    lds_barrier();
+  }
+}
+
+}  // namespace dev
+}  // namespace coltt

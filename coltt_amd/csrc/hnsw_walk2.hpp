@@ -17,6 +17,7 @@
 //
 // The wave must be the only one in its workgroup (wave_sync is a wave-level LDS fence).  VISG (HBM byte map) only.
 #pragma once
+#include <type_traits>
 #include "hnsw_dev.hpp"
 
 namespace coltt {
@@ -149,30 +150,47 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
   }
 }
 
+// Where the distances of a chunk come from.  The throughput kernels evaluate them in place (one lane pair per row, exact.hpp); the
+// latency kernel (hnsw_lat.hpp) hands the chunk to all four waves of its workgroup.  Called by every lane of the walking wave.
+template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
+  static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
+  __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+  __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
+    if (!fresh) return 0.f;
+    if constexpr (ADJN) return eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
+    else return eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+  }
+};
+enum { VIS_HBM = 0, VIS_LDS = 1 };   // visited set of search_level2: HBM byte map (behind the Bloom filter) | LDS hash that is never reset (err 8)
+
 // searchLevel (hnsw.go:345-389) on level 0.  On return res[0, len) holds the result set ascending by (d, slot).
-template <int METRIC, int QUANT, int PROFILE, int OPT>
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool ALWAYS_PREF = false, class EVAL = PairEval<METRIC, QUANT, PROFILE, (OPT & W2_ADJN) != 0 && METRIC == M_COS>>
 __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef, int lane_in,
-                                              uint32_t& out_len) {
-  constexpr bool BLOOM = (OPT & W2_BLOOM) != 0, DELTA = (OPT & W2_DELTA) != 0, ADJN = (OPT & W2_ADJN) != 0 && METRIC == M_COS;
+                                              uint32_t& out_len, EVAL&& ev = EVAL()) {
+  constexpr bool BLOOM = (OPT & W2_BLOOM) != 0 && VISMODE == VIS_HBM, DELTA = (OPT & W2_DELTA) != 0, ADJN = (OPT & W2_ADJN) != 0 && METRIC == M_COS;
 #ifdef COLTT_NO_ADJ_PREFETCH
-  constexpr bool PREF = false;
+  constexpr bool PREF = ALWAYS_PREF;
 #else
-  constexpr bool PREF = QUANT != Q_NONE;  // see hnsw_dev.hpp: the adjacency prefetch pays for 2-/1-byte rows only
+  constexpr bool PREF = ALWAYS_PREF || QUANT != Q_NONE;  // see hnsw_dev.hpp: in the throughput kernels the adjacency prefetch pays for 2-/1-byte rows only
 #endif
   int lane = lane_in;
   unsigned long long* const res = w.res0;
-  if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
-    for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
-    __threadfence();
-    w.epoch = 1;
-  }
+  uint32_t vis_count = 1;
+  if constexpr (VISMODE == VIS_HBM) {
+    if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
+      for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
+      __threadfence();
+      w.epoch = 1;
+    }
+  } else vis_clear(w, lane);
   if constexpr (BLOOM) {
     for (uint32_t i = (uint32_t)lane * 4; i < w.bloom_words; i += 256) *reinterpret_cast<u32x4v*>(w.bloom + i) = u32x4v{0, 0, 0, 0};
   }
   if (lane == 0) res[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
   wave_sync();
   if (lane == 0) {
-    __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (VISMODE == VIS_HBM) __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else vis_insert(w.vis, w.hcap_mask, ep);
     if constexpr (BLOOM) {
       const uint32_t h = ep * 0x9E3779B1u;
       w.bloom[h >> w.bloom_shift] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
@@ -210,6 +228,9 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       dlane = wave_argmin_key(d_un, dl.hi, dl.lo, kd);
     }
     if (ci < 0 && dlane < 0) break;
+    if constexpr (VISMODE == VIS_LDS) {
+      if (vis_count + 64 > (w.hcap >> 2) * 3) { w.err |= 8u; break; }   // the table would need the reset path: give up, the host re-runs the call on the one-wave kernel
+    }
     const bool from_delta = kd < kci;
     const unsigned long long ce = from_delta ? kd : kci;
     unsigned long long runner_key = ~0ull;
@@ -222,6 +243,14 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         runner_key = kcj < kd ? kcj : kd;
       }
     }
+    // evaluators that fetch the chunk's adjacency rows with its vectors (hnsw_lat.hpp): the only adjacency row that can be
+    // needed next and is not on chip then is the runner-up's — requested now, it flies during the whole expansion
+    typedef typename std::remove_reference<EVAL>::type eval_t;
+    uint32_t runner_nb = NBR_NONE;
+    if constexpr (eval_t::CHUNK_ADJ && PREF) {
+      if (runner_key != ~0ull && (uint32_t)p < g.mMax0) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * g.mMax0 + p];
+    }
+    int best_src = -1;   // lane of the smallest key admitted in this expansion's (single) chunk
     COLTT_PT(w, 0)  // pop
     // lowerBound: the distance of the largest member, sampled once per pop (hnsw.go:357)
     unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
@@ -245,7 +274,9 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
       if (nk_ != ~0ull) {                                                                            \
         pre_slot = (uint32_t)nk_ >> 1;                                                               \
-        pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;             \
+        if (eval_t::CHUNK_ADJ && width <= 32 && runner_key < best_new) pre_nb = runner_nb;           \
+        else if (eval_t::CHUNK_ADJ && width <= 32 && best_src >= 0) pre_nb = (uint32_t)p < width ? ev.chunk_adj(best_src >> 1, p) : NBR_NONE; \
+        else pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;        \
         if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \
       }                                                                                              \
     }
@@ -271,11 +302,14 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
           const uint32_t old = atomicOr(&w.bloom[h >> w.bloom_shift], bits);
           maybe = (old & bits) == bits;
         }
-        if (maybe) {
-          const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
-        } else fresh_i = 1;
-        if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+        else {
+          if (maybe) {
+            const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
+          } else fresh_i = 1;
+          if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);  // even lane's verdict to its pair: quad_perm [0,0,2,2]
       const bool fresh = fresh_i != 0;
@@ -284,12 +318,8 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       COLTT_PT(w, 2)  // visited test-and-set
       const bool last_chunk = c0 + 32 >= width;
       if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT2() } continue; }
-      w.n_dist += nfresh;
-      float d = 0.f;
-      if (fresh) {
-        if constexpr (ADJN) d = eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
-        else d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
-      }
+      w.n_dist += nfresh; vis_count += nfresh;
+      const float d = ev(g, w, nb, fresh, nrm, half, lane);
       const uint32_t rank = __popcll(E & lt_mask);
       const bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
 #ifdef COLTT_PHASE_TIMING
@@ -303,7 +333,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       const unsigned long long mykey = adm ? (((unsigned long long)khi << 32) | klo) : ~0ull;
       if constexpr (DELTA) {
         if (m) {
-          if constexpr (PREF) { unsigned long long mn; (void)wave_argmin_key(adm, khi, klo, mn); best_new = mn < best_new ? mn : best_new; }
+          if constexpr (PREF) { unsigned long long mn; const int bl = wave_argmin_key(adm, khi, klo, mn); if (mn < best_new) { best_new = mn; best_src = bl; } }
         }
         if (last_chunk) { COLTT_PREFETCH_NEXT2() }
         if (m == 0) continue;
@@ -335,7 +365,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         if (m) {  // the smallest admitted key is the one of rank 0
           const unsigned long long z = __ballot(adm && myrank == 0);
           const unsigned long long mn = readlane_u64(mykey, __builtin_ctzll(z));
-          best_new = mn < best_new ? mn : best_new;
+          if (mn < best_new) { best_new = mn; best_src = (int)__builtin_ctzll(z); }
         }
         if (last_chunk) { COLTT_PREFETCH_NEXT2() }
         if (m == 0) continue;

@@ -102,9 +102,11 @@ __global__ void row_norms_kernel(const uint8_t* __restrict__ rows, size_t stride
 // one lane walks it — but over an LDS copy the whole wave fetched with coalesced loads, and the element-wise half
 // (divide, Lower, decode) runs on all 64 lanes.  (One THREAD per query, each striding through its own row, cost 330 us for
 // 256 x 768 queries: 5 % of a batched FLAT search.)
+// qn != null (dim <= PQ_CHUNK): also ||q_eff||^2 in AVX order (what query_norms_kernel computes), from the LDS copy of the vector just
+// written — one launch less on the single-query path, where every launch is ~10 us of a ~100 us search.
 template <int QUANT>
 __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ raw, uint64_t nq, int dim, int normalize,
-                                                          float* __restrict__ q_eff) {
+                                                          float* __restrict__ q_eff, float* __restrict__ qn) {
   __shared__ __attribute__((aligned(16))) float buf[PQ_CHUNK];
   __shared__ float s_norm;
   const uint64_t i = blockIdx.x;
@@ -133,11 +135,34 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     if constexpr (QUANT == Q_F8) x = __uint_as_float(f8bits_to_f32bits(f32bits_to_f8bits(__float_as_uint(x))));
     else if constexpr (QUANT != Q_NONE) x = f16bits_to_f32(f32bits_to_f16bits(__float_as_uint(x)));
     out[e] = x;
+    if (qn) buf[e] = x;
+  }
+  if (qn) {   // the norm_a accumulator of avx.cpp:51-75 for this query: lanes 0 / 1 are the two halves of the 8-lane register
+    __syncthreads();
+    if (lane < 2) {
+      const int half = lane, n8 = dim >> 3;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      int t = 0;
+      for (; t + 4 <= n8; t += 4) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(buf + 8 * t + 4 * half), r1 = *reinterpret_cast<const f32x4*>(buf + 8 * (t + 1) + 4 * half);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(buf + 8 * (t + 2) + 4 * half), r3 = *reinterpret_cast<const f32x4*>(buf + 8 * (t + 3) + 4 * half);
+        f32x4 p = r0 * r0; acc = acc + p; p = r1 * r1; acc = acc + p; p = r2 * r2; acc = acc + p; p = r3 * r3; acc = acc + p;
+      }
+      for (; t < n8; t++) { const f32x4 r = *reinterpret_cast<const f32x4*>(buf + 8 * t + 4 * half); const f32x4 p = r * r; acc = acc + p; }
+      float sq = pair_hsum(acc, half);
+      for (int e = n8 * 8; e < dim; e++) { const float r = buf[e]; sq += r * r; }
+      if (lane == 0) qn[i] = sq;
+    }
   }
 }
+static __global__ void query_norms_kernel(const float* __restrict__ q_eff, uint64_t nq, int dim, float* __restrict__ qn);
+// q_eff <- Normalize / Lower / decode of the raw queries; qn (may be null) <- their AVX-order squared norms
 template <int QUANT>
-inline void launch_prep_queries(hipStream_t st, const float* raw, uint64_t nq, int dim, int normalize, float* q_eff) {
-  if (nq) prep_queries_kernel<QUANT><<<(unsigned)nq, 64, 0, st>>>(raw, nq, dim, normalize, q_eff);
+inline void launch_prep_queries(hipStream_t st, const float* raw, uint64_t nq, int dim, int normalize, float* q_eff, float* qn = nullptr) {
+  if (!nq) return;
+  const bool fused = qn && dim <= PQ_CHUNK;
+  prep_queries_kernel<QUANT><<<(unsigned)nq, 64, 0, st>>>(raw, nq, dim, normalize, q_eff, fused ? qn : nullptr);
+  if (qn && !fused) query_norms_kernel<<<(unsigned)((nq * 2 + 255) / 256), 256, 0, st>>>(q_eff, nq, dim, qn);
 }
 static __global__ void query_norms_kernel(const float* __restrict__ q_eff, uint64_t nq, int dim, float* __restrict__ qn) {
   uint64_t pair = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;

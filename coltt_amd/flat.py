@@ -102,13 +102,13 @@ class FlatSpace:
                                                  C.c_void_p(d_ids), C.c_void_p(d_scores), C.c_void_p(d_counts)))
 
     # -- FilterableVertexSearch (edge/none_vectorstore.go:182-253): candidates = ids from the inverted index
-    def FilterableVertexSearch(self, candidates, targets, topK, select=L.SELECT_REFERENCE):
+    def FilterableVertexSearch(self, candidates, targets, topK, select=L.SELECT_REFERENCE, mode=L.MODE_EXACT):
         q = np.ascontiguousarray(targets, np.float32).reshape(-1, self.dim)
         cand = np.ascontiguousarray(candidates, np.uint64).reshape(-1)
         nq = q.shape[0]
         ids = np.zeros((nq, max(topK, 1)), np.uint64); sc = np.zeros((nq, max(topK, 1)), np.float32); cnt = np.zeros(nq, np.uint32)
-        L.check(L.lib().coltt_flat_search_ids(self.h, L.vp(q), C.c_size_t(nq), C.c_uint32(topK), select, L.vp(cand),
-                                              C.c_size_t(len(cand)), L.vp(ids), L.vp(sc), L.vp(cnt)))
+        L.check(L.lib().coltt_flat_search_ids_mode(self.h, L.vp(q), C.c_size_t(nq), C.c_uint32(topK), select, mode, L.vp(cand),
+                                                   C.c_size_t(len(cand)), L.vp(ids), L.vp(sc), L.vp(cnt)))
         return ids, sc, cnt
 
     # -- SaveVertex / LoadVertex (edge/none_vectorstore.go:308-516)

@@ -325,7 +325,8 @@ func FlatSearch(h Handle, dim uint32, queries []float32, nq int, k uint32, sel, 
 		})
 	} else {
 		err = call(func() C.int {
-			return C.coltt_flat_search_ids(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.int(sel), uptr(cand), C.size_t(len(cand)), uptr(ids), fptr(sc), cp)
+			// mode: ModeExact = the exact-order gather scan (one query per RPC); ModeMfma = candidates from the gathered rows on the matrix cores
+			return C.coltt_flat_search_ids_mode(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.int(sel), C.int(mode), uptr(cand), C.size_t(len(cand)), uptr(ids), fptr(sc), cp)
 		})
 	}
 	return ids, sc, cnt, err

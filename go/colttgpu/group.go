@@ -28,6 +28,7 @@ const (
 	ExchangeAuto = int(C.COLTT_EXCHANGE_AUTO)
 	ExchangeRccl = int(C.COLTT_EXCHANGE_RCCL)
 	ExchangeHost = int(C.COLTT_EXCHANGE_HOST)
+	ExchangeShm  = int(C.COLTT_EXCHANGE_SHM) // processes of one box: POSIX shared memory + process-shared counters (coltt_shm_*)
 )
 
 // GroupOpts mirrors coltt_group_opts.  WorldSize / RankBase / UniqueID are only needed when the collection spans more than one

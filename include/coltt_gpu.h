@@ -108,6 +108,11 @@ int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fal
 int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,
                           const uint64_t* cand_ids, size_t n_cand,
                           uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+/* the same with an explicit mode: COLTT_MODE_MFMA generates candidates on the matrix cores from the GATHERED rows (batches of
+ * filtered queries; same ids, ranks and score bits as COLTT_MODE_EXACT, which coltt_flat_search_ids uses) */
+int coltt_flat_search_ids_mode(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode,
+                               const uint64_t* cand_ids, size_t n_cand,
+                               uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
 
 /* SaveVertex / LoadVertex (edge/none_vectorstore.go:308-516; f16_vectorstore.go:317-532 and the f8/bf16 twins): 16 shards
  * x {u64 count, count x {u64 key, u32 vecLen, vecLen x big-endian STORED code (f32 | u16 | u8), u32 metaCount, typed

@@ -128,3 +128,89 @@ def test_group_rccl_init_rank_path_single_process(gpu):
     a = g.Search(Q, k)
     assert np.array_equal(a[0], want[0]) and np.array_equal(bits(a[1]), bits(want[1]))
     g.close()
+
+
+_TWO_PROC = r'''
+import json, os, sys, numpy as np
+sys.path.insert(0, {root!r})
+import coltt_amd as G
+from coltt_amd import group as GG
+from oracle import oracle as O
+rank, world, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+uid = bytes.fromhex(sys.argv[4])
+assert G.lib().coltt_init(0) == 0
+n, d, k = 4000, 48, 10
+X = O.fill_normal(1700, (n, d)); lv = O.levels(1701, n)
+ids = np.arange(n, dtype=np.uint64) * np.uint64(104729) + np.uint64(3)
+Q = O.fill_normal(1702, (45, d))
+if kind == "flat":
+    g = G.Group([0], d, O.L2, O.Q_F16, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_SHM, world_size=world, rank_base=rank, uid=uid)
+    kept = g.ChangedVertex(ids, X)                                   # every process is OFFERED every vertex and keeps its shard's
+    a = g.Search(Q, k, select=G.SELECT_NEAREST); b = g.Search(Q, k, select=G.SELECT_REFERENCE)
+    g.Remove(ids[:40]); c = g.Search(Q[:7], k)
+    res = {{"kept": int(kept), "len": int(g.Len()), "info": g.info(), "near": [a[0].tolist(), a[1].view(np.uint32).tolist(), a[2].tolist()],
+           "ref": [b[0].tolist(), b[1].view(np.uint32).tolist(), b[2].tolist()], "after_remove": [c[0].tolist(), c[1].view(np.uint32).tolist()]}}
+else:
+    g = G.Group([0], d, O.COSINE, O.Q_BF16, kind=GG.GROUP_HNSW, cfg=G.HnswCfg.default(ef_construction=60), exchange=GG.EXCHANGE_SHM,
+                world_size=world, rank_base=rank, uid=uid)
+    kept = g.Insert(ids, X, lv, batch=1)
+    a = g.Search(Q, k, ef=200)
+    m = G.Hnsw.__new__(G.Hnsw); m.h = g.member(0); m.dim = d; m.quantization = O.Q_BF16; m.cfg = G.HnswCfg(); m.Config()
+    gr = m.ExportRaw(); rows = m.FetchRows(); ex = m.Export()
+    sl, sc, cn, _, _ = O.csr_search(rows, O.Q_BF16, gr["adj0"], gr["upper_off"], gr["adjU"], d, O.COSINE, gr["entry"], gr["entry_level"], Q, k, 200, threads=2)
+    m.h = None
+    mine = [[(float(sc[q, j]), int(ex["ids"][sl[q, j]])) for j in range(cn[q])] for q in range(len(Q))]   # this shard's oracle answers
+    res = {{"kept": int(kept), "len": int(g.Len()), "info": g.info(), "near": [a[0].tolist(), a[1].view(np.uint32).tolist(), a[2].tolist()],
+           "shard_oracle": mine, "shard_ids": sorted(int(i) for i in ex["ids"])}}
+print("RESULT " + json.dumps(res))
+g.close()
+'''
+
+
+@pytest.mark.parametrize("kind", ["flat", "hnsw"])
+def test_two_processes_one_device_rank_wise_group_over_shared_memory(gpu, kind, monkeypatch):
+    """The one-process-per-shard layout (world_size 2, rank_base = rank, every process offered every vertex) with BOTH processes on
+    device 0 — RCCL cannot form a communicator there, so the packed per-shard top-k travel through COLTT_EXCHANGE_SHM (same records,
+    same merge).  Every process must end with the answers of the unsharded store (FLAT, exact) / of the merged per-shard oracle
+    walks (HNSW).  The batch fits one slot here; the CPU twin (tests/test_multi_rank.py) covers the chunked exchange."""
+    import json, os, subprocess, sys
+    from coltt_amd import group as GG
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = GG.unique_id().hex()
+    code = _TWO_PROC.format(root=root)
+    env = dict(os.environ, COLTT_SHM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", kind, uid], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    n, d, k = 4000, 48, 10
+    X = O.fill_normal(1700, (n, d)); ids = np.arange(n, dtype=np.uint64) * np.uint64(104729) + np.uint64(3)
+    Q = O.fill_normal(1702, (45, d))
+    sh = _shards(ids, 2)
+    for r in range(2):
+        assert outs[r]["info"] == {"n_local": 1, "world": 2, "exchange": "shm", "rank_base": r}
+        assert outs[r]["kept"] == int((sh == r).sum())
+    assert outs[0]["near"] == outs[1]["near"]           # an all-gather: both processes hold the merged answer
+    gi = np.array(outs[0]["near"][0], np.uint64); gs = np.array(outs[0]["near"][1], np.uint32).view(np.float32); gc = np.array(outs[0]["near"][2])
+    if kind == "flat":
+        whole = O.Flat(d, O.L2, O.Q_F16); whole.upsert(ids, X)
+        ri = np.array(outs[1]["ref"][0], np.uint64); rs = np.array(outs[1]["ref"][1], np.uint32).view(np.float32)
+        for qi in range(len(Q)):
+            wi, ws = whole.search(Q[qi], k, nearest=True, mode=2)
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"near q{qi}")
+            wi, ws = whole.search(Q[qi], k, nearest=False, mode=2)
+            assert_same_results(ri[qi], rs[qi], wi, ws, f"ref q{qi}")
+        whole.remove(ids[:40])
+        ai = np.array(outs[0]["after_remove"][0], np.uint64); as_ = np.array(outs[0]["after_remove"][1], np.uint32).view(np.float32)
+        for qi in range(7):
+            wi, ws = whole.search(Q[qi], k, nearest=True, mode=2)
+            assert_same_results(ai[qi], as_[qi], wi, ws, f"after remove q{qi}")
+        assert outs[0]["len"] + outs[1]["len"] == n - 40
+    else:
+        for r in range(2):
+            assert outs[r]["shard_ids"] == sorted(int(i) for i in ids[sh == r])      # routing: exactly this shard's vertices
+        for qi in range(len(Q)):
+            u = sorted(tuple(x) for r in range(2) for x in outs[r]["shard_oracle"][qi])[:k]
+            assert [(float(gs[qi, j]), int(gi[qi, j])) for j in range(gc[qi])] == [(float(np.float32(a)), int(b)) for a, b in u], qi

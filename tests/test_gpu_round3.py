@@ -124,3 +124,36 @@ def test_cosine_mfma_is_closed_for_rows_of_odd_norm(gpu):
     g2 = gpu.FlatSpace(d, O.COSINE, O.Q_NONE); g2.ChangedVertex(ids, X)
     g2.VertexSearch(Q, 10, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
     assert g2.Stats()["mfma_groups"] > 0
+
+
+@pytest.mark.parametrize("metric,quant,n,d", [(O.COSINE, O.Q_NONE, 40000, 128), (O.COSINE, O.Q_F16, 30000, 768), (O.L2, O.Q_BF16, 20000, 200),
+                                              (O.L2, O.Q_NONE, 12000, 768)])
+def test_filtered_search_through_the_matrix_cores(gpu, metric, quant, n, d):
+    """FilterableVertexSearch (edge/none_vectorstore.go:182-253) with COLTT_MODE_MFMA: the gathered rows feed the matrix-core candidate
+    kernel (flat_mfma3.hpp, GATHER), survivors are re-scored in exact order — ids, ranks and score bits equal exact mode and the
+    oracle's scan over exactly the candidate rows.  Candidate lists: strided, random, tiny (< one tile), with unknown and removed ids
+    (skipped, :201) and repeated ids (scored once)."""
+    X = O.fill_normal(5000 + d + quant, (n, d)); X[300:310] = X[4]
+    ids = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(7)
+    gf = gpu.FlatSpace(d, metric, quant); gf.ChangedVertex(ids, X)
+    gone = ids[100:140]; gf.RemoveVertex(gone)
+    rows, row_ids = gf.FetchRows(with_ids=True)                       # the store's rows in scan order, after the removal
+    slot_of = {int(i): s for s, i in enumerate(row_ids)}
+    rng = np.random.default_rng(11)
+    lists = {"strided": ids[::7], "random": np.sort(rng.choice(ids, n // 3, replace=False)), "tiny": ids[1000:1100],
+             "dirty": np.concatenate([ids[::5], ids[:50], gone, np.uint64(10**12) + np.arange(30, dtype=np.uint64)])}
+    before = gf.Stats()["mfma_groups"]
+    for name, cand in lists.items():
+        live = np.array(sorted({slot_of[int(c)] for c in cand if int(c) in slot_of}), np.int64)
+        sub = np.ascontiguousarray(rows[live])
+        for nq, k in ((1, 10), (40, 10), (130, 25)):
+            Q = np.concatenate([X[4:5], O.fill_normal(5100 + nq, (nq - 1, d))]) if nq > 1 else O.fill_normal(5101, (1, d))
+            for nearest in (True, False):
+                sel = gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE
+                ei, es, ec = gf.FilterableVertexSearch(cand, Q, k, sel, gpu.MODE_EXACT)
+                mi, ms, mc = gf.FilterableVertexSearch(cand, Q, k, sel, gpu.MODE_MFMA)
+                assert np.array_equal(ec, mc) and np.array_equal(ei, mi) and np.array_equal(bits(es), bits(ms)), (name, nq, k, nearest)
+                sl, sc, cn, _ = O.flat_scan(sub, quant, d, metric, Q[:6], k, nearest=nearest, threads=4)
+                for qi in range(min(nq, 6)):
+                    assert_same_results(mi[qi, :mc[qi]], ms[qi, :mc[qi]], row_ids[live[sl[qi, :cn[qi]].astype(np.int64)]], sc[qi, :cn[qi]], f"{name} nq{nq} q{qi} near{nearest}")
+    assert gf.Stats()["mfma_groups"] > before, "the filtered searches must really have gone through the matrix cores"

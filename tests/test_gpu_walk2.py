@@ -148,3 +148,24 @@ def test_epoch_wrap_with_the_bloom_filter(gpu, walk, monkeypatch):
             for qi in range(2):
                 assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"rep{rep} q{qi}")
             assert {k_: st[k_] for k_ in ost} == ost
+
+
+@pytest.mark.parametrize("m,metric,quant,d", [(16, O.COSINE, O.Q_NONE, 96), (16, O.L2, O.Q_F16, 77), (4, O.COSINE, O.Q_NONE, 48), (24, O.L2, O.Q_NONE, 48),
+                                              (32, O.COSINE, O.Q_BF16, 40), (16, O.L2, O.Q_F8, 33)])
+def test_latency_kernel_equals_oracle(gpu, monkeypatch, m, metric, quant, d):
+    """The 256-thread latency kernel (hnsw_lat.hpp): rows of one chunk take the walk that is software-pipelined over expansions
+    (search_level_lat2), wider rows (mMax0 = 48, 64) the sequential one; dims with a scalar tail, 1-/2-/4-byte rows; small ef where
+    the speculatively chosen next candidate can be truncated away; single queries and batches; k > ef; counters equal the oracle's."""
+    monkeypatch.setenv("COLTT_LAT_MAX_NQ", "64"); monkeypatch.setenv("COLTT_WALK2", "off")
+    n = 5000
+    X = O.fill_normal(3600 + m + d, (n, d)); lv = O.levels(3601 + m, n, m)
+    gh = _gpu_build(gpu, X, lv, metric, quant, gpu.HnswCfg.default(m=m, ef_construction=48), batch=128)
+    Q = O.fill_normal(3602 + d, (40, d))
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    for nq, k, efs in ((1, 10, (10, 64, 128)), (40, 1, (1, 2, 3, 7)), (40, 10, (20, 100)), (8, 50, (50, 120))):   # Hnsw.Search walks with max(ef, k) (hnsw.go:258)
+        for ef in efs:
+            gi, gs, gc, st = gh.Search(Q[:nq], k, ef=ef, with_stats=True)
+            sl, sc, cn, ost, _ = O.csr_search(rows, quant, g["adj0"], g["upper_off"], g["adjU"], d, metric, g["entry"], g["entry_level"], Q[:nq], k, ef, threads=4)
+            for qi in range(nq):
+                assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"nq{nq} k{k} ef{ef} q{qi}")
+            assert {k_: st[k_] for k_ in ost} == ost, (nq, k, ef, st, ost)

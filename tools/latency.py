@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Single-query / small-batch latency of Hnsw.Search on the GPU: one wave per query vs the multi-wave (latency) kernel
-(COLTT_MW_MAX_NQ).  `python tools/latency.py [n] [quant]` — builds n x 768 (default 10 M f32) with the batched builder, then times
+"""Single-query / small-batch latency of Hnsw.Search on the GPU: one wave per query vs the 256-thread latency kernel
+(coltt_amd/csrc/hnsw_lat.hpp, COLTT_LAT_MAX_NQ).  `python tools/latency.py [n] [quant]` — builds n x 768 (default 10 M f32) with the batched builder, then times
 nq in {1, 4, 16, 64, 128} queries per call (kernel time from the hipEvent pair on the search stream, and wall time of the call)."""
 import json
 import os
@@ -31,7 +31,7 @@ def main():
     res = {"n": n, "dim": dim, "quant": quant, "ef": ef, "build_s": build_s, "rows": []}
     ref = {}
     for mw in ("0", "128"):
-        os.environ["COLTT_MW_MAX_NQ"] = mw
+        os.environ["COLTT_LAT_MAX_NQ"] = mw
         for nq in (1, 4, 16, 64, 128):
             ms, wall = [], []
             for r in range(40):
@@ -43,7 +43,7 @@ def main():
             ids = out.ids[:nq].cpu().numpy().copy(); sc = out.sc[:nq].cpu().numpy().copy()
             if mw == "0": ref[nq] = (ids, sc)
             same = bool(np.array_equal(ids, ref[nq][0]) and np.array_equal(sc.view(np.uint32), ref[nq][1].view(np.uint32)))
-            res["rows"].append({"kernel": "256-thread staged (latency) kernel" if mw != "0" else "one wave per query", "nq": nq, "kernel_ms_median": float(np.median(ms[5:])),
+            res["rows"].append({"kernel": "256-thread latency kernel (hnsw_lat.hpp)" if mw != "0" else "one wave per query", "nq": nq, "kernel_ms_median": float(np.median(ms[5:])),
                                 "call_wall_ms_median": float(np.median(wall[5:])), "equals_one_wave_answers": same})
             print(res["rows"][-1], flush=True)
     print(json.dumps(res))

@@ -84,6 +84,32 @@ void both(const uint8_t* table, uint64_t nrows, uint32_t row_bytes, int w, uint3
   fflush(stdout);
 }
 
+// Dependent-load latency: ONE wave, every step reads 64/G fresh random rows (16 B per lane, G lanes per row) whose indices depend on
+// the previous step's data — the round trip (DRAM + a cold translation per row) a single-query HNSW walk pays per dependent step.
+template <int G>
+__global__ __launch_bounds__(64) void chase_kernel(const uint8_t* __restrict__ table, uint64_t nrows, uint32_t row_bytes, uint32_t steps, uint32_t* __restrict__ sink) {
+  const int lane = threadIdx.x, sub = lane % G, rl = lane / G;
+  uint32_t prev = 0;
+  for (uint32_t s = 0; s < steps; s++) {
+    const uint64_t r = mix(((uint64_t)prev << 20) ^ ((uint64_t)s << 8) ^ (uint64_t)rl) % nrows;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(table + r * (uint64_t)row_bytes + (uint32_t)sub * 16u);
+    uint32_t x = v.x ^ v.y ^ v.z ^ v.w;
+    for (int m = 32; m >= 1; m >>= 1) x ^= (uint32_t)__shfl_xor((int)x, m, 64);   // every lane's data feeds the next address
+    prev = x + s;
+  }
+  if (prev == 0x12345678u) sink[0] = 1;
+}
+template <int G> void chase(const uint8_t* table, uint64_t nrows, uint32_t rb, uint32_t* sink, double gib) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const uint32_t steps = 4000;
+  chase_kernel<G><<<1, 64>>>(table, nrows, rb, 200, sink); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0)); chase_kernel<G><<<1, 64>>>(table, nrows, rb, steps, sink); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("{\"table_GiB\": %.1f, \"row_bytes\": %u, \"dependent_step\": \"%d random rows x %d B, one wave\", \"ns_per_step\": %.0f}\n", gib, rb, 64 / G, 16 * G, ms * 1e6 / steps);
+  fflush(stdout);
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
 // also callable from a process that already holds a HIP runtime (python -c "import torch, ctypes; ctypes.CDLL('./gather.so').gather_run(...)")
 extern "C" int gather_run(double gib, int quick);
 int main(int argc, char** argv) { return gather_run(argc > 1 ? atof(argv[1]) : 15.0, argc > 2 ? atoi(argv[2]) : 0); }
@@ -95,6 +121,11 @@ extern "C" int gather_run(double gib, int quick) {
   CK(hipMemset(table, 1, bytes)); CK(hipMemset(sink, 0, 1 << 20));
   CK(hipDeviceSynchronize());
   const uint32_t rbs[2] = {1536, 3072};
+  if (quick == 2) {   // latency probe only
+    for (uint32_t rb : rbs) { chase<2>(table, bytes / rb, rb, sink, gib); chase<8>(table, bytes / rb, rb, sink, gib); chase<64>(table, bytes / rb, rb, sink, gib); }
+    CK(hipFree(table)); CK(hipFree(sink));
+    return 0;
+  }
   for (uint32_t rb : rbs) {
     const uint64_t nrows = bytes / rb;
     const int ws[3] = {4, 8, 16};

@@ -3,7 +3,7 @@
 roofline.traffic).  Procedure (MI355X_MICROARCH.md, HBM / rocprofv3 section: counters in their OWN pass, no trace domains):
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "hnsw_search_kernel|flat_scan_kernel" -f csv -d /tmp/pmc -o p -- \\
+    rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "hnsw_search|flat_scan_kernel" -f csv -d /tmp/pmc -o p -- \\
         python $REPO/bench.py --no-cpu-baseline
     python $REPO/tools/pmc_traffic.py /tmp/pmc/p_counter_collection.csv --bench-json <the JSON line bench.py printed>
 
@@ -32,7 +32,10 @@ def read_counter(path, counter="FETCH_SIZE"):
             per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])
     out = collections.defaultdict(list)
     for (_, name, grid), v in per_dispatch.items():
-        if "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
+        if "hnsw_search2_kernel" in name:   # round 3: the large-ef walk (hnsw_walk2.hpp) — always the HBM visited map; <METRIC, QUANT, PROFILE, OPT>
+            q = name.split("hnsw_search2_kernel<")[1].split(",")[1].strip() if "hnsw_search2_kernel<" in name else "0"
+            short = "hnsw_search_kernel/hbm" + ("" if q == "0" else f"/q{q}")
+        elif "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
             q = name.split("hnsw_search_kernel<")[1].split(",")[1].strip() if "hnsw_search_kernel<" in name else "0"   # <METRIC, QUANT, VISG>
             short = ("hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds") + ("" if q == "0" else f"/q{q}")
         elif "flat_scan_kernel" in name:   # flat_scan_kernel<METRIC, QUANT, ...>: the calibration launches of each row format apart
