@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
                                                              uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
                                                              uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
                                                              float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                             unsigned long long* __restrict__ stats) {
+                                                             unsigned long long* __restrict__ stats, int lat_sequential) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveCtx w;
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 #endif
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    if (wave == 0) {   // hnsw_walk2.hpp's level-0 walk on wave 0, the chunks evaluated by all four waves (hnsw_lat.hpp: LatEval)
+    if (g.mMax0 <= 32 && !lat_sequential) {   // rows of one chunk: the walk that is software-pipelined over expansions (hnsw_lat.hpp)
+      search_level_lat3<METRIC, QUANT>(g, w, xs, stage, cur, curd, ef, wave, lane, len);  // :258-259
+    } else if (wave == 0) {   // hnsw_walk2.hpp's level-0 walk on wave 0, the chunks evaluated by all four waves (hnsw_lat.hpp: LatEval)
       if (lane == 0) xs->ctl[0] = 1u;
       LatEval<METRIC, QUANT> ev{xs, stage};
       search_level2<METRIC, QUANT, PROF_SEARCH_LDS, W2_DELTA, VIS_LDS, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259
@@ -727,16 +729,23 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   (void)region_base;
   auto kern = hnsw_search_lat_kernel<METRIC, QUANT>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
+  const char* seq = getenv("COLTT_LAT_SEQ");
   kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq && *seq == '1' ? 1 : 0);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
 
 // Batches of at most COLTT_LAT_MAX_NQ queries (default below; COLTT_MW_MAX_NQ is the round-2 name of the knob) take the
 // 256-thread latency kernel (hnsw_lat.hpp).
+// Measured at 10 M x 768 f32, ef 128 (profiles/r03_latency.json): 1 query 1.04 ms against 1.43 ms on the one-wave kernel, 128 queries
+// 1.45 against 1.97 ms; beyond ~256 queries every CU already holds a workgroup and the one-wave kernel's 1024+ resident traversals win.
 #ifndef COLTT_LAT_MAX_NQ_DEFAULT
-#define COLTT_LAT_MAX_NQ_DEFAULT 0
+#define COLTT_LAT_MAX_NQ_DEFAULT 256
+#endif
+#ifndef COLTT_LAT_MIN_STRIDE
+#define COLTT_LAT_MIN_STRIDE 1024   // bytes per stored row below which a lane pair streams the whole row in one burst anyway
 #endif
 uint32_t lat_max_nq() {
   const char* e = getenv("COLTT_LAT_MAX_NQ");
@@ -775,6 +784,7 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
     // LDS: query + result set + exchange words + the staging area (32 padded rows) + the visited hash
     const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (size_t)LAT_ROWS * (x->stride + LAT_PAD);
     if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to stage 32 at a time
+    else if (x->stride < COLTT_LAT_MIN_STRIDE && !getenv("COLTT_LAT_MAX_NQ") && !getenv("COLTT_MW_MAX_NQ")) mw = false;   // short rows: the one-wave kernel (unless asked for)
     else {
       m.hcap = 32768; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;
       m.lds = fixed + (size_t)m.hcap * 4;

@@ -243,5 +243,146 @@ __device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx&
   }
 }
 
+// searchLevel on level 0 for rows of at most one chunk (mMax0 <= 32), SOFTWARE-PIPELINED over expansions, all four waves.
+// With LatEval an expansion is  pop -> visited -> [fetch -> evaluate] -> admission / eviction  in sequence on wave 0, ~3.4 us of
+// single-wave VALU / LDS work around a ~3.5 us fetch + evaluation (phase timing, profiles/r03_latency.json).  Here the NEXT candidate is
+// chosen the moment the distances are known — it is min(runner-up, smallest admitted key), both available without touching the
+// set — its neighbours (their adjacency row came along with the vectors) are tested and published at once, all four waves start
+// fetching them, and wave 0 does the previous expansion's set work under the shadow of its own loads (the `mid` hook of
+// lat_eval_chunk): admitted keys into the delta, eviction down to ef, lowerBound / free slots for the expansion in flight, and the
+// next runner-up, whose adjacency row is requested right then.  Same set, same pops, same counters as hnsw_walk2.hpp:
+//   * the set after the admissions is top-ef(S ∪ admitted); its smallest unexpanded member is the smaller of S's smallest unexpanded
+//     member other than the candidate just expanded (the runner-up) and the smallest admitted key;
+//   * if that member does not survive the truncation to ef (it is larger than the new worst member), the canonical loop would find
+//     nothing to expand and stop: the speculative fetch is dropped, nothing of it is counted.
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w, LatShared* xs, uint8_t* stage, uint32_t ep, float epd,
+                                                  uint32_t ef, int wave, int lane_in, uint32_t& out_len) {
+  int lane = lane_in;
+  const int tid = wave * 64 + lane;
+  unsigned long long* const res = w.res0;
+  const uint32_t width = g.mMax0;
+  for (uint32_t i = tid; i < w.hcap; i += 256) w.vis[i] = VIS_EMPTY;
+  __syncthreads();
+  uint32_t len = 1, vis_count = 1, scan_lo = 1;
+  Delta dl; dl.hi = dl.lo = 0xffffffffu; dl.n = 0; dl.mx = 0ull; dl.mx_lane = -1;
+  float lower_bound = epd; uint32_t free_slots = ef - 1;
+  unsigned long long runner_key = ~0ull; uint32_t runner_nb = NBR_NONE; int runner_idx = -1, runner_dlane = -1;
+  uint32_t nb = NBR_NONE; bool fresh = false;       // the expansion in flight (wave 0, lane pair p <-> neighbour p)
+  unsigned long long pA = 0, pnext = ~0ull; uint32_t pkhi = 0, pklo = 0, pm = 0; bool locate = false, dead = false;
+
+  auto absorb = [&]() {   // the admitted keys of the previous expansion: into the delta, then keep the ef smallest
+    if (!pm) return;
+    if (dl.n + pm > 64u) delta_flush(res, len, dl, scan_lo, lane);
+    unsigned long long am = pA; uint32_t t = dl.n;
+    while (am) {
+      const int jj = __builtin_ctzll(am); am &= am - 1;
+      const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)pkhi, jj), vl = (uint32_t)__builtin_amdgcn_readlane((int)pklo, jj);
+      if ((uint32_t)lane == t) { dl.hi = vh; dl.lo = vl; }
+      t++;
+    }
+    dl.n += pm; pm = 0;
+    dl.refresh_max(lane);
+    const uint32_t total = len + dl.n;
+    if (total > ef) evict_largest(res, len, dl, total - ef, lane);
+  };
+  auto mid = [&]() {      // wave 0, under the shadow of the fetch
+    if (wave != 0) return;
+    absorb();
+    if (!locate) return;
+    locate = false;
+    unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
+    worst = dl.mx > worst ? dl.mx : worst;
+    if (pnext > worst) { dead = true; return; }   // the candidate in flight was truncated away: the canonical loop ends here
+    w.n_exp++;
+    lower_bound = __uint_as_float((uint32_t)(worst >> 32));
+    free_slots = ef - (len + dl.n);
+    // the runner-up: the smallest unexpanded member of main ∪ delta (the candidate in flight is already marked)
+    int ci = -1;
+    for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
+      const uint32_t i = base + lane;
+      const bool un = i < len && !(res[i] & 1ull);
+      const unsigned long long mm = __ballot(un);
+      if (mm) { ci = (int)base + __builtin_ctzll(mm); break; }
+    }
+    scan_lo = ci >= 0 ? (uint32_t)ci : len;
+    const unsigned long long kci = ci >= 0 ? res[ci] : ~0ull;
+    unsigned long long kd;
+    const int dlane = wave_argmin_key((uint32_t)lane < dl.n && !(dl.lo & 1u), dl.hi, dl.lo, kd);
+    if (kd < kci) { runner_key = kd; runner_dlane = dlane; runner_idx = -1; }
+    else { runner_key = kci; runner_idx = ci; runner_dlane = -1; }
+    runner_nb = NBR_NONE;
+    if (runner_key != ~0ull && (uint32_t)(lane >> 1) < width) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * width + (lane >> 1)];
+  };
+
+  if (wave == 0) {   // the entrypoint is popped at once (it is the only member)
+    const int half = lane & 1, p = lane >> 1;
+    if (lane == 0) { res[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1) | 1ull; vis_insert(w.vis, w.hcap_mask, ep); }
+    w.n_exp++;
+    nb = (uint32_t)p < width ? g.adj0[(size_t)ep * width + p] : NBR_NONE;
+    const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+    wave_sync();
+    int fresh_i = 0;
+    if (valid && half == 0) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+    fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);
+    fresh = fresh_i != 0;
+    if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = (uint32_t)fresh_i; }
+    if (lane == 0) xs->ctl[0] = 1u;
+  }
+  for (uint32_t iters = 0;; iters++) {
+    lane = opaque_lane(lane_in);
+    const int half = lane & 1, p = lane >> 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    COLTT_LT(w, 0)   // choose + visited + publish (wave 0)
+    lds_barrier();
+    if (xs->ctl[0] == 0u) break;
+    lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, wave, lane, mid);
+    lds_barrier();
+    COLTT_LT(w, 4)
+    if (wave == 0) {
+      if (dead || iters > (1u << 22)) { if (!dead) w.err |= 2u; if (lane == 0) xs->ctl[0] = 0u; continue; }
+      // ---- which of the distances that just arrived are admitted (hnsw.go:374: the stale lowerBound, the free slots first)
+      const unsigned long long E = __ballot(fresh && half == 0);
+      const uint32_t nfresh = __popcll(E);
+      unsigned long long A = 0, best_new = ~0ull; uint32_t m = 0, khi = 0, klo = 0; bool adm = false; int best_lane = -1;
+      if (nfresh) {
+        vis_count += nfresh; w.n_dist += nfresh;
+        const float d = xs->d[p];
+        const uint32_t rank = __popcll(E & lt_mask);
+        adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
+        A = __ballot(adm); m = __popcll(A);
+        khi = __float_as_uint(d); klo = nb << 1;
+        if (m) best_lane = wave_argmin_key(adm, khi, klo, best_new);
+      }
+      // ---- the next candidate, its neighbours, their visited test
+      const unsigned long long nk = runner_key < best_new ? runner_key : best_new;
+      bool go = nk != ~0ull;
+      if (go && vis_count + 64 > (w.hcap >> 2) * 3) { w.err |= 8u; go = false; }   // would need the reset path: give up (host falls back)
+      if (go) {
+        pnext = nk; locate = true;
+        if (runner_key < best_new) {   // the runner-up: mark it where it sits (nothing has moved since it was found)
+          if (runner_dlane >= 0) { if (lane == runner_dlane) dl.lo |= 1u; }
+          else if (lane == 0) res[runner_idx] = runner_key | 1ull;
+          nb = runner_nb;
+        } else {                       // a vertex admitted just now: it enters the set already marked; its adjacency row came with its vector
+          if (lane == best_lane) klo |= 1u;
+          nb = (uint32_t)p < width ? xs->adjn[best_lane >> 1][p] : NBR_NONE;
+        }
+        const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+        int fresh_i = 0;
+        if (valid && half == 0) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+        fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);
+        fresh = fresh_i != 0;
+        if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = (uint32_t)fresh_i; }
+      }
+      pA = A; pm = m; pkhi = khi; pklo = klo;
+      if (lane == 0) xs->ctl[0] = go ? 1u : 0u;
+      COLTT_LT(w, 5)
+    }
+  }
+  if (wave == 0) { absorb(); delta_flush(res, len, dl, scan_lo, lane); }   // the last expansion's admissions; one sorted array for the caller
+  out_len = len;   // meaningful on wave 0
+}
+
 }  // namespace dev
 }  // namespace coltt

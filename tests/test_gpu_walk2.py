@@ -152,11 +152,12 @@ def test_epoch_wrap_with_the_bloom_filter(gpu, walk, monkeypatch):
 
 @pytest.mark.parametrize("m,metric,quant,d", [(16, O.COSINE, O.Q_NONE, 96), (16, O.L2, O.Q_F16, 77), (4, O.COSINE, O.Q_NONE, 48), (24, O.L2, O.Q_NONE, 48),
                                               (32, O.COSINE, O.Q_BF16, 40), (16, O.L2, O.Q_F8, 33)])
-def test_latency_kernel_equals_oracle(gpu, monkeypatch, m, metric, quant, d):
+@pytest.mark.parametrize("seq", ["0", "1"], ids=["pipelined", "sequential"])
+def test_latency_kernel_equals_oracle(gpu, monkeypatch, m, metric, quant, d, seq):
     """The 256-thread latency kernel (hnsw_lat.hpp): rows of one chunk take the walk that is software-pipelined over expansions
     (search_level_lat2), wider rows (mMax0 = 48, 64) the sequential one; dims with a scalar tail, 1-/2-/4-byte rows; small ef where
     the speculatively chosen next candidate can be truncated away; single queries and batches; k > ef; counters equal the oracle's."""
-    monkeypatch.setenv("COLTT_LAT_MAX_NQ", "64"); monkeypatch.setenv("COLTT_WALK2", "off")
+    monkeypatch.setenv("COLTT_LAT_MAX_NQ", "64"); monkeypatch.setenv("COLTT_WALK2", "off"); monkeypatch.setenv("COLTT_LAT_SEQ", seq)
     n = 5000
     X = O.fill_normal(3600 + m + d, (n, d)); lv = O.levels(3601 + m, n, m)
     gh = _gpu_build(gpu, X, lv, metric, quant, gpu.HnswCfg.default(m=m, ef_construction=48), batch=128)

@@ -48,18 +48,18 @@ def read_counter(path, counter="FETCH_SIZE"):
 
 
 def calibrate(flat_launches, rows, stride):
-    """flat_scan_kernel launches of the recall leg: a small unfiltered first segment + the remainder, together `rows` rows.
-    Returns known_bytes / reported_bytes over the launches of the LARGEST grid (the remainder: least edge effects)."""
+    """flat_scan_kernel launches of the recall leg: every 16-query group scans the store in a few segments (512 rows, then 32x what has
+    been seen, ...) that together cover each of the `rows` rows exactly once, so
+        factor = groups x rows x stride / (sum of the counter over ALL the launches).
+    groups = launches per distinct segment shape (the smallest grid belongs to the first segment only).  (Round 2 divided the last
+    segment alone; since the 16 Ki / 512 Ki segments share the capped grid with it that reading is off by the segment count.)"""
     if not flat_launches:
         return None, None
-    big = max(g for g, _ in flat_launches)
-    vals = [v for g, v in flat_launches if g == big]
-    small = [v for g, v in flat_launches if g != big]
-    # rows covered by the big launches = rows - rows of the first segment; first segment = 65536 rows (flat.hip: min(cap, ...))
-    first_rows = 65536 if small else 0
-    known_kib = (rows - first_rows) * stride / 1024.0
-    mean = sum(vals) / len(vals)
-    return known_kib / mean, {"launches": len(vals), "FETCH_SIZE_KiB_mean": mean, "known_KiB": known_kib}
+    small = min(g for g, _ in flat_launches)
+    groups = sum(1 for g, _ in flat_launches if g == small)
+    total = sum(v for _, v in flat_launches)
+    known_kib = groups * rows * stride / 1024.0
+    return known_kib / total, {"launches": len(flat_launches), "groups": groups, "FETCH_SIZE_KiB_sum": total, "known_KiB": known_kib}
 
 
 def flat_searches(path, counter="FETCH_SIZE"):
