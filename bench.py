@@ -459,8 +459,8 @@ def leg_published_hnsw_point(G, torch, dev, O, args, k):
 
 def leg_filtered(G, torch, dev, O, args, dim, k):
     """SURVEY §8 f3, reported separately: FilterableVertexSearch (edge/none_vectorstore.go:182-253) — the inverted index hands over
-    an ascending id list (roaring ToArray), the library translates ids to slots on the host and scans those rows only: one query
-    per call (the reference's RPC shape) through the exact-order GATHER scan, batches through the matrix cores' gather mode
+    an ascending id list (roaring ToArray), the library translates ids to slots on the host and scans those rows only: <= 4 queries
+    per call (the reference's RPC shape is one) through the one-launch exact-order GATHER scan (flat_one_kernel), batches through the matrix cores' gather mode
     (flat_mfma3.hpp: candidates from the gathered rows + exact re-score; answers equal exact mode's, checked here).
     1 M x 768 f32; every 10th id a candidate (100 k rows, 30 KB apart), and every id (1 M candidates)."""
     n = 1_000_000
@@ -472,11 +472,15 @@ def leg_filtered(G, torch, dev, O, args, dim, k):
     r_first = None
     for lname, cand in (("every_10th", np.arange(0, n, 10, dtype=np.uint64)), ("all_ids", np.arange(n, dtype=np.uint64))):
         out = {}
-        for nq in (1, 16, 64):
+        for nq in (1, 4, 16, 64):
             ex = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST, G.MODE_EXACT)
-            for mode, mname in ((G.MODE_EXACT, "exact"), (G.MODE_MFMA, "mfma")):
-                if mode == G.MODE_MFMA and nq == 1:
-                    continue
+            for mode, mname in ((G.MODE_EXACT, "exact"), (G.MODE_MFMA, "mfma"), (G.MODE_EXACT, "exact_chain")):
+                if mode == G.MODE_MFMA and nq <= 4:
+                    continue   # <= 4 queries are served by flat_one_kernel whatever the mode
+                if mname == "exact_chain":   # the scan + select launch chain the one-launch kernel replaced (COLTT_FLAT_ONE=0)
+                    if nq > 4:
+                        continue
+                    os.environ["COLTT_FLAT_ONE"] = "0"
                 if mode == G.MODE_EXACT and nq == 64 and len(cand) > 200_000:
                     continue   # 4 exact passes over 3 GB: not what a batch is served by
                 r = fl.FilterableVertexSearch(cand, q[:nq], k, G.SELECT_NEAREST, mode)
@@ -488,6 +492,7 @@ def leg_filtered(G, torch, dev, O, args, dim, k):
                 out[f"batch_{nq}_{mname}"] = {"call_ms": float(np.median(t)) * 1e3, "kernels_ms": km, "queries_per_s": nq / float(np.median(t)),
                                              "gathered_GBps": len(cand) * dim * 4 / (km / 1e3) / 1e9, "frac_of_hbm_peak": len(cand) * dim * 4 / (km / 1e3) / 1e9 / HBM_PEAK_GBS,
                                              "equals_exact_mode": bool(np.array_equal(r[0], ex[0]) and np.array_equal(r[1].view(np.uint32), ex[1].view(np.uint32)))}
+                os.environ.pop("COLTT_FLAT_ONE", None)
                 if r_first is None:
                     r_first = r
         res["lists"][lname] = {"candidates": int(len(cand)), **out}
@@ -521,6 +526,14 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
             fl.VertexSearchDevice(q.data_ptr(), batch, k, *out.ptrs(), select=G.SELECT_NEAREST, mode=mode)
             if r: ms.append(fl.last_kernel_ms())
         return float(np.mean(ms)) / 1e3, out.ids.cpu().numpy().copy(), out.sc.cpu().numpy().copy()
+    one = batch <= 4 and k <= 64 and os.environ.get("COLTT_FLAT_ONE", "") != "0"   # flat_one_kernel serves these shapes in ONE launch
+    chain = None
+    if one:   # the launch chains it replaces, for the record
+        os.environ["COLTT_FLAT_ONE"] = "0"
+        try:
+            chain = {"exact_scan_select_chain_ms": run(G.MODE_EXACT, reps)[0] * 1e3, "mfma_pick_rescore_select_chain_ms": run(G.MODE_MFMA, reps)[0] * 1e3}
+        finally:
+            del os.environ["COLTT_FLAT_ONE"]
     te, ei, es = run(G.MODE_EXACT, 1)
     tm, mi, msc = run(G.MODE_MFMA, reps)
     t0 = time.perf_counter()
@@ -538,6 +551,12 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
                         "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
                         "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
                                  "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}
+    if one:
+        res["workload"] = f"edge FLAT cosine, {n}x{dim} {QNAME[quant]}, batch {batch}, k={k}, nearest-k, one-launch small-batch search (BASELINE.json {tag})"
+        res["roofline"]["kernel"] = "flat_one_kernel (exact-order scan + per-wave / per-block k best + selection by the last block: ONE launch; hipEvent pair around it)"
+        res["roofline"].pop("mfma")
+        res["launch_chains_replaced"] = chain
+        res["one_launch_searches"] = fl.OneLaunchSearches()
     if not args.no_cpu_baseline:
         try:
             rows_cpu = min(n, cpu_rows)
@@ -730,7 +749,9 @@ def main():
             achieved = bytes_per_query * nq / launch_s / 1e9
             tr, tr_src = pmc_traffic(args, n_total, dim, nq)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": tr, "traffic_source": tr_src, "kernel": "hnsw_search_kernel", "avg_launch_ms": launch_s * 1e3}
+                    "traffic": tr, "traffic_source": tr_src, "avg_launch_ms": launch_s * 1e3,
+                    "kernel": "hnsw_search_kernel (hnsw_dev.hpp:search_level)" if os.environ.get("COLTT_WALK2_LDS", "") == "off" else
+                              "hnsw_search2_kernel<.., VIS_LDS> (hnsw_walk2.hpp over the LDS visited hash: adjacency-carried norms)"}
         h.close()
         op = None
         if "op" in legs:

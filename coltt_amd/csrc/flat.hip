@@ -38,6 +38,65 @@ constexpr int QB = 16;            // queries per row read in the exact scan (dim
 // all QB queries (queries broadcast from LDS).  Survivors of the per-query threshold are appended to a
 // candidate list as (score_key << 32 | slot).
 // ---------------------------------------------------------------------------------------------------
+// exact-order score keys of ONE row (a lane pair: `half` takes elements 4*half .. 4*half+3 of every 8) against the QB queries of
+// the LDS tile qs[QB][dimp]; both lanes of the pair return the keys
+template <int METRIC, int QUANT, int QB, int U = 4>   // U: 16-byte loads per lane in flight (x2 with the prefetched next batch)
+__device__ __forceinline__ void flat_eval_row(const uint8_t* __restrict__ row, float rn, const float* __restrict__ qs, int dimp, int dim,
+                                              int half, const float (&qn)[QB], uint32_t (&sk)[QB]) {
+  const int n8 = dim >> 3;
+  f32x4 acc[QB];
+#pragma unroll
+  for (int q = 0; q < QB; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nb = n8 / U;
+  typename Raw4<QUANT>::type cur[U], nxt[U];  // raw bits stay in the pipeline registers; decoded at use
+  if (nb > 0) {
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = load_raw4<QUANT>(row, 8 * u + 4 * half);
+  }
+  for (int b = 0; b < nb; b++) {
+    if (b + 1 < nb) {
+#pragma unroll
+      for (int u = 0; u < U; u++) nxt[u] = load_raw4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float* qp = qs + 8 * (b * U + u) + 4 * half;
+      const f32x4 rc = decode4<QUANT>(cur[u]);
+#pragma unroll
+      for (int q = 0; q < QB; q++) {
+        f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
+        if constexpr (METRIC == M_COS) { f32x4 pr = qq * rc; acc[q] = acc[q] + pr; }
+        else { f32x4 d = qq - rc; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = nxt[u];
+  }
+  for (int t = nb * U; t < n8; t++) {
+    f32x4 r = load4<QUANT>(row, 8 * t + 4 * half);
+    const float* qp = qs + 8 * t + 4 * half;
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
+      if constexpr (METRIC == M_COS) { f32x4 pr = qq * r; acc[q] = acc[q] + pr; }
+      else { f32x4 d = qq - r; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QB; q++) {
+    float s = pair_hsum(acc[q], half);
+    for (int e = n8 * 8; e < dim; e++) {
+      float r = load1<QUANT>(row, e);
+      if constexpr (METRIC == M_COS) s += qs[q * dimp + e] * r;
+      else { float d = qs[q * dimp + e] - r; s += d * d; }
+    }
+    float score;
+    if constexpr (METRIC == M_COS) score = cos_epilogue(s, qn[q], rn);
+    else score = go_sqrt(s);
+    sk[q] = score_key(score);
+  }
+}
+
 template <int METRIC, int QUANT, bool GATHER, int QB>
 __global__ __launch_bounds__(256) void flat_scan_kernel(
     const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms,
@@ -58,72 +117,196 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(
 #pragma unroll
   for (int q = 0; q < QB; q++) { qn[q] = q < nq_grp ? qnorms[q] : 0.f; th[q] = q < nq_grp ? thr[q] : 0u; }
   const uint64_t ngroups = (end - begin + 31) / 32;
-  const int n8 = dim >> 3;
   for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += (uint64_t)gridDim.x * 4) {
     uint64_t pos = begin + g * 32 + p;
     bool valid = pos < end;
     uint32_t slot = GATHER ? gather[valid ? pos : begin] : (uint32_t)(valid ? pos : begin);
     const uint8_t* row = rows + (size_t)slot * stride;
-    f32x4 acc[QB];
-#pragma unroll
-    for (int q = 0; q < QB; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
-    const int nb = n8 / U;
-    typename Raw4<QUANT>::type cur[U], nxt[U];  // raw bits stay in the pipeline registers; decoded at use
-    if (nb > 0) {
-#pragma unroll
-      for (int u = 0; u < U; u++) cur[u] = load_raw4<QUANT>(row, 8 * u + 4 * half);
-    }
-    for (int b = 0; b < nb; b++) {
-      if (b + 1 < nb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) nxt[u] = load_raw4<QUANT>(row, 8 * ((b + 1) * U + u) + 4 * half);
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const float* qp = qs + 8 * (b * U + u) + 4 * half;
-        const f32x4 rc = decode4<QUANT>(cur[u]);
-#pragma unroll
-        for (int q = 0; q < QB; q++) {
-          f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
-          if constexpr (METRIC == M_COS) { f32x4 pr = qq * rc; acc[q] = acc[q] + pr; }
-          else { f32x4 d = qq - rc; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) cur[u] = nxt[u];
-    }
-    for (int t = nb * U; t < n8; t++) {
-      f32x4 r = load4<QUANT>(row, 8 * t + 4 * half);
-      const float* qp = qs + 8 * t + 4 * half;
-#pragma unroll
-      for (int q = 0; q < QB; q++) {
-        f32x4 qq = *reinterpret_cast<const f32x4*>(qp + q * dimp);
-        if constexpr (METRIC == M_COS) { f32x4 pr = qq * r; acc[q] = acc[q] + pr; }
-        else { f32x4 d = qq - r; f32x4 pr = d * d; acc[q] = acc[q] + pr; }
-      }
-    }
     float rn = 0.f;
     if constexpr (METRIC == M_COS) rn = norms[slot];
+    uint32_t sk[QB];
+    flat_eval_row<METRIC, QUANT, QB>(row, rn, qs, dimp, dim, half, qn, sk);
 #pragma unroll
     for (int q = 0; q < QB; q++) {
-      float s = pair_hsum(acc[q], half);
-      for (int e = n8 * 8; e < dim; e++) {
-        float r = load1<QUANT>(row, e);
-        if constexpr (METRIC == M_COS) s += qs[q * dimp + e] * r;
-        else { float d = qs[q * dimp + e] - r; s += d * d; }
-      }
-      float score;
-      if constexpr (METRIC == M_COS) score = cos_epilogue(s, qn[q], rn);
-      else score = go_sqrt(s);
-      uint32_t sk = score_key(score);
-      bool pass = valid && half == 0 && q < nq_grp && (nearest ? sk <= th[q] : sk >= th[q]);
+      bool pass = valid && half == 0 && q < nq_grp && (nearest ? sk[q] <= th[q] : sk[q] >= th[q]);
       if (pass) {
         uint32_t idx = atomicAdd(&cnt[q], 1u);
-        if (idx < cap) cand[(size_t)q * cap + idx] = ((unsigned long long)sk << 32) | slot;
+        if (idx < cap) cand[(size_t)q * cap + idx] = ((unsigned long long)sk[q] << 32) | slot;
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Small batches (<= 4 queries, k <= 64) in ONE launch: the reference serves one query per RPC (edge/edge_search.go -> VertexSearch,
+// none_vectorstore.go:104-180), and a chain of scan + select launches over a few hundred thousand rows is all launch gaps.
+//   every wave   scans its 32-row groups in exact order and keeps its own k best per query as a sorted 64-lane register array
+//                (ascending (key', id'): key' = score key ^ flip, id' = id ^ idflip — the canonical (score, id) order, best first);
+//   every block  merges its four waves' lists (LDS rank sort of <= 256 entries), writes its k best records to HBM and lowers
+//                bucket[q][block % k] to its BEST key': the k buckets end up holding k different rows, so their maximum bounds the
+//                collection's k-th best from above — closely (about its k ln k-th best);
+//   the LAST block to finish (ticket counter) gathers the records with key' <= max bucket[q][.] — a few dozen — into the candidate
+//                list and runs the ordinary selection (select.hpp) on them; it leaves the counter and the buckets reset.
+// Same (score, id) total order and same exact-order score bits as flat_scan_kernel + flat_select_kernel: identical answers.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t ONE_KMAX = 64;
+constexpr uint32_t ONE_MAX_BLOCKS = 2048;
+constexpr int ONE_QMAX = 4;
+typedef unsigned long long OneRec;   // key' << 32 | slot (the id' that ordered it inside the block is recomputed by the selection)
+struct OneState { uint32_t done, pad[3]; uint32_t bucket[ONE_QMAX * ONE_KMAX]; };
+constexpr size_t ONE_STATE_BYTES = 2048;
+static_assert(sizeof(OneState) <= ONE_STATE_BYTES && ONE_QMAX * ONE_KMAX == 256, "the last block resets one bucket per thread");
+
+static __device__ __forceinline__ void one_wave_sync() {   // LDS written by some lanes of this wave, read by others
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int METRIC, int QUANT, bool GATHER, int QB>
+__global__ __launch_bounds__(256) void flat_one_kernel(
+    const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, const uint32_t* __restrict__ gather, uint64_t total,
+    const float* __restrict__ q_eff, const float* __restrict__ qnorms, int nq_grp, int dim, uint32_t k, int nearest,
+    const uint64_t* __restrict__ ids, uint64_t dense_base, OneRec* __restrict__ recs, OneState* __restrict__ st,
+    unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t* __restrict__ thr, uint32_t cap, uint32_t* __restrict__ ovf,
+    uint64_t* __restrict__ out_ids, float* __restrict__ out_scores, uint32_t* __restrict__ out_counts) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  __shared__ __attribute__((aligned(16))) uint32_t m_key[4 * ONE_KMAX];
+  __shared__ __attribute__((aligned(16))) uint64_t m_id[4 * ONE_KMAX];
+  __shared__ uint32_t m_slot[4 * ONE_KMAX];
+  __shared__ uint32_t s_wn[4], s_last, s_n, s_bmax;
+  constexpr int U = QB == 1 ? 8 : 4;
+  const int dimp = (dim + 3) & ~3;
+  for (int i = threadIdx.x; i < QB * dimp; i += blockDim.x) {
+    const int q = i / dimp, e = i - q * dimp;
+    qs[i] = (q < nq_grp && e < dim) ? q_eff[(size_t)q * dim + e] : 0.f;
+  }
+  __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane & 1, p = lane >> 1;
+  const uint32_t flip = nearest ? 0u : 0xffffffffu;
+  const uint64_t idflip = nearest ? 0ull : ~0ull;
+  uint32_t* const w_key = m_key + wave * 64; uint64_t* const w_id = m_id + wave * 64; uint32_t* const w_slot = m_slot + wave * 64;   // this wave's merge scratch
+  float qn[QB];
+  uint32_t bk[QB], bs[QB], bn[QB], tk[QB];
+  uint64_t bi[QB], ti[QB];
+#pragma unroll
+  for (int q = 0; q < QB; q++) { qn[q] = q < nq_grp ? qnorms[q] : 0.f; bk[q] = 0xffffffffu; bs[q] = 0xffffffffu; bi[q] = ~0ull; bn[q] = 0; tk[q] = 0xffffffffu; ti[q] = ~0ull; }
+  const uint64_t ngroups = (total + 31) / 32;
+  for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g < ngroups; g += (uint64_t)gridDim.x * 4) {
+    const uint64_t pos = g * 32 + p;
+    const bool valid = pos < total;
+    const uint32_t slot = GATHER ? gather[valid ? pos : 0] : (uint32_t)(valid ? pos : 0);
+    const uint8_t* row = rows + (size_t)slot * stride;
+    float rn = 0.f;
+    if constexpr (METRIC == M_COS) rn = norms[slot];
+    const uint64_t rid = (ids ? ids[slot] : dense_base + slot) ^ idflip;
+    uint32_t sk[QB];
+    flat_eval_row<METRIC, QUANT, QB, U>(row, rn, qs, dimp, dim, half, qn, sk);
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      const uint32_t kq = sk[q] ^ flip;
+      const bool pass = valid && half == 0 && q < nq_grp && (bn[q] < k || kq < tk[q] || (kq == tk[q] && rid < ti[q]));
+      const unsigned long long m = __ballot(pass);
+      if (!m) continue;
+      // Parallel merge of the passing rows into the sorted list: one uniform loop over the candidates gives every existing entry
+      // the number of candidates in front of it and every candidate its rank among the candidates plus the number of existing
+      // entries in front of it — final positions, a permutation — then one scatter through the wave's LDS scratch.
+      const bool have = (uint32_t)lane < bn[q];
+      uint32_t e_shift = 0, c_rank = 0, c_below = 0;
+      for (unsigned long long mm = m; mm; mm &= mm - 1) {
+        const int j = __builtin_ctzll(mm);
+        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)kq, j);
+        bool c_lt_e = kc < bk[q], c_lt_c = kc < kq;   // candidate j in front of this lane's entry / of this lane's candidate
+        if (__ballot((have && kc == bk[q]) || (pass && kc == kq && lane != j))) {   // equal keys (rare): the ids decide
+          const uint64_t ic = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rid >> 32), j) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rid, j);
+          c_lt_e = c_lt_e || (kc == bk[q] && ic < bi[q]);
+          c_lt_c = c_lt_c || (kc == kq && ic < rid);
+        }
+        e_shift += (have && c_lt_e) ? 1u : 0u;
+        const uint32_t below = (uint32_t)__builtin_popcountll(__ballot(have && !c_lt_e));   // (ids are unique: never equal)
+        if (lane == j) c_below = below;
+        c_rank += (pass && c_lt_c) ? 1u : 0u;
+      }
+      const uint32_t pe = (uint32_t)lane + e_shift, pc = c_rank + c_below;
+      if (have && pe < 64u) { w_key[pe] = bk[q]; w_id[pe] = bi[q]; w_slot[pe] = bs[q]; }
+      if (pass && pc < 64u) { w_key[pc] = kq; w_id[pc] = rid; w_slot[pc] = slot; }
+      one_wave_sync();
+      const uint32_t nn = bn[q] + (uint32_t)__builtin_popcountll(m);
+      bn[q] = nn < 64u ? nn : 64u;
+      if ((uint32_t)lane < bn[q]) { bk[q] = w_key[lane]; bi[q] = w_id[lane]; bs[q] = w_slot[lane]; }
+      if (bn[q] >= k) { tk[q] = w_key[k - 1]; ti[q] = w_id[k - 1]; }
+      one_wave_sync();
+    }
+  }
+  // ---- block merge: the four waves' lists -> the block's k best, in order
+#pragma unroll
+  for (int q = 0; q < QB; q++) {
+    if (q >= nq_grp) break;
+    __syncthreads();
+    const uint32_t mine = bn[q] < k ? bn[q] : k;
+    if ((uint32_t)lane < k) {
+      const uint32_t i = (uint32_t)wave * k + lane;
+      const bool have = (uint32_t)lane < mine;
+      m_key[i] = have ? bk[q] : 0xffffffffu; m_id[i] = have ? bi[q] : ~0ull; m_slot[i] = have ? bs[q] : 0xffffffffu;
+    }
+    if (lane == 0) s_wn[wave] = mine;
+    __syncthreads();
+    const uint32_t all = s_wn[0] + s_wn[1] + s_wn[2] + s_wn[3];
+    // Records travel between blocks (and XCDs: one L2 each) as agent-scope atomic stores / loads — written through to the coherence
+    // point, so no wave needs a release fence at agent scope (an L2 write-back per wave: 8192 of them cost more than the scan of a
+    // million rows).
+    OneRec* out = recs + ((size_t)q * gridDim.x + blockIdx.x) * k;   // [q][block][k]: one query's records are contiguous
+    if ((uint32_t)tid < 4 * k && m_slot[tid] != 0xffffffffu) {
+      const uint32_t ki = m_key[tid]; const uint64_t ii = m_id[tid];
+      const uint32_t rank = sel_rank(m_key, m_id, 4 * k, ki, ii);
+      if (rank < k) {
+        __hip_atomic_store(out + rank, ((unsigned long long)ki << 32) | m_slot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rank == 0) atomicMin(&st->bucket[q * ONE_KMAX + blockIdx.x % k], ki);
+      }
+    }
+    if ((uint32_t)tid < k && (uint32_t)tid >= all)   // fewer than k rows here
+      __hip_atomic_store(out + tid, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- the last block to arrive finishes the search
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores and atomics have been acknowledged
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&st->done, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint32_t per_q = gridDim.x * k;
+  for (int q = 0; q < nq_grp; q++) {
+    if (tid == 0) { s_n = 0; s_bmax = 0; }
+    __syncthreads();
+    if ((uint32_t)tid < k) atomicMax(&s_bmax, __hip_atomic_load(&st->bucket[q * ONE_KMAX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const uint32_t bound = s_bmax;   // an empty bucket (fewer than k blocks) is 0xffffffff: every record passes, and there are < k * k of them
+    OneRec* src = recs + (size_t)q * per_q;
+    constexpr int B = 16;   // records per thread in flight: the loop is all L2 / fabric latency
+    for (uint32_t i0 = tid; i0 < per_q; i0 += 256 * B) {
+      unsigned long long e[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        e[u] = i < per_q ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const uint32_t ek = (uint32_t)(e[u] >> 32), es = (uint32_t)e[u];
+        if (es == 0xffffffffu || ek > bound) continue;
+        const uint32_t j = atomicAdd(&s_n, 1u);
+        if (j < cap) cand[(size_t)q * cap + j] = ((unsigned long long)(ek ^ flip) << 32) | es;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) cnt[q] = s_n;
+    __syncthreads();
+    flat_select_block<SELECT_SMALL>(q, cand, cnt, thr, cap, k, nearest, ids, dense_base, ovf, out_ids, out_scores, out_counts);
+    __syncthreads();
+  }
+  if (tid == 0) { st->done = 0; }
+  st->bucket[tid] = 0xffffffffu;
 }
 
 // stored codes of the edge .vertex stream (big-endian f32 / u16, raw u8) at arbitrary byte offsets -> rows
@@ -162,6 +345,8 @@ struct FCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  DevBuf w_one;            // flat_one_kernel: OneState | per-block records (reserved once, at its maximum)
+  bool one_ready = false;  // ... and its state words initialised (the kernel leaves them reset)
   int init() {  // the caller has selected the store's device
     COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     COLTT_HIP(hipEventCreate(&ev0));
@@ -190,6 +375,7 @@ struct Flat : Object {
   float max_norm() const { return __builtin_bit_cast(float, norm_bits[0]); }   // scales the Euclidean matrix-core margin
   float min_norm() const { return __builtin_bit_cast(float, ~norm_bits[1]); }   // NaN bits while the store is empty
   std::atomic<uint64_t> mfma_groups{0}, mfma_fallbacks{0};  // groups served by the MFMA path / sent back to the exact path
+  std::atomic<uint64_t> one_groups{0};                      // searches served by the one-launch kernel (<= 4 queries)
   ~Flat() override {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamDestroy(stream);
@@ -323,6 +509,56 @@ int search_group_exact(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neare
     for (uint64_t b = 0; b < total; b += seg) COLTT_TRY(scan(b, std::min<uint64_t>(total, b + seg)));
   }
   return COLTT_OK;
+}
+
+// <= 4 prepared queries [q0, q0+g) over positions [0, total), k <= 64: one launch (flat_one_kernel).
+// COLTT_FLAT_ONE=0 sends small batches through the scan + select chain instead (measurement and test knob).
+bool flat_one_enabled() {
+  const char* e = getenv("COLTT_FLAT_ONE");
+  return !(e && *e == '0');
+}
+
+template <int METRIC, int QUANT, bool GATHER, int QBT>
+int launch_one(Flat* f, FCtx* c, const uint32_t* gather, uint64_t total, const float* qe, const float* qn, int g, uint32_t k, int nearest,
+               uint64_t* oi, float* os, uint32_t* oc, uint32_t cap) {
+  const uint64_t groups = (total + 31) / 32;
+  // two 32-row groups per wave where the collection allows: 8 groups per block; at most 8 blocks per CU
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((groups + 7) / 8, ONE_MAX_BLOCKS));
+  const size_t lds = (size_t)QBT * ((f->dim + 3) & ~3u) * 4;
+  auto kern = flat_one_kernel<METRIC, QUANT, GATHER, QBT>;
+  if (lds > 40 * 1024) COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  uint8_t* base = c->w_one.as<uint8_t>();
+  OneState* st = reinterpret_cast<OneState*>(base);
+  OneRec* recs = reinterpret_cast<OneRec*>(base + ONE_STATE_BYTES);
+  uint32_t* cnt = c->w_cnt.as<uint32_t>();
+  kern<<<grid, 256, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), gather, total, qe, qn, g, (int)f->dim, k, nearest,
+                                      f->dense ? nullptr : f->ids.as<uint64_t>(), f->dense_base, recs, st,
+                                      c->w_cand.as<unsigned long long>(), cnt, cnt + 256, cap, cnt + 512, oi, os, oc);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+int search_group_one(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total,
+                     uint64_t* d_out_ids, float* d_out_sc, uint32_t* d_out_cnt, uint32_t cap) {
+  if (!c->one_ready) {
+    COLTT_TRY(c->w_one.reserve(ONE_STATE_BYTES + (size_t)ONE_MAX_BLOCKS * ONE_QMAX * ONE_KMAX * sizeof(OneRec)));
+    COLTT_HIP(hipMemsetAsync(c->w_one.p, 0xff, ONE_STATE_BYTES, c->stream));   // bucket[] = "no bound yet"
+    COLTT_HIP(hipMemsetAsync(c->w_one.p, 0, 16, c->stream));       // done = 0
+    c->one_ready = true;
+  }
+  const float* qe = c->w_qeff.as<float>() + q0 * f->dim;
+  const float* qn = c->w_qn.as<float>() + q0;
+  uint64_t* oi = d_out_ids + q0 * k; float* os = d_out_sc + q0 * k; uint32_t* oc = d_out_cnt + q0;
+#define COLTT_ONE_ARGS f, c, d_gather, total, qe, qn, g, k, nearest, oi, os, oc, cap
+#define COLTT_ONE_Q(M, Q) (d_gather ? (g <= 1 ? launch_one<M, Q, true, 1>(COLTT_ONE_ARGS) : launch_one<M, Q, true, ONE_QMAX>(COLTT_ONE_ARGS)) \
+                                    : (g <= 1 ? launch_one<M, Q, false, 1>(COLTT_ONE_ARGS) : launch_one<M, Q, false, ONE_QMAX>(COLTT_ONE_ARGS)))
+  int rc = COLTT_OK;
+#define COLTT_ONE(Q) rc = f->metric == COLTT_COSINE ? COLTT_ONE_Q(M_COS, Q) : COLTT_ONE_Q(M_L2, Q)
+  COLTT_DISPATCH_QUANT(f->quant, COLTT_ONE)
+#undef COLTT_ONE
+#undef COLTT_ONE_Q
+#undef COLTT_ONE_ARGS
+  return rc;
 }
 
 // The FLAT matrix-core kernel is flat_mfma3.hpp (split LDS-DMA rings).  A -DCOLTT_EXPERIMENTS build also carries generations 1, 2
@@ -496,6 +732,20 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   //  superseded experiment generations have none)
   const bool mfma = mode == COLTT_MODE_MFMA && (!d_gather || mfma_generation() == 3) && (cos_ok || l2_ok) &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 128 && f->dim <= 4096 && total > 0;
+  // small batches: the whole search in one launch, whatever the mode asked for (exact-order scores either way)
+  // (2-4 queries: while the scan is short — its four-query tile streams at about half the one-query rate, and past ~400 MB the chain's
+  //  launch gaps no longer matter: 1 M x 128 f32 x 4 queries 286 us here, 212 us through the chain; 100 k x 768: 123 vs 185)
+  const bool one = k <= ONE_KMAX && total > 0 && flat_one_enabled() &&
+                   (nq == 1 || (nq <= (size_t)ONE_QMAX && total * (uint64_t)f->stride <= (400ull << 20)));
+  if (one) {
+    COLTT_TRY(c->w_cand.reserve((size_t)QB * cap * 8));
+    COLTT_TRY(c->w_cnt.reserve(4096 + 4));
+    COLTT_HIP(hipEventRecord(c->ev0, c->stream));
+    COLTT_TRY(search_group_one(f, c, 0, (int)nq, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+    COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+    f->one_groups.fetch_add(1);
+    return COLTT_OK;
+  }
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
   if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * ((f->dim + MF_BK - 1) / MF_BK * MF_BK) * 2)); }
@@ -937,6 +1187,13 @@ int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fal
   if (!f) return fail(COLTT_E_NOT_FOUND, "flat_stats: unknown handle");
   if (mfma_groups) *mfma_groups = f->mfma_groups.load();
   if (mfma_fallbacks) *mfma_fallbacks = f->mfma_fallbacks.load();
+  return COLTT_OK;
+}
+
+int coltt_flat_one_launch_searches(coltt_handle_t h, uint64_t* out) {
+  auto f = lookup<Flat>(h);
+  if (!f || !out) return fail(COLTT_E_NOT_FOUND, "flat_one_launch_searches: unknown handle");
+  *out = f->one_groups.load();
   return COLTT_OK;
 }
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 
 // Hnsw.Search for large ef (HBM visited map): the level-0 walk of hnsw_walk2.hpp — delta result set, LDS Bloom filter in front
 // of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
-template <int METRIC, int QUANT, int PROFILE, int OPT>
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM>
 __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                          uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t bloom_words,
@@ -114,11 +114,19 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
-  w.vis = nullptr;
-  w.bloom = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
-  w.bloom_words = bloom_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(bloom_words | 0x80000000u);
-  w.ef_pad = ef_pad; w.hcap = 0; w.hcap_mask = 0;
-  w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
+  w.ef_pad = ef_pad;
+  if constexpr (VISMODE == VIS_LDS) {   // small ef: the LDS hash (bloom_words carries its capacity); a table that fills up is err 8
+    w.vis = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
+    w.hcap = bloom_words; w.hcap_mask = bloom_words - 1;
+    w.bloom = nullptr; w.bloom_words = 0; w.bloom_shift = 0;
+    w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
+  } else {
+    w.vis = nullptr;
+    w.bloom = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
+    w.bloom_words = bloom_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(bloom_words | 0x80000000u);
+    w.hcap = 0; w.hcap_mask = 0;
+    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
+  }
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    search_level2<METRIC, QUANT, PROFILE, OPT>(g, w, cur, curd, ef, lane, len);  // :258-259
+    search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE>(g, w, cur, curd, ef, lane, len);  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {
       const unsigned long long e = w.res0[i];
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
 #endif
     }
   }
-  if (lane == 0) vis_epoch[blockIdx.x] = w.epoch;
+  if constexpr (VISMODE == VIS_HBM) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 
@@ -524,7 +532,7 @@ int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
 
 uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; int w2 = -1; uint32_t bloom_words = 0; };  // w2: hnsw_walk2.hpp variant (OPT bits | 8 = deep profile), -1 = hnsw_dev.hpp:search_level
+struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; int w2 = -1; uint32_t bloom_words = 0; bool w2_lds = false; };  // w2: hnsw_walk2.hpp variant (OPT bits | 8 = deep profile), -1 = hnsw_dev.hpp:search_level
 
 #ifndef COLTT_VISG_MIN_EF
 #define COLTT_VISG_MIN_EF 128
@@ -625,10 +633,27 @@ int walk2_policy() {
   return atoi(e) & 15;
 }
 
+// The walk of the LDS-visited searches (ef <= 128 by default).  COLTT_WALK2_LDS=off: hnsw_dev.hpp:search_level; 2 / 4 / 6: hnsw_walk2.hpp
+// with the delta result set / adjacency-carried norms / both.  A traversal that would overflow the hash table re-runs the call on
+// search_level (which re-seeds the table from the result set) — never seen on the benchmark collections.
+// 10 M x 768 f32, 10 000 queries, ms per launch (profiles/r03_walk_lds_f32_10m.json): ef 128 off 22.39, 2 22.25, 4 21.19, 6 21.28;
+// ef 64 off 11.80, 2 11.77, 4 11.10, 6 11.25 — the norms riding with the adjacency rows are the gain; the delta set costs a little
+// when the whole result set is two 64-entry chunks.  The default build carries 4 (2 and 6: -DCOLTT_WALK_EXPERIMENTS).
+#ifndef COLTT_WALK2_LDS_DEFAULT
+#define COLTT_WALK2_LDS_DEFAULT 4
+#endif
+int walk2_lds_policy() {
+  const char* e = getenv("COLTT_WALK2_LDS");
+  if (!e || !*e) return COLTT_WALK2_LDS_DEFAULT;
+  if (!strcmp(e, "off")) return -1;
+  const int v = atoi(e) & 6;
+  return v ? v : -1;
+}
+
 // resident waves per CU of the walk2 profiles: see waves_per_cu_cap
 size_t waves_per_cu_cap(int quant);
 
-SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false) {
+SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2_lds = false) {
   SearchGeom s;
   s.ef = ef;
   s.ef_pad = (ef + 63) & ~63u;
@@ -654,6 +679,11 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false) {
       if (kb >= 2 && fixed + p2 * 1024 <= 160 * 1024) { s.bloom_words = (uint32_t)(p2 * 256); s.lds = fixed + p2 * 1024; }
       else s.w2 &= ~1;
     }
+  }
+  if (!s.visg && for_search && !no_w2_lds && x->cfg.m_max0 <= 1024) {
+    // small ef: the same walk over the LDS hash (delta result set, adjacency-carried norms; no Bloom filter — the hash is on chip)
+    const int pol = walk2_lds_policy();
+    if (pol >= 0) { s.w2 = pol; s.w2_lds = true; }
   }
   return s;
 }
@@ -681,6 +711,16 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
                          uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
   kern_t kern = nullptr;
 #define COLTT_W2(V, PROF, OPT) case V: kern = hnsw_search2_kernel<METRIC, QUANT, PROF, OPT>; break;
+  if (sg.w2_lds) {
+    switch (sg.w2) {
+#ifdef COLTT_WALK_EXPERIMENTS
+      case 2: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 2, VIS_LDS>; break;
+      case 6: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 6, VIS_LDS>; break;
+#endif
+      case 4: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>; break;
+      default: break;
+    }
+  } else
 #ifdef COLTT_WALK_EXPERIMENTS
   if constexpr (METRIC == M_COS && QUANT != Q_F8) {
     switch (sg.w2) {
@@ -702,7 +742,7 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
   if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                        k, sg.ef, sg.ef_pad, sg.bloom_words, counter, oi, os, oc, stats,
+                                        k, sg.ef, sg.ef_pad, sg.w2_lds ? sg.hcap : sg.bloom_words, counter, oi, os, oc, stats,
                                         x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
                                         x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());
@@ -754,7 +794,8 @@ uint32_t lat_max_nq() {
 }
 
 int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
-                  uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, bool force_single_wave = false) {
+                  uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, int force = 0) {
+  const bool force_single_wave = (force & 1) != 0;   // force: 1 = not the latency kernel, 2 = not the walk2 LDS-hash kernel (both after an err 8)
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (nq == 0) return COLTT_OK;
   if (k == 0) return fail(COLTT_E_INVALID, "hnsw_search: k must be >= 1");
@@ -774,13 +815,13 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
   if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: ef=%u > 4096", ef);
   if (wants_visg(ef)) COLTT_TRY(ensure_visg(x));  // lazily: N bytes x <= 2048 regions are only worth having for ef > 128
-  SearchGeom sg = search_geom(x, ef, true);
+  SearchGeom sg = search_geom(x, ef, true, (force & 2) != 0);
   if (sg.lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: dim/ef need %zu B of LDS (> 160 KiB)", sg.lds);
   // latency kernel for small batches.  Its LDS hash must never need the reset path, so it gets the largest table that fits beside the
   // staging area (one workgroup per CU); if even that is too small for this ef the one-wave kernel serves the call.
   bool mw = nq <= lat_max_nq() && !force_single_wave;
   if (mw) {
-    SearchGeom m = sg; m.w2 = -1; m.bloom_words = 0; m.visg = false;
+    SearchGeom m = sg; m.w2 = -1; m.w2_lds = false; m.bloom_words = 0; m.visg = false;
     // LDS: query + result set + exchange words + the staging area (32 padded rows) + the visited hash
     const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (size_t)LAT_ROWS * (x->stride + LAT_PAD);
     if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to stage 32 at a time
@@ -845,7 +886,9 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   x->last_ms.store(ms);
   if (mw && (h_stats[4] & 8ull))  // the multi-wave kernel's visited table would have needed a reset: same call on the single-wave kernel
-    return search_common(x, c, queries, on_device, nq, k, ef_override, out_ids, out_scores, out_counts, stats, true);
+    return search_common(x, c, queries, on_device, nq, k, ef_override, out_ids, out_scores, out_counts, stats, force | 1);
+  if (sg.w2_lds && (h_stats[4] & 8ull))  // same for the walk2 kernel with the LDS hash: hnsw_dev.hpp:search_level has the reset-and-reseed path
+    return search_common(x, c, queries, on_device, nq, k, ef_override, out_ids, out_scores, out_counts, stats, force | 3);
   if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_search: traversal watchdog tripped (code %llu)", h_stats[4]);
   if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = h_stats[3]; }
   return COLTT_OK;

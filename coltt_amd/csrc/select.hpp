@@ -36,17 +36,43 @@ static __device__ __forceinline__ uint32_t sel_rank(const uint32_t* __restrict__
   return rank;
 }
 
-static __global__ __launch_bounds__(256) void flat_select_kernel(
-    unsigned long long* __restrict__ cand_all, uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all,
+// digit search of a radix-select pass by the whole block: the first bin b with hist[0..b] >= need, and what is still needed inside it.
+// (A serial scan of the 256 bins by one thread is 256 dependent LDS reads, ~7 us per pass; twelve passes in the worst case.)
+static __device__ __forceinline__ void sel_find_digit(const uint32_t* __restrict__ hist, uint32_t need, uint32_t* __restrict__ wave_tot,
+                                                      uint32_t* __restrict__ s_digit, uint32_t* __restrict__ s_need) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t h = hist[tid];
+  uint32_t inc = h;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; w++) base += wave_tot[w];
+  inc += base;
+  const uint32_t exc = inc - h;
+  if (exc < need && need <= inc) { *s_digit = (uint32_t)tid; *s_need = need - exc; }
+}
+
+// The selection of query q by ONE 256-thread block (every thread of the block calls it; the LDS arrays are reused by the next call
+// after a __syncthreads()).  flat_select_kernel runs it with one block per query; the fused small-batch search (flat_one.hpp) runs
+// it in the last block to finish.
+template <uint32_t KCAP = K_MAX>   // LDS capacity: >= k and >= SELECT_SMALL (the one-launch kernel serves k <= 64 and sizes it 512)
+static __device__ __forceinline__ void flat_select_block(
+    const int q, unsigned long long* __restrict__ cand_all, uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all,
     uint32_t cap, uint32_t k, int nearest, const uint64_t* __restrict__ ids, uint64_t dense_base,
     uint32_t* __restrict__ overflow, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
     uint32_t* __restrict__ out_counts) {
+  static_assert(KCAP >= SELECT_SMALL, "the short-list path keeps every candidate in LDS");
   __shared__ uint32_t hist[256];
-  __shared__ __attribute__((aligned(16))) uint32_t sel_key[K_MAX + 4];
-  __shared__ uint32_t sel_slot[K_MAX];
-  __shared__ __attribute__((aligned(16))) uint64_t sel_id[K_MAX + 4];
-  __shared__ uint32_t s_digit, s_need, s_nsel;
-  const int q = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint32_t sel_key[KCAP + 4];
+  __shared__ uint32_t sel_slot[KCAP];
+  __shared__ __attribute__((aligned(16))) uint64_t sel_id[KCAP + 4];
+  __shared__ uint32_t s_digit, s_need, s_nsel, s_wtot[4];
+  const int tid = threadIdx.x;
   unsigned long long* cand = cand_all + (size_t)q * cap;
   uint32_t c = cnt_all[q];
   if (c > cap) { if (tid == 0) atomicOr(overflow, 1u); c = cap; }
@@ -92,11 +118,7 @@ static __global__ __launch_bounds__(256) void flat_select_kernel(
       if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t cum = 0, b = 0;
-      for (; b < 256; b++) { if (cum + hist[b] >= need) break; cum += hist[b]; }
-      s_digit = b; s_need = need - cum;
-    }
+    sel_find_digit(hist, need, s_wtot, &s_digit, &s_need);
     __syncthreads();
     prefix |= s_digit << shift; mask |= 255u << shift; need = s_need;
     __syncthreads();
@@ -120,11 +142,7 @@ static __global__ __launch_bounds__(256) void flat_select_kernel(
         if ((ip & imask) == ipre) atomicAdd(&hist[(ip >> shift) & 255ull], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        uint32_t cum = 0, b = 0;
-        for (; b < 256; b++) { if (cum + hist[b] >= ineed) break; cum += hist[b]; }
-        s_digit = b; s_need = ineed - cum;
-      }
+      sel_find_digit(hist, ineed, s_wtot, &s_digit, &s_need);
       __syncthreads();
       ipre |= (uint64_t)s_digit << shift; imask |= 255ull << shift; ineed = s_need;
     }
@@ -140,7 +158,7 @@ static __global__ __launch_bounds__(256) void flat_select_kernel(
     uint64_t ip = slot_id(ids, dense_base, (uint32_t)e) ^ idflip;
     if (kp == T && ip > idT) continue;
     uint32_t j = atomicAdd(&s_nsel, 1u);
-    if (j < K_MAX) { sel_key[j] = kp; sel_slot[j] = (uint32_t)e; sel_id[j] = ip; }
+    if (j < KCAP) { sel_key[j] = kp; sel_slot[j] = (uint32_t)e; sel_id[j] = ip; }
   }
   __syncthreads();
   const uint32_t ns = s_nsel < kk ? s_nsel : kk;  // == kk by construction
@@ -161,6 +179,14 @@ static __global__ __launch_bounds__(256) void flat_select_kernel(
     out_counts[q] = ns; cnt_all[q] = ns;
     thr_all[q] = (ns == k) ? (T ^ flip) : (nearest ? 0xffffffffu : 0u);
   }
+}
+
+static __global__ __launch_bounds__(256) void flat_select_kernel(
+    unsigned long long* __restrict__ cand_all, uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ thr_all,
+    uint32_t cap, uint32_t k, int nearest, const uint64_t* __restrict__ ids, uint64_t dense_base,
+    uint32_t* __restrict__ overflow, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+    uint32_t* __restrict__ out_counts) {
+  flat_select_block<K_MAX>((int)blockIdx.x, cand_all, cnt_all, thr_all, cap, k, nearest, ids, dense_base, overflow, out_ids, out_scores, out_counts);
 }
 
 // group state: cnt[256] | thr[256] | overflow

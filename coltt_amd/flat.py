@@ -130,6 +130,11 @@ class FlatSpace:
         L.check(L.lib().coltt_flat_stats(self.h, C.byref(a), C.byref(b)))
         return {"mfma_groups": a.value, "mfma_fallbacks": b.value}
 
+    def OneLaunchSearches(self):
+        a = C.c_uint64(0)
+        L.check(L.lib().coltt_flat_one_launch_searches(self.h, C.byref(a)))
+        return a.value
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

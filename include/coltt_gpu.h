@@ -103,6 +103,10 @@ int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq
 /* how many <= 256-query groups went through the matrix cores since creation, and how many of those overflowed their candidate
  * list and were re-run in exact mode (adversarial data only; the answers are the exact mode's either way) */
 int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fallbacks);
+/* searches of <= 4 queries and k <= 64 are served by ONE kernel launch whatever `mode` says (scan in exact order, per-wave and
+ * per-block k best, selection by the last block to finish): the reference's one-query-per-RPC shape (edge/edge_search.go).  Same
+ * answers as both modes; this counts them (COLTT_FLAT_ONE=0 in the environment turns the path off). */
+int coltt_flat_one_launch_searches(coltt_handle_t h, uint64_t* out);
 /* FilterableVertexSearch (edge/none_vectorstore.go:182-253): the candidate ids come from the roaring
  * index (pkg/inverted/search.go:113-119) on the Go side; ids not present are skipped (:201). */
 int coltt_flat_search_ids(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select,

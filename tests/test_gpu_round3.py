@@ -157,3 +157,45 @@ def test_filtered_search_through_the_matrix_cores(gpu, metric, quant, n, d):
                 for qi in range(min(nq, 6)):
                     assert_same_results(mi[qi, :mc[qi]], ms[qi, :mc[qi]], row_ids[live[sl[qi, :cn[qi]].astype(np.int64)]], sc[qi, :cn[qi]], f"{name} nq{nq} q{qi} near{nearest}")
     assert gf.Stats()["mfma_groups"] > before, "the filtered searches must really have gone through the matrix cores"
+
+
+@pytest.mark.parametrize("metric,quant,d,n", [(O.COSINE, O.Q_NONE, 128, 70000), (O.L2, O.Q_NONE, 77, 20000), (O.COSINE, O.Q_F16, 768, 9000),
+                                              (O.L2, O.Q_F8, 40, 30000), (O.COSINE, O.Q_BF16, 200, 12000), (O.L2, O.Q_F16, 12, 300000)])
+def test_small_batches_in_one_launch_equal_the_oracle(gpu, monkeypatch, metric, quant, d, n):
+    """<= 4 queries, k <= 64: scan, per-wave / per-block k best and the final selection in ONE kernel (flat.hip: flat_one_kernel) —
+    the shape of the reference's RPC (one query per VertexSearch call, edge/none_vectorstore.go:104-180).  Ids, ranks and score bits
+    equal the oracle's for both queue directions, every k, unfiltered and filtered (none_vectorstore.go:182-253), with score ties
+    (duplicated rows: broken by id, and the ids are NOT in slot order) and for stores smaller than k, a wave and a block."""
+    X = O.fill_normal(6000 + d + quant, (n, d)); X[500:600] = X[3]; X[n - 40:] = X[3]
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 33)
+    Q = np.concatenate([X[3:4], O.fill_normal(6100 + d, (3, d))])
+    calls = 0
+    for m in (3, 31, 700, n):
+        gf = gpu.FlatSpace(d, metric, quant); gf.ChangedVertex(ids[n - m:], X[n - m:])
+        of = O.Flat(d, metric, quant); of.upsert(ids[n - m:], X[n - m:])
+        rng = np.random.default_rng(m)
+        cand = np.concatenate([np.unique(np.concatenate([rng.choice(ids[n - m:], max(1, m // 3), replace=False), ids[n - 2:]])),   # a roaring ToArray(): ascending, unique
+                               np.uint64(10**13) + np.arange(5, dtype=np.uint64)])
+        calls = 0
+        for nq in (1, 2, 4):
+            for k in (1, 10, 64):
+                for nearest in (True, False):
+                    sel = gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE
+                    mode = gpu.MODE_EXACT if (nq + k) % 2 else gpu.MODE_MFMA      # the mode is irrelevant for these shapes
+                    gi, gs, gc = gf.VertexSearch(Q[:nq], k, sel, mode)
+                    fi, fs, fc = gf.FilterableVertexSearch(cand, Q[:nq], k, sel, mode)
+                    calls += 2
+                    for qi in range(nq):
+                        wi, ws = of.search(Q[qi], k, nearest=nearest, mode=2)
+                        assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], wi, ws, f"m{m} nq{nq} k{k} near{nearest} q{qi}")
+                        wi, ws = of.search(Q[qi], k, nearest=nearest, mode=2, cand=cand)
+                        assert_same_results(fi[qi, :fc[qi]], fs[qi, :fc[qi]], wi, ws, f"filtered m{m} nq{nq} k{k} near{nearest} q{qi}")
+        assert gf.OneLaunchSearches() == calls, (m, gf.OneLaunchSearches(), calls)
+    # the chain of scan + select launches gives the same answers (COLTT_FLAT_ONE=0), and k > 64 / more than four queries still take it
+    e1 = gf.VertexSearch(Q[:1], 10, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    monkeypatch.setenv("COLTT_FLAT_ONE", "0")
+    e0 = gf.VertexSearch(Q[:1], 10, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert np.array_equal(e0[0], e1[0]) and np.array_equal(bits(e0[1]), bits(e1[1])) and gf.OneLaunchSearches() == calls + 1
+    monkeypatch.delenv("COLTT_FLAT_ONE")
+    gf.VertexSearch(Q[:1], 65, gpu.SELECT_NEAREST, gpu.MODE_EXACT); gf.VertexSearch(np.concatenate([Q, Q]), 10, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert gf.OneLaunchSearches() == calls + 1

@@ -170,3 +170,38 @@ def test_latency_kernel_equals_oracle(gpu, monkeypatch, m, metric, quant, d, seq
             for qi in range(nq):
                 assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"nq{nq} k{k} ef{ef} q{qi}")
             assert {k_: st[k_] for k_ in ost} == ost, (nq, k, ef, st, ost)
+
+
+@pytest.mark.parametrize("lds_walk", ["off", "4"], ids=["round2-kernel", "walk2-lds"])
+@pytest.mark.parametrize("metric,quant,n,d", [(O.COSINE, O.Q_NONE, 5000, 96), (O.L2, O.Q_NONE, 4000, 20), (O.COSINE, O.Q_F16, 5000, 77),
+                                              (O.COSINE, O.Q_BF16, 2500, 768), (O.L2, O.Q_F8, 3000, 40)])
+def test_small_ef_walk_over_the_lds_hash_equals_oracle(gpu, monkeypatch, lds_walk, metric, quant, n, d):
+    """ef <= 128 (the LDS visited hash): the walk of hnsw_walk2.hpp (delta result set, adjacency-carried norms; COLTT_WALK2_LDS,
+    the default) and hnsw_dev.hpp:search_level give the oracle's ids, score bits and traversal counters."""
+    monkeypatch.setenv("COLTT_WALK2_LDS", lds_walk)
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
+    X = O.fill_normal(3600 + d, (n, d)); lv = O.levels(3601 + d, n)
+    gh = _gpu_build(gpu, X, lv, metric, quant, gpu.HnswCfg.default(ef_construction=60), batch=256)
+    Q = O.fill_normal(3602 + d, (48, d))
+    _check(gh, Q, quant, metric, (1, 2, 5), k=1)
+    _check(gh, Q, quant, metric, (10, 63, 64, 65, 100, 128))
+    _check(gh, Q[:8], quant, metric, (128,), k=128)
+
+
+def test_lds_hash_overflow_reruns_on_the_resetting_kernel(gpu, monkeypatch):
+    """COLTT_VISG=0 keeps ef = 4096 on the LDS hash: the walk2 kernel gives up when the table would need a reset (err 8) and the
+    call is served by search_level's reset-and-reseed path — same answers as the oracle, resets reported."""
+    monkeypatch.setenv("COLTT_VISG", "0")
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
+    n, d = 40000, 8
+    X = O.fill_normal(3700, (n, d)); lv = O.levels(3701, n)
+    gh = _gpu_build(gpu, X, lv, O.L2, O.Q_NONE, gpu.HnswCfg.default(ef_construction=40), batch=2048)
+    g = gh.ExportRaw(); rows = gh.FetchRows()
+    Q = O.fill_normal(3702, (6, d))
+    for pol in ("4", "off"):
+        monkeypatch.setenv("COLTT_WALK2_LDS", pol)
+        gi, gs, gc, st = gh.Search(Q, 10, ef=4096, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search(rows, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], Q, 10, 4096, threads=4)
+        for qi in range(len(Q)):
+            assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"{pol} q{qi}")
+        assert st["n_visit_resets"] > 0, (pol, st)

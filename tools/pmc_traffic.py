@@ -14,6 +14,7 @@ picked by grid size (one 64-thread workgroup per resident wave, 10 000-query lau
 import argparse
 import collections
 import csv
+import re
 import json
 import os
 import sys
@@ -32,9 +33,12 @@ def read_counter(path, counter="FETCH_SIZE"):
             per_dispatch[key] = per_dispatch.get(key, 0.0) + float(r["Counter_Value"])
     out = collections.defaultdict(list)
     for (_, name, grid), v in per_dispatch.items():
-        if "hnsw_search2_kernel" in name:   # round 3: the large-ef walk (hnsw_walk2.hpp) — always the HBM visited map; <METRIC, QUANT, PROFILE, OPT>
-            q = name.split("hnsw_search2_kernel<")[1].split(",")[1].strip() if "hnsw_search2_kernel<" in name else "0"
-            short = "hnsw_search_kernel/hbm" + ("" if q == "0" else f"/q{q}")
+        if "hnsw_search2_kernel" in name:   # round 3: hnsw_walk2.hpp — <METRIC, QUANT, PROFILE, OPT[, VISMODE]>; VISMODE 1 = the LDS hash (ef <= 128)
+            m = re.search(r"hnsw_search2_kernel<([^>]*)>", name)
+            t = [x.strip() for x in m.group(1).split(",")] if m else ["0", "0"]
+            q = t[1]
+            lds = len(t) >= 5 and t[4].endswith("1")
+            short = ("hnsw_search_kernel/lds" if lds else "hnsw_search_kernel/hbm") + ("" if q == "0" else f"/q{q}")
         elif "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
             q = name.split("hnsw_search_kernel<")[1].split(",")[1].strip() if "hnsw_search_kernel<" in name else "0"   # <METRIC, QUANT, VISG>
             short = ("hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds") + ("" if q == "0" else f"/q{q}")

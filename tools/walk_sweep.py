@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--variants", default="off,0,1,2,3,4,5,6,7,8,10,14,15")
     ap.add_argument("--bloom-kb", default="", help="comma list of COLTT_BLOOM_KB values tried for variants with the Bloom bit ('' = the library's choice)")
     ap.add_argument("--waves", default="", help="comma list of COLTT_WAVES_PER_CU values ('' = the library's choice)")
+    ap.add_argument("--env-var", default="COLTT_WALK2", help="COLTT_WALK2 (ef > 128: HBM visited map) or COLTT_WALK2_LDS (ef <= 128: off,2,4,6)")
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -54,13 +55,13 @@ def main():
     combos = []
     for v in [x for x in a.variants.split(",") if x]:
         bl = [""]
-        if v != "off" and (int(v) & 1) and a.bloom_kb:
+        if v != "off" and (int(v) & 1) and a.bloom_kb and a.env_var == "COLTT_WALK2":
             bl = a.bloom_kb.split(",")
         for b in bl:
             for wv in (a.waves.split(",") if a.waves else [""]):
                 combos.append((v, b, wv))
     for v, b, wv in combos:
-        os.environ["COLTT_WALK2"] = v
+        os.environ[a.env_var] = v
         for key, val in (("COLTT_BLOOM_KB", b), ("COLTT_WAVES_PER_CU", wv)):
             if val: os.environ[key] = val
             else: os.environ.pop(key, None)
