@@ -435,16 +435,23 @@ def leg_published_hnsw_point(G, torch, dev, O, args, k):
     qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 13)
     q = ds.rows(nq, qgen)
     out = Out(torch, dev, nq, k)
-    wall = []
+    wall, kern = [], []
     for i in range(300):
         t0 = time.perf_counter()
         h.SearchDevice(q.data_ptr() + i * dim * 4, 1, k, *out.ptrs())
-        wall.append(time.perf_counter() - t0)
+        wall.append(time.perf_counter() - t0); kern.append(h.last_kernel_ms())
+    qh = q[:300].cpu().numpy()
+    hwall = []
+    for i in range(300):   # the same call with HOST buffers (what a cgo caller hands over): query in, ids / scores / counts out
+        t0 = time.perf_counter()
+        h.Search(qh[i:i + 1], k)
+        hwall.append(time.perf_counter() - t0)
     h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs())
     batch_ms = h.last_kernel_ms()
     res = {"workload": f"core/vectorindex HNSW defaults (M=16 efSearch=20 efConstruction=200), {n}x{dim} float32 uniform[0,1), cosine, k={k}: the reference's published "
                        f"search point (0.87 ms/query through gRPC, UPDATE-LOG.md:142; build 2 897 s through gRPC, benchmark/coltt_core.go:107-116)",
            "single_query_call_ms_median": float(np.median(wall[20:]) * 1e3), "single_query_call_ms_p99": float(np.percentile(wall[20:], 99) * 1e3),
+           "single_query_kernel_ms_median": float(np.median(kern[20:])), "single_query_host_buffer_call_ms_median": float(np.median(hwall[20:]) * 1e3),
            "batch_of_10000_queries_per_s": nq / (batch_ms / 1e3), "build_s": build_s, "published_reference_ms_per_query": 0.87}
     if O is not None:
         try:
@@ -557,6 +564,10 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
         res["roofline"].pop("mfma")
         res["launch_chains_replaced"] = chain
         res["one_launch_searches"] = fl.OneLaunchSearches()
+        qh = q.cpu().numpy(); hw = []
+        for _ in range(200):   # the same search with HOST buffers (what a cgo caller hands over): page-locked staging, answers in one D2H
+            t0 = time.perf_counter(); fl.VertexSearch(qh, k, G.SELECT_NEAREST, G.MODE_MFMA); hw.append(time.perf_counter() - t0)
+        res["host_buffer_call_ms_median"] = float(np.median(hw[20:]) * 1e3)
     if not args.no_cpu_baseline:
         try:
             rows_cpu = min(n, cpu_rows)

@@ -74,6 +74,28 @@ struct DevBuf {
   template <class T> T* as() const { return (T*)p; }
 };
 
+// Page-locked host staging of a search context.  A small call (the reference's RPC shape: one query in, k answers out) through
+// pageable user buffers costs one staged, blocking copy per array — four D2H copies were a third of a single-query call.  Small
+// inputs are copied into this buffer and sent with one asynchronous H2D; the answers come back packed in ONE D2H.
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return COLTT_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    COLTT_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return COLTT_OK;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+constexpr size_t SMALL_CALL_BYTES = 64 * 1024;   // queries and answers up to this size take the staged path
+inline bool small_call_staging() { const char* e = getenv("COLTT_STAGING"); return !(e && *e == '0'); }   // COLTT_STAGING=0: A/B knob
+
 // Locking discipline = the reference's (RWMutex per shard / per vertex level: edge/none_vectorstore.go:40, core/vectorindex/hnsw.go:51,
 // hnsw_vertex.go:39): searches hold the object's lock SHARED and run concurrently, each on its own stream with its own
 // workspaces (CtxPool below); Insert / Remove / Load / upsert hold it EXCLUSIVE.  Mutations complete (stream synchronised)

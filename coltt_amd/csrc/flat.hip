@@ -345,6 +345,8 @@ struct FCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  DevBuf w_pack;           // small host-buffer calls: ids | scores | counts in one block (one D2H; see PinnedBuf)
+  PinnedBuf h_in, h_out;
   DevBuf w_one;            // flat_one_kernel: OneState | per-block records (reserved once, at its maximum)
   bool one_ready = false;  // ... and its state words initialised (the kernel leaves them reset)
   int init() {  // the caller has selected the store's device
@@ -690,7 +692,11 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   // ONE big segment left p = k/8192 for the whole scan: 72 % of the wave-blocks took the element path, 12k survivors/query.)
   // (the seed is small: all of its s0 x g scores are appended through atomics — 8192 rows x 256 queries took 0.7 ms)
   static const uint64_t seed_rows = [] { const char* e = getenv("COLTT_MFMA_SEED"); long v = e && *e ? atol(e) : 1024; return (uint64_t)(v < 256 ? 256 : v); }();
-  uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(seed_rows, 16ull * k)});
+  // (batches up to 64: a 4 Ki-row seed — 1 M x 768 f32 over 100 k gathered rows, batch 16: 0.201 -> 0.188 ms, batch 64 0.231 -> 0.217; all
+  //  1 M rows 0.758 -> 0.738 / 0.809 -> 0.785; above, the seed's g x s0 appended scores cost more than the tighter threshold gains)
+  static const bool seed_set = [] { const char* e = getenv("COLTT_MFMA_SEED"); return e && *e; }();
+  const uint64_t seed_now = seed_set ? seed_rows : (g <= 64 ? 4096 : 1024);
+  uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, std::max<uint64_t>(seed_now, 16ull * k)});
   static const uint64_t grow = [] { const char* e = getenv("COLTT_MFMA_GROW"); long v = e && *e ? atol(e) : 16; return (uint64_t)(v < 2 ? 2 : v); }();
   for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * grow)) COLTT_TRY(scan(b, e));
   // exact re-score of the survivors + the ordinary select, queued behind the scans with no host round trip in between; the
@@ -793,26 +799,43 @@ int flat_search_common(Flat* f, FCtx* c, const float* queries, bool q_on_device,
   if (mode != COLTT_MODE_EXACT && mode != COLTT_MODE_MFMA) return fail(COLTT_E_INVALID, "flat search: bad mode %d", mode);
   if (nq == 0) return COLTT_OK;
   const float* d_q = queries;
+  const size_t pack_bytes = nq * k * 12 + nq * 4;
+  const bool small_q = !q_on_device && nq * f->dim * 4 <= SMALL_CALL_BYTES && small_call_staging();
+  const bool packed = !out_on_device && pack_bytes <= SMALL_CALL_BYTES && small_call_staging();
   if (!q_on_device) {
     COLTT_TRY(c->w_qraw.reserve(nq * f->dim * 4));
-    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, queries, nq * f->dim * 4, hipMemcpyHostToDevice, c->stream));
+    const void* src = queries;
+    if (small_q) { COLTT_TRY(c->h_in.reserve(SMALL_CALL_BYTES)); std::memcpy(c->h_in.p, queries, nq * f->dim * 4); src = c->h_in.p; }
+    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, src, nq * f->dim * 4, hipMemcpyHostToDevice, c->stream));
     d_q = c->w_qraw.as<float>();
   }
   COLTT_TRY(prep_queries(f, c, d_q, nq));
   uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
-  if (!out_on_device) {
+  if (packed) {
+    COLTT_TRY(c->w_pack.reserve(SMALL_CALL_BYTES));
+    COLTT_TRY(c->h_out.reserve(SMALL_CALL_BYTES));
+    uint8_t* b = c->w_pack.as<uint8_t>();
+    d_oi = reinterpret_cast<uint64_t*>(b); d_os = reinterpret_cast<float*>(b + nq * k * 8); d_oc = reinterpret_cast<uint32_t*>(b + nq * k * 12);
+  } else if (!out_on_device) {
     COLTT_TRY(c->w_out_ids.reserve(nq * k * 8));
     COLTT_TRY(c->w_out_sc.reserve(nq * k * 4));
     COLTT_TRY(c->w_out_cnt.reserve(nq * 4));
     d_oi = c->w_out_ids.as<uint64_t>(); d_os = c->w_out_sc.as<float>(); d_oc = c->w_out_cnt.as<uint32_t>();
   }
   COLTT_TRY(search_prepared(f, c, nq, k, select, mode, d_gather, total, d_oi, d_os, d_oc));
-  if (!out_on_device) {
+  if (packed) COLTT_HIP(hipMemcpyAsync(c->h_out.p, c->w_pack.p, pack_bytes, hipMemcpyDeviceToHost, c->stream));
+  else if (!out_on_device) {
     COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
     COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
     COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
   }
   COLTT_HIP(hipStreamSynchronize(c->stream));
+  if (packed) {
+    const uint8_t* hb = c->h_out.as<uint8_t>();
+    std::memcpy(out_ids, hb, nq * k * 8);
+    std::memcpy(out_scores, hb + nq * k * 8, nq * k * 4);
+    std::memcpy(out_counts, hb + nq * k * 12, nq * 4);
+  }
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   f->last_ms.store(ms);

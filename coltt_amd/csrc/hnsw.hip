@@ -425,7 +425,8 @@ __global__ void add_base_kernel(uint64_t* ids, size_t n, uint64_t base) {
 struct HCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  DevBuf w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc;
+  DevBuf w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc, w_pack;
+  PinnedBuf h_in, h_out;   // small calls: see PinnedBuf
   int init() {  // the caller has selected the index's device
     COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     COLTT_HIP(hipEventCreate(&ev0));
@@ -800,7 +801,17 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   if (nq == 0) return COLTT_OK;
   if (k == 0) return fail(COLTT_E_INVALID, "hnsw_search: k must be >= 1");
   uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
-  if (!on_device) {
+  // small host-buffer calls: the work counter, the traversal counters and the three answer arrays live in ONE device block that
+  // comes back in one copy through page-locked staging (layout: 256 B counter + stats | ids | scores | counts)
+  const size_t pack_bytes = 256 + nq * k * 12 + nq * 4;
+  const bool packed = !on_device && pack_bytes <= SMALL_CALL_BYTES && nq * x->dim * 4 <= SMALL_CALL_BYTES && small_call_staging();
+  if (packed) {
+    COLTT_TRY(c->w_pack.reserve(SMALL_CALL_BYTES + 256));
+    COLTT_TRY(c->h_out.reserve(SMALL_CALL_BYTES + 256));
+    COLTT_TRY(c->h_in.reserve(SMALL_CALL_BYTES));
+    uint8_t* b = c->w_pack.as<uint8_t>();
+    d_oi = reinterpret_cast<uint64_t*>(b + 256); d_os = reinterpret_cast<float*>(b + 256 + nq * k * 8); d_oc = reinterpret_cast<uint32_t*>(b + 256 + nq * k * 12);
+  } else if (!on_device) {
     COLTT_TRY(c->w_out_ids.reserve(nq * k * 8));
     COLTT_TRY(c->w_out_sc.reserve(nq * k * 4));
     COLTT_TRY(c->w_out_cnt.reserve(nq * 4));
@@ -839,14 +850,17 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   const float* d_q = queries;
   if (!on_device) {
     COLTT_TRY(c->w_qraw.reserve(nq * x->dim * 4));
-    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, queries, nq * x->dim * 4, hipMemcpyHostToDevice, c->stream));
+    const void* src = queries;
+    if (packed) { std::memcpy(c->h_in.p, queries, nq * x->dim * 4); src = c->h_in.p; }
+    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, src, nq * x->dim * 4, hipMemcpyHostToDevice, c->stream));
     d_q = c->w_qraw.as<float>();
   }
   COLTT_TRY(prep_queries_any(x, c, d_q, nq));
   COLTT_TRY(c->w_misc.reserve(256));
-  uint32_t* counter = c->w_misc.as<uint32_t>();
-  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->w_misc.as<uint8_t>() + 16);
-  COLTT_HIP(hipMemsetAsync(c->w_misc.p, 0, 256, c->stream));
+  uint8_t* misc = packed ? c->w_pack.as<uint8_t>() : c->w_misc.as<uint8_t>();
+  uint32_t* counter = reinterpret_cast<uint32_t*>(misc);
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(misc + 16);
+  COLTT_HIP(hipMemsetAsync(misc, 0, 256, c->stream));
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
 #define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
@@ -860,17 +874,27 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   COLTT_HIP(hipEventRecord(c->ev1, c->stream));
   if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, c->stream>>>(d_oi, nq * k, x->dense_base);
   unsigned long long h_stats[5] = {0, 0, 0, 0, 0};
-  if (!on_device) {
-    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
-    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
-    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  if (packed) COLTT_HIP(hipMemcpyAsync(c->h_out.p, c->w_pack.p, pack_bytes, hipMemcpyDeviceToHost, c->stream));
+  else {
+    if (!on_device) {
+      COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
+      COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+      COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
   }
-  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
 #ifdef COLTT_PHASE_TIMING
   unsigned long long h_pt[8] = {0};
   COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, c->stream));
 #endif
   COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
+  if (packed) {
+    const uint8_t* hb = c->h_out.as<uint8_t>();
+    std::memcpy(h_stats, hb + 16, 40);
+    std::memcpy(out_ids, hb + 256, nq * k * 8);
+    std::memcpy(out_scores, hb + 256 + nq * k * 8, nq * k * 4);
+    std::memcpy(out_counts, hb + 256 + nq * k * 12, nq * 4);
+  }
 #ifdef COLTT_PHASE_TIMING
   {
     static const char* nm_w[8] = {"pop", "adjacency", "visited", "rows+dist", "merge", "prologue(upper levels)", "writeout", "-"};

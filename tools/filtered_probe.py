@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default="")
+    ap.add_argument("--lists", default="every_10th,random_10pct,all")
+    ap.add_argument("--nqs", default="1,16,64")
+    ap.add_argument("--modes", default="exact,mfma")
     a = ap.parse_args()
     import torch
     import coltt_amd as G
@@ -40,8 +43,13 @@ def main():
     rows = []
     sb = B.QBYTES[a.quant]
     for name, cand in lists.items():
-        for nq in (1, 16, 64):
+        if name not in a.lists.split(","):
+            continue
+        for nq in [int(x) for x in a.nqs.split(",")]:
+            ref = None
             for mode, mname in ((G.MODE_EXACT, "exact"), (G.MODE_MFMA, "mfma")):
+                if mname not in a.modes.split(","):
+                    continue
                 try:
                     r = fl.FilterableVertexSearch(cand, q[:nq], a.k, G.SELECT_NEAREST, mode)
                     ms, wall = [], []
@@ -50,7 +58,7 @@ def main():
                         wall.append(time.perf_counter() - t0); ms.append(fl.last_kernel_ms())
                     if mode == G.MODE_EXACT:
                         ref = r
-                    same = bool(np.array_equal(r[0], ref[0]) and np.array_equal(r[1].view(np.uint32), ref[1].view(np.uint32)))
+                    same = None if ref is None else bool(np.array_equal(r[0], ref[0]) and np.array_equal(r[1].view(np.uint32), ref[1].view(np.uint32)))
                     km = float(np.median(ms))
                     row = {"list": name, "candidates": int(len(cand)), "nq": nq, "mode": mname, "kernels_ms": km, "call_ms": float(np.median(wall)) * 1e3,
                            "gathered_GBps": len(cand) * a.dim * sb / (km / 1e3) / 1e9, "equals_exact_mode": same, "stats": fl.Stats()}
