@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 
 // Hnsw.Search for large ef (HBM visited map): the level-0 walk of hnsw_walk2.hpp — delta result set, LDS Bloom filter in front
 // of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
-template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM>
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false>   // APREF: adjacency prefetch for f32 rows too (small batches)
 __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                          uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t bloom_words,
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE>(g, w, cur, curd, ef, lane, len);  // :258-259
+    search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len);  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {
       const unsigned long long e = w.res0[i];
@@ -718,7 +718,7 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
       case 2: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 2, VIS_LDS>; break;
       case 6: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 6, VIS_LDS>; break;
 #endif
-      case 4: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>; break;
+      case 4: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>; break;   // (adjacency prefetch for f32 rows in small batches: measured, no gain — 1 M x 128, ef 20, one query 105 vs 111 us)
       default: break;
     }
   } else
