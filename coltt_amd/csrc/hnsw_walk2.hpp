@@ -369,6 +369,34 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         }
         if (last_chunk) { COLTT_PREFETCH_NEXT2() }
         if (m == 0) continue;
+        if (w.ef_pad <= 128u) {
+          // Small result sets (two entries per lane) — the headline configuration: ONE LDS round trip fetches the whole set, one
+          // uniform loop over the admitted keys gives every key its position (members in front of it, counted by ballots) and
+          // every member its shift (admitted keys in front of it): no binary search (7 dependent LDS reads), no second loop.
+          const unsigned long long e0 = (uint32_t)lane < len ? res[lane] : ~0ull;
+          const unsigned long long e1 = 64u + (uint32_t)lane < len ? res[64 + lane] : ~0ull;
+          uint32_t sh0 = 0, sh1 = 0, spos = 0;
+          {
+            unsigned long long am = A;
+            while (am) {
+              const int j = __builtin_ctzll(am); am &= am - 1;
+              const unsigned long long kj = readlane_u64(mykey, j);
+              const bool lt0 = e0 < kj, lt1 = e1 < kj;   // members in front of admitted key j (a fresh vertex: never equal to a member)
+              const uint32_t below = (uint32_t)__popcll(__ballot(lt0)) + (uint32_t)__popcll(__ballot(lt1));
+              if (lane == j) spos = below;
+              sh0 += lt0 ? 0u : 1u; sh1 += lt1 ? 0u : 1u;
+            }
+          }
+          const uint32_t minpos = (uint32_t)__builtin_amdgcn_readlane((int)spos, __builtin_ctzll(__ballot(adm && myrank == 0)));
+          scan_lo = minpos < scan_lo ? minpos : scan_lo;
+          { const uint32_t np = (uint32_t)lane + sh0; if ((uint32_t)lane < len && sh0 && np < ef) res[np] = e0; }
+          { const uint32_t np = 64u + (uint32_t)lane + sh1; if (64u + (uint32_t)lane < len && sh1 && np < ef) res[np] = e1; }
+          { const uint32_t np = spos + myrank; if (adm && np < ef) res[np] = mykey; }
+          len = len + m < ef ? len + m : ef;
+          wave_sync();
+          COLTT_PT(w, 4)  // merge
+          continue;
+        }
         // in-place merge from the tail down to the chunk of the smallest new key (hnsw_dev.hpp:search_level)
         uint32_t mypos = 0xffffffffu;
         if (adm) {
