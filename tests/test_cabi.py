@@ -162,6 +162,34 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
     assert all(k in committed for k in t)
 
 
+def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path):
+    """Round 3: the committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op` -> the HBM traffic bench.py reports for
+    the headline kernel (`hnsw_search2_kernel<.., VIS_LDS>`: 5 template arguments, the last one 1) and for the recall-0.98 kernel
+    (HBM visited map).  Re-derived here from the raw CSV and compared with profiles/pmc_traffic.json."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import pmc_traffic as T
+    src = os.path.join(root, "profiles", "r03_pmc_fetch_size_raw.csv")
+    bj = os.path.join(root, "profiles", "r03_bench_10m_under_pmc.json")
+    out = tmp_path / "t.json"
+    T.main([src, "--bench-json", bj, "--out", str(out)])
+    T.main([src, "--bench-json", bj, "--leg", "op", "--out", str(out)])
+    t = json.load(open(out))
+    committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    head = "hnsw n=10000000 dim=768 quant=0 ef=128 m=16 queries=10000 dataset=normal"
+    op = "hnsw n=10000000 dim=768 quant=1 ef=1024 m=16 queries=10000 dataset=lowrank:32:1.0"
+    assert set(t) == {head, op}
+    for key, lo, hi in ((head, 0.97, 1.03), (op, 1.0, 1.05)):
+        r = t[key]
+        assert lo <= r["traffic_over_algorithmic"] <= hi, (key, r)
+        assert r["dispatches_used"] >= 5 and "x1.99" in r["correction"], r
+        assert abs(committed[key]["hbm_bytes_per_launch"] - r["hbm_bytes_per_launch"]) < 1.0, key
+    c = T.read_counter(src)
+    assert len(c["hnsw_search_kernel/lds"]) >= 10 and len(c["hnsw_search_kernel/hbm/q1"]) >= 7   # <0, 0, 1, 4, 1> and <0, 1, 2, 7, 0>
+
+
 def test_trace_by_grid_tool_separates_launch_shapes(tmp_path):
     """tools/trace_by_grid.py: rocprofv3's --stats averages every launch of a kernel NAME; the per-(kernel, grid) table keeps the
     10 000-query steps apart from single-query calls of the same kernel, and its largest-cluster average ignores an outlier shape."""
