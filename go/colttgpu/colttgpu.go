@@ -333,6 +333,14 @@ func FlatSearch(h Handle, dim uint32, queries []float32, nq int, k uint32, sel, 
 }
 
 // FlatSaveVertex / FlatLoadVertex: the edge `.vertex` stream (none_vectorstore.go:308-516 and the f16/f8/bf16 twins).
+// FlatOneLaunchSearches: how many searches of <= 4 queries the one-launch kernel served (coltt_flat_one_launch_searches) —
+// a diagnostic for dashboards: the RPC path of the reference issues exactly this shape (edge/edge.go:610-690).
+func FlatOneLaunchSearches(h Handle) (uint64, error) {
+	var n C.uint64_t
+	err := call(func() C.int { return C.coltt_flat_one_launch_searches(h, &n) })
+	return uint64(n), err
+}
+
 func FlatSaveVertex(h Handle, metaIds []uint64, metaBlobs [][]byte) ([]byte, error) {
 	n := len(metaIds)
 	var cptr **C.uint8_t
