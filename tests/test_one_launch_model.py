@@ -54,3 +54,54 @@ def test_blocks_own_kth_best_alone_would_be_a_loose_bound():
     ids = np.arange(n, dtype=np.uint64)
     _, _, n_tight, _ = one_launch_model(keys, ids, k, rpb)
     assert n_loose > 500 and n_tight < 100, (n_loose, n_tight)
+
+
+# ---- the two register/LDS merges of round 3, modelled lane by lane (what every lane computes, then one scatter) ----------------
+
+def parallel_merge_model(entries, cands, cap=64):
+    """flat_one_kernel's per-wave list update: `entries` sorted ascending (<= 64), `cands` unordered; every existing entry counts the
+    candidates in front of it, every candidate its rank among the candidates plus the entries in front of it — final positions."""
+    out = [None] * cap
+    for i, e in enumerate(entries):
+        pe = i + sum(1 for c in cands if c < e)
+        if pe < cap:
+            assert out[pe] is None
+            out[pe] = e
+    for c in cands:
+        pc = sum(1 for d in cands if d < c) + sum(1 for e in entries if e < c)
+        if pc < cap:
+            assert out[pc] is None          # positions are a permutation: no two writers per slot
+            out[pc] = c
+    n = min(cap, len(entries) + len(cands))
+    return out[:n]
+
+
+def small_set_merge_model(res, admitted, ef):
+    """hnsw_walk2.hpp, ef <= 128: members shift by the number of admitted keys not behind them, an admitted key lands at
+    (#members in front of it) + (its rank among the admitted); entries pushed past ef are dropped."""
+    out = {}
+    for i, e in enumerate(res):
+        np_ = i + sum(1 for a in admitted if not (e < a))
+        if np_ < ef:
+            assert np_ not in out
+            out[np_] = e
+    for a in admitted:
+        np_ = sum(1 for e in res if e < a) + sum(1 for b in admitted if b < a)
+        if np_ < ef:
+            assert np_ not in out
+            out[np_] = a
+    n = min(ef, len(res) + len(admitted))
+    return [out[i] for i in range(n)]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_merge_models_equal_a_sort(seed):
+    rng = np.random.default_rng(seed)
+    universe = rng.permutation(5000)                      # distinct keys (the kernels compare (key, id) pairs: never equal)
+    n_e, n_c = int(rng.integers(0, 65)), int(rng.integers(0, 33))
+    entries = sorted(universe[:n_e].tolist()); cands = universe[n_e:n_e + n_c].tolist()
+    assert parallel_merge_model(entries, cands) == sorted(entries + cands)[:64]
+    ef = int(rng.choice([1, 7, 20, 64, 100, 128]))
+    res = sorted(universe[1000:1000 + int(rng.integers(0, ef + 1))].tolist())
+    adm = universe[2000:2000 + int(rng.integers(0, 33))].tolist()
+    assert small_set_merge_model(res, adm, ef) == sorted(res + adm)[:ef]
