@@ -205,3 +205,19 @@ def test_lds_hash_overflow_reruns_on_the_resetting_kernel(gpu, monkeypatch):
         for qi in range(len(Q)):
             assert_same_results(gi[qi, :gc[qi]], gs[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64), sc[qi, :cn[qi]], f"{pol} q{qi}")
         assert st["n_visit_resets"] > 0, (pol, st)
+
+
+@pytest.mark.parametrize("m", [24, 32])
+def test_two_chunk_rows_at_small_ef(gpu, monkeypatch, m):
+    """mMax0 = 48 / 64 with ef <= 128: two 32-neighbour chunks per expansion go through the small-set merge of hnsw_walk2.hpp (the
+    free slots and the stale lowerBound carry from the first chunk to the second, hnsw.go:357,374) — both kernels, oracle's counters."""
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
+    n, d = 3000, 32
+    X = O.fill_normal(3800 + m, (n, d)); lv = O.levels(3801 + m, n, m)
+    gh = _gpu_build(gpu, X, lv, O.COSINE, O.Q_NONE, gpu.HnswCfg.default(m=m, ef_construction=48), batch=128)
+    assert gh.cfg.m_max0 == 2 * m
+    Q = O.fill_normal(3802, (32, d))
+    for pol in ("4", "off"):
+        monkeypatch.setenv("COLTT_WALK2_LDS", pol)
+        _check(gh, Q, O.Q_NONE, O.COSINE, (3,), k=1)          # Hnsw.Search walks with max(ef, k) (hnsw.go:258)
+        _check(gh, Q, O.Q_NONE, O.COSINE, (10, 64, 128))
