@@ -113,6 +113,37 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
     const float* qT = w.qs + (size_t)j * n8p;
     if (fresh) {
       int gq = 0;
+#ifdef COLTT_LAT_EVAL_PIPE   // experiment: the LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run
+#define COLTT_LAT_LD(G0, RV, QV)                                                                         \
+      {                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) RV[u] = lat_elem<QUANT>(srow, 8 * ((G0) + u) + j); \
+        _Pragma("unroll") for (int u = 0; u < 4; u++) QV[u] = *reinterpret_cast<const f32x4*>(qT + (G0) + 4 * u); \
+      }
+#define COLTT_LAT_ACC(RV, QV)                                                                            \
+      {                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) {                                                 \
+          const float qe = QV[u >> 2][u & 3];                                                            \
+          if constexpr (METRIC == M_COS) { const float pp = qe * RV[u]; acc = acc + pp; }                \
+          else { const float df = qe - RV[u]; const float pp = df * df; acc = acc + pp; }                \
+        }                                                                                                \
+      }
+      {
+        const int nblk = n8 >> 4;
+        float rv0[16], rv1[16]; f32x4 qv0[4], qv1[4];
+        if (nblk > 0) COLTT_LAT_LD(0, rv0, qv0)
+        for (int b = 0; b < nblk; b += 2) {
+          if (b + 1 < nblk) COLTT_LAT_LD(16 * (b + 1), rv1, qv1)
+          COLTT_LAT_ACC(rv0, qv0)
+          if (b + 1 < nblk) {
+            if (b + 2 < nblk) COLTT_LAT_LD(16 * (b + 2), rv0, qv0)
+            COLTT_LAT_ACC(rv1, qv1)
+          }
+        }
+        gq = nblk << 4;
+      }
+#undef COLTT_LAT_LD
+#undef COLTT_LAT_ACC
+#endif
       for (; gq + 16 <= n8; gq += 16) {
         float rv[16]; f32x4 qv[4];
 #pragma unroll
