@@ -1,0 +1,103 @@
+"""bench.py's driver-facing contract: the LAST stdout line is a compact JSON object (target <= 4 KB, never
+above 8 KB — round 3's 23 KB line left BENCH_r03.json unparsed), every detail goes to bench_full.json / an earlier line, and
+`--gpus N` means N ranks (self-launch under torch.distributed.run; loud failure when the devices are not there)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _full_record():
+    """a real full record (round 3's 23 KB line) — the worst case seen so far"""
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_bench_10m_full.json")))
+
+
+def test_final_line_of_a_real_record_is_small_and_complete():
+    res = _full_record()
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    assert "\n" not in line
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert c["value"] == pytest.approx(res["value"], rel=1e-5)
+    assert c["config"]["workload"] and "model" not in c["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    assert c["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], rel=1e-4)
+    for k in ("value", "unit", "cores", "kind"):
+        assert k in c["cpu_baseline"], k
+    # the operating point and the FLAT legs are first-class, one short object each
+    assert c["op"]["recall_at_10"] >= 0.98 and 0 < c["op"]["frac"] < 1 and c["op"]["ef"] == res["operating_point"]["ef"]
+    for leg in ("c1", "c2", "c3"):
+        assert set(c[leg]) >= {"value", "ms", "frac"}, leg
+    assert "trimmed" not in c
+
+
+def test_final_line_is_bounded_whatever_the_legs_hold():
+    """pathological strings everywhere: the line is trimmed leg by leg, the contract's fields survive"""
+    res = _full_record()
+    res["config"]["workload"] = "w" * 300
+    res["roofline"]["kernel"] = "k" * 400
+    res["cpu_baseline"]["sample_short"] = "s" * 500
+    res["secondary"]["pq"] = {"value": 1.0, "ms_per_batch_kernels": 2.0, "roofline": {"frac": 0.5}, "equals_oracle": True}
+    res["secondary"]["shard"] = {"value": 1.0, "exchange": "rccl", "world": 8, "shard_rows": 5, "n_total": 40}
+    res["secondary"]["f3"]["lists"]["every_10th"].update({f"batch_{i}_mfma": {"kernels_ms": 0.123456, "frac_of_hbm_peak": 0.2, "equals_exact_mode": True} for i in range(100, 400)})
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_HARD
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert "f3" in c["trimmed"]
+
+
+def test_an_error_in_a_leg_stays_short():
+    res = _full_record()
+    res["operating_point"] = {"error": "x" * 5000}
+    res["secondary"]["c3"] = {"error": "y" * 5000}
+    c = json.loads(bench.final_line(res))
+    assert len(c["op"]["error"]) <= 160 and len(c["c3"]["error"]) <= 160
+
+
+def test_gpus_n_without_devices_fails_loudly():
+    """no launcher around it and no GPUs: `--gpus 2` must not silently run world 1"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "HIP device(s) visible" in (p.stderr + p.stdout)
+
+
+def test_gpus_n_under_a_launcher_of_another_size_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_gpus_2_launches_two_ranks_on_one_device(gpu):
+    """the command shape the driver uses for SCALE (`python bench.py --gpus N`), two ranks sharing cuda:0: n_gpus == 2, the sharded
+    layout exchanged through shared memory, answers equal to the same shards held by ONE process."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["COLTT_BENCH_EXCHANGE"] = "shm"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--n", "20000",
+                        "--dim", "64", "--queries", "256", "--legs", "none", "--no-cpu-baseline", "--steps", "2", "--warmup", "1",
+                        "--build-batch", "1024"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    last = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(last) <= bench.LINE_TARGET
+    c = json.loads(last)
+    assert c["n_gpus"] == 2 and c["config"]["mode"] == "replica"
+    assert c["shard"]["exchange"] == "shm" and c["shard"]["world"] == 2
+    assert c["shard"]["equals_single_process_group"] is True
+    full = json.load(open(os.path.join(ROOT, "bench_full.json")))
+    assert full["secondary"]["shard"]["n_total"] == 20000
