@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,f3 ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,f3,pq ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -637,6 +637,84 @@ def verify_shard_leg(G, torch, dev, args, world, local, dim, k, out):
     return same
 
 
+def leg_pq(G, torch, dev, O, args, dim, k):
+    """the product-quantiser ADC scan — 10 M x 768 vectors as 96 one-byte codes (NumSubVectors 96 of 8 dims,
+    NumCentroids 256; pkg/models/hnsw_common.go:20-33), codebooks trained on the GPU from a 10 000-vector sample (TriggerThreshold's
+    maximum), rows encoded on the GPU.  Timed: ONE query per call (the whole table staged in LDS, the code stream read once: the
+    HBM-roofline shape) and one 64-query call.  Roofline = rows of the dominant scan launch x 96 B / that launch's hipEvent time."""
+    n, m, c = args.n, 96, 256
+    if dim % m:
+        m = 8
+    ds = Dataset(torch, dev, dim, "normal")
+    gen = torch.Generator(device=dev); gen.manual_seed(args.seed + 606)
+    pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, m, c)
+    sample = ds.rows(10_000, gen)
+    t0 = time.time(); pq.Fit(sample.cpu().numpy(), 4); train_s = time.time() - t0
+    t0 = time.time(); done = 0
+    while done < n:
+        cnt = min(1 << 20, n - done)
+        x = ds.rows(cnt, gen)
+        pq.InsertDevice(x.data_ptr(), cnt, first_id=done)
+        done += cnt
+        del x
+    ingest_s = time.time() - t0
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 19)
+    nq = 64
+    q = ds.rows(nq, qgen)
+    out = Out(torch, dev, nq, k)
+    one_ms, one_scan = [], []
+    for i in range(24):
+        pq.SearchDevice(q.data_ptr() + (i % nq) * dim * 4, 1, k, *out.ptrs())
+        a, b = pq.last_kernel_ms()
+        if i >= 4:
+            one_ms.append(a); one_scan.append(b)
+    scan_rows = pq.last_scan_rows
+    t0 = time.perf_counter()
+    for i in range(10):
+        pq.SearchDevice(q.data_ptr() + (i % nq) * dim * 4, 1, k, *out.ptrs())
+    wall1 = (time.perf_counter() - t0) / 10
+    bms = []
+    for i in range(4):
+        pq.SearchDevice(q.data_ptr(), nq, k, *out.ptrs())
+        if i:
+            bms.append(pq.last_kernel_ms()[0])
+    gi = out.ids.cpu().numpy().astype(np.uint64); gs = out.sc.cpu().numpy()
+    scan_s = float(np.mean(one_scan)) / 1e3
+    res = {"workload": f"product-quantiser ADC scan, {n}x{dim} float32 as {m} one-byte codes ({c} centroids of {dim // m} dims), squared-L2 tables, k={k}; "
+                       f"one query per call and one {nq}-query call",
+           "value": 1.0 / wall1, "unit": "queries/s (one query per call, device buffers)", "ms_per_batch_kernels": float(np.mean(one_ms)),
+           "single_query_scan_launch_ms": scan_s * 1e3, "scan_rows_of_that_launch": int(scan_rows), "batch_64_kernels_ms": float(np.mean(bms)),
+           "batch_64_queries_per_s": nq / (float(np.mean(bms)) / 1e3), "train_s": train_s, "encode_and_ingest_s": ingest_s,
+           "roofline": {"bound": "hbm", "achieved": scan_rows * m / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": scan_rows * m / scan_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": scan_s * 1e3,
+                        "kernel": "pq_scan_kernel<4,1> (table in LDS, one ds_read_b32 per code byte; tile-interleaved codes, 16 B per lane per load)",
+                        "bytes_per_launch": int(scan_rows * m),
+                        "lds_note": "one table lookup per code byte: random ds_read_b32 over 32 banks is the second ceiling (~0.7 of the HBM peak)"}}
+    if O is not None:
+        try:
+            threads = O.cpu_count(); th = quota_cpus(threads)
+            codes = np.empty((n, m), np.uint8)
+            step = 1 << 21
+            for b0 in range(0, n, step):
+                codes[b0:b0 + step] = pq.FetchCodes(b0, min(step, n - b0))[0]
+            cb = pq.Codebooks(); qh = q.cpu().numpy()
+            O.set_pin_policy(2)
+            r1 = O.pq_search(O.PQ_EUCLIDEAN, cb, codes, qh[:1], k, threads=1, pin=True)
+            sample_q = int(max(th, min(nq, args.cpu_seconds / r1[3] * th)))
+            sample_q = min(nq, sample_q - sample_q % th if sample_q >= th else th)
+            ra = O.pq_search(O.PQ_EUCLIDEAN, cb, codes, qh[:sample_q], k, threads=th, pin=True)
+            res["cpu_baseline"] = {"value": sample_q / ra[3], "unit": "queries/s", "cores": th, "host_cpus": threads, "kind": "port",
+                                   "single_thread_ms_per_query": r1[3] * 1e3,
+                                   "sample": f"{sample_q} of the batch's queries over all {n} rows of codes copied out of HBM (row-major), oracle ADC scan, {th} pinned threads",
+                                   "gpu_equals_oracle_on_sample": bool(np.array_equal(gi[:sample_q], ra[0]) and np.array_equal(gs[:sample_q].view(np.uint32), ra[1].view(np.uint32)))}
+            res["equals_oracle"] = res["cpu_baseline"]["gpu_equals_oracle_on_sample"]
+            del codes
+        except Exception as e:
+            res["cpu_baseline"] = {"error": str(e)}
+    pq.close()
+    return res
+
+
 def leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k):
     """north-star layout: ShardVertex partition, per-shard HNSW, ONE RCCL all-gather of packed top-k inside the library
     (coltt_group_*), host merge.  Each rank generates only its own shard's vectors."""
@@ -779,7 +857,8 @@ def compact(res):
         o = {"value": leg.get("value"), "ms": leg.get("ms_per_batch_kernels"), "frac": r.get("frac")}
         if r.get("mfma"):
             o["mfma_frac"] = r["mfma"].get("frac")
-        o.update(_pick(leg, "identical_to_exact_mode", "exact_mode_ms_per_batch", "equals_oracle", "host_buffer_call_ms_median"))
+        o.update(_pick(leg, "identical_to_exact_mode", "exact_mode_ms_per_batch", "equals_oracle", "host_buffer_call_ms_median",
+                       "single_query_scan_launch_ms", "batch_64_queries_per_s"))
         c = leg.get("cpu_baseline")
         if isinstance(c, dict):
             o["cpu_value"] = c.get("value_scaled_to_full_scan", c.get("value"))
@@ -870,7 +949,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "f3"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "f3", "pq"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -964,6 +1043,11 @@ def main():
                 secondary["f3"] = leg_filtered(G, torch, dev, O, args, dim, k)
             except Exception as e:
                 secondary["f3"] = {"error": str(e)}
+        if "pq" in legs:
+            try:
+                secondary["pq"] = leg_pq(G, torch, dev, O, args, dim, k)
+            except Exception as e:
+                secondary["pq"] = {"error": str(e)}
         if "h1" in legs:
             try:
                 secondary["h1"] = leg_published_hnsw_point(G, torch, dev, O, args, k)

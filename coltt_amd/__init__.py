@@ -11,6 +11,7 @@ from ._lib import (COSINE, EUCLIDEAN, Q_NONE, Q_F16, Q_F8, Q_BF16, SELECT_REFERE
 from .flat import FlatSpace  # noqa: F401
 from .hnsw import Hnsw, HnswCfg  # noqa: F401
 from .cflat import MultiVectorSpace  # noqa: F401
+from .pq import PQSpace, PQ_COSINE, PQ_EUCLIDEAN, PQ_DOT  # noqa: F401
 from . import kernels  # noqa: F401
 from . import group  # noqa: F401
 from .group import Group  # noqa: F401

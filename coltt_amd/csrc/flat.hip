@@ -269,7 +269,13 @@ __global__ __launch_bounds__(256) void flat_one_kernel(
       __hip_atomic_store(out + tid, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- the last block to arrive finishes the search
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores and atomics have been acknowledged
+  // Every wave waits for ITS OWN record stores and bucket atomics to be acknowledged before the barrier that precedes the ticket:
+  // they are agent-scope (sc1, written through to the coherence point), so once vmcnt reaches 0 they are visible to any block on
+  // any XCD that later observes the ticket.  (A workgroup-scope release fence is NOT enough: on gfx9 it waits for lgkmcnt only, and
+  // the ticket could reach L2 before the stores of the same block — ADVICE r3.  An agent-scope release fence would add an L2
+  // write-back per wave, which is what this design avoids.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (tid == 0) s_last = atomicAdd(&st->done, 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
@@ -744,10 +750,13 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   const bool one = k <= ONE_KMAX && total > 0 && flat_one_enabled() &&
                    (nq == 1 || (nq <= (size_t)ONE_QMAX && total * (uint64_t)f->stride <= (400ull << 20)));
   if (one) {
-    COLTT_TRY(c->w_cand.reserve((size_t)QB * cap * 8));
+    // the last block may have to keep EVERY block record (mass ties: a zero cosine query, a store of duplicates — all keys equal the
+    // bound): the list is sized for grid x k records per query, so it cannot overflow and the (score, id) winners are exact
+    const uint32_t cap1 = std::max<uint32_t>(cap, ONE_MAX_BLOCKS * k);
+    COLTT_TRY(c->w_cand.reserve(std::max<size_t>((size_t)QB * cap, (size_t)ONE_QMAX * cap1) * 8));
     COLTT_TRY(c->w_cnt.reserve(4096 + 4));
     COLTT_HIP(hipEventRecord(c->ev0, c->stream));
-    COLTT_TRY(search_group_one(f, c, 0, (int)nq, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap));
+    COLTT_TRY(search_group_one(f, c, 0, (int)nq, k, nearest, d_gather, total, d_out_ids, d_out_sc, d_out_cnt, cap1));
     COLTT_HIP(hipEventRecord(c->ev1, c->stream));
     f->one_groups.fetch_add(1);
     return COLTT_OK;

@@ -291,6 +291,49 @@ int coltt_group_merge_host(const void* recs, int world, size_t nq, uint32_t k, i
 /* sharding.ShardVertex on the host (pkg/sharding/shard.go:34-41): the routing rule of a group, no device needed */
 uint64_t coltt_shard_vertex_host(uint64_t id, uint64_t shard_count);
 
+/* ---- product-quantised store: codebooks, Encode, the per-query distance table and the ADC scan -----------
+ * The reference declares the parameters (models.ProductQuantizerParameters, pkg/models/hnsw_common.go:20-33: NumCentroids in
+ * [2,256] -> one uint8 code per sub-vector, NumSubVectors >= 2) and ships the arithmetic (pkg/distancepq/distance.go:30-42 over
+ * asm/dot.s:7-55 and asm/euclidean.s:7-65), but the package that drove them (pkg/hnswpq, imported by
+ * playground/hnswpq_verification.go:29; call shape :69-73, 90-105, 154, 190-199) is not in its tree.  These entry points are what a
+ * binding of that package's quantiser would call; their results are DEFINED from the distancepq arithmetic (oracle/coltt_oracle.cpp,
+ * "Product quantiser"):
+ *   Encode  code[j] = argmin_c SquaredEuclideanDistance(x_j, centroid[j][c])  (strict <, c ascending, from MaxFloat32)
+ *   LUT     lut[j][c] = distFn(q_j, centroid[j][c]);   score = sum over j = 0..m-1 of lut[j][code[j]], f32, in j order
+ *   top-k   the k smallest by (score bits, id), ascending.
+ * metric = which distancepq function is distFn: */
+enum { COLTT_PQ_COSINE = 0 /* cosineDistance = 1 - Dot */, COLTT_PQ_EUCLIDEAN = 1 /* euclideanDistance = SQUARED L2 */,
+       COLTT_PQ_DOT = 2 /* dotProductDistance = -Dot */ };
+int coltt_pq_create(uint32_t dim, int metric, uint32_t num_subvectors, uint32_t num_centroids, coltt_handle_t* out);
+int coltt_pq_destroy(coltt_handle_t h);
+/* codebooks trained elsewhere: [num_subvectors][num_centroids][dim / num_subvectors] f32, row-major.  Refused once rows are stored. */
+int coltt_pq_set_codebooks(coltt_handle_t h, const float* codebooks);
+int coltt_pq_get_codebooks(coltt_handle_t h, float* out_codebooks);
+/* the quantiser's training step on a sample of n >= num_centroids vectors (TriggerThreshold, hnsw_common.go:29-32): deterministic
+ * Lloyd iterations — centroid c of sub-space j starts as sub-vector j of sample vector c; assignment = Encode; update = f32 sum in
+ * sample order / float32(count); an empty cluster keeps its centroid.  Refused once rows are stored. */
+int coltt_pq_train(coltt_handle_t h, const float* vecs, size_t n, uint32_t iterations);
+/* Encode without storing: out_codes [n][num_subvectors] */
+int coltt_pq_encode(coltt_handle_t h, const float* vecs, size_t n, uint8_t* out_codes);
+/* store vectors (encoded on the GPU) / ready codes under ids; existing ids are overwritten; codes >= num_centroids are refused */
+int coltt_pq_upsert(coltt_handle_t h, const uint64_t* ids, const float* vecs, size_t n);
+int coltt_pq_upsert_device(coltt_handle_t h, const uint64_t* ids, uint64_t first_id, const float* d_vecs, size_t n);
+int coltt_pq_upsert_codes(coltt_handle_t h, const uint64_t* ids, const uint8_t* codes, size_t n);
+int coltt_pq_remove(coltt_handle_t h, const uint64_t* ids, size_t n);
+int coltt_pq_len(coltt_handle_t h, uint64_t* out);
+/* stored codes of rows [first_slot, first_slot + n) in scan order ([n][num_subvectors]) and their ids; either output may be NULL */
+int coltt_pq_fetch_codes(coltt_handle_t h, uint64_t first_slot, uint64_t n, uint8_t* out_codes, uint64_t* out_ids);
+/* the distance table of one query: out_lut [num_subvectors][num_centroids] */
+int coltt_pq_lut(coltt_handle_t h, const float* query, float* out_lut);
+/* ADC search of a batch: out_ids / out_scores [nq][k], out_counts[q] = min(k, len); rows ascending by (score, id) */
+int coltt_pq_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
+                    uint32_t* out_counts);
+int coltt_pq_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_scores,
+                           uint32_t* d_out_counts);
+/* hipEvent times of the most recent search of this store: the whole call's kernels, and the scan launch over the last (largest)
+ * segment alone — the kernel the roofline of the PQ leg is quoted on — with the number of rows that launch covered */
+int coltt_pq_last_kernel_ms(coltt_handle_t h, float* out_search_ms, float* out_scan_ms, uint64_t* out_scan_rows);
+
 #ifdef __cplusplus
 }
 #endif

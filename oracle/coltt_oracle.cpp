@@ -1605,3 +1605,116 @@ int orc_flat_scan_mt(const void* rows_v, int quant, uint64_t n, uint32_t dim, in
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Product quantiser: codebook LUT + ADC scan (BASELINE.json north_star "PQ-codebook kernels").
+//
+// PARITY UNPINNED — THIS SECTION IS A DEFINITION, not a restatement of reference code.  What the reference holds:
+//   * the parameters — pkg/models/hnsw_common.go:20-33: NumCentroids in [2, 256] (one uint8 code per sub-vector),
+//     NumSubVectors >= 2 (the paper's m), TriggerThreshold = size of the training sample;
+//   * the arithmetic — pkg/distancepq: euclideanDistance = SQUARED L2 (distance.go:30-32), cosineDistance = 1 - dot
+//     (:40-42), dotProductDistance = -dot (:36-38), over asm.SquaredEuclideanDistance / asm.Dot (asm/euclidean.s:7-65,
+//     asm/dot.s:7-55: FMA, 4 x 8-lane accumulators, scalar-FMA tail — pq_l2sq / pq_dot above), selected at init on AVX2+FMA hosts
+//     (distance_amd64.go:28-36);
+//   * the call shape — playground/hnswpq_verification.go:69-73, 90-105, 154, 190-199 (NumSubVectors 32, NumCentroids 256, train,
+//     Fit, then search with the float vectors dropped) — but the package it drives, pkg/hnswpq, is NOT in the tree, and nothing else
+//     imports pkg/distancepq (SURVEY §0 finding 9).
+// So the scan is defined from the distancepq arithmetic in the form every product quantiser over such kernels takes (Jegou et al.,
+// the paper the parameter comments cite):
+//   codebooks [m][C][dsub] f32, dim = m * dsub; a stored vector is m uint8 codes;
+//   Encode: code[j] = argmin_c SquaredEuclideanDistance(x_j, centroid[j][c]), scanning c upwards from minDist = MaxFloat32 with a
+//           strict `<` (ties -> the lowest c; a NaN distance is never chosen);
+//   LUT   : lut[j][c] = distFn(q_j, centroid[j][c]), distFn = the store's distancepq function (metric 0 cosineDistance,
+//           1 euclideanDistance, 2 dotProductDistance);
+//   score : dist = 0; for j = 0..m-1: dist += lut[j][code[j]]           (f32, in j order: "var dist float32; dist += ...")
+//   top-k : the k smallest in the canonical (score bits, id) order used everywhere in this oracle;
+//   Train : Lloyd iterations with everything deterministic (centroid c of sub-space j starts as sub-vector j of training vector c;
+//           assignment = Encode; update = f32 sum in training-index order / float32(count); an empty cluster keeps its centroid).
+// ------------------------------------------------------------------------------------------------
+enum { PQ_COSINE = 0, PQ_EUCLIDEAN = 1, PQ_DOT = 2 };
+static inline float pq_fn(int metric, const float* x, const float* y, size_t len) {
+  if (metric == PQ_EUCLIDEAN) return pq_l2sq(x, y, len);          // euclideanDistance (squared)
+  if (metric == PQ_COSINE) return 1 - pq_dot(x, y, len);           // cosineDistance
+  return -pq_dot(x, y, len);                                       // dotProductDistance
+}
+static void pq_lut(int metric, const float* cb, int m, int C, int dsub, const float* q, float* lut /* [m][C] */) {
+  for (int j = 0; j < m; j++)
+    for (int c = 0; c < C; c++) lut[(size_t)j * C + c] = pq_fn(metric, q + (size_t)j * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
+}
+static void pq_encode(const float* cb, int m, int C, int dsub, const float* x, uint8_t* code) {
+  for (int j = 0; j < m; j++) {
+    float minDist = 3.40282346638528859811704183484516925440e+38f;  // math.MaxFloat32
+    int best = 0;
+    for (int c = 0; c < C; c++) {
+      const float d = pq_l2sq(x + (size_t)j * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
+      if (d < minDist) { minDist = d; best = c; }
+    }
+    code[j] = (uint8_t)best;
+  }
+}
+static inline float pq_adc(const float* lut, int m, int C, const uint8_t* code) {
+  float dist = 0;
+  for (int j = 0; j < m; j++) dist += lut[(size_t)j * C + code[j]];
+  return dist;
+}
+
+extern "C" {
+
+void orc_pq_lut(int metric, const float* codebooks, int m, int C, int dsub, const float* query, float* out) {
+  pq_lut(metric, codebooks, m, C, dsub, query, out);
+}
+void orc_pq_encode(const float* codebooks, int m, int C, int dsub, const float* vecs, size_t n, uint8_t* out_codes) {
+  for (size_t i = 0; i < n; i++) pq_encode(codebooks, m, C, dsub, vecs + i * (size_t)m * dsub, out_codes + i * (size_t)m);
+}
+void orc_pq_adc(const float* lut, int m, int C, const uint8_t* codes, size_t n, float* out) {
+  for (size_t i = 0; i < n; i++) out[i] = pq_adc(lut, m, C, codes + i * (size_t)m);
+}
+// Lloyd iterations as defined above; codebooks is in/out only in the sense that it is fully overwritten.  n >= C.
+int orc_pq_train(float* codebooks, int m, int C, int dsub, const float* vecs, size_t n, int iters) {
+  if ((size_t)C > n) return -1;
+  const size_t dim = (size_t)m * dsub;
+  for (int j = 0; j < m; j++)
+    for (int c = 0; c < C; c++) std::memcpy(codebooks + ((size_t)j * C + c) * dsub, vecs + (size_t)c * dim + (size_t)j * dsub, (size_t)dsub * 4);
+  std::vector<uint8_t> codes(n * (size_t)m);
+  for (int it = 0; it < iters; it++) {
+    for (size_t i = 0; i < n; i++) pq_encode(codebooks, m, C, dsub, vecs + i * dim, &codes[i * m]);
+    for (int j = 0; j < m; j++)
+      for (int c = 0; c < C; c++) {
+        uint32_t cnt = 0;
+        for (size_t i = 0; i < n; i++) cnt += codes[i * m + j] == c;
+        if (!cnt) continue;
+        for (int e = 0; e < dsub; e++) {
+          float s = 0;
+          for (size_t i = 0; i < n; i++) if (codes[i * m + j] == c) s += vecs[i * dim + (size_t)j * dsub + e];
+          codebooks[((size_t)j * C + c) * dsub + e] = s / (float)cnt;
+        }
+      }
+  }
+  return 0;
+}
+// The ADC search over contiguous codes [n][m] (row-major) on n_threads pinned threads, one query per thread: per query the LUT, then
+// one pass over the codes with the bounded queue in the canonical (score, id) order.  ids == NULL: id = slot.
+int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub, const uint8_t* codes, const uint64_t* ids, uint64_t n,
+                     const float* queries, size_t nq, int k, int n_threads, int pin, uint64_t* out_ids, float* out_scores,
+                     int32_t* out_counts, double* wall_s) {
+  if (n_threads < 1) n_threads = 1;
+  const size_t dim = (size_t)m * dsub;
+  std::atomic<size_t> next{0};
+  double w = run_threads(n_threads, pin, [&](int) {
+    std::vector<float> lut((size_t)m * C);
+    for (;;) {
+      size_t qi = next.fetch_add(1);
+      if (qi >= nq) break;
+      pq_lut(metric, codebooks, m, C, dsub, queries + qi * dim, lut.data());
+      TopK tk{k, true, {}};
+      for (uint64_t r = 0; r < n; r++) tk.add({pq_adc(lut.data(), m, C, codes + r * (size_t)m), ids ? ids[r] : r});
+      std::sort(tk.h.begin(), tk.h.end(), scored_less);
+      out_counts[qi] = (int32_t)tk.h.size();
+      for (size_t j = 0; j < tk.h.size(); j++) { out_ids[qi * k + j] = tk.h[j].tie; out_scores[qi * k + j] = tk.h[j].score; }
+    }
+  });
+  if (wall_s) *wall_s = w;
+  return 0;
+}
+
+}  // extern "C"

@@ -479,3 +479,59 @@ def membw(arr, threads=None, reps=1, max_bytes=8 << 30):
     L.orc_membw.argtypes = [_vp, C.c_size_t, C.c_int, C.c_int]
     nbytes = int(min(arr.nbytes, max_bytes))
     return float(L.orc_membw(arr.ctypes.data_as(_vp), C.c_size_t(nbytes), int(threads or cpu_count()), int(reps)))
+
+
+# ------------------------------------------------------------------ product quantiser (a DEFINITION, see coltt_oracle.cpp)
+PQ_COSINE, PQ_EUCLIDEAN, PQ_DOT = 0, 1, 2
+
+
+def _cb(codebooks):
+    cb = _f32(codebooks)
+    assert cb.ndim == 3, "codebooks are [m][C][dsub]"
+    return cb, cb.shape[0], cb.shape[1], cb.shape[2]
+
+
+def pq_lut(metric, codebooks, query):
+    """lut[j][c] = distFn(q_j, centroid[j][c]) with the store's distancepq function"""
+    cb, m, c, ds = _cb(codebooks)
+    q = _f32(query).reshape(m * ds)
+    out = np.empty((m, c), np.float32)
+    lib().orc_pq_lut(int(metric), _p(cb), m, c, ds, _p(q), _p(out))
+    return out
+
+
+def pq_encode(codebooks, vecs):
+    cb, m, c, ds = _cb(codebooks)
+    v = _f32(vecs).reshape(-1, m * ds)
+    out = np.empty((len(v), m), np.uint8)
+    lib().orc_pq_encode(_p(cb), m, c, ds, _p(v), C.c_size_t(len(v)), _p(out))
+    return out
+
+
+def pq_adc(lut, codes):
+    lut = _f32(lut); codes = np.ascontiguousarray(codes, np.uint8)
+    out = np.empty(len(codes), np.float32)
+    lib().orc_pq_adc(_p(lut), lut.shape[0], lut.shape[1], _p(codes), C.c_size_t(len(codes)), _p(out))
+    return out
+
+
+def pq_train(vecs, m, c, iters):
+    v = _f32(vecs); n, dim = v.shape
+    assert dim % m == 0
+    cb = np.empty((m, c, dim // m), np.float32)
+    rc = lib().orc_pq_train(_p(cb), int(m), int(c), dim // m, _p(v), C.c_size_t(n), int(iters))
+    if rc != 0:
+        raise ValueError("pq_train: fewer training vectors than centroids")
+    return cb
+
+
+def pq_search(metric, codebooks, codes, queries, k, ids=None, threads=1, pin=False):
+    """ADC top-k (k smallest in the canonical (score, id) order) over contiguous codes [n][m].  Returns ids, scores, counts, wall s."""
+    cb, m, c, ds = _cb(codebooks)
+    codes = np.ascontiguousarray(codes, np.uint8); n = len(codes)
+    q = _f32(queries).reshape(-1, m * ds); nq = len(q)
+    oi = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32); cn = np.zeros(nq, np.int32); wall = C.c_double(0)
+    idp = None if ids is None else np.ascontiguousarray(ids, np.uint64)
+    lib().orc_pq_search_mt(int(metric), _p(cb), m, c, ds, _p(codes), _p(idp) if idp is not None else None, C.c_uint64(n), _p(q), C.c_size_t(nq),
+                           int(k), int(threads), int(bool(pin)), _p(oi), _p(sc), _p(cn), C.byref(wall))
+    return oi, sc, cn, wall.value

@@ -359,3 +359,123 @@ def edge_queue(scores_ids, max_size):
         if len(h) > max_size:
             h.pop()
     return sorted(h.a, key=lambda t: (t[0], t[1]))
+
+
+# ------------------------------------------------------------------------------------------------
+# pkg/distancepq and the product-quantiser scan defined on top of it — an INDEPENDENT restatement,
+# written from asm/dot.s:7-55, asm/euclidean.s:7-65 and distance.go:30-42 alone, with the fused multiply-adds evaluated in EXACT
+# rational arithmetic and rounded once (round-to-nearest-even to binary32), so it shares no code path with the C++ oracle's
+# std::fmaf.  Pure Python: small cases only.
+# ------------------------------------------------------------------------------------------------
+from fractions import Fraction as _Fr
+
+
+def _round_f32(x):
+    """a non-zero exact rational -> the nearest binary32 (ties to even), subnormals and overflow included"""
+    neg = x < 0
+    a = -x if neg else x
+    e = a.numerator.bit_length() - a.denominator.bit_length()
+    if _Fr(2) ** e > a:
+        e -= 1
+    elif _Fr(2) ** (e + 1) <= a:
+        e += 1
+    q = max(e, -126) - 23                  # the spacing of binary32 around a is 2^q (2^-149 below the normal range)
+    n = a / _Fr(2) ** q
+    f = n.numerator // n.denominator
+    rem = n - f
+    if rem > _Fr(1, 2) or (rem == _Fr(1, 2) and (f & 1)):
+        f += 1
+    v = _Fr(f) * _Fr(2) ** q
+    r = np.float32(np.inf) if v >= _Fr(2) ** 128 else np.float32(float(v))   # v is representable: float() is exact
+    return -r if neg else r
+
+
+def fma32(a, b, c):
+    """fused multiply-add on binary32 operands: a*b + c exactly, ONE rounding (VFMADD231PS / VFMADD231SS)"""
+    a, b, c = np.float32(a), np.float32(b), np.float32(c)
+    if not (np.isfinite(a) and np.isfinite(b) and np.isfinite(c)):
+        return np.float32(np.float64(a) * np.float64(b) + np.float64(c))   # inf / nan propagate the same way through any order
+    ex = _Fr(float(a)) * _Fr(float(b)) + _Fr(float(c))
+    if ex == 0:
+        pneg = bool(np.signbit(a)) != bool(np.signbit(b))
+        if (a == 0 or b == 0) and c == 0 and pneg and bool(np.signbit(c)):
+            return np.float32(-0.0)        # (-0) + (-0)
+        return np.float32(0.0)             # exact cancellation, or zeros of unlike sign: +0 under round-to-nearest
+    return _round_f32(ex)
+
+
+def _pq_reduce(acc, tail):
+    f = np.float32
+    s = [f(f(f(acc[0][j] + acc[1][j]) + acc[2][j]) + acc[3][j]) for j in range(8)]      # VADDPS Y0,Y1 ; +Y2 ; +Y3
+    t = [f(s[j] + s[j + 4]) for j in range(4)]                                         # VEXTRACTF128 $1 ; VADDPS X0, X1
+    t = [f(t[0] + tail), f(t[1] + f(0)), f(t[2] + f(0)), f(t[3] + f(0))]               # VADDPS X0, X4   (X4 = {tail, 0, 0, 0})
+    return f(f(t[0] + t[1]) + f(t[2] + t[3]))                                          # VHADDPS ; VHADDPS
+
+
+def pq_dot(x, y):
+    """asm.Dot (pkg/distancepq/asm/dot.s:7-55)"""
+    x = np.asarray(x, np.float32); y = np.asarray(y, np.float32)
+    acc = [[np.float32(0)] * 8 for _ in range(4)]
+    i = 0
+    while len(x) - i >= 32:                                     # blockloop: Y0..Y3 += x[i+8r .. i+8r+7] * y[...]
+        for r in range(4):
+            for j in range(8):
+                acc[r][j] = fma32(x[i + 8 * r + j], y[i + 8 * r + j], acc[r][j])
+        i += 32
+    tail = np.float32(0)
+    while i < len(x):                                           # tailloop: VFMADD231SS into lane 0 of X4
+        tail = fma32(x[i], y[i], tail); i += 1
+    return _pq_reduce(acc, tail)
+
+
+def pq_l2sq(x, y):
+    """asm.SquaredEuclideanDistance (pkg/distancepq/asm/euclidean.s:7-65): VSUBPS then VFMADD231PS d, d, acc"""
+    x = np.asarray(x, np.float32); y = np.asarray(y, np.float32)
+    acc = [[np.float32(0)] * 8 for _ in range(4)]
+    i = 0
+    while len(x) - i >= 32:
+        for r in range(4):
+            for j in range(8):
+                d = np.float32(x[i + 8 * r + j] - y[i + 8 * r + j])
+                acc[r][j] = fma32(d, d, acc[r][j])
+        i += 32
+    tail = np.float32(0)
+    while i < len(x):
+        d = np.float32(x[i] - y[i]); tail = fma32(d, d, tail); i += 1
+    return _pq_reduce(acc, tail)
+
+
+def pq_fn(metric, x, y):
+    """distance.go:30-42: 0 cosineDistance = 1 - dot, 1 euclideanDistance = squared L2, 2 dotProductDistance = -dot"""
+    if metric == 1:
+        return pq_l2sq(x, y)
+    d = pq_dot(x, y)
+    return np.float32(np.float32(1) - d) if metric == 0 else np.float32(-d)
+
+
+def pq_search(metric, codebooks, vectors, ids, query, k):
+    """the product-quantiser scan as DEFINED in oracle/coltt_oracle.cpp ("Product quantiser"): Encode every vector, build the query's
+    table, sum it in sub-vector order, keep the k smallest by (score bits, id).  Returns codes, lut, ids, scores."""
+    cb = np.asarray(codebooks, np.float32); m, c, ds = cb.shape
+    codes = np.zeros((len(vectors), m), np.uint8)
+    for i, v in enumerate(np.asarray(vectors, np.float32)):
+        for j in range(m):
+            best, md = 0, np.float32(3.4028234663852886e38)
+            for cc in range(c):
+                d = pq_l2sq(v[j * ds:(j + 1) * ds], cb[j, cc])
+                if d < md:
+                    best, md = cc, d
+            codes[i, j] = best
+    q = np.asarray(query, np.float32)
+    lut = np.array([[pq_fn(metric, q[j * ds:(j + 1) * ds], cb[j, cc]) for cc in range(c)] for j in range(m)], np.float32)
+    scored = []
+    for i in range(len(codes)):
+        dist = np.float32(0)
+        for j in range(m):
+            dist = np.float32(dist + lut[j, codes[i, j]])
+        u = int(np.float32(dist).view(np.uint32))
+        key = (~u & 0xFFFFFFFF) if (u & 0x80000000) else (u | 0x80000000)
+        scored.append((key, int(ids[i]), dist))
+    scored.sort(key=lambda t: (t[0], t[1]))
+    top = scored[:k]
+    return codes, lut, np.array([t[1] for t in top], np.uint64), np.array([t[2] for t in top], np.float32)

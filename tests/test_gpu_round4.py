@@ -1,0 +1,76 @@
+"""Round-4 GPU cases for the one-launch FLAT search (flat.hip: flat_one_kernel):
+* the block records and bucket minima of one search must be visible to the last block of THAT search: many back-to-back
+  single-query searches with different queries (a stale record of the previous query, or a missed top-k member, shows as a
+  difference from the scan + select chain);
+* a store of duplicates puts every block record on the bound — 2048 blocks x k = 131 072 records per query, more than the 65 536
+  entries the candidate list used to hold: the (score, id) winners must still be exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def test_back_to_back_one_query_searches_equal_the_chain(gpu, monkeypatch):
+    n, d, k, nq = 300_000, 64, 10, 400
+    import torch
+    g = torch.Generator(device="cuda:0"); g.manual_seed(41)
+    x = torch.randn((n, d), device="cuda:0", dtype=torch.float32, generator=g)
+    q = torch.randn((nq, d), device="cuda:0", dtype=torch.float32, generator=g)
+    torch.cuda.synchronize()
+    f = gpu.FlatSpace(d, gpu.COSINE, gpu.Q_NONE)
+    f.ChangedVertexDevice(x.data_ptr(), n, first_id=0)
+    qh = q.cpu().numpy()
+    monkeypatch.setenv("COLTT_FLAT_ONE", "0")
+    chain = [f.VertexSearch(qh[i:i + 1], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT) for i in range(nq)]
+    monkeypatch.delenv("COLTT_FLAT_ONE")
+    before = f.OneLaunchSearches()
+    oi = torch.empty((nq, k), dtype=torch.int64, device="cuda:0"); osc = torch.empty((nq, k), dtype=torch.float32, device="cuda:0")
+    oc = torch.empty(nq, dtype=torch.int32, device="cuda:0")
+    for rep in range(3):      # no host work between the launches: device-resident queries and answers
+        for i in range(nq):
+            f.VertexSearchDevice(q.data_ptr() + i * d * 4, 1, k, oi.data_ptr() + i * k * 8, osc.data_ptr() + i * k * 4, oc.data_ptr() + i * 4,
+                                 select=gpu.SELECT_NEAREST, mode=gpu.MODE_EXACT)
+        gi = oi.cpu().numpy().astype(np.uint64); gs = osc.cpu().numpy()
+        for i in range(nq):
+            assert np.array_equal(gi[i], chain[i][0][0]) and np.array_equal(bits(gs[i]), bits(chain[i][1][0])), (rep, i)
+    assert f.OneLaunchSearches() == before + 3 * nq
+    # spot check against the oracle
+    of = O.Flat(d, O.COSINE, O.Q_NONE); of.upsert(np.arange(20_000, dtype=np.uint64), x[:20_000].cpu().numpy())
+    f2 = gpu.FlatSpace(d, gpu.COSINE, gpu.Q_NONE); f2.ChangedVertex(np.arange(20_000, dtype=np.uint64), x[:20_000].cpu().numpy())
+    for i in range(5):
+        wi, ws = of.search(qh[i], k, nearest=True, mode=2)
+        r = f2.VertexSearch(qh[i:i + 1], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+        assert np.array_equal(r[0][0], wi) and np.array_equal(bits(r[1][0]), bits(ws))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_a_store_of_duplicates_keeps_the_exact_winners_in_one_launch(gpu, monkeypatch, metric):
+    n, d, k = 330_000, 32, 64
+    row = O.fill_normal(77, (1, d))
+    X = np.repeat(row, n, axis=0)
+    better = O.fill_normal(78, (1, d))
+    X[[17, 200_001, 329_999]] = better                      # three rows that differ
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 40)     # ids NOT in slot order
+    f = gpu.FlatSpace(d, metric, gpu.Q_NONE); f.ChangedVertex(ids, X)
+    Q = np.concatenate([better, row, O.fill_normal(79, (1, d))])
+    for nearest in (True, False):
+        sel = gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE
+        one = [f.VertexSearch(Q[i:i + 1], k, sel, gpu.MODE_EXACT) for i in range(3)]
+        n_one = f.OneLaunchSearches()
+        monkeypatch.setenv("COLTT_FLAT_ONE", "0")
+        chain = [f.VertexSearch(Q[i:i + 1], k, sel, gpu.MODE_EXACT) for i in range(3)]
+        monkeypatch.delenv("COLTT_FLAT_ONE")
+        assert f.OneLaunchSearches() == n_one
+        for i in range(3):
+            assert np.array_equal(one[i][0], chain[i][0]) and np.array_equal(bits(one[i][1]), bits(chain[i][1])), (nearest, i)
+            sc = one[i][1][0]; idv = one[i][0][0]
+            for a in range(k - 1):                           # canonical order: (score, id) ascending in the output
+                assert (bits(sc[a]) < bits(sc[a + 1])) or (bits(sc[a]) == bits(sc[a + 1]) and idv[a] < idv[a + 1]) or not nearest
+    # against the oracle on the tie-heavy answer: the 64 smallest ids among the duplicates follow the three better rows
+    of = O.Flat(d, metric, O.Q_NONE); of.upsert(ids, X)
+    wi, ws = of.search(Q[0], k, nearest=True, mode=2)
+    r = f.VertexSearch(Q[:1], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert np.array_equal(r[0][0], wi) and np.array_equal(bits(r[1][0]), bits(ws))
