@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
     ap.add_argument("--shard-leg-n", type=int, default=0, help="vectors in the whole sharded collection of the secondary.shard leg (0 = --n)")
+    # ranks started by self_launch() get their arguments through the environment: torch.distributed.run's own parser would read
+    # `--n 20000` as an abbreviation of one of ITS options (--nnodes, --nproc-per-node, ...) even behind the script path
+    if len(sys.argv) == 1 and os.environ.get("COLTT_BENCH_ARGS"):
+        return ap.parse_args(json.loads(os.environ["COLTT_BENCH_ARGS"]))
     return ap.parse_args()
 
 
@@ -912,8 +916,9 @@ def self_launch(args):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible (use --share-device to put every rank on cuda:0 — plumbing test only)")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)]
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "1")
+    env["COLTT_BENCH_ARGS"] = json.dumps(sys.argv[1:])
     raise SystemExit(subprocess.call(cmd, env=env))
 
 

@@ -666,6 +666,11 @@ float l2_eps(const Flat* f) {
   return 4.0f * acc + (f->quant == COLTT_Q_NONE ? 9.8e-4f : 0.f);
 }
 
+// K of the candidate GEMM: dim padded to whole 32-column steps, and to at least FOUR steps — the kernel's raw-norm parity buffers
+// assume >= 4 K steps per tile.  Short rows (dim < 128: 64- and 96-d collections) therefore run with K = 128: a row's K range ends in
+// the rows stored behind it (finite bits, multiplied by zero query columns), exactly like the overhang of a dim % 32 != 0 row.
+inline int mfma_kdim(const Flat* f) { return std::max<int>(4 * MF_BK, (int)((f->dim + MF_BK - 1) / MF_BK * MF_BK)); }
+
 // One group of <= 256 prepared queries through the matrix cores (cosine, 2-byte codes, dim % 64 == 0), then exact re-score.
 int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest, const uint32_t* d_gather, uint64_t total, uint64_t* d_out_ids, float* d_out_sc,
                       uint32_t* d_out_cnt, uint32_t cap, uint32_t* ovf) {
@@ -678,7 +683,7 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   const float* qn = c->w_qn.as<float>() + q0;
   _Float16* q16 = c->w_q16.as<_Float16>();
   const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
-  const int dimp = (int)((f->dim + MF_BK - 1) / MF_BK * MF_BK);   // K padded to whole steps with zero query columns
+  const int dimp = mfma_kdim(f);   // K padded to whole steps (and to at least four of them) with zero query columns
   mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * dimp, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, dimp, q16, cnt, thr, ovf, nearest);
   auto scan = [&](uint64_t b, uint64_t e) -> int {
     const bool seed = b == 0 && e - b <= cap;
@@ -739,11 +744,11 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // (padding, head of the next row — all finite as long as no stored norm ever was non-finite; Flat::reserve zeroes the rest)
   // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
   const bool finite_rows = max_norm == max_norm && max_norm < 3.0e38f;
-  const bool k_ok = f->dim % MF_BK == 0 || (mfma_generation() >= 2 && finite_rows);
+  const bool k_ok = (f->dim % MF_BK == 0 && f->dim >= 4 * MF_BK) || (mfma_generation() >= 3 && finite_rows);
   // (a filtered search — d_gather: positions of a slot list — takes the matrix cores too, through the kernel's gather mode; the
   //  superseded experiment generations have none)
   const bool mfma = mode == COLTT_MODE_MFMA && (!d_gather || mfma_generation() == 3) && (cos_ok || l2_ok) &&
-                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 128 && f->dim <= 4096 && total > 0;
+                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 8 && f->dim <= 4096 && total > 0;
   // small batches: the whole search in one launch, whatever the mode asked for (exact-order scores either way)
   // (2-4 queries: while the scan is short — its four-query tile streams at about half the one-query rate, and past ~400 MB the chain's
   //  launch gaps no longer matter: 1 M x 128 f32 x 4 queries 286 us here, 212 us through the chain; 100 k x 768: 123 vs 185)
@@ -763,7 +768,7 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   }
   const size_t gq = mfma ? 256 : (size_t)scan_qb(f);
   COLTT_TRY(c->w_cand.reserve((size_t)std::max<size_t>(gq, QB) * cap * 8));
-  if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * ((f->dim + MF_BK - 1) / MF_BK * MF_BK) * 2)); }
+  if (mfma) { COLTT_TRY(c->w_cand2.reserve((size_t)gq * cap * 8)); COLTT_TRY(c->w_q16.reserve((size_t)256 * mfma_kdim(f) * 2)); }
   const size_t n_groups = (nq + gq - 1) / gq;
   COLTT_TRY(c->w_cnt.reserve(4096 + n_groups * 4));
   uint32_t* d_ovf = c->w_cnt.as<uint32_t>() + 1024;   // one overflow flag per matrix-core group, checked once after the last group

@@ -96,6 +96,17 @@ func bptr(v []byte) *C.uint8_t {
 
 func Init(device int) error { return call(func() C.int { return C.coltt_init(C.int(device)) }) }
 
+// Normalize — edge.Normalize / vectorindex.Normalize (edge/vectorstore.go:173-189; core/vectorindex/metadata.go:107-123) computed by
+// the library (coltt_normalize); a zero vector comes back as zeros, as in the reference.
+func Normalize(v []float32) ([]float32, error) {
+	out := make([]float32, len(v))
+	if len(v) == 0 {
+		return out, nil
+	}
+	err := call(func() C.int { return C.coltt_normalize(fptr(v), 1, C.uint32_t(len(v)), fptr(out)) })
+	return out, err
+}
+
 // ------------------------------------------------------------------------------------------------ HNSW
 func HnswCreate(dim uint32, metric, quant int, cfg *HnswCfg) (Handle, error) {
 	var h Handle

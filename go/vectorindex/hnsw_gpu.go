@@ -165,19 +165,14 @@ func decodeMetadata(blob []byte) (Metadata, error) {
 	return m, nil
 }
 
-// Normalize — metadata.go:107-123 (kept for callers; the library applies the same arithmetic to what it stores)
+// Normalize — metadata.go:107-123.  Kept as an identifier for callers (core/core_helper.go); the arithmetic lives in the library
+// (coltt_normalize: the same sequential f32 sum, float64 sqrt and per-element divide the reference runs), so there is ONE copy of it.
+// The reference's Normalize cannot fail; a device error here panics, which the RPC goroutine recovers into reply.Error
+// (edge/edge.go:618-624).
 func Normalize(v []float32) []float32 {
-	var norm float32
-	out := make([]float32, len(v))
-	for i := range v {
-		norm += v[i] * v[i]
-	}
-	if norm == 0 {
-		return out
-	}
-	norm = float32(math.Sqrt(float64(norm)))
-	for i := range v {
-		out[i] = v[i] / norm
+	out, err := colttgpu.Normalize(v)
+	if err != nil {
+		panic(err)
 	}
 	return out
 }

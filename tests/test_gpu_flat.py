@@ -201,7 +201,7 @@ def test_flat_mfma_many_tiles_per_workgroup_smallest_dim(gpu, metric, quant, gen
     """200 k x 128: 782 row tiles over 256 persistent workgroups (three or four tiles each, the raw-norm parity buffers flip with
     every tile) at the SMALLEST dim the matrix-core mode takes (4 K steps per tile: the DMA rings run three tiles ahead of the
     epilogue).  Ragged batch, batch 256 and a last tile of 64 rows; both kernel generations; == exact mode bit for bit.
-    (dim 96 / 64 / 32 are served by the exact scan: `Stats()` shows no matrix-core group.)"""
+    (Round 4: dim 96 / 64 / 32 run with K padded to 128 — `Stats()` shows their matrix-core group too; tests/test_gpu_round4.py.)"""
     import subprocess, sys, os, json
     if gen != "3" and b"+experiments" not in gpu.lib().coltt_version():
         pytest.skip("generation 4 lives in tools/experiments/: only a -DCOLTT_EXPERIMENTS build carries it")
@@ -230,7 +230,7 @@ print(json.dumps({{"ok": ok, "groups": st["mfma_groups"], "fallbacks": st["mfma_
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["ok"] and r["groups"] > 0 and r["small_groups"] == 0, r
+    assert r["ok"] and r["groups"] > 0 and r["small_groups"] == (1 if gen == "3" else 0), r
 
 
 @pytest.mark.parametrize("d", [130, 200, 300])

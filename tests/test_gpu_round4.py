@@ -74,3 +74,33 @@ def test_a_store_of_duplicates_keeps_the_exact_winners_in_one_launch(gpu, monkey
     wi, ws = of.search(Q[0], k, nearest=True, mode=2)
     r = f.VertexSearch(Q[:1], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
     assert np.array_equal(r[0][0], wi) and np.array_equal(bits(r[1][0]), bits(ws))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("quant", [0, 1])
+@pytest.mark.parametrize("d", [8, 24, 64, 96, 100])
+def test_short_rows_go_through_the_matrix_cores(gpu, metric, quant, d):
+    """dim < 128 (64- / 96-d collections): the candidate GEMM runs with K padded to 128 — a row's K range ends in the rows stored
+    behind it, against zero query columns — and the exact re-score makes ids, ranks and score bits equal the exact scan's and the
+    oracle's (edge/none_vectorstore.go:129-180, f16_vectorstore.go:131-186)."""
+    n, nq, k = 5000, 40, 10
+    X = O.fill_normal(8100 + d, (n, d)); X[100:140] = X[7]                 # ties
+    Q = np.concatenate([X[7:8], O.fill_normal(8200 + d, (nq - 1, d))])
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 36)
+    f = gpu.FlatSpace(d, metric, quant); f.ChangedVertex(ids, X)
+    of = O.Flat(d, metric, quant); of.upsert(ids, X)
+    for nearest in (True, False):
+        sel = gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE
+        before = f.Stats()["mfma_groups"]
+        m = f.VertexSearch(Q, k, sel, gpu.MODE_MFMA)
+        assert f.Stats()["mfma_groups"] == before + 1 and f.Stats()["mfma_fallbacks"] == 0
+        e = f.VertexSearch(Q, k, sel, gpu.MODE_EXACT)
+        assert np.array_equal(m[0], e[0]) and np.array_equal(bits(m[1]), bits(e[1]))
+        for qi in (0, 1, nq - 1):
+            wi, ws = of.search(Q[qi], k, nearest=nearest, mode=2)
+            assert np.array_equal(m[0][qi], wi) and np.array_equal(bits(m[1][qi]), bits(ws)), (nearest, qi)
+    # filtered batches (gather mode) too
+    cand = ids[::3].copy(); cand.sort()
+    mf = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
+    ef = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert np.array_equal(mf[0], ef[0]) and np.array_equal(bits(mf[1]), bits(ef[1]))
