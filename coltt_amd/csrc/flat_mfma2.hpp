@@ -99,20 +99,10 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
                                               uint32_t* __restrict__ cnt, uint32_t cap, float* ep,
                                               const uint32_t* __restrict__ gather = nullptr) {  // gather: row numbers are positions of a slot list
   float t[16];
-#ifdef COLTT_M2_PK_EPI   // experiment: two elements per v_pk_mul_f32 / v_pk_add_f32 — same IEEE products and sums, half the VALU issue slots
-  typedef float f32x2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const f32x2v a = {acc[r], acc[r + 1]}, n = {ir[r >> 2][r & 3], ir[r >> 2][(r & 3) + 1]};
-    f32x2v v;
-    if constexpr (METRIC == M_COS) v = a * n;
-    else { const f32x2v two = {2.0f, 2.0f}; const f32x2v a2 = two * a; v = n - a2; }
-    t[r] = v.x; t[r + 1] = v.y;
-  }
-#else
+  // (v_pk_mul_f32 / v_pk_add_f32 on pairs of elements — half the VALU issue slots, same IEEE results — was measured in round 4 and
+  //  changes nothing: C3 4.975 -> 4.953 ms, C2 0.645 -> 0.648 ms, profiles/r04_flat_c3_pkepi_ab.txt; the epilogue is not what binds.)
 #pragma unroll
   for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
-#endif
   // the approximate candidate value of element r from its parked t
   auto value = [&](float tv) { return METRIC == M_COS ? fabsf(1.0f - tv * qc.iq) : qc.iq + tv; };
   if constexpr (SEED) {

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 
 // Hnsw.Search for large ef (HBM visited map): the level-0 walk of hnsw_walk2.hpp — delta result set, LDS Bloom filter in front
 // of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
-template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false>   // APREF: adjacency prefetch for f32 rows too (small batches)
+// EV8: the level-0 distances come from the eight-lanes-per-row core over GraphView::rows8 (rows8.hpp); the upper levels and the
+// entrypoint (a few dozen evaluations) stay on the pair-owned rows.
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false, bool EV8 = false>   // APREF: adjacency prefetch for f32 rows too (small batches)
 __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                          uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t bloom_words,
@@ -113,6 +115,12 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
   WaveCtx w;
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
+  w.qp = nullptr; w.scr = nullptr;
+  if constexpr (EV8) {   // [qs | qp | scratch] then the result set (search_geom adds the same bytes)
+    w.qp = reinterpret_cast<float*>(smem + off);
+    w.scr = reinterpret_cast<uint32_t*>(smem + 2 * off);
+    off = 2 * off + 96 * 4;
+  }
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   w.ef_pad = ef_pad;
   if constexpr (VISMODE == VIS_LDS) {   // small ef: the LDS hash (bloom_words carries its capacity); a table that fills up is err 8
@@ -137,7 +145,11 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     w.t_last = __builtin_amdgcn_s_memtime();
 #endif
     wave_sync();
-    for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    for (int e = lane; e < g.dim; e += 64) {
+      const float v = q_eff[(size_t)qi * g.dim + e];
+      w.qs[e] = v;
+      if constexpr (EV8) w.qp[rows8_qindex<QUANT>(e)] = v;
+    }
     w.qnorm = qnorms[qi];
     wave_sync();
     uint32_t cur = (uint32_t)entry;
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len);  // :258-259
+    if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS>());
+    else search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len);  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {
       const unsigned long long e = w.res0[i];
@@ -447,6 +460,12 @@ struct Hnsw : Object {
   int32_t entry = -1, entry_level = 0;
   bool any_deleted = false;
   DevBuf rows, norms, ids, adj0, adj0_d, adj0_n, upper_off, adjU, adjU_d, del_bits;
+  // rows8.hpp: line-transposed copy of `rows` for the eight-lanes-per-row distance core.  Derived data: writers permute the slots they
+  // added before they release the exclusive lock (sync_rows8); slots are never rewritten (Insert refuses an existing id, Remove
+  // is a tombstone), so [0, n8done) stays valid until the index is replaced.  Off for shapes rows8 does not cover, with
+  // COLTT_ROWS8=0, or when the second copy cannot be allocated.
+  DevBuf rows8; bool rows8_on = false; uint64_t n8done = 0;
+  std::atomic<uint64_t> ev8_launches{0};   // search launches whose level-0 distances came from rows8
   bool dense = true; uint64_t dense_base = 0;
   std::unordered_map<uint64_t, uint32_t> id2slot;
   std::vector<uint64_t> h_ids;       // !dense
@@ -470,6 +489,7 @@ struct Hnsw : Object {
   GraphView view() const {
     GraphView g;
     g.rows = rows.as<uint8_t>(); g.stride = stride; g.norms = norms.as<float>();
+    g.rows8 = (rows8_on && n8done == n) ? rows8.as<uint8_t>() : nullptr;
     g.ids = dense ? nullptr : ids.as<uint64_t>();
     g.adj0 = adj0.as<uint32_t>(); g.adj0_d = adj0_d.as<float>(); g.upper_off = upper_off.as<uint32_t>();
     g.adj0_n = metric == COLTT_COSINE ? adj0_n.as<float>() : nullptr;
@@ -482,6 +502,11 @@ struct Hnsw : Object {
     if (slots > cap) {
       uint64_t nc = std::max<uint64_t>({slots, cap + cap / 2, 1024});
       COLTT_TRY(rows.reserve(nc * stride, true, stream));
+      if (rows8_on && rows8.reserve(nc * stride, true, stream) != COLTT_OK) {   // no room for the second copy: the pair-owned walk serves
+        rows8_on = false; n8done = 0;
+        if (rows8.p) { (void)hipFree(rows8.p); rows8.p = nullptr; rows8.cap = 0; }
+        fprintf(stderr, "[coltt_gpu] hnsw: no memory for the line-transposed row copy (%llu B) — searches use the pair-owned rows\n", (unsigned long long)(nc * stride));
+      }
       COLTT_TRY(norms.reserve(nc * 4, true, stream));
       if (!dense) COLTT_TRY(ids.reserve(nc * 8, true, stream));
       COLTT_TRY(adj0.reserve(nc * cfg.m_max0 * 4, true, stream));
@@ -519,6 +544,28 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
   return COLTT_OK;
 }
 
+// rows8 of the slots added since the last call (rows8.hpp); completes on the device before it returns
+int sync_rows8(Hnsw* x) {
+  if (!x->rows8_on || x->n8done >= x->n) { if (x->n8done > x->n) x->n8done = x->n; return COLTT_OK; }
+  const uint64_t b = x->n8done, m = x->n - b;
+  const uint64_t chunks = (uint64_t)x->stride / 16;
+  if (x->quant == COLTT_Q_NONE)
+    rows8_permute_kernel<Q_NONE><<<ceil_div(m * chunks, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->rows8.as<uint8_t>(), x->stride, (int)x->dim, b, m);
+  else
+    rows8_permute_kernel<Q_F16><<<ceil_div(m * chunks, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->rows8.as<uint8_t>(), x->stride, (int)x->dim, b, m);
+  COLTT_HIP(hipGetLastError());
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  x->n8done = x->n;
+  return COLTT_OK;
+}
+// does this shape have a rows8 copy (rows8.hpp: f32 / 2-byte rows whose byte length is a multiple of 128)?
+bool rows8_shape(uint32_t dim, int quant) {
+  if (quant == COLTT_Q_F8) return false;
+  const char* e = getenv("COLTT_ROWS8");
+  if (e && *e == '0') return false;
+  return ((size_t)dim * quant_bytes(quant)) % 128 == 0;
+}
+
 int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
   COLTT_TRY(c->w_qeff.reserve(nq * x->dim * 4));
   COLTT_TRY(c->w_qn.reserve(nq * 4));
@@ -533,7 +580,7 @@ int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
 
 uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; int w2 = -1; uint32_t bloom_words = 0; bool w2_lds = false; };  // w2: hnsw_walk2.hpp variant (OPT bits | 8 = deep profile), -1 = hnsw_dev.hpp:search_level
+struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t max_grid; int w2 = -1; uint32_t bloom_words = 0; bool w2_lds = false; bool ev8 = false; };  // w2: hnsw_walk2.hpp variant (OPT bits | 8 = deep profile), -1 = hnsw_dev.hpp:search_level
 
 #ifndef COLTT_VISG_MIN_EF
 #define COLTT_VISG_MIN_EF 128
@@ -654,11 +701,20 @@ int walk2_lds_policy() {
 // resident waves per CU of the walk2 profiles: see waves_per_cu_cap
 size_t waves_per_cu_cap(int quant);
 
+// COLTT_EV8=0: level-0 distances from the pair-owned rows even when the index carries the line-transposed copy (A/B and test knob)
+bool ev8_policy() { const char* e = getenv("COLTT_EV8"); return !(e && *e == '0'); }
+
 SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2_lds = false) {
   SearchGeom s;
   s.ef = ef;
   s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8;   // query + result set (merged in place)
+  const size_t qbytes = ((size_t)x->dim * 4 + 15) & ~(size_t)15;
+  // eight lanes per row (rows8.hpp): a second, permuted copy of the query and 96 words of scratch per wave.  Served by the shipped
+  // walk2 variants only (LDS hash: 4; HBM map: 6 / 7).
+  const bool vis_hbm = wants_visg(ef) && x->vis_stride != 0 && x->vis_regions > 0;
+  const bool want8 = for_search && x->rows8_on && x->n8done == x->n && x->n > 0 && ev8_policy() && x->cfg.m_max0 <= 1024 &&
+                     (vis_hbm ? (walk2_policy() == 6 || walk2_policy() == 7) : (!no_w2_lds && walk2_lds_policy() == 4));
+  const size_t fixed = qbytes + (want8 ? qbytes + 96 * 4 : 0) + (size_t)s.ef_pad * 8;   // query (+ permuted copy + scratch) + result set (merged in place)
   // LDS visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
   s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
   // large ef x dim: shrink it until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps results exact;
@@ -686,6 +742,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2
     const int pol = walk2_lds_policy();
     if (pol >= 0) { s.w2 = pol; s.w2_lds = true; }
   }
+  s.ev8 = want8 && s.w2 >= 0;
   return s;
 }
 
@@ -718,7 +775,10 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
       case 2: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 2, VIS_LDS>; break;
       case 6: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 6, VIS_LDS>; break;
 #endif
-      case 4: kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>; break;   // (adjacency prefetch for f32 rows in small batches: measured, no gain — 1 M x 128, ef 20, one query 105 vs 111 us)
+      case 4:
+        kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>;
+        if constexpr (QUANT != Q_F8) { if (sg.ev8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true>; }
+        break;   // (adjacency prefetch for f32 rows in small batches: measured, no gain — 1 M x 128, ef 20, one query 105 vs 111 us)
       default: break;
     }
   } else
@@ -738,9 +798,14 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
       COLTT_W2(6, PROF_SEARCH_HBM, 6) COLTT_W2(7, PROF_SEARCH_HBM, 7)
       default: break;
     }
+    if constexpr (QUANT != Q_F8) {
+      if (sg.ev8 && sg.w2 == 6) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, true>;
+      if (sg.ev8 && sg.w2 == 7) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, true>;
+    }
   }
 #undef COLTT_W2
   if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
+  if (sg.ev8) x->ev8_launches.fetch_add(1);
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                         k, sg.ef, sg.ef_pad, sg.w2_lds ? sg.hcap : sg.bloom_words, counter, oi, os, oc, stats,
@@ -1078,7 +1143,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     x->n += b; x->live += b; x->n_upper += up; i += b;
   }
   COLTT_HIP(hipStreamSynchronize(x->stream));
-  return COLTT_OK;
+  return sync_rows8(x);
 }
 
 // the derived neighbour-norm rows of every slot (bulk installs; Insert / Remove maintain them incrementally in their kernels)
@@ -1092,7 +1157,7 @@ int fill_adj_norms(Hnsw* x) {
 
 // A failed (re)load must not leave a half-installed index behind: fall back to the empty index (memory-safe, searchable).
 void make_empty(Hnsw* x) {
-  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false;
+  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false; x->n8done = 0;
   x->h_levels.clear(); x->h_upper_off.clear(); x->h_del.clear(); x->h_ids.clear(); x->id2slot.clear();
   x->dense = true; x->dense_base = 0;
 }
@@ -1174,7 +1239,7 @@ int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* 
   x->h_del = std::move(h_del);
   x->any_deleted = any_deleted; x->live = live;
   if (!x->dense) { x->h_ids.assign(ids, ids + n); x->id2slot = std::move(id2slot); }
-  x->n = n; x->n_upper = n_upper;
+  x->n = n; x->n_upper = n_upper; x->n8done = 0;   // every row is about to be rewritten (the callers upload the vectors next)
   x->entry = n ? entry_slot : -1;
   x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
   return COLTT_OK;
@@ -1212,6 +1277,7 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
+  x->rows8_on = rows8_shape(dim, quant);
   COLTT_DEVICE(device); device = coltt_dev_scope_.device();
   x->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
@@ -1274,7 +1340,7 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_rows8(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   return COLTT_OK;
 }
 
@@ -1396,7 +1462,7 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_rows8(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   if (out_n) *out_n = n;
   for (uint64_t i = 0; i < n && i < cap_n; i++) {
     if (out_ids) out_ids[i] = ids[i];
@@ -1692,6 +1758,15 @@ int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_le
   }
   if (out_row) COLTT_HIP(hipMemcpy(out_row, x->rows.as<uint8_t>() + slot * x->stride, (size_t)x->dim * quant_bytes(x->quant), hipMemcpyDeviceToHost));
   if (out_level) *out_level = x->h_levels[slot];
+  return COLTT_OK;
+}
+
+int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t* out_has_copy) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_rows8_searches: unknown handle");
+  ReadLock g(x->rw);
+  if (out_launches) *out_launches = x->ev8_launches.load();
+  if (out_has_copy) *out_has_copy = (x->rows8_on && x->n8done == x->n) ? 1 : 0;
   return COLTT_OK;
 }
 

@@ -31,6 +31,7 @@ constexpr uint32_t NBR_NONE = 0xffffffffu;
 
 struct GraphView {
   const uint8_t* rows; size_t stride; const float* norms; const uint64_t* ids;
+  const uint8_t* rows8;               // rows8.hpp: line-transposed copy of rows for the eight-lanes-per-row distance core, or null
   uint32_t* adj0; float* adj0_d;      // [cap][mMax0]   level-0 rows, ascending slot, padded with NBR_NONE
   float* adj0_n;                      // [cap][mMax0]   norms[adj0[..]] — cosine only, else null: the neighbours' ||row||^2 ride with the
                                       //                adjacency row instead of one 4-byte gather (= one cache line) per evaluation
@@ -43,6 +44,7 @@ struct GraphView {
 
 struct WaveCtx {
   float* qs; unsigned long long* res0; uint32_t* vis;  // res buffer b = res0 + b * ef_pad
+  float* qp; uint32_t* scr;           // rows8.hpp kernels: the query in rows8 order, and 96 words of scratch (slot | norm | distance of <= 32 fresh rows)
   uint32_t ef_pad, hcap_mask, hcap;
   float qnorm;
   // counters (wave-uniform)

@@ -113,7 +113,10 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
     const float* qT = w.qs + (size_t)j * n8p;
     if (fresh) {
       int gq = 0;
-#ifdef COLTT_LAT_EVAL_PIPE   // experiment: the LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run
+      // The LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run (the adds of a block otherwise wait for
+      // its reads: ~1.1 us per chunk of 32 rows at dim 768 against ~0.4 us of dependent VALU).  A/B at 10 M x 768 f32, ef 128
+      // (profiles/r04_latency_evalpipe_ab.txt): 1 query 1.032 -> 1.015 ms, 16 queries 1.260 -> 1.239, 128 queries 1.444 -> 1.425;
+      // same answers and counters.  Adopted in round 4 (it was the -DCOLTT_LAT_EVAL_PIPE experiment of round 3).
 #define COLTT_LAT_LD(G0, RV, QV)                                                                         \
       {                                                                                                  \
         _Pragma("unroll") for (int u = 0; u < 16; u++) RV[u] = lat_elem<QUANT>(srow, 8 * ((G0) + u) + j); \
@@ -143,7 +146,6 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
       }
 #undef COLTT_LAT_LD
 #undef COLTT_LAT_ACC
-#endif
       for (; gq + 16 <= n8; gq += 16) {
         float rv[16]; f32x4 qv[4];
 #pragma unroll

@@ -19,6 +19,7 @@
 #pragma once
 #include <type_traits>
 #include "hnsw_dev.hpp"
+#include "rows8.hpp"
 
 namespace coltt {
 namespace dev {
@@ -159,6 +160,50 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
     if (!fresh) return 0.f;
     if constexpr (ADJN) return eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
     else return eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+  }
+};
+// Eight lanes per row over the line-transposed copy (rows8.hpp).  The fresh neighbours of the chunk are compacted through LDS (slot
+// and norm at their rank among the fresh ones), every 8-lane group evaluates ROWS of them per pass — 8 x ROWS rows per pass, whole
+// 128-byte lines per load instruction — and the distances travel back through LDS to the lane pairs that own the neighbours in the
+// walk (admission, ranks and keys stay where they were).  Same values in the same order as PairEval: same bits.
+#ifndef COLTT_G8_ROWS
+#define COLTT_G8_ROWS 2
+#endif
+#ifndef COLTT_G8_U
+#define COLTT_G8_U 6
+#endif
+template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
+  static constexpr bool CHUNK_ADJ = false;
+  __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+  __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int lane) const {
+    constexpr int ROWS = COLTT_G8_ROWS;
+    const bool mine = fresh && half == 0;
+    const unsigned long long E = __ballot(mine);
+    const uint32_t nf = (uint32_t)__popcll(E);
+    const uint32_t rank = (uint32_t)__popcll(E & ((1ull << lane) - 1ull));
+    uint32_t* const s_nb = w.scr; float* const s_nr = reinterpret_cast<float*>(w.scr + 32); float* const s_d = reinterpret_cast<float*>(w.scr + 64);
+    if (mine) { s_nb[rank] = nb; if constexpr (ADJN) s_nr[rank] = nrm; }
+    wave_sync();
+    const int grp = lane >> 3, rj = lane & 7;
+    const int nl = (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7;
+    for (uint32_t base = 0; base < nf; base += 8 * ROWS) {          // wave-uniform
+      const uint8_t* rp[ROWS]; float rn[ROWS], d[ROWS]; uint32_t idx[ROWS];
+#pragma unroll
+      for (int i = 0; i < ROWS; i++) {
+        idx[i] = base + (uint32_t)(i * 8 + grp);
+        const uint32_t slot = s_nb[idx[i] < nf ? idx[i] : 0];       // an idle group re-reads the first row (its result is dropped)
+        rp[i] = g.rows8 + (size_t)slot * g.stride;
+        rn[i] = 0.f;
+        if constexpr (METRIC == M_COS) { if constexpr (ADJN) rn[i] = s_nr[idx[i] < nf ? idx[i] : 0]; else rn[i] = g.norms[slot]; }
+      }
+      group8_distance<METRIC, QUANT, ROWS, COLTT_G8_U>(rp, w.qp, nl, w.qnorm, rn, rj, d);
+#pragma unroll
+      for (int i = 0; i < ROWS; i++) if (rj == 0 && idx[i] < nf) s_d[idx[i]] = d[i];
+    }
+    wave_sync();
+    const float r = mine ? s_d[rank] : 0.f;
+    wave_sync();   // the next chunk rewrites the scratch
+    return r;
   }
 };
 enum { VIS_HBM = 0, VIS_LDS = 1 };   // visited set of search_level2: HBM byte map (behind the Bloom filter) | LDS hash that is never reset (err 8)

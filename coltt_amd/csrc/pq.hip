@@ -89,8 +89,10 @@ __device__ __forceinline__ float pq_dist(const float* __restrict__ x, const floa
 // ---- the per-query distance table: lut[q][j][c], c < 256 (entries c >= C and rows j >= m are +0.0 / never read)
 template <int KIND>
 __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ cb, int m, int C, int dsub, const float* __restrict__ queries,
-                                                     int mp, float* __restrict__ lut) {
+                                                     int mp, float* __restrict__ lut, uint32_t* __restrict__ cnt, uint32_t* __restrict__ thr,
+                                                     uint32_t* __restrict__ ovf) {
   const int j = blockIdx.x, q = blockIdx.y, c = threadIdx.x;
+  if (cnt && j == 0 && c == 0) { cnt[q] = 0; thr[q] = 0xffffffffu; if (q == 0) *ovf = 0; }   // the search's group state (one launch less)
   float v = 0.f;
   if (j < m && c < C) v = pq_dist<KIND>(queries + ((size_t)q * m + j) * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
   lut[((size_t)q * mp + j) * 256 + c] = v;
@@ -490,9 +492,9 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   {
     dim3 grid(p->mp, (uint32_t)nq);
-    if (p->metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut);
-    else if (p->metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut);
-    else pq_lut_kernel<2><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut);
+    if (p->metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut, cnt, thr, ovf);
+    else if (p->metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut, cnt, thr, ovf);
+    else pq_lut_kernel<2><<<grid, 256, 0, c->stream>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q, p->mp, lut, cnt, thr, ovf);
   }
   bool timed_scan = false;
   auto scan = [&](uint64_t b, uint64_t e, bool big) -> int {
@@ -502,14 +504,15 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
     flat_select_kernel<<<(uint32_t)nq, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, 1, ids, p->dense_base, ovf, d_oi, d_os, d_oc);
     return COLTT_OK;
   };
-  pq_init_kernel<<<ceil_div(nq, 256), 256, 0, c->stream>>>(cnt, thr, ovf, (int)nq);
   if (total == 0) {
     flat_select_kernel<<<(uint32_t)nq, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, 1, ids, p->dense_base, ovf, d_oi, d_os, d_oc);
   } else {
-    // a small unfiltered first segment, then segments 32x what has been seen, each behind the threshold the selection published from
-    // everything before it (a row passes with probability ~k / seen: every list stays on the selection's short path)
-    uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, (std::max<uint64_t>(512, 4ull * k) + 63) & ~63ull});
-    for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * 32)) COLTT_TRY(scan(b, e, e == total));
+    // an unfiltered first segment of 4 Ki rows (one radix selection over 4 Ki candidates), then segments 64x what has been seen, each
+    // behind the threshold the selection published from everything before it: a row passes with probability ~k / seen, so every
+    // later list is a few hundred entries (the selection's short path) and 10 M rows take three scan + select pairs, not four
+    // (r04a: 0.32 ms per single-query search of which the dominant scan was 0.18 — the rest was launches)
+    uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, (std::max<uint64_t>(4096, 4ull * k) + 63) & ~63ull});
+    for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * 64)) COLTT_TRY(scan(b, e, e == total));
     uint32_t h_ovf = 0;
     COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
     COLTT_HIP(hipStreamSynchronize(c->stream));
@@ -787,9 +790,9 @@ int coltt_pq_lut(coltt_handle_t h, const float* query, float* out_lut) {
   COLTT_TRY(d_q.reserve((size_t)p->dim * 4)); COLTT_TRY(d_l.reserve((size_t)p->mp * 256 * 4));
   COLTT_HIP(hipMemcpy(d_q.p, query, (size_t)p->dim * 4, hipMemcpyHostToDevice));
   dim3 grid(p->mp, 1);
-  if (p->metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>());
-  else if (p->metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>());
-  else pq_lut_kernel<2><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>());
+  if (p->metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>(), nullptr, nullptr, nullptr);
+  else if (p->metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>(), nullptr, nullptr, nullptr);
+  else pq_lut_kernel<2><<<grid, 256>>>(p->cb.as<float>(), (int)p->m, (int)p->C, (int)p->dsub, d_q.as<float>(), p->mp, d_l.as<float>(), nullptr, nullptr, nullptr);
   COLTT_HIP(hipGetLastError());
   COLTT_HIP(hipMemcpy2D(out_lut, (size_t)p->C * 4, d_l.p, 256 * 4, (size_t)p->C * 4, p->m, hipMemcpyDeviceToHost));
   return COLTT_OK;

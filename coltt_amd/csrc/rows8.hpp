@@ -1,0 +1,142 @@
+// rows8.hpp — "eight lanes per row": a second, line-transposed copy of the stored vectors and the distance core that walks it.
+//
+// Why (profiles/r03_gather_*.jsonl, r03_pmc_walk_utcl*.csv): with a row owned by a lane PAIR (exact.hpp) one load
+// instruction of a wave touches 32 rows x 32 bytes — 32 different cache lines and 32 translations, and a line is complete only after
+// four consecutive instructions.  On a 10 M x 768 index that is a UTCL1 miss rate of 9-17 % and an L2 TLB that is busy 95-99 % of the
+// kernel.  Eight lanes per row make an instruction touch 8 rows x ONE WHOLE 128-byte line (6 % UTCL1 misses in tools/micro/gather.hip).
+//
+// The reference's AVX order (avx.cpp:15-32, 51-75) puts element i into partial sum i mod 8, partial sums growing in increasing i.
+// Lane j of an 8-lane group therefore has to own residue j — every 8th element — while a coalesced 16-byte load hands a lane 8 (f16)
+// or 4 (f32) CONSECUTIVE elements.  Instead of transposing through LDS per evaluation (hnsw_lat.hpp) the transposition is done ONCE, at
+// ingest: rows8 holds every row with each 128-byte line rewritten so that its 16-byte chunk r carries residue r's S = 16 / elem_bytes
+// consecutive AVX steps:
+//        rows8 element (l * 8 + r) * S + t   =   row element 8 * (S * l + t) + r            l = line, r = residue, t = step in the line
+// Lane r of the group loads chunk r of every line and adds its products in increasing step order: the same values in the same order
+// as the pair-owned walk, hence the same bits.  The query is staged in LDS with the same permutation (qp), so lane r reads its S
+// query elements of a line with one (f32 rows) or two (2-byte rows) ds_read_b128.
+//
+// rows8 is DERIVED data (like adj0_n): written by the index's writers right after the canonical rows, never read back by the host,
+// not part of any stream format.  It exists for f32 / 2-byte rows whose byte length is a multiple of 128 (dim % 32 == 0 / dim % 64 == 0:
+// 128, 256, 512, 768, 1024, 1536 ...); other shapes keep the pair-owned walk.
+#pragma once
+#include "exact.hpp"
+
+namespace coltt {
+namespace dev {
+
+template <int QUANT> __device__ __host__ __forceinline__ constexpr int rows8_steps() { return QUANT == Q_NONE ? 4 : 8; }   // AVX steps per 128-byte line
+
+// canonical rows [slot_begin, slot_begin + n) -> rows8 (same stride).  One thread per 16-byte destination chunk.
+template <int QUANT>
+__global__ __launch_bounds__(256) void rows8_permute_kernel(const uint8_t* __restrict__ rows, uint8_t* __restrict__ rows8, size_t stride, int dim,
+                                                            uint64_t slot_begin, uint64_t n) {
+  constexpr int S = rows8_steps<QUANT>();
+  constexpr int EB = 16 / S;                    // bytes per element (4 | 2)
+  const int chunks = dim * EB / 16;             // 16-byte chunks per row (dim * EB is a multiple of 128)
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (uint64_t)chunks) return;
+  const uint64_t row = slot_begin + t / chunks;
+  const int c = (int)(t % chunks), l = c >> 3, r = c & 7;
+  const uint8_t* src = rows + row * stride;
+  uint8_t* dst = rows8 + row * stride + (size_t)c * 16;
+  if constexpr (EB == 4) {
+    f32x4 v;
+#pragma unroll
+    for (int s = 0; s < 4; s++) v[s] = *reinterpret_cast<const float*>(src + (size_t)(8 * (4 * l + s) + r) * 4);
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else {
+    unsigned short h[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) h[s] = *reinterpret_cast<const unsigned short*>(src + (size_t)(8 * (8 * l + s) + r) * 2);
+    u32x4e v = {(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16), (uint32_t)h[4] | ((uint32_t)h[5] << 16),
+                (uint32_t)h[6] | ((uint32_t)h[7] << 16)};
+    *reinterpret_cast<u32x4e*>(dst) = v;
+  }
+}
+
+// index of query element e in the permuted LDS copy qp
+template <int QUANT> __device__ __forceinline__ int rows8_qindex(int e) {
+  constexpr int S = rows8_steps<QUANT>();
+  const int step = e >> 3, r = e & 7;
+  return ((step / S) * 8 + r) * S + (step % S);
+}
+
+// 8-lane sum of one accumulator per lane in the reference's tree ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)); result in all 8 lanes.
+// DPP only (quad_perm, row_half_mirror): every lane of the wave must be active.
+__device__ __forceinline__ float group8_hsum(float a) {
+  const float b = a + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  const float c = b + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  return c + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, c), 0x141, 0xf, 0xf, true));            // row_half_mirror: lane i <-> 7 - i
+}
+
+// Distance(query, row) of ROWS rows per 8-lane group at once (ROWS x U..2U 16-byte loads per lane in flight); rj = this lane's
+// residue (lane & 7).  row8[i] -> the rows8 copy of row i, qp -> the permuted query in LDS, nl = 128-byte lines per row.
+template <int METRIC, int QUANT, int ROWS, int U>
+__device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROWS], const float* __restrict__ qp, int nl, float qnorm,
+                                                const float (&rnorm)[ROWS], int rj, float (&out)[ROWS]) {
+  constexpr int S = rows8_steps<QUANT>();
+  float acc[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; i++) acc[i] = 0.f;
+  const float* qb = qp + rj * S;
+  struct Raw { u32x4e v[ROWS]; };
+#define COLTT_G8_LD(L, DST) { _Pragma("unroll") for (int i = 0; i < ROWS; i++) DST.v[i] = *reinterpret_cast<const u32x4e*>(row8[i] + (size_t)(L) * 128 + rj * 16); }
+#define COLTT_G8_CS(RAW, L)                                                                                                   \
+  {                                                                                                                           \
+    if constexpr (QUANT == Q_NONE) {                                                                                          \
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + (L) * 32);                                                        \
+      _Pragma("unroll") for (int i = 0; i < ROWS; i++) {                                                                      \
+        const f32x4 x = __builtin_bit_cast(f32x4, RAW.v[i]);                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                                       \
+          if constexpr (METRIC == M_COS) { const float p = q0[s] * x[s]; acc[i] = acc[i] + p; }                               \
+          else { const float d = q0[s] - x[s]; const float p = d * d; acc[i] = acc[i] + p; }                                  \
+        }                                                                                                                     \
+      }                                                                                                                       \
+    } else {                                                                                                                  \
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + (L) * 64), q1 = *reinterpret_cast<const f32x4*>(qb + (L) * 64 + 4); \
+      _Pragma("unroll") for (int i = 0; i < ROWS; i++) {                                                                      \
+        const u32x2e lo = {RAW.v[i].x, RAW.v[i].y}, hi = {RAW.v[i].z, RAW.v[i].w};                                            \
+        const f32x4 x0 = __builtin_convertvector(__builtin_bit_cast(f16x4, lo), f32x4);                                       \
+        const f32x4 x1 = __builtin_convertvector(__builtin_bit_cast(f16x4, hi), f32x4);                                       \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                                       \
+          if constexpr (METRIC == M_COS) { const float p = q0[s] * x0[s]; acc[i] = acc[i] + p; }                              \
+          else { const float d = q0[s] - x0[s]; const float p = d * d; acc[i] = acc[i] + p; }                                 \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 4; s++) {                                                                       \
+          if constexpr (METRIC == M_COS) { const float p = q1[s] * x1[s]; acc[i] = acc[i] + p; }                              \
+          else { const float d = q1[s] - x1[s]; const float p = d * d; acc[i] = acc[i] + p; }                                 \
+        }                                                                                                                     \
+      }                                                                                                                       \
+    }                                                                                                                         \
+  }
+  {
+    const int nb = nl / U;
+    Raw cur[U], nxt[U];
+    if (nb > 0) {
+#pragma unroll
+      for (int u = 0; u < U; u++) COLTT_G8_LD(u, cur[u])
+    }
+    for (int b = 0; b < nb; b++) {
+      if (b + 1 < nb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) COLTT_G8_LD((b + 1) * U + u, nxt[u])
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) COLTT_G8_CS(cur[u], b * U + u)
+#pragma unroll
+      for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    for (int l = nb * U; l < nl; l++) { Raw r1; COLTT_G8_LD(l, r1) COLTT_G8_CS(r1, l) }   // lines beyond whole bursts (nl % U)
+  }
+#undef COLTT_G8_LD
+#undef COLTT_G8_CS
+#pragma unroll
+  for (int i = 0; i < ROWS; i++) {
+    const float s = group8_hsum(acc[i]);
+    if constexpr (METRIC == M_COS) out[i] = cos_epilogue(s, qnorm, rnorm[i]);
+    else out[i] = go_sqrt(s);
+  }
+}
+
+}  // namespace dev
+}  // namespace coltt

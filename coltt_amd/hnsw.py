@@ -171,6 +171,12 @@ class Hnsw:
         L.check(L.lib().coltt_hnsw_fetch_rows(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out)))
         return out
 
+    def Rows8(self):
+        """(search launches served by the eight-lanes-per-row core, whether the line-transposed row copy is complete)"""
+        a, f = C.c_uint64(0), C.c_int32(0)
+        L.check(L.lib().coltt_hnsw_rows8_searches(self.h, C.byref(a), C.byref(f)))
+        return a.value, bool(f.value)
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

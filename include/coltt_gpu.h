@@ -192,6 +192,13 @@ int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats);
 int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
                              uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats);
+/* Round 4: indexes whose rows are f32 / 2-byte codes of a byte length that is a multiple of 128 (dim 128, 256, 512, 768, 1024, 1536 ...)
+ * keep a second, line-transposed copy of their rows (derived data, like the adjacency-carried norms) and evaluate the level-0
+ * distances of a search with EIGHT lanes per row over it — whole 128-byte lines per load instruction — in the reference's summation
+ * order: same ids, score bits and counters (coltt_amd/csrc/rows8.hpp).  COLTT_ROWS8=0 (at create) keeps an index without the copy,
+ * COLTT_EV8=0 (per call) searches the pair-owned rows.  This reports how many search launches the eight-lane core served and whether
+ * the copy is complete. */
+int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t* out_has_copy);
 /* graph export in the bulk_load layout (what Hnsw.Commit serialises, hnsw_commit.go:69-162).
  * Call with NULL arrays to get sizes.  With any array non-NULL, *n_slots / *n_rows / *n_edges are IN-OUT: on entry the
  * capacities of the caller's arrays (slots: ids, levels, deleted; rows + 1: row_offsets; edges: nbr, nbr_dist) — normally the

@@ -55,7 +55,7 @@ def test_codes_tables_and_search_equal_the_oracle(gpu, metric, dim, m, c):
     pq.close()
 
 
-@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 511, 512, 513, 20000, 70001])
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 513, 4095, 4096, 4097, 70001, 262145])
 def test_sizes_around_tiles_and_segments(gpu, n):
     dim, m, c = 32, 8, 64
     T = O.fill_normal(600, (200, dim)); cb = O.pq_train(T, m, c, 1)
