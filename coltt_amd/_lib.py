@@ -10,6 +10,11 @@ SELECT_REFERENCE, SELECT_NEAREST = 0, 1
 MODE_EXACT, MODE_MFMA = 0, 1
 
 _lib = None
+_env_seen = None
+# the knobs the library snapshots (coltt_amd/csrc/common.hpp: Policy); when the test / tool changes one of them in os.environ the
+# binding asks the library to re-read them before the next call
+_KNOBS = ("COLTT_FLAT_ONE", "COLTT_STAGING", "COLTT_EV8", "COLTT_ROWS8", "COLTT_VISG", "COLTT_WALK2", "COLTT_WALK2_LDS", "COLTT_BLOOM_KB",
+          "COLTT_WAVES_PER_CU", "COLTT_LAT_SEQ", "COLTT_LAT_MAX_NQ", "COLTT_MW_MAX_NQ", "COLTT_VISG_BUDGET_MB")
 
 
 class ColttError(RuntimeError):
@@ -28,9 +33,22 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(coltt_[a-z0-9_]+)\s*\(", hdr)))
 
 
+def _sync_policy():
+    global _env_seen
+    get = os.environ.get
+    now = tuple(get(k) for k in _KNOBS)
+    if now != _env_seen:
+        if _env_seen is not None:
+            _lib.coltt_policy_reload()
+        _env_seen = now
+
+
 def lib():
     """Load the HIP extension.  There is no fallback: a missing .so is an error."""
     global _lib
+    if _lib is not None:
+        _sync_policy()
+        return _lib
     if _lib is None:
         # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Two HIP runtimes in one process cannot both own
         # the GPU ("No HIP GPUs are available"), so when torch is installed it is imported FIRST: the dynamic linker then
@@ -48,6 +66,7 @@ def lib():
         L.coltt_last_error.restype = C.c_char_p
         L.coltt_version.restype = C.c_char_p
         _lib = L
+        _sync_policy()
     return _lib
 
 

@@ -1,6 +1,9 @@
 // common.hip — registry, error string, device selection.
 #include "common.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace coltt {
 
 thread_local std::string g_last_error;
@@ -61,6 +64,39 @@ int use_device(int device) {
   return COLTT_OK;
 }
 
+namespace {
+std::shared_mutex g_pol_mu;
+Policy g_policy;
+bool g_policy_loaded = false;
+Policy read_policy_from_env() {
+  Policy p;
+  auto off = [](const char* n) { const char* e = getenv(n); return e && *e == '0'; };
+  auto num = [](const char* n, bool& set) -> long long { const char* e = getenv(n); set = e && *e; return set ? atoll(e) : 0; };
+  bool set = false; long long v;
+  p.flat_one = !off("COLTT_FLAT_ONE"); p.staging = !off("COLTT_STAGING"); p.ev8 = !off("COLTT_EV8"); p.rows8 = !off("COLTT_ROWS8");
+  v = num("COLTT_VISG", set); p.visg = set ? (int)v : -1;
+  { const char* e = getenv("COLTT_WALK2"); p.walk2 = (!e || !*e) ? 7 : (!strcmp(e, "off") ? -1 : (atoi(e) & 15)); }
+  { const char* e = getenv("COLTT_WALK2_LDS"); if (!e || !*e) p.walk2_lds = 4; else if (!strcmp(e, "off")) p.walk2_lds = -1; else { const int w = atoi(e) & 6; p.walk2_lds = w ? w : -1; } }
+  v = num("COLTT_BLOOM_KB", set); p.bloom_kb = set ? (int)std::max<long long>(1, std::min<long long>(64, v)) : 0;
+  v = num("COLTT_WAVES_PER_CU", set); p.waves_per_cu = set ? (int)std::max<long long>(1, std::min<long long>(8, v)) : 0;
+  { const char* e = getenv("COLTT_LAT_SEQ"); p.lat_seq = e && *e == '1'; }
+  v = num("COLTT_LAT_MAX_NQ", set); if (!set) v = num("COLTT_MW_MAX_NQ", set);
+  p.lat_knob_set = set; p.lat_max_nq = set ? (uint32_t)std::max<long long>(0, v) : 0;
+  v = num("COLTT_VISG_BUDGET_MB", set); p.visg_budget_mb = set ? v : -1;
+  return p;
+}
+}  // namespace
+
+Policy policy() {
+  {
+    std::shared_lock<std::shared_mutex> g(g_pol_mu);
+    if (g_policy_loaded) return g_policy;
+  }
+  std::unique_lock<std::shared_mutex> g(g_pol_mu);
+  if (!g_policy_loaded) { g_policy = read_policy_from_env(); g_policy_loaded = true; }
+  return g_policy;
+}
+
 size_t max_search_ctx() {
   static const size_t v = [] { const char* e = getenv("COLTT_MAX_SEARCH_CTX"); long n = e && *e ? atol(e) : 32; return (size_t)(n < 1 ? 1 : (n > 256 ? 256 : n)); }();
   return v;
@@ -94,6 +130,13 @@ int coltt_device_count(void) {
 }
 
 const char* coltt_last_error(void) { return g_last_error.c_str(); }
+
+int coltt_policy_reload(void) {
+  Policy p = read_policy_from_env();
+  std::unique_lock<std::shared_mutex> g(g_pol_mu);
+  g_policy = p; g_policy_loaded = true;
+  return COLTT_OK;
+}
 const char* coltt_version(void) {
 #ifdef COLTT_EXPERIMENTS
   return "coltt_gpu 0.3 (gfx950) +experiments";   // superseded kernel generations compiled in (tools/experiments/)

@@ -94,7 +94,27 @@ struct PinnedBuf {
   template <class T> T* as() const { return (T*)p; }
 };
 constexpr size_t SMALL_CALL_BYTES = 64 * 1024;   // queries and answers up to this size take the staged path
-inline bool small_call_staging() { const char* e = getenv("COLTT_STAGING"); return !(e && *e == '0'); }   // COLTT_STAGING=0: A/B knob
+
+// Measurement / test knobs (COLTT_* environment variables).  They are read ONCE — when the library is first used — into a process-wide
+// snapshot; no search call touches the environment (~10 getenv per call).  A program that changes a knob afterwards
+// calls coltt_policy_reload() (the Python binding does it when it sees the environment change; tests and tools toggle knobs that way).
+struct Policy {
+  bool flat_one = true;        // COLTT_FLAT_ONE=0: <= 4-query FLAT searches through the scan + select chain
+  bool staging = true;         // COLTT_STAGING=0: no page-locked staging of small host-buffer calls
+  bool ev8 = true;             // COLTT_EV8=0: level-0 distances from the pair-owned rows even when rows8 exists
+  bool rows8 = true;           // COLTT_ROWS8=0: new indexes keep no line-transposed row copy (read at create)
+  int visg = -1;               // COLTT_VISG: -1 default (byte map above ef 128), 0 LDS hash, 1 byte map
+  int walk2 = 7;               // COLTT_WALK2: -1 off, else OPT bits | 8 deep profile
+  int walk2_lds = 4;           // COLTT_WALK2_LDS: -1 off, 2 / 4 / 6
+  int bloom_kb = 0;            // COLTT_BLOOM_KB: 0 = sized by the occupancy budget
+  int waves_per_cu = 0;        // COLTT_WAVES_PER_CU: 0 = per row format
+  bool lat_seq = false;        // COLTT_LAT_SEQ=1
+  bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
+  uint32_t lat_max_nq = 0;     // ... and its value
+  long long visg_budget_mb = -1;  // COLTT_VISG_BUDGET_MB (test knob)
+};
+Policy policy();               // a copy of the current snapshot
+inline bool small_call_staging() { return policy().staging; }
 
 // Locking discipline = the reference's (RWMutex per shard / per vertex level: edge/none_vectorstore.go:40, core/vectorindex/hnsw.go:51,
 // hnsw_vertex.go:39): searches hold the object's lock SHARED and run concurrently, each on its own stream with its own

@@ -521,10 +521,7 @@ int search_group_exact(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neare
 
 // <= 4 prepared queries [q0, q0+g) over positions [0, total), k <= 64: one launch (flat_one_kernel).
 // COLTT_FLAT_ONE=0 sends small batches through the scan + select chain instead (measurement and test knob).
-bool flat_one_enabled() {
-  const char* e = getenv("COLTT_FLAT_ONE");
-  return !(e && *e == '0');
-}
+bool flat_one_enabled() { return policy().flat_one; }
 
 template <int METRIC, int QUANT, bool GATHER, int QBT>
 int launch_one(Flat* f, FCtx* c, const uint32_t* gather, uint64_t total, const float* qe, const float* qn, int g, uint32_t k, int nearest,

@@ -116,10 +116,10 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
   w.qs = reinterpret_cast<float*>(smem);
   w.qp = nullptr; w.scr = nullptr;
-  if constexpr (EV8) {   // [qs | qp | scratch] then the result set (search_geom adds the same bytes)
-    w.qp = reinterpret_cast<float*>(smem + off);
-    w.scr = reinterpret_cast<uint32_t*>(smem + 2 * off);
-    off = 2 * off + 96 * 4;
+  if constexpr (EV8) {   // [query in rows8 order | scratch] then the result set (search_geom adds the same bytes); no natural-order copy
+    w.qp = w.qs; w.qs = nullptr;
+    w.scr = reinterpret_cast<uint32_t*>(smem + off);
+    off += 96 * 4;
   }
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   w.ef_pad = ef_pad;
@@ -147,16 +147,20 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     wave_sync();
     for (int e = lane; e < g.dim; e += 64) {
       const float v = q_eff[(size_t)qi * g.dim + e];
-      w.qs[e] = v;
-      if constexpr (EV8) w.qp[rows8_qindex<QUANT>(e)] = v;
+      if constexpr (EV8) w.qp[rows8_qindex<QUANT>(e)] = v; else w.qs[e] = v;
     }
     w.qnorm = qnorms[qi];
     wave_sync();
     uint32_t cur = (uint32_t)entry;
-    float curd = eval_pair<METRIC, QUANT, PROFILE>(g, w, cur, lane & 1);  // hnsw.go:253
+    float curd;
+    if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false>().one(g, w, cur, lane);
+    else curd = eval_pair<METRIC, QUANT, PROFILE>(g, w, cur, lane & 1);  // hnsw.go:253
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
-    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROFILE>(g, w, cur, curd, l, lane);  // :254-256
+    for (int l = entry_level; l > 0; l--) {  // :254-256
+      if constexpr (EV8) greedy_level8<METRIC, QUANT>(g, w, cur, curd, l, lane);
+      else greedy_level<METRIC, QUANT, PROFILE>(g, w, cur, curd, l, lane);
+    }
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
@@ -560,9 +564,7 @@ int sync_rows8(Hnsw* x) {
 }
 // does this shape have a rows8 copy (rows8.hpp: f32 / 2-byte rows whose byte length is a multiple of 128)?
 bool rows8_shape(uint32_t dim, int quant) {
-  if (quant == COLTT_Q_F8) return false;
-  const char* e = getenv("COLTT_ROWS8");
-  if (e && *e == '0') return false;
+  if (quant == COLTT_Q_F8 || !policy().rows8) return false;
   return ((size_t)dim * quant_bytes(quant)) % 128 == 0;
 }
 
@@ -599,7 +601,7 @@ int ensure_visg(Hnsw* x) {
   size_t free_b = 0, total_b = 0;
   COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
   uint64_t budget = std::min<uint64_t>(total_b / 4, free_b / 2);
-  if (const char* e = getenv("COLTT_VISG_BUDGET_MB")) { if (*e) budget = std::min<uint64_t>(budget, (uint64_t)atol(e) << 20); }  // test knob
+  if (policy().visg_budget_mb >= 0) budget = std::min<uint64_t>(budget, (uint64_t)policy().visg_budget_mb << 20);  // test knob
   const uint64_t regions = std::min<uint64_t>(VIS_MAX_REGIONS, budget / stride);
   x->vis_stride = stride;
   x->vis_regions = 0;
@@ -657,10 +659,7 @@ void acquire_regions(Hnsw* x, uint32_t want, RegionLease& out) {
 // COLTT_VISG=0 / 1 forces the LDS hash / the HBM byte map (measurement and test knob, read at every call); default: the
 // byte map above ef 128.  Measured on 10 M x 768 f16 (lowrank:32), queries/s LDS hash -> byte map: ef 128 728 k -> 724 k,
 // ef 256 246 k -> 404 k, ef 512 62 k -> 212 k, ef 1024 25 k -> 105 k; build (efConstruction 200) 36 s -> 22 s.
-int visg_policy() {
-  const char* e = getenv("COLTT_VISG");
-  return e && *e ? atoi(e) : -1;
-}
+int visg_policy() { return policy().visg; }
 
 // does this ef want the HBM visited set (policy only; whether the workspace could be had is vis_regions > 0)
 bool wants_visg(uint32_t ef) {
@@ -674,12 +673,7 @@ bool wants_visg(uint32_t ef) {
 #ifndef COLTT_WALK2_DEFAULT
 #define COLTT_WALK2_DEFAULT 7
 #endif
-int walk2_policy() {
-  const char* e = getenv("COLTT_WALK2");
-  if (!e || !*e) return COLTT_WALK2_DEFAULT;
-  if (!strcmp(e, "off")) return -1;
-  return atoi(e) & 15;
-}
+int walk2_policy() { const int v = policy().walk2; return v == 7 ? COLTT_WALK2_DEFAULT : v; }
 
 // The walk of the LDS-visited searches (ef <= 128 by default).  COLTT_WALK2_LDS=off: hnsw_dev.hpp:search_level; 2 / 4 / 6: hnsw_walk2.hpp
 // with the delta result set / adjacency-carried norms / both.  A traversal that would overflow the hash table re-runs the call on
@@ -690,19 +684,13 @@ int walk2_policy() {
 #ifndef COLTT_WALK2_LDS_DEFAULT
 #define COLTT_WALK2_LDS_DEFAULT 4
 #endif
-int walk2_lds_policy() {
-  const char* e = getenv("COLTT_WALK2_LDS");
-  if (!e || !*e) return COLTT_WALK2_LDS_DEFAULT;
-  if (!strcmp(e, "off")) return -1;
-  const int v = atoi(e) & 6;
-  return v ? v : -1;
-}
+int walk2_lds_policy() { const int v = policy().walk2_lds; return v == 4 ? COLTT_WALK2_LDS_DEFAULT : v; }
 
 // resident waves per CU of the walk2 profiles: see waves_per_cu_cap
 size_t waves_per_cu_cap(int quant);
 
 // COLTT_EV8=0: level-0 distances from the pair-owned rows even when the index carries the line-transposed copy (A/B and test knob)
-bool ev8_policy() { const char* e = getenv("COLTT_EV8"); return !(e && *e == '0'); }
+bool ev8_policy() { return policy().ev8; }
 
 SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2_lds = false) {
   SearchGeom s;
@@ -714,7 +702,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2
   const bool vis_hbm = wants_visg(ef) && x->vis_stride != 0 && x->vis_regions > 0;
   const bool want8 = for_search && x->rows8_on && x->n8done == x->n && x->n > 0 && ev8_policy() && x->cfg.m_max0 <= 1024 &&
                      (vis_hbm ? (walk2_policy() == 6 || walk2_policy() == 7) : (!no_w2_lds && walk2_lds_policy() == 4));
-  const size_t fixed = qbytes + (want8 ? qbytes + 96 * 4 : 0) + (size_t)s.ef_pad * 8;   // query (+ permuted copy + scratch) + result set (merged in place)
+  const size_t fixed = qbytes + (want8 ? 96 * 4 : 0) + (size_t)s.ef_pad * 8;   // query (+ the eight-lane core's scratch) + result set (merged in place)
   // LDS visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
   s.hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
   // large ef x dim: shrink it until the wave's state fits the CU's 160 KiB (the reset-and-reseed path keeps results exact;
@@ -730,7 +718,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2
       const size_t waves = (s.w2 & 8) ? 4 : waves_per_cu_cap(x->quant);
       const size_t budget = (160 * 1024) / waves;
       size_t kb = 32;
-      if (const char* e = getenv("COLTT_BLOOM_KB")) { if (*e) kb = (size_t)std::max(1, std::min(64, atoi(e))); }
+      if (policy().bloom_kb > 0) kb = (size_t)policy().bloom_kb;
       else while (kb >= 2 && fixed + kb * 1024 > budget) kb >>= 1;
       size_t p2 = 1; while (p2 * 2 <= kb) p2 *= 2;   // power of two
       if (kb >= 2 && fixed + p2 * 1024 <= 160 * 1024) { s.bloom_words = (uint32_t)(p2 * 256); s.lds = fixed + p2 * 1024; }
@@ -750,8 +738,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2
 // CU measured slower both in search (ef 256: 160 k vs 197 k q/s) and in the 10 M build (61 s vs 50 s).  COLTT_WAVES_PER_CU
 // overrides (measurement knob).
 size_t waves_per_cu_cap(int quant) {
-  const char* e = getenv("COLTT_WAVES_PER_CU");
-  if (e && *e) return (size_t)std::max(1, std::min(8, atoi(e)));
+  if (policy().waves_per_cu > 0) return (size_t)policy().waves_per_cu;
   return quant == Q_NONE ? 4 : 8;
 }
 
@@ -836,9 +823,9 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   auto kern = hnsw_search_lat_kernel<METRIC, QUANT>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
-  const char* seq = getenv("COLTT_LAT_SEQ");
+  const bool seq = policy().lat_seq;
   kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq && *seq == '1' ? 1 : 0);
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq ? 1 : 0);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -853,11 +840,7 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
 #ifndef COLTT_LAT_MIN_STRIDE
 #define COLTT_LAT_MIN_STRIDE 1024   // bytes per stored row below which a lane pair streams the whole row in one burst anyway
 #endif
-uint32_t lat_max_nq() {
-  const char* e = getenv("COLTT_LAT_MAX_NQ");
-  if (!e || !*e) e = getenv("COLTT_MW_MAX_NQ");
-  return e && *e ? (uint32_t)atoi(e) : (uint32_t)COLTT_LAT_MAX_NQ_DEFAULT;
-}
+uint32_t lat_max_nq() { const Policy p = policy(); return p.lat_knob_set ? p.lat_max_nq : (uint32_t)COLTT_LAT_MAX_NQ_DEFAULT; }
 
 int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override,
                   uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, int force = 0) {
@@ -901,7 +884,7 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
     // LDS: query + result set + exchange words + the staging area (32 padded rows) + the visited hash
     const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (size_t)LAT_ROWS * (x->stride + LAT_PAD);
     if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to stage 32 at a time
-    else if (x->stride < COLTT_LAT_MIN_STRIDE && !getenv("COLTT_LAT_MAX_NQ") && !getenv("COLTT_MW_MAX_NQ")) mw = false;   // short rows: the one-wave kernel (unless asked for)
+    else if (x->stride < COLTT_LAT_MIN_STRIDE && !policy().lat_knob_set) mw = false;   // short rows: the one-wave kernel (unless asked for)
     else {
       m.hcap = 32768; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;
       m.lds = fixed + (size_t)m.hcap * 4;

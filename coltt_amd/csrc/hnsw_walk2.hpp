@@ -175,6 +175,7 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
 template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
   static constexpr bool CHUNK_ADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+  // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int lane) const {
     constexpr int ROWS = COLTT_G8_ROWS;
     const bool mine = fresh && half == 0;
@@ -187,25 +188,71 @@ template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
     const int grp = lane >> 3, rj = lane & 7;
     const int nl = (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7;
     for (uint32_t base = 0; base < nf; base += 8 * ROWS) {          // wave-uniform
-      const uint8_t* rp[ROWS]; float rn[ROWS], d[ROWS]; uint32_t idx[ROWS];
+      const uint8_t* rp[ROWS]; float rn[ROWS], d[ROWS]; uint32_t idx[ROWS]; bool live[ROWS];
 #pragma unroll
       for (int i = 0; i < ROWS; i++) {
         idx[i] = base + (uint32_t)(i * 8 + grp);
-        const uint32_t slot = s_nb[idx[i] < nf ? idx[i] : 0];       // an idle group re-reads the first row (its result is dropped)
+        live[i] = idx[i] < nf;
+        const uint32_t slot = s_nb[live[i] ? idx[i] : 0];
         rp[i] = g.rows8 + (size_t)slot * g.stride;
         rn[i] = 0.f;
-        if constexpr (METRIC == M_COS) { if constexpr (ADJN) rn[i] = s_nr[idx[i] < nf ? idx[i] : 0]; else rn[i] = g.norms[slot]; }
+        if constexpr (METRIC == M_COS) { if constexpr (ADJN) rn[i] = s_nr[live[i] ? idx[i] : 0]; else rn[i] = g.norms[slot]; }
       }
-      group8_distance<METRIC, QUANT, ROWS, COLTT_G8_U>(rp, w.qp, nl, w.qnorm, rn, rj, d);
+      group8_distance<METRIC, QUANT, ROWS, COLTT_G8_U>(rp, live, w.qp, nl, w.qnorm, rn, rj, d);
 #pragma unroll
-      for (int i = 0; i < ROWS; i++) if (rj == 0 && idx[i] < nf) s_d[idx[i]] = d[i];
+      for (int i = 0; i < ROWS; i++) if (rj == 0 && live[i]) s_d[idx[i]] = d[i];
     }
     wave_sync();
-    const float r = mine ? s_d[rank] : 0.f;
+    float r = mine ? s_d[rank] : 0.f;
     wave_sync();   // the next chunk rewrites the scratch
+    r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));   // even lane's value to its pair: quad_perm [0,0,2,2]
     return r;
   }
+  // Distance(query, one row), the same value in every lane (entrypoint, hnsw.go:253)
+  __device__ __forceinline__ float one(const GraphView& g, const WaveCtx& w, uint32_t slot, int lane) const {
+    const uint8_t* rp[1] = {g.rows8 + (size_t)slot * g.stride};
+    const bool live[1] = {true};
+    float rn[1] = {0.f}, d[1];
+    if constexpr (METRIC == M_COS) rn[0] = g.norms[slot];
+    group8_distance<METRIC, QUANT, 1, COLTT_G8_U>(rp, live, w.qp, (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7, w.qnorm, rn, lane & 7, d);
+    return d[0];
+  }
 };
+
+// greedyClosestNeighbor (hnsw.go:320-343) with the eight-lane core: hnsw_dev.hpp:greedy_level with the distances of a chunk coming
+// from Group8Eval (the upper rows carry no norms: the 4-byte gather serves the handful of evaluations up here)
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void greedy_level8(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level, int lane_in) {
+  const Group8Eval<METRIC, QUANT, false> ev;
+  for (uint32_t hops = 0;; hops++) {
+    const int lane = opaque_lane(lane_in);
+    const int half = lane & 1, p = lane >> 1;
+    if (hops > (1u << 20)) { w.err |= 4u; break; }
+    uint32_t width;
+    const uint32_t* row = adj_row(g, cur, level, width);
+    unsigned long long best = ~0ull;
+    uint32_t best_slot = NBR_NONE;
+    for (uint32_t c0 = 0; c0 < width; c0 += 32) {
+      const uint32_t idx = c0 + p;
+      const uint32_t nb = idx < width ? row[idx] : NBR_NONE;
+      const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+      float d = 0.f;
+      if (__ballot(valid)) d = ev(g, w, nb, valid, 0.f, half, lane);
+      w.n_dist += __popcll(__ballot(valid && half == 0));
+      const unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;
+      const unsigned long long km = wave_min_u64(key);
+      if (km < best) {
+        best = km;
+        const int src = (int)(((uint32_t)km - c0) * 2);
+        best_slot = (uint32_t)__builtin_amdgcn_readlane((int)nb, src);
+      }
+    }
+    w.n_hops++;
+    const float bd = __uint_as_float((uint32_t)(best >> 32));
+    if (best != ~0ull && bd < curd) { cur = best_slot; curd = bd; }
+    else break;
+  }
+}
 enum { VIS_HBM = 0, VIS_LDS = 1 };   // visited set of search_level2: HBM byte map (behind the Bloom filter) | LDS hash that is never reset (err 8)
 
 // searchLevel (hnsw.go:345-389) on level 0.  On return res[0, len) holds the result set ascending by (d, slot).

@@ -51,6 +51,9 @@ int coltt_init(int device);                 /* selects the HIP device for the ca
 int coltt_device_count(void);
 const char* coltt_last_error(void);
 const char* coltt_version(void);
+/* The COLTT_* measurement / test knobs (INTEGRATION.md "Knobs") are read from the environment ONCE, into a process-wide snapshot,
+ * when the library is first used; no search call reads the environment.  A program that changes one of them later calls this. */
+int coltt_policy_reload(void);
 
 /* ---- kernels exposed one-to-one (pkg/distance, pkg/compresshelper, pkg/sharding, pkg/distancepq) --- */
 /* distance.Space.Distance(a,b) for n independent pairs: a,b are row-major [n][dim] host arrays
