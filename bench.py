@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
+    ap.add_argument("--no-reserve", dest="reserve", action="store_false", help="let the index arrays grow by halves during the build instead of reserving the known size")
     ap.add_argument("--shard-leg-n", type=int, default=0, help="vectors in the whole sharded collection of the secondary.shard leg (0 = --n)")
     # ranks started by self_launch() get their arguments through the environment: torch.distributed.run's own parser would read
     # `--n 20000` as an abbreviation of one of ITS options (--nnodes, --nproc-per-node, ...) even behind the script path
@@ -131,6 +132,8 @@ def build_index(G, torch, dev, ds, n, dim, args, seed, quant, ids=None, h=None, 
     """Generate n vectors in HBM chunk by chunk and Insert them (batched builder).  ids: explicit u64 ids (shards)."""
     if h is None:
         h = G.Hnsw(dim, G.COSINE, G.HnswCfg.default(m=args.m, ef=ef or args.ef, ef_construction=args.efc), quantization=quant)
+    if getattr(args, "reserve", True):
+        h.Reserve(n)      # the collection's size is known: every array is allocated once (coltt_hnsw_reserve)
     gen = torch.Generator(device=dev); gen.manual_seed(seed)
     levels = draw_levels(n, args.m, seed)
     chunk = min(n, 1 << 20); done = 0
@@ -431,6 +434,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
             cpu = cpu_hnsw(G, torch, O, h, args, dim, quant, ef_op, q, k, out, args.m)
         except Exception as e:
             cpu = {"error": str(e)}
+    op_ev8 = h.Rows8()[0]
     h.close()
     res = {"workload": f"core/vectorindex HNSW M={args.m} efConstruction={args.efc}, {n}x{dim} f16 codes, cosine, k={k}, dataset {args.op_dataset} "
                        f"(x = mu_c + A z + sigma eps), {nq} queries/step",
@@ -440,7 +444,9 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
            "per_query": {"n_dist": nd, "n_exp": ne, "bytes": bpq},
            "roofline": {"bound": "hbm", "achieved": bpq * nq / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bpq * nq / launch_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[0],
-                        "traffic_source": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[1], "kernel": "hnsw_search2_kernel (hnsw_walk2.hpp: HBM visited map behind an LDS Bloom filter, delta result set, 2-byte rows)",
+                        "traffic_source": pmc_traffic(args, n, dim, nq, 1, ef_op, args.op_dataset)[1],
+                        "kernel": "hnsw_search2_kernel (hnsw_walk2.hpp: HBM visited map behind an LDS Bloom filter, delta result set, 2-byte rows" +
+                                  ("; eight lanes per row over rows8)" if op_ev8 > 0 else ")"),
                         "avg_launch_ms": launch_s * 1e3},
            "cpu_baseline": cpu}
     if cpu and "value" in cpu:
@@ -1028,6 +1034,7 @@ def main():
                 except Exception as e:
                     cpu = {"error": str(e)}
         launch_s = float(np.mean(kernel_ms)) / 1e3
+        ev8_launches = h.Rows8()[0]
         roof = None
         if bytes_per_query is not None:
             achieved = bytes_per_query * nq / launch_s / 1e9
@@ -1035,7 +1042,9 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": tr_src, "avg_launch_ms": launch_s * 1e3,
                     "kernel": "hnsw_search_kernel (hnsw_dev.hpp:search_level)" if os.environ.get("COLTT_WALK2_LDS", "") == "off" else
-                              "hnsw_search2_kernel<.., VIS_LDS> (hnsw_walk2.hpp over the LDS visited hash: adjacency-carried norms)"}
+                              ("hnsw_search2_kernel<.., VIS_LDS, EV8> (hnsw_walk2.hpp over the LDS visited hash; level-0 distances by eight lanes per row over the line-transposed row copy, rows8.hpp)"
+                               if ev8_launches > 0 else "hnsw_search2_kernel<.., VIS_LDS> (hnsw_walk2.hpp over the LDS visited hash: adjacency-carried norms)"),
+                    "eight_lane_launches": ev8_launches}
         h.close()
         op = None
         if "op" in legs:

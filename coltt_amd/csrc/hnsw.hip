@@ -153,18 +153,19 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     wave_sync();
     uint32_t cur = (uint32_t)entry;
     float curd;
-    if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false>().one(g, w, cur, lane);
+    constexpr bool H16 = EV8 && QUANT != Q_NONE && VISMODE == VIS_HBM;   // Group8Eval: rows x burst depth of the HBM-visited 2-byte kernels
+    if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false, H16>().one(g, w, cur, lane);
     else curd = eval_pair<METRIC, QUANT, PROFILE>(g, w, cur, lane & 1);  // hnsw.go:253
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
     for (int l = entry_level; l > 0; l--) {  // :254-256
-      if constexpr (EV8) greedy_level8<METRIC, QUANT>(g, w, cur, curd, l, lane);
+      if constexpr (EV8) greedy_level8<METRIC, QUANT, H16>(g, w, cur, curd, l, lane);
       else greedy_level<METRIC, QUANT, PROFILE>(g, w, cur, curd, l, lane);
     }
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS>());
+    if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS, H16>());
     else search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len);  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {
@@ -1742,6 +1743,17 @@ int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_le
   if (out_row) COLTT_HIP(hipMemcpy(out_row, x->rows.as<uint8_t>() + slot * x->stride, (size_t)x->dim * quant_bytes(x->quant), hipMemcpyDeviceToHost));
   if (out_level) *out_level = x->h_levels[slot];
   return COLTT_OK;
+}
+
+int coltt_hnsw_reserve(coltt_handle_t h, uint64_t n_slots, uint64_t n_upper_rows) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_reserve: unknown handle");
+  if (n_slots >= 0x7fffffffull) return fail(COLTT_E_UNSUPPORTED, "hnsw_reserve: more than 2^31-1 slots");
+  WriteLock g(x->rw);
+  COLTT_DEVICE(x->device);
+  // upper rows: a vertex of level L owns L of them; the level draw floor(-ln(u) / ln(M)) averages 1 / (M - 1) per vertex
+  if (n_upper_rows == 0) n_upper_rows = n_slots / (uint64_t)std::max(2, x->cfg.m - 1) + n_slots / 64 + 1024;
+  return x->reserve(n_slots, n_upper_rows);
 }
 
 int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t* out_has_copy) {

@@ -166,18 +166,29 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
 // and norm at their rank among the fresh ones), every 8-lane group evaluates ROWS of them per pass — 8 x ROWS rows per pass, whole
 // 128-byte lines per load instruction — and the distances travel back through LDS to the lane pairs that own the neighbours in the
 // walk (admission, ranks and keys stay where they were).  Same values in the same order as PairEval: same bits.
+// Rows per lane group in flight x burst depth (128-byte lines), per kernel family — measured on the two 10 M x 768 shapes, every
+// variant in one process against the pair-owned walk (profiles/r04d_ev8_variants.md, r04e_*): two rows x 6 lines for f32 rows and for
+// the LDS-visited 2-byte kernel (one wave per SIMD), ONE row with all of its 12 lines in flight for the HBM-visited 2-byte kernels (two
+// waves per SIMD; the deeper two-row bursts lose there: 2 x 12 lines -35 % on f32, -11 % on 2-byte rows).
 #ifndef COLTT_G8_ROWS
 #define COLTT_G8_ROWS 2
 #endif
 #ifndef COLTT_G8_U
 #define COLTT_G8_U 6
 #endif
-template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
+#ifndef COLTT_G8_ROWS_H16
+#define COLTT_G8_ROWS_H16 1
+#endif
+#ifndef COLTT_G8_U_H16
+#define COLTT_G8_U_H16 12
+#endif
+template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eval {
+  static constexpr int G8R = HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS, G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
   static constexpr bool CHUNK_ADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int lane) const {
-    constexpr int ROWS = COLTT_G8_ROWS;
+    constexpr int ROWS = G8R;
     const bool mine = fresh && half == 0;
     const unsigned long long E = __ballot(mine);
     const uint32_t nf = (uint32_t)__popcll(E);
@@ -198,7 +209,7 @@ template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
         rn[i] = 0.f;
         if constexpr (METRIC == M_COS) { if constexpr (ADJN) rn[i] = s_nr[live[i] ? idx[i] : 0]; else rn[i] = g.norms[slot]; }
       }
-      group8_distance<METRIC, QUANT, ROWS, COLTT_G8_U>(rp, live, w.qp, nl, w.qnorm, rn, rj, d);
+      group8_distance<METRIC, QUANT, ROWS, G8U>(rp, live, w.qp, nl, w.qnorm, rn, rj, d);
 #pragma unroll
       for (int i = 0; i < ROWS; i++) if (rj == 0 && live[i]) s_d[idx[i]] = d[i];
     }
@@ -214,16 +225,16 @@ template <int METRIC, int QUANT, bool ADJN> struct Group8Eval {
     const bool live[1] = {true};
     float rn[1] = {0.f}, d[1];
     if constexpr (METRIC == M_COS) rn[0] = g.norms[slot];
-    group8_distance<METRIC, QUANT, 1, COLTT_G8_U>(rp, live, w.qp, (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7, w.qnorm, rn, lane & 7, d);
+    group8_distance<METRIC, QUANT, 1, G8U>(rp, live, w.qp, (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7, w.qnorm, rn, lane & 7, d);
     return d[0];
   }
 };
 
 // greedyClosestNeighbor (hnsw.go:320-343) with the eight-lane core: hnsw_dev.hpp:greedy_level with the distances of a chunk coming
 // from Group8Eval (the upper rows carry no norms: the 4-byte gather serves the handful of evaluations up here)
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, bool HBM16>
 __device__ __forceinline__ void greedy_level8(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level, int lane_in) {
-  const Group8Eval<METRIC, QUANT, false> ev;
+  const Group8Eval<METRIC, QUANT, false, HBM16> ev;
   for (uint32_t hops = 0;; hops++) {
     const int lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;

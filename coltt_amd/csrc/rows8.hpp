@@ -71,7 +71,7 @@ __device__ __forceinline__ float group8_hsum(float a) {
 
 // Distance(query, row) of ROWS rows per 8-lane group at once (ROWS x U..2U 16-byte loads per lane in flight); rj = this lane's
 // residue (lane & 7).  row8[i] -> the rows8 copy of row i, qp -> the permuted query in LDS, nl = 128-byte lines per row.
-// live[i] == false: this group has no i-th row in this pass — its loads are skipped (EXEC-masked), its result is garbage.
+// live[i] == false: this group has no i-th row in this pass — row8[i] then points at some live row, the result is dropped by the caller.
 template <int METRIC, int QUANT, int ROWS, int U>
 __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROWS], const bool (&live)[ROWS], const float* __restrict__ qp, int nl,
                                                 float qnorm, const float (&rnorm)[ROWS], int rj, float (&out)[ROWS]) {
@@ -81,7 +81,9 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
   for (int i = 0; i < ROWS; i++) acc[i] = 0.f;
   const float* qb = qp + rj * S;
   struct Raw { u32x4e v[ROWS]; };
-#define COLTT_G8_LD(L, DST) { _Pragma("unroll") for (int i = 0; i < ROWS; i++) { DST.v[i] = u32x4e{0u, 0u, 0u, 0u}; if (live[i]) DST.v[i] = *reinterpret_cast<const u32x4e*>(row8[i] + (size_t)(L) * 128 + rj * 16); } }
+  // (the loads are NOT predicated on `live`: wrapping each of them in its own EXEC save / restore broke the back-to-back issue of a burst —
+  //  10 M x 768 f32, ef 128: 19.9 -> 27.3 ms per 10 k queries, profiles/r04d_ev8_variants.md; an idle group re-reads a live row instead)
+#define COLTT_G8_LD(L, DST) { _Pragma("unroll") for (int i = 0; i < ROWS; i++) DST.v[i] = *reinterpret_cast<const u32x4e*>(row8[i] + (size_t)(L) * 128 + rj * 16); }
 #define COLTT_G8_CS(RAW, L)                                                                                                   \
   {                                                                                                                           \
     if constexpr (QUANT == Q_NONE) {                                                                                          \

@@ -171,6 +171,9 @@ class Hnsw:
         L.check(L.lib().coltt_hnsw_fetch_rows(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out)))
         return out
 
+    def Reserve(self, n_slots, n_upper_rows=0):
+        L.check(L.lib().coltt_hnsw_reserve(self.h, C.c_uint64(int(n_slots)), C.c_uint64(int(n_upper_rows))))
+
     def Rows8(self):
         """(search launches served by the eight-lanes-per-row core, whether the line-transposed row copy is complete)"""
         a, f = C.c_uint64(0), C.c_int32(0)

@@ -195,6 +195,11 @@ int coltt_hnsw_search(coltt_handle_t h, const float* queries, size_t nq, uint32_
                       uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats);
 int coltt_hnsw_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override,
                              uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats);
+/* Capacity for n_slots vertices (and n_upper_rows upper-level adjacency rows; 0 = the expectation for this index's M) in ONE allocation per
+ * array, before the inserts.  Optional — Insert grows the arrays by half their size when they are full — but an index whose final size is
+ * known should reserve it: growth copies every array (30 GB of rows at 10 M x 768 f32), and arrays allocated once from an empty heap get the
+ * largest contiguous physical fragments, which the random row reads of a search feel in their TLB miss rate. */
+int coltt_hnsw_reserve(coltt_handle_t h, uint64_t n_slots, uint64_t n_upper_rows);
 /* Round 4: indexes whose rows are f32 / 2-byte codes of a byte length that is a multiple of 128 (dim 128, 256, 512, 768, 1024, 1536 ...)
  * keep a second, line-transposed copy of their rows (derived data, like the adjacency-carried norms) and evaluate the level-0
  * distances of a search with EIGHT lanes per row over it — whole 128-byte lines per load instruction — in the reference's summation

@@ -24,13 +24,13 @@ def main():
     assert G.lib().coltt_init(0) == 0
     dev = torch.device("cuda", 0)
 
-    class A: m = 16; ef = 128; efc = 200; build_batch = 16384
+    class A: m = 16; ef = 128; efc = 200; build_batch = 16384; reserve = not (len(sys.argv) > 5 and sys.argv[5] == "noreserve")
     ds = B.Dataset(torch, dev, dim, dataset)
     h, build_s = B.build_index(G, torch, dev, ds, n, dim, A, 0xC0177, quant)
     gen = torch.Generator(device=dev); gen.manual_seed(0x5EED5)
     q = ds.rows(nq, gen)
     out = B.Out(torch, dev, nq, k)
-    res = {"n": n, "dim": dim, "quant": quant, "dataset": dataset, "build_s": build_s, "rows8": h.Rows8(), "ef": {}}
+    res = {"n": n, "dim": dim, "quant": quant, "dataset": dataset, "build_s": build_s, "reserved": A.reserve, "rows8": h.Rows8(), "ef": {}}
     for ef in efs:
         row = {}
         keep = {}

@@ -57,6 +57,9 @@ def main():
 
     def num(v):
         m = re.search(r"[-+]?\d+(\.\d+)?", str(v)); return float(m.group(0)) if m else float("nan")
+    if os.environ.get("POWER_PROBE_RAW"):   # every rocm-smi sample (power, clocks, temperatures) and every search time, as taken
+        with open(os.environ["POWER_PROBE_RAW"], "w") as f:
+            json.dump({"lib": os.path.basename(os.environ.get("COLTT_LIB", "default")), "case": list(case), "samples": samples, "search_ms": ms}, f)
     late = [x for x in samples if x["t"] > 1.5]
     pw = [num(v) for x in late for k, v in x.items() if "power" in k.lower()]
     sc = [num(v) for x in late for k, v in x.items() if k.startswith("sclk clock speed")]
