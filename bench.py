@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,f3,pq ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,c3f8,f3,pq ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -589,6 +589,11 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
                         "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
                         "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
                                  "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}
+    if quant == 2:
+        res["roofline"]["note"] = ("1-byte rows: the candidate GEMM streams their derived binary16 copy (2 bytes per element, flat.hip f8_expand_kernel), so HBM traffic is "
+                                   "2x the algorithmic row bytes this fraction is quoted on; the exact-order scan it replaces is VALU-bound (exact_mode_ms_per_batch)")
+        res["roofline"]["streamed_bytes_per_batch"] = 2 * nbytes
+        res["roofline"]["mfma"]["note"] = "v_mfma_f32_32x32x16_f16 over the binary16 copy of the f8 rows (exact values x 2^24); candidates only"
     if one:
         res["workload"] = f"edge FLAT cosine, {n}x{dim} {QNAME[quant]}, batch {batch}, k={k}, nearest-k, one-launch small-batch search (BASELINE.json {tag})"
         res["roofline"]["kernel"] = "flat_one_kernel (exact-order scan + per-wave / per-block k best + selection by the last block: ONE launch; hipEvent pair around it)"
@@ -960,7 +965,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "f3", "pq"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "c3f8", "f3", "pq"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -1069,7 +1074,8 @@ def main():
                 secondary["h1"] = {"error": str(e)}
         for tag, (fn, fd, fq, fb, cfgname, cpu_rows) in {"c1": (100_000, 128, 0, 1, "configs[0]: the reference's own CPU-runnable case, one query per call", 100_000),
                                                          "c2": (1_000_000, dim, 0, 64, "configs[1]", 1_000_000),
-                                                         "c3": (10_000_000, dim, 1, 256, "configs[2]", 1_000_000)}.items():
+                                                         "c3": (10_000_000, dim, 1, 256, "configs[2]", 1_000_000),
+                                                         "c3f8": (10_000_000, dim, 2, 256, "configs[2] shape on the reference's 1-byte 'f8' codes (edge/f8_vectorstore.go:132-187)", 1_000_000)}.items():
             if tag in legs:
                 try:
                     secondary[tag] = leg_flat(G, torch, dev, O, args, fd, k, fn, fq, fb, cfgname, cpu_rows)

@@ -102,6 +102,7 @@ struct Policy {
   bool flat_one = true;        // COLTT_FLAT_ONE=0: <= 4-query FLAT searches through the scan + select chain
   bool staging = true;         // COLTT_STAGING=0: no page-locked staging of small host-buffer calls
   bool ev8 = true;             // COLTT_EV8=0: level-0 distances from the pair-owned rows even when rows8 exists
+  bool f8_mfma = true;         // COLTT_F8_MFMA=0: new "f8" cosine stores keep no binary16 copy: their batches run the exact scan (read at create)
   bool rows8 = true;           // COLTT_ROWS8=0: new indexes keep no line-transposed row copy (read at create)
   int visg = -1;               // COLTT_VISG: -1 default (byte map above ef 128), 0 LDS hash, 1 byte map
   int walk2 = 7;               // COLTT_WALK2: -1 off, else OPT bits | 8 deep profile

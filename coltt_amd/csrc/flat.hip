@@ -315,6 +315,31 @@ __global__ __launch_bounds__(256) void flat_one_kernel(
   st->bucket[tid] = 0xffffffffu;
 }
 
+// "f8" rows through the matrix cores.  The reference's Float8 decodes to eight values (float8.go:233-266; exact.hpp:
+// f8bits_to_f32bits): 0, 2^-24, 2^-23, 1.5 * 2^-23, each possibly with bit 15 of the f32 pattern set (+2^-8, +2^-8, +2^-8 / 1.5 relative;
+// a code whose low two bits are 0 decodes to 0 or to the denormal 2^-134).  Scaled by 2^24 every one of them is exactly a binary16 number
+// (0, 1, 2, 3, 1 + 2^-8, 2 + 2^-7, 3 + 2^-7; the denormal becomes 0: a relative 2^-110 of any product) — so a DERIVED copy of the rows,
+// rows16 = decode(code) * 2^24 as binary16, with norms16 = ||row||^2 * 2^48, feeds the unchanged 2-byte candidate GEMM: products
+// exact, f32 accumulation, the cosine value scale-free — the same candidate margin as for binary16 codes — and the survivors are re-scored
+// from the 1-byte rows in the reference's order.  Cosine only: the Euclidean candidate value is not scale-free.
+__device__ __forceinline__ unsigned short f8_to_scaled_f16bits(uint32_t code) {
+  const uint32_t m = code & 3u, sgn = (code >> 7) & 1u;
+  if (m == 0) return 0;
+  const uint32_t base = m == 1 ? 0x3C00u : (m == 2 ? 0x4000u : 0x4200u);   // 1.0, 2.0, 3.0
+  // bit 15 of the f32 pattern = 2^-8 of the mantissa scale: 1 + 2^-8 (4 ulp of binary16 at 1), 2 * (1 + 2^-8), 2 * (1.5 + 2^-8)
+  return (unsigned short)(base + (sgn ? 4u : 0u));
+}
+__global__ void f8_expand_kernel(const uint8_t* __restrict__ rows, size_t stride, const float* __restrict__ norms, const uint32_t* __restrict__ slots,
+                                 uint64_t slot_base, uint64_t n, int dim, uint8_t* __restrict__ rows16, size_t stride16, float* __restrict__ norms16) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = (int)(stride16 / 2);   // binary16 elements per destination row incl. its zero padding
+  if (t >= n * (uint64_t)per) return;
+  const uint64_t i = t / per; const int e = (int)(t - i * per);
+  const uint64_t slot = slots ? slots[i] : slot_base + i;
+  reinterpret_cast<unsigned short*>(rows16 + slot * stride16)[e] = e < dim ? f8_to_scaled_f16bits(rows[slot * stride + e]) : (unsigned short)0;
+  if (e == 0) norms16[slot] = norms[slot] * 281474976710656.0f;   // 2^48: an exponent shift
+}
+
 // stored codes of the edge .vertex stream (big-endian f32 / u16, raw u8) at arbitrary byte offsets -> rows
 template <int QUANT>
 __global__ void be_codes_kernel(const uint8_t* __restrict__ chunk, const uint64_t* __restrict__ offs, uint64_t m, int dim,
@@ -350,7 +375,7 @@ struct FBEW {
 struct FCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  DevBuf w_qraw, w_qeff, w_qn, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
+  DevBuf w_qraw, w_qeff, w_qn, w_qn16, w_cand, w_cand2, w_q16, w_cnt, w_out_ids, w_out_sc, w_out_cnt, w_gather;
   DevBuf w_pack;           // small host-buffer calls: ids | scores | counts in one block (one D2H; see PinnedBuf)
   PinnedBuf h_in, h_out;
   DevBuf w_one;            // flat_one_kernel: OneState | per-block records (reserved once, at its maximum)
@@ -372,6 +397,7 @@ struct Flat : Object {
   uint32_t dim = 0; int metric = 0, quant = 0; size_t stride = 0;
   uint64_t n = 0, cap = 0;
   DevBuf rows, norms, ids;
+  DevBuf rows16, norms16; size_t stride16 = 0; bool f8x = false;   // f8 + cosine: the binary16 copy the candidate GEMM reads (f8_expand_kernel)
   bool dense = true; uint64_t dense_base = 0;     // id = dense_base + slot, no map
   std::unordered_map<uint64_t, uint32_t> id2slot;  // !dense
   std::vector<uint64_t> h_ids;                     // !dense : slot -> id (host mirror)
@@ -403,6 +429,15 @@ struct Flat : Object {
       COLTT_HIP(hipStreamSynchronize(stream));
     }
     COLTT_TRY(norms.reserve((ncap + 2 * ROW_SLACK) * 4, true, stream));
+    if (f8x) {
+      const size_t old16 = rows16.cap;
+      COLTT_TRY(rows16.reserve((ncap + ROW_SLACK) * stride16, true, stream));
+      if (rows16.cap > old16) {
+        COLTT_HIP(hipMemsetAsync(rows16.as<uint8_t>() + old16, 0, rows16.cap - old16, stream));
+        COLTT_HIP(hipStreamSynchronize(stream));
+      }
+      COLTT_TRY(norms16.reserve((ncap + 2 * ROW_SLACK) * 4, true, stream));
+    }
     if (!dense) COLTT_TRY(ids.reserve(ncap * 8, true, stream));
     cap = ncap;
     return COLTT_OK;
@@ -428,6 +463,10 @@ int launch_prep_rows(Flat* f, const float* d_raw, uint64_t n, const uint32_t* d_
   row_norms_kernel<QUANT><<<ceil_div(n * 2, 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, d_slots,
                                                                        slot_base, n, (int)f->dim, f->norms.as<float>(), f->d_maxn.as<uint32_t>());
   COLTT_HIP(hipMemcpyAsync(f->norm_bits, f->d_maxn.p, 8, hipMemcpyDeviceToHost, f->stream));  // complete at the caller's stream sync
+  if constexpr (QUANT == Q_F8) {
+    if (f->f8x) f8_expand_kernel<<<ceil_div(n * (f->stride16 / 2), 256), 256, 0, f->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), d_slots, slot_base, n,
+                                                                                       (int)f->dim, f->rows16.as<uint8_t>(), f->stride16, f->norms16.as<float>());
+  }
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -577,9 +616,17 @@ static int mfma_generation() {
 #endif
 }
 
+// what the candidate GEMM streams: the stored rows, or — "f8" stores — their derived binary16 copy (f8_expand_kernel)
+struct RowSrc { const uint8_t* rows; size_t stride; const float* norms; };
+inline RowSrc mfma_rows(const Flat* f) {
+  if (f->quant == COLTT_Q_F8) return RowSrc{f->rows16.as<uint8_t>(), f->stride16, f->norms16.as<float>()};
+  return RowSrc{f->rows.as<uint8_t>(), f->stride, f->norms.as<float>()};
+}
+
 template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                        unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim, const uint32_t* d_gather) {
+  const RowSrc src = mfma_rows(f);
   if (d_gather) {   // rows[gather[pos]] for pos in [b, e): FilterableVertexSearch through the matrix cores (flat_mfma3.hpp, GATHER)
     auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_COS, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_COS, true>)
                                           : (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_L2, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_L2, true>);
@@ -587,7 +634,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap, d_gather);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -600,7 +647,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -612,7 +659,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -623,7 +670,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
     uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
-    kern<<<grid, MF_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+    kern<<<grid, MF_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
                                         nearest, cand, cnt, cap);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -641,7 +688,7 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t tiles = (e - b + BM - 1) / BM;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), b, e, q16, qn, g, kdim, thr,
+    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
                                           nearest, cand, cnt, cap, nullptr);
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
@@ -681,7 +728,13 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   _Float16* q16 = c->w_q16.as<_Float16>();
   const int BN = g <= 64 ? 64 : (g <= 128 ? 128 : 256);
   const int dimp = mfma_kdim(f);   // K padded to whole steps (and to at least four of them) with zero query columns
-  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * dimp, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, dimp, q16, cnt, thr, ovf, nearest);
+  // "f8" stores: the query (already lowered + decoded: the same eight values) goes in scaled by 2^24, its norm by 2^48 (see f8_expand_kernel)
+  const bool f8 = f->quant == COLTT_Q_F8;
+  if (f8) COLTT_TRY(c->w_qn16.reserve(256 * 4));
+  mfma_prep_queries_kernel<<<ceil_div((uint64_t)BN * dimp, 256), 256, 0, c->stream>>>(qe, g, BN, (int)f->dim, dimp, q16, cnt, thr, ovf, nearest,
+                                                                                      f8 ? 16777216.0f : 1.0f, f8 ? qn : nullptr, f8 ? c->w_qn16.as<float>() : nullptr);
+  const float* qn_exact = qn;                 // the exact re-score keeps the unscaled norms
+  if (f8) qn = c->w_qn16.as<float>();
   auto scan = [&](uint64_t b, uint64_t e) -> int {
     const bool seed = b == 0 && e - b <= cap;
     if (BN == 64) COLTT_TRY(launch_mfma_scan<64>(f, c, b, e, q16, qn, g, thr, nearest, cur, cnt, cap, seed, dimp, d_gather));
@@ -711,8 +764,8 @@ int search_group_mfma(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int neares
   // overflow flag is read once at the end (a group whose candidate list overflowed is re-run in exact mode by the caller)
   {
     dim3 grid(16, g);
-#define COLTT_RS(M, Q) flat_rescore_kernel<M, Q><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn, (int)f->dim, cur, cnt, cap)
-    if (f->metric == COLTT_COSINE) { if (f->quant == COLTT_Q_NONE) COLTT_RS(M_COS, Q_NONE); else COLTT_RS(M_COS, Q_F16); }
+#define COLTT_RS(M, Q) flat_rescore_kernel<M, Q><<<grid, 64, 0, c->stream>>>(f->rows.as<uint8_t>(), f->stride, f->norms.as<float>(), qe, qn_exact, (int)f->dim, cur, cnt, cap)
+    if (f->metric == COLTT_COSINE) { if (f->quant == COLTT_Q_NONE) COLTT_RS(M_COS, Q_NONE); else if (f8) COLTT_RS(M_COS, Q_F8); else COLTT_RS(M_COS, Q_F16); }
     else { if (f->quant == COLTT_Q_NONE) COLTT_RS(M_L2, Q_NONE); else COLTT_RS(M_L2, Q_F16); }
 #undef COLTT_RS
   }
@@ -736,7 +789,8 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // binary16 on their way into the fragments, which is a RELATIVE perturbation only while the elements stay in binary16's normal
   // range.  Upserts normalise (none_vectorstore.go:63-65), but a loaded stream is stored as it is (vectorstore load paths do not
   // re-normalise), so a store that ever held a row with ||row||^2 outside [1/4, 4] answers through the exact scan.
-  const bool cos_ok = f->metric == COLTT_COSINE && min_norm >= 0.25f && max_norm <= 4.0f;
+  // ("f8" rows: their binary16 copy holds exact values and the candidate value is scale-free — any finite, non-zero-range store qualifies)
+  const bool cos_ok = f->metric == COLTT_COSINE && (f->quant == COLTT_Q_F8 ? (f->f8x && max_norm == max_norm && max_norm < 3.0e38f) : (min_norm >= 0.25f && max_norm <= 4.0f));
   // K need not be a multiple of the 32-column step with the DMA kernels: the query tile is zero-padded and the rows' overhang
   // (padding, head of the next row — all finite as long as no stored norm ever was non-finite; Flat::reserve zeroes the rest)
   // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
@@ -745,7 +799,8 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // (a filtered search — d_gather: positions of a slot list — takes the matrix cores too, through the kernel's gather mode; the
   //  superseded experiment generations have none)
   const bool mfma = mode == COLTT_MODE_MFMA && (!d_gather || mfma_generation() == 3) && (cos_ok || l2_ok) &&
-                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16) && k_ok && f->dim >= 8 && f->dim <= 4096 && total > 0;
+                    (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16 || (f->quant == COLTT_Q_F8 && f->f8x && f->metric == COLTT_COSINE)) &&
+                    k_ok && f->dim >= 8 && f->dim <= 4096 && total > 0;
   // small batches: the whole search in one launch, whatever the mode asked for (exact-order scores either way)
   // (2-4 queries: while the scan is short — its four-query tile streams at about half the one-query rate, and past ~400 MB the chain's
   //  launch gaps no longer matter: 1 M x 128 f32 x 4 queries 286 us here, 212 us through the chain; 100 k x 768: 123 vs 185)
@@ -896,6 +951,8 @@ int coltt::flat_create_on(int device, uint32_t dim, int metric, int quant, coltt
   auto f = std::make_shared<Flat>();
   f->dim = dim; f->metric = metric; f->quant = quant;
   f->stride = ((size_t)dim * quant_bytes(quant) + 15) & ~(size_t)15;
+  f->stride16 = ((size_t)dim * 2 + 15) & ~(size_t)15;
+  f->f8x = quant == COLTT_Q_F8 && metric == COLTT_COSINE && policy().f8_mfma;
   f->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
   COLTT_TRY(f->d_maxn.reserve(16));
@@ -1000,6 +1057,11 @@ int coltt_flat_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
       uint8_t* R = f->rows.as<uint8_t>();
       COLTT_HIP(hipMemcpyAsync(R + (size_t)s * f->stride, R + (size_t)last * f->stride, f->stride, hipMemcpyDeviceToDevice, f->stream));
       COLTT_HIP(hipMemcpyAsync(f->norms.as<float>() + s, f->norms.as<float>() + last, 4, hipMemcpyDeviceToDevice, f->stream));
+      if (f->f8x) {
+        uint8_t* R16 = f->rows16.as<uint8_t>();
+        COLTT_HIP(hipMemcpyAsync(R16 + (size_t)s * f->stride16, R16 + (size_t)last * f->stride16, f->stride16, hipMemcpyDeviceToDevice, f->stream));
+        COLTT_HIP(hipMemcpyAsync(f->norms16.as<float>() + s, f->norms16.as<float>() + last, 4, hipMemcpyDeviceToDevice, f->stream));
+      }
       uint64_t moved = f->h_ids[last];
       f->h_ids[s] = moved;
       f->id2slot[moved] = s;
@@ -1161,6 +1223,8 @@ int coltt_flat_load_vertex(coltt_handle_t h, const uint8_t* buf, uint64_t len, u
         (void)hipMemcpyAsync(f->norm_bits, f->d_maxn.p, 8, hipMemcpyDeviceToHost, f->stream); } while (0)
       COLTT_DISPATCH_QUANT(f->quant, COLTT_BE)
 #undef COLTT_BE
+      if (f->f8x) f8_expand_kernel<<<ceil_div(m * (f->stride16 / 2), 256), 256, 0, f->stream>>>(R, f->stride, f->norms.as<float>(), nullptr, b, m, (int)f->dim,
+                                                                                         f->rows16.as<uint8_t>(), f->stride16, f->norms16.as<float>());
       COLTT_HIP(hipGetLastError());
       COLTT_HIP(hipStreamSynchronize(f->stream));
     }

@@ -45,17 +45,20 @@ template <int BN> constexpr size_t mfma_lds_bytes() { return (size_t)2 * (MF_BM 
 
 // queries as f16 [BN][dim]: exact for the 2-byte stores (q_eff went through Lower), rounded to nearest for f32 stores
 // (also resets the group state cnt[256] | thr[256] | overflow: one launch less in the chain)
+// qscale: the query is multiplied by it on its way to binary16 ("f8" stores: 2^24, flat.hip f8_expand_kernel), qn_out = qn_in * qscale^2
 __global__ void mfma_prep_queries_kernel(const float* __restrict__ q_eff, int nq, int bn, int dim, int dimp, _Float16* __restrict__ q16,
-                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ thr, uint32_t* __restrict__ overflow, int nearest) {
+                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ thr, uint32_t* __restrict__ overflow, int nearest,
+                                         float qscale = 1.0f, const float* __restrict__ qn_in = nullptr, float* __restrict__ qn_out = nullptr) {
   if (blockIdx.x == 0) {
     if (threadIdx.x < 256) { cnt[threadIdx.x] = 0; thr[threadIdx.x] = nearest ? 0xffffffffu : 0u; }
     if (threadIdx.x == 0) *overflow = 0;
+    if (qn_out && (int)threadIdx.x < nq) qn_out[threadIdx.x] = qn_in[threadIdx.x] * qscale * qscale;
   }
   // q16 = [bn][dimp]: queries beyond nq and columns beyond dim (K padded to whole 32-column steps) are zero
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)bn * dimp) return;
   const int q = (int)(i / dimp), e = (int)(i - (size_t)q * dimp);
-  q16[i] = (q < nq && e < dim) ? (_Float16)q_eff[(size_t)q * dim + e] : (_Float16)0.f;
+  q16[i] = (q < nq && e < dim) ? (_Float16)(q_eff[(size_t)q * dim + e] * qscale) : (_Float16)0.f;
 }
 
 // ---- epilogue shared by both GEMM kernels -----------------------------------------------------------------------------

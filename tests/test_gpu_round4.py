@@ -104,3 +104,46 @@ def test_short_rows_go_through_the_matrix_cores(gpu, metric, quant, d):
     mf = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
     ef = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
     assert np.array_equal(mf[0], ef[0]) and np.array_equal(bits(mf[1]), bits(ef[1]))
+
+
+@pytest.mark.parametrize("d", [64, 100, 128, 768])
+def test_f8_rows_go_through_the_matrix_cores(gpu, d):
+    """The reference's Float8 decodes to eight values (pkg/compresshelper/float8.go:233-266); scaled by 2^24 they are exact binary16
+    numbers, so a derived binary16 copy of the rows feeds the 2-byte candidate GEMM (flat.hip: f8_expand_kernel) and the survivors are
+    re-scored from the 1-byte rows in the reference's order: ids, ranks and score bits equal the exact scan's and the oracle's
+    (edge/f8_vectorstore.go:132-187) — after overwrites and removals too, unfiltered and filtered.  Euclidean f8 stays on the exact scan."""
+    n, nq, k = 6000, 48, 10
+    X = (O.fill_normal(8300 + d, (n, d)) * np.float32(3e-7)).astype(np.float32)       # magnitudes around the codec's 2^-24 .. 2^-22 steps
+    X[200:230] = X[9]                                                                 # ties
+    Q = np.concatenate([X[9:10], (O.fill_normal(8400 + d, (nq - 1, d)) * np.float32(3e-7)).astype(np.float32)])
+    ids = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 36)
+    f = gpu.FlatSpace(d, gpu.COSINE, gpu.Q_F8); f.ChangedVertex(ids, X)
+    of = O.Flat(d, O.COSINE, O.Q_F8); of.upsert(ids, X)
+
+    def check(tag):
+        for nearest in (True, False):
+            sel = gpu.SELECT_NEAREST if nearest else gpu.SELECT_REFERENCE
+            before = f.Stats()["mfma_groups"]
+            m = f.VertexSearch(Q, k, sel, gpu.MODE_MFMA)
+            assert f.Stats()["mfma_groups"] == before + 1, tag
+            e = f.VertexSearch(Q, k, sel, gpu.MODE_EXACT)
+            same = np.array_equal(m[0], e[0]) and np.array_equal(bits(m[1]), bits(e[1]))
+            nan = np.isnan(e[1]).any()
+            assert same or nan, (tag, nearest)      # NaN scores (a zero-norm code row under cosine) are outside the parity contract (DESIGN §4)
+            for qi in (0, 1, nq - 1):
+                wi, ws = of.search(Q[qi], k, nearest=nearest, mode=2)
+                if not np.isnan(ws).any():
+                    assert np.array_equal(m[0][qi], wi) and np.array_equal(bits(m[1][qi]), bits(ws)), (tag, nearest, qi)
+    check("fresh")
+    up = ids[50:90]; X2 = (O.fill_normal(8500 + d, (40, d)) * np.float32(3e-7)).astype(np.float32)
+    f.ChangedVertex(up, X2); of.upsert(up, X2)
+    rm = ids[::11]
+    f.RemoveVertex(rm); of.remove(rm)
+    check("after overwrite + remove")
+    cand = np.sort(ids[1::3])
+    mf = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
+    ef = f.FilterableVertexSearch(cand, Q[:20], k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert np.array_equal(mf[0], ef[0]) and np.array_equal(bits(mf[1]), bits(ef[1]))
+    g = gpu.FlatSpace(d, gpu.EUCLIDEAN, gpu.Q_F8); g.ChangedVertex(ids[:2000], X[:2000])
+    a = g.VertexSearch(Q, k, gpu.SELECT_NEAREST, gpu.MODE_MFMA); b = g.VertexSearch(Q, k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
+    assert g.Stats()["mfma_groups"] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
