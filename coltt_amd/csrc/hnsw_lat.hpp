@@ -82,11 +82,16 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
   const int pieces = (int)(g.stride >> 4);          // 16-byte pieces per row (the stride is a multiple of 16)
   const int n8 = g.dim >> 3, n8p = lat_n8p(g.dim);
   float rn = 0.f;
+  const bool r8 = QUANT != Q_F8 && g.rows8 != nullptr;
+  float acc8 = 0.f;
   if (__ballot(fresh)) {
     // ---- fetch: every piece of every fresh row of this wave in flight before the first one is stored
     u32x4v tmp[LAT_MAX_PIECES];
     u32x4v adj = {NBR_NONE, NBR_NONE, NBR_NONE, NBR_NONE};
-    const uint8_t* src = g.rows + (size_t)nb * g.stride;
+    // Round 4: an index that carries the line-transposed row copy (rows8.hpp) hands lane j of the group, with the very same addresses,
+    // chunk j of every line = residue j's consecutive steps: the pieces are evaluated straight out of the registers they landed in —
+    // no staging through LDS, no element-wise read-back (r8 is wave-uniform).
+    const uint8_t* src = (r8 ? g.rows8 : g.rows) + (size_t)nb * g.stride;
 #pragma unroll
     for (int t = 0; t < LAT_MAX_PIECES; t++) {
       const int pc = t * 8 + j;
@@ -95,12 +100,50 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
     if constexpr (ADJ) { if (fresh && (uint32_t)(j * 4) < g.mMax0) adj = *reinterpret_cast<const u32x4v*>(g.adj0 + (size_t)nb * g.mMax0 + j * 4); }
     if constexpr (METRIC == M_COS) { if (fresh) rn = g.norms[nb]; }
     mid();
+    if (r8) {
+      if constexpr (QUANT != Q_F8) {
+        constexpr int S = QUANT == Q_NONE ? 4 : 8;      // steps per 128-byte line
+        const float* qT8 = w.qs + (size_t)j * n8p;
+        if (fresh) {
 #pragma unroll
-    for (int t = 0; t < LAT_MAX_PIECES; t++) {
-      const int pc = t * 8 + j;
-      if (fresh && pc < pieces) *reinterpret_cast<u32x4v*>(srow + (size_t)pc * 16) = tmp[t];
+          for (int t = 0; t < LAT_MAX_PIECES; t++) {
+            if (t * 8 < pieces) {                        // line t exists (wave-uniform)
+              if constexpr (QUANT == Q_NONE) {
+                const f32x4 x = __builtin_bit_cast(f32x4, tmp[t]);
+                const f32x4 q = *reinterpret_cast<const f32x4*>(qT8 + S * t);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  if constexpr (METRIC == M_COS) { const float pp = q[u] * x[u]; acc8 = acc8 + pp; }
+                  else { const float df = q[u] - x[u]; const float pp = df * df; acc8 = acc8 + pp; }
+                }
+              } else {
+                const u32x2e lo = {tmp[t].x, tmp[t].y}, hi = {tmp[t].z, tmp[t].w};
+                const f32x4 x0 = __builtin_convertvector(__builtin_bit_cast(f16x4, lo), f32x4);
+                const f32x4 x1 = __builtin_convertvector(__builtin_bit_cast(f16x4, hi), f32x4);
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qT8 + S * t), q1 = *reinterpret_cast<const f32x4*>(qT8 + S * t + 4);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  if constexpr (METRIC == M_COS) { const float pp = q0[u] * x0[u]; acc8 = acc8 + pp; }
+                  else { const float df = q0[u] - x0[u]; const float pp = df * df; acc8 = acc8 + pp; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                  if constexpr (METRIC == M_COS) { const float pp = q1[u] * x1[u]; acc8 = acc8 + pp; }
+                  else { const float df = q1[u] - x1[u]; const float pp = df * df; acc8 = acc8 + pp; }
+                }
+              }
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < LAT_MAX_PIECES; t++) {
+        const int pc = t * 8 + j;
+        if (fresh && pc < pieces) *reinterpret_cast<u32x4v*>(srow + (size_t)pc * 16) = tmp[t];
+      }
     }
-    COLTT_LT(w, 2)   // fetch issued + landed + staged
+    COLTT_LT(w, 2)   // fetch issued + landed + staged (or, rows8, evaluated)
     if constexpr (ADJ) { if (fresh) *reinterpret_cast<u32x4v*>(&xs->adjn[idx][j * 4]) = adj; }
   } else mid();
   wave_sync();   // the rows of this wave were staged by this wave
@@ -109,9 +152,9 @@ __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx
     // ---- evaluate out of LDS: lane j = residue j of the 8-lane accumulator, groups in increasing order.  Blocks of 16 groups:
     // the 16 row elements and the 16 query elements (4 x ds_read_b128 of the transposed query) are requested together, then
     // the 16 multiply / add pairs run in order.
-    float acc = 0.f;
+    float acc = acc8;
     const float* qT = w.qs + (size_t)j * n8p;
-    if (fresh) {
+    if (fresh && !r8) {
       int gq = 0;
       // The LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run (the adds of a block otherwise wait for
       // its reads: ~1.1 us per chunk of 32 rows at dim 768 against ~0.4 us of dependent VALU).  A/B at 10 M x 768 f32, ef 128

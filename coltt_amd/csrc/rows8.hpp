@@ -129,7 +129,16 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
 #pragma unroll
       for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
-    for (int l = nb * U; l < nl; l++) { Raw r1; COLTT_G8_LD(l, r1) COLTT_G8_CS(r1, l) }   // lines beyond whole bursts (nl % U)
+    // lines beyond whole bursts (nl % U; the whole row when nl < U — 128-d f32 rows are 4 lines): ONE predicated burst, every load
+    // in flight before the first is consumed (a line-by-line loop here made a short row cost nl dependent round trips: 1 M x 128 f32,
+    // one query, 0.111 -> 0.191 ms in the first bench run of this core)
+    const int l0 = nb * U;
+    if (l0 < nl) {
+#pragma unroll
+      for (int u = 0; u < U; u++) if (l0 + u < nl) COLTT_G8_LD(l0 + u, cur[u])
+#pragma unroll
+      for (int u = 0; u < U; u++) if (l0 + u < nl) COLTT_G8_CS(cur[u], l0 + u)
+    }
   }
 #undef COLTT_G8_LD
 #undef COLTT_G8_CS

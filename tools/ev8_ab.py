@@ -20,11 +20,12 @@ def main():
     quant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     dataset = sys.argv[3] if len(sys.argv) > 3 else "normal"
     efs = [int(e) for e in (sys.argv[4] if len(sys.argv) > 4 else "128,256,1024").split(",")]
-    dim, k, nq = 768, 10, 10_000
+    dim = int(os.environ.get("EV8_AB_DIM", "768")); k, nq = 10, 10_000
+    build_ef = int(os.environ.get("EV8_AB_CFG_EF", "128"))
     assert G.lib().coltt_init(0) == 0
     dev = torch.device("cuda", 0)
 
-    class A: m = 16; ef = 128; efc = 200; build_batch = 16384; reserve = not (len(sys.argv) > 5 and sys.argv[5] == "noreserve")
+    class A: m = 16; ef = build_ef; efc = 200; build_batch = 16384; reserve = not (len(sys.argv) > 5 and sys.argv[5] == "noreserve")
     ds = B.Dataset(torch, dev, dim, dataset)
     h, build_s = B.build_index(G, torch, dev, ds, n, dim, A, 0xC0177, quant)
     gen = torch.Generator(device=dev); gen.manual_seed(0x5EED5)
@@ -48,6 +49,17 @@ def main():
             bpq = B.hnsw_bytes_per_query(st["n_dist"] / nq, st["n_exp"] / nq, dim, quant, 16)
             t = float(np.median(ms)) / 1e3
             row[name] = {"ms_per_launch": t * 1e3, "min_ms": float(min(ms)), "queries_per_s": nq / t, "frac_of_hbm_peak": bpq * nq / t / 8e12}
+        for name, env in (("eight_lanes", None), ("lane_pairs", "0")):   # ONE query per call (kernel time, median of 60)
+            if env is None:
+                os.environ.pop("COLTT_EV8", None)
+            else:
+                os.environ["COLTT_EV8"] = env
+            one = []
+            for r in range(70):
+                h.SearchDevice(q.data_ptr() + (r % 64) * dim * 4, 1, k, *out.ptrs(), ef=ef)
+                if r >= 10:
+                    one.append(h.last_kernel_ms())
+            row[name]["one_query_kernel_ms"] = float(np.median(one))
         os.environ.pop("COLTT_EV8", None)
         a, b = keep["eight_lanes"], keep["lane_pairs"]
         row["identical"] = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and a[2] == b[2])
