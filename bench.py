@@ -701,7 +701,8 @@ def leg_pq(G, torch, dev, O, args, dim, k):
            "single_query_scan_launch_ms": scan_s * 1e3, "scan_rows_of_that_launch": int(scan_rows), "batch_64_kernels_ms": float(np.mean(bms)),
            "batch_64_queries_per_s": nq / (float(np.mean(bms)) / 1e3), "train_s": train_s, "encode_and_ingest_s": ingest_s,
            "roofline": {"bound": "hbm", "achieved": scan_rows * m / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": scan_rows * m / scan_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": scan_s * 1e3,
+                        "frac": scan_rows * m / scan_s / 1e9 / HBM_PEAK_GBS, "traffic": pq_pmc_traffic(n, dim, m)[0], "traffic_source": pq_pmc_traffic(n, dim, m)[1],
+                        "avg_launch_ms": scan_s * 1e3,
                         "kernel": "pq_scan_kernel<4,1> (table in LDS, one ds_read_b32 per code byte; tile-interleaved codes, 16 B per lane per load)",
                         "bytes_per_launch": int(scan_rows * m),
                         "lds_note": "one table lookup per code byte: random ds_read_b32 over 32 banks is the second ceiling (~0.7 of the HBM peak)"}}
@@ -1168,6 +1169,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pq_pmc_traffic(n, dim, m):
+    """HBM bytes of the dominant PQ scan launch from the committed PMC pass (tools/pmc_traffic.py --pq), for this very shape only"""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(p)).get(f"pq n={n} dim={dim} m={m}", {})
+        return rec.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
+    except Exception:
+        return None, None
 
 
 def flat_pmc_traffic(n, dim, quant, batch):

@@ -1288,6 +1288,19 @@ int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fal
   return COLTT_OK;
 }
 
+int coltt_flat_norm_bounds(coltt_handle_t h, float* out_min, float* out_max, int32_t* out_cosine_matrix_core_open) {
+  auto f = lookup<Flat>(h);
+  if (!f) return fail(COLTT_E_NOT_FOUND, "flat_norm_bounds: unknown handle");
+  ReadLock g(f->rw);
+  const float mx = f->max_norm(), mn = f->min_norm();
+  if (out_min) *out_min = mn;
+  if (out_max) *out_max = mx;
+  if (out_cosine_matrix_core_open)
+    *out_cosine_matrix_core_open = f->metric == COLTT_COSINE &&
+      (f->quant == COLTT_Q_F8 ? (f->f8x && mx == mx && mx < 3.0e38f) : (mn >= 0.25f && mx <= 4.0f)) ? 1 : 0;
+  return COLTT_OK;
+}
+
 int coltt_flat_one_launch_searches(coltt_handle_t h, uint64_t* out) {
   auto f = lookup<Flat>(h);
   if (!f || !out) return fail(COLTT_E_NOT_FOUND, "flat_one_launch_searches: unknown handle");

@@ -163,8 +163,11 @@ int shm_open_exchange(const uint8_t* unique_id, int world, int n_local, int rank
 }
 
 int shm_allgather(ShmExchange* x, const void* local, uint64_t bytes, void* out) {
-  if (bytes > x->cap) return fail(COLTT_E_INVALID, "shm allgather: %llu bytes per rank > the segment's %llu", (unsigned long long)bytes, (unsigned long long)x->cap);
   ShmHdr* h = x->hdr;
+  if (bytes > x->cap) {   // the peers are (or will be) waiting for this rank: release them
+    h->failed.store(1, std::memory_order_release);
+    return fail(COLTT_E_INVALID, "shm allgather: %llu bytes per rank > the segment's %llu", (unsigned long long)bytes, (unsigned long long)x->cap);
+  }
   const uint64_t g = x->gen, W = (uint64_t)x->world;
   auto give_up = [&](const char* what) { h->failed.store(1, std::memory_order_release); return fail(COLTT_E_DEVICE, "shm allgather (generation %llu): %s", (unsigned long long)g, what); };
   if (!x->wait_for([&] { return h->consumed.load(std::memory_order_acquire) >= g * W; })) return give_up("a peer never finished reading the previous generation");
@@ -511,10 +514,24 @@ int coltt_group_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
 
 // VertexSearch / Hnsw.Search over the whole collection.  d_queries_per_member != NULL: the batch already lives on every
 // member's device ([n_local] pointers, nq x dim f32 each); otherwise `queries` is a host array broadcast to the members.
+static int group_search_impl(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
+                             int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+// A process of a shared-memory group that fails ANYWHERE in its search (a member's search, a copy, an argument the peers did not
+// share) marks the segment failed before it returns: its peers, which are or will be waiting for its contribution, stop at once
+// instead of spinning for COLTT_SHM_TIMEOUT_S.  A failed exchange is final — the group has to be re-created.
 static int group_search(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
                         int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  const int rc = group_search_impl(g, queries, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
+  if (rc != COLTT_OK && g->exchange == COLTT_EXCHANGE_SHM && g->shm && g->shm->hdr) g->shm->hdr->failed.store(1, std::memory_order_release);
+  return rc;
+}
+static int group_search_impl(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
+                             int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
   if (nq == 0) return COLTT_OK;
   if (k == 0) return fail(COLTT_E_INVALID, "group_search: k must be >= 1");
+  if (g->exchange == COLTT_EXCHANGE_SHM && g->shm && (uint64_t)k * sizeof(Rec) > g->shm->cap)
+    return fail(COLTT_E_INVALID, "group_search: k = %u needs %llu bytes per rank and query, the shared segment holds %llu per rank (COLTT_SHM_MB)", k,
+                (unsigned long long)((uint64_t)k * sizeof(Rec)), (unsigned long long)g->shm->cap);
   std::lock_guard<std::mutex> lk(g->call_mu);
   const size_t nm = g->m.size();
   const bool hn = g->kind == COLTT_GROUP_HNSW;

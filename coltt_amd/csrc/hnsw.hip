@@ -565,7 +565,12 @@ int sync_rows8(Hnsw* x) {
 }
 // does this shape have a rows8 copy (rows8.hpp: f32 / 2-byte rows whose byte length is a multiple of 128)?
 bool rows8_shape(uint32_t dim, int quant) {
-  if (quant == COLTT_Q_F8 || !policy().rows8) return false;
+  const int pol = policy().rows8;
+  if (quant == COLTT_Q_F8 || pol == 0) return false;
+  // Short rows stay on the lane pairs: the eight-lane core pays a fixed LDS hand-off per chunk of neighbours, which a 128-element row does
+  // not amortise (1 M x 128 f32, ef 20 — the reference's published point: 1.41 ms per 10 k queries against 1.17, one query 0.130 against
+  // 0.103 ms; 2 M x 256 f16, ef 64: 4.24 against 5.17 ms, +22 % — profiles/r04h_ev8_short_rows.json).  COLTT_ROWS8=2 lifts the limit.
+  if (pol == 1 && dim < 256) return false;
   return ((size_t)dim * quant_bytes(quant)) % 128 == 0;
 }
 

@@ -43,6 +43,22 @@ __device__ float seq_l2sq(const float* a, const float* b, int dim) {
   for (int i = nl; i < dim; i++) { float d = a[i] - b[i]; r += d * d; }
   return r;
 }
+// manhattan_distance (avx.cpp:34-49, sse.cpp:35-53): sqrt(d * d) per lane in the vector part (the rounded square, a correctly rounded
+// sqrt — not |d|), abs(d) in the scalar tail; native_impl.go:33-40: gomath.Abs sequentially
+template <int LANES>
+__device__ float seq_l1(const float* a, const float* b, int dim) {
+  float acc[LANES];
+  for (int j = 0; j < LANES; j++) acc[j] = 0.f;
+  int nl = LANES == 1 ? 0 : (dim / LANES) * LANES;
+  for (int i = 0; i < nl; i += LANES)
+    for (int j = 0; j < LANES; j++) { float d = a[i + j] - b[i + j]; float m = d * d; acc[j] = acc[j] + go_sqrt(m); }
+  float r;
+  if (LANES == 8) r = ((acc[0] + acc[1 % LANES]) + (acc[2 % LANES] + acc[3 % LANES])) + ((acc[4 % LANES] + acc[5 % LANES]) + (acc[6 % LANES] + acc[7 % LANES]));
+  else if (LANES == 4) r = ((acc[0] + acc[1 % LANES]) + acc[2 % LANES]) + acc[3 % LANES];
+  else r = 0.f;
+  for (int i = nl; i < dim; i++) { float d = a[i] - b[i]; r += fabsf(d); }
+  return r;
+}
 template <int LANES>
 __device__ void seq_cos(const float* a, const float* b, int dim, float& dot, float& na, float& nb) {
   float d[LANES], x[LANES], y[LANES];
@@ -68,7 +84,9 @@ __global__ void pairs_seq_kernel(int metric, int order, const float* __restrict_
   if (i >= n) return;
   const float* ai = a + i * dim;
   const float* bi = b + i * dim;
-  if (metric == COLTT_EUCLIDEAN) {
+  if (metric == COLTT_MANHATTAN) {
+    out[i] = order == 0 ? seq_l1<8>(ai, bi, dim) : (order == 1 ? seq_l1<4>(ai, bi, dim) : seq_l1<1>(ai, bi, dim));
+  } else if (metric == COLTT_EUCLIDEAN) {
     float s = order == 1 ? seq_l2sq<4>(ai, bi, dim) : seq_l2sq<1>(ai, bi, dim);
     out[i] = go_sqrt(s);
   } else {
@@ -173,7 +191,7 @@ extern "C" {
 int coltt_distance_pairs(int metric, int order, const float* a, const float* b, size_t n, uint32_t dim, float* out) {
   if (n == 0) return COLTT_OK;
   if (!a || !b || !out || dim == 0) return fail(COLTT_E_INVALID, "distance_pairs: NULL/empty input");
-  if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN) return fail(COLTT_E_INVALID, "distance_pairs: bad metric");
+  if (metric != COLTT_COSINE && metric != COLTT_EUCLIDEAN && metric != COLTT_MANHATTAN) return fail(COLTT_E_INVALID, "distance_pairs: bad metric");
   if (order < 0 || order > 2) return fail(COLTT_E_INVALID, "distance_pairs: order must be 0 (avx), 1 (sse) or 2 (native)");
   COLTT_DEVICE(-1);
   Stage st; float *da, *db, *dout;
@@ -182,7 +200,9 @@ int coltt_distance_pairs(int metric, int order, const float* a, const float* b, 
   COLTT_TRY(st.alloc((void**)&da, bytes + 64)); COLTT_TRY(st.alloc((void**)&db, bytes + 64)); COLTT_TRY(st.alloc((void**)&dout, n * 4));
   COLTT_HIP(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
   COLTT_HIP(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-  if (order == 0 && dim % 4 == 0) {
+  if (metric == COLTT_MANHATTAN) {   // a leaf of distance.SpaceImpl with no caller in the reference: the sequential emulation serves all three orders
+    pairs_seq_kernel<<<ceil_div(n, 64), 64>>>(metric, order, da, db, n, (int)dim, dout);
+  } else if (order == 0 && dim % 4 == 0) {
     if (metric == COLTT_COSINE) pairs_avx_kernel<M_COS><<<ceil_div(n, 32), 64>>>(da, db, n, (int)dim, dout);
     else pairs_avx_kernel<M_L2><<<ceil_div(n, 32), 64>>>(da, db, n, (int)dim, dout);
   } else if (order == 0) {

@@ -130,6 +130,12 @@ class FlatSpace:
         L.check(L.lib().coltt_flat_stats(self.h, C.byref(a), C.byref(b)))
         return {"mfma_groups": a.value, "mfma_fallbacks": b.value}
 
+    def NormBounds(self):
+        """(min, max) of the stored ||row||^2 over everything ever stored, and whether the cosine matrix-core path is open"""
+        a, b_, o = C.c_float(0), C.c_float(0), C.c_int32(0)
+        L.check(L.lib().coltt_flat_norm_bounds(self.h, C.byref(a), C.byref(b_), C.byref(o)))
+        return a.value, b_.value, bool(o.value)
+
     def OneLaunchSearches(self):
         a = C.c_uint64(0)
         L.check(L.lib().coltt_flat_one_launch_searches(self.h, C.byref(a)))

@@ -31,6 +31,9 @@ enum { COLTT_OK = 0, COLTT_E_INVALID = -1, COLTT_E_EXISTS = -2, COLTT_E_NOT_FOUN
 
 /* edgepb.Distance (idl/proto/v4/edge.proto:70-73) */
 enum { COLTT_COSINE = 0, COLTT_EUCLIDEAN = 1 };
+/* distance.SpaceImpl.ManhattanDistance (pkg/distance/space.go:25-29,73-79; simd/cpp/avx.cpp:34-49): exposed by the reference's kernel
+ * interface, used by none of its stores — served by coltt_distance_pairs only */
+enum { COLTT_MANHATTAN = 2 };
 /* edgepb.Quantization (idl/proto/v4/edge.proto:75-80).  NB the reference's "BF16" is IEEE binary16
  * (pkg/compresshelper/bf16.go:233-317 == float16.go:237-321) and its "F8" decodes to 8 distinct
  * values (float8.go:233-313); both are reproduced bit-for-bit. */
@@ -57,7 +60,7 @@ int coltt_policy_reload(void);
 
 /* ---- kernels exposed one-to-one (pkg/distance, pkg/compresshelper, pkg/sharding, pkg/distancepq) --- */
 /* distance.Space.Distance(a,b) for n independent pairs: a,b are row-major [n][dim] host arrays
- * (pkg/distance/space.go:61-63,93-95).  order: 0 avx (default dispatch on AVX hosts), 1 sse, 2 native
+ * (pkg/distance/space.go:61-63,77-79,93-95; metric COLTT_COSINE, COLTT_EUCLIDEAN or COLTT_MANHATTAN).  order: 0 avx (default dispatch on AVX hosts), 1 sse, 2 native
  * (space.go:40-49). */
 int coltt_distance_pairs(int metric, int order, const float* a, const float* b, size_t n, uint32_t dim,
                          float* out);
@@ -106,6 +109,11 @@ int coltt_flat_search_device(coltt_handle_t h, const float* d_queries, size_t nq
 /* how many <= 256-query groups went through the matrix cores since creation, and how many of those overflowed their candidate
  * list and were re-run in exact mode (adversarial data only; the answers are the exact mode's either way) */
 int coltt_flat_stats(coltt_handle_t h, uint64_t* mfma_groups, uint64_t* mfma_fallbacks);
+/* Running bounds of the stored ||row||^2 over EVERYTHING the store ever held (they are not recomputed on removal), and whether the cosine
+ * matrix-core path is open: it is closed for a store that ever held a row with ||row||^2 outside [1/4, 4] (a zero vector, a loaded stream
+ * that was never normalised) — such a store answers COLTT_MODE_MFMA batches through the exact scan: same answers, ~25x the time at batch
+ * 256.  Nothing is logged when the latch closes; this is where a caller sees it.  An empty store reports NaN bounds. */
+int coltt_flat_norm_bounds(coltt_handle_t h, float* out_min, float* out_max, int32_t* out_cosine_matrix_core_open);
 /* searches of <= 4 queries and k <= 64 are served by ONE kernel launch whatever `mode` says (scan in exact order, per-wave and
  * per-block k best, selection by the last block to finish): the reference's one-query-per-RPC shape (edge/edge_search.go).  Same
  * answers as both modes; this counts them (COLTT_FLAT_ONE=0 in the environment turns the path off). */

@@ -115,6 +115,31 @@ static void cos_parts(int order, const float* a, const float* b, size_t len, flo
   }
 }
 
+// manhattan_distance (avx.cpp:34-49 / sse.cpp:35-53): the vector part adds sqrt(d * d) per lane — NOT |d|: the square is rounded to
+// f32 first (it underflows to 0 for |d| < 2^-75 and overflows to +Inf above 2^64) and _mm256_sqrt_ps is correctly rounded — the scalar
+// tail adds abs(d); native_impl.go:33-40 adds gomath.Abs(d) sequentially.  Manhattan.Distance returns the sum itself (space.go:77-79).
+static inline float sqrt_rn(float x) { return (float)std::sqrt((double)x); }   // correctly rounded f32 sqrt (53 >= 2 * 24 + 2)
+static float manhattan(int order, const float* a, const float* b, size_t len) {
+  if (order == ORDER_AVX) {
+    v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0, n8 = (len / 8) * 8;
+    for (; i < n8; i += 8) { v8f d = ld8(a + i) - ld8(b + i); v8f m = d * d; for (int j = 0; j < 8; j++) acc[j] = acc[j] + sqrt_rn(m[j]); }
+    float r = hsum8(acc);
+    for (; i < len; i++) { float d = a[i] - b[i]; r += (d < 0) ? -d : d; }
+    return r;
+  } else if (order == ORDER_SSE) {
+    v4f acc = {0, 0, 0, 0};
+    size_t i = 0, n4 = (len / 4) * 4;
+    for (; i < n4; i += 4) { v4f d = ld4(a + i) - ld4(b + i); v4f m = d * d; for (int j = 0; j < 4; j++) acc[j] = acc[j] + sqrt_rn(m[j]); }
+    float r = hsum4(acc);
+    for (; i < len; i++) { float d = a[i] - b[i]; r += (d < 0) ? -d : d; }
+    return r;
+  }
+  float r = 0;
+  for (size_t i = 0; i < len; i++) r += (float)std::fabs((double)(a[i] - b[i]));   // gomath.Abs
+  return r;
+}
+
 // gomath.Sqrt: float32(math.Sqrt(float64(x)))  (pkg/gomath/math.go:48-50)
 static inline float go_sqrt(float x) { return (float)std::sqrt((double)x); }
 // gomath.Abs: float32(math.Abs(float64(x)))     (pkg/gomath/math.go:35-37)
@@ -1141,6 +1166,7 @@ extern "C" {
 float orc_l2(int order, const float* a, const float* b, size_t d) { return dist_l2(order, a, b, d); }
 float orc_cosine(int order, const float* a, const float* b, size_t d) { return dist_cos(order, a, b, d); }
 float orc_l2sq(int order, const float* a, const float* b, size_t d) { return l2sq(order, a, b, d); }
+float orc_manhattan(int order, const float* a, const float* b, size_t d) { return manhattan(order, a, b, d); }
 void orc_cosine_parts(int order, const float* a, const float* b, size_t d, float* dot, float* na, float* nb) {
   cos_parts(order, a, b, d, dot, na, nb);
 }

@@ -56,6 +56,7 @@ def lib():
         L.orc_l2.restype = C.c_float
         L.orc_cosine.restype = C.c_float
         L.orc_l2sq.restype = C.c_float
+        L.orc_manhattan.restype = C.c_float
         for n in ("orc_pq_dot", "orc_pq_l2sq", "orc_pq_dot_pure", "orc_pq_l2sq_pure", "orc_pq_hamming",
                   "orc_pq_jaccard"):
             getattr(L, n).restype = C.c_float
@@ -99,6 +100,12 @@ def _f32(a):
 def l2(a, b, order=ORDER_AVX):
     a, b = _f32(a), _f32(b)
     return np.float32(lib().orc_l2(order, _p(a), _p(b), C.c_size_t(a.size)))
+
+
+def manhattan(a, b, order=ORDER_AVX):
+    """Manhattan.Distance (pkg/distance/space.go:77-79) in the avx.cpp / sse.cpp / native order"""
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_manhattan(order, _p(a), _p(b), C.c_size_t(a.size)))
 
 
 def cosine(a, b, order=ORDER_AVX):

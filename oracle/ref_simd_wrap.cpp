@@ -30,6 +30,10 @@ void ref_l2sq(int order, size_t len, const float* a, const float* b, float* resu
   if (order == 0) ref_avx::euclidean_distance_squared(len, (float*)a, (float*)b, result);
   else ref_sse::euclidean_distance_squared(len, (float*)a, (float*)b, result);
 }
+void ref_manhattan(int order, size_t len, const float* a, const float* b, float* result) {
+  if (order == 0) ref_avx::manhattan_distance(len, (float*)a, (float*)b, result);
+  else ref_sse::manhattan_distance(len, (float*)a, (float*)b, result);
+}
 void ref_cos_dot_norm(int order, size_t len, const float* a, const float* b, float* dot, float* norm_sq) {
   if (order == 0) ref_avx::cosine_similarity_dot_norm(len, (float*)a, (float*)b, dot, norm_sq);
   else ref_sse::cosine_similarity_dot_norm(len, (float*)a, (float*)b, dot, norm_sq);

@@ -67,3 +67,16 @@ def test_distancepq(gpu):
     assert np.array_equal(bits(gpu.kernels.pq_bit_scan(1, q, rows)), bits(np.array([O.pq_jaccard(q, r) for r in rows], np.float32)))
     z = np.zeros(12, np.uint64)
     assert gpu.kernels.pq_bit_scan(1, z, rows[7:8])[0] == 0.0
+
+
+def test_manhattan_pairs_all_three_orders(gpu):
+    """distance.SpaceImpl.ManhattanDistance (pkg/distance/space.go:25-29, simd/cpp/avx.cpp:34-49, sse.cpp:35-53, native_impl.go:33-40):
+    no store of the reference calls it; the leaf kernel has a device twin, bit-exact in every order incl. magnitudes where sqrt(d * d) != |d|."""
+    K = gpu.kernels
+    for d in (1, 7, 8, 9, 31, 33, 128, 770):
+        a = O.fill_normal(700 + d, (12, d)); b = O.fill_normal(800 + d, (12, d))
+        a[3] *= np.float32(1e-25); b[3] *= np.float32(1e-25); a[5] *= np.float32(1e25)
+        for order in (0, 1, 2):
+            want = np.array([O.manhattan(a[i], b[i], order) for i in range(12)], np.float32)
+            got = K.distance_pairs(2, a, b, order)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (d, order)

@@ -120,10 +120,14 @@ def test_cosine_mfma_is_closed_for_rows_of_odd_norm(gpu):
             wi, ws = of.search(Q[qi], 10, nearest=nearest, mode=2)
             assert_same_results(mi[qi, :mc[qi]], ms[qi, :mc[qi]], wi, ws, f"nearest{nearest} q{qi}")
     assert gf.Stats()["mfma_groups"] == before, "norms outside [1/2, 2]: the matrix-core path must not have been taken"
+    mn, mx, open_ = gf.NormBounds()          # the latch is visible to the caller (coltt_flat_norm_bounds, round 4)
+    assert not open_ and mn < 1e-8 and mx > 1e6
     # a well-formed store next to it still takes the matrix cores
     g2 = gpu.FlatSpace(d, O.COSINE, O.Q_NONE); g2.ChangedVertex(ids, X)
     g2.VertexSearch(Q, 10, gpu.SELECT_NEAREST, gpu.MODE_MFMA)
     assert g2.Stats()["mfma_groups"] > 0
+    mn, mx, open_ = g2.NormBounds()
+    assert open_ and 0.99 < mn <= mx < 1.01
 
 
 @pytest.mark.parametrize("metric,quant,n,d", [(O.COSINE, O.Q_NONE, 40000, 128), (O.COSINE, O.Q_F16, 30000, 768), (O.L2, O.Q_BF16, 20000, 200),

@@ -38,7 +38,9 @@ def _oracle_check(gh, Q, quant, metric, ef, k, del_bits=None):
 @pytest.mark.parametrize("metric", [O.COSINE, O.L2])
 @pytest.mark.parametrize("quant,d", [(O.Q_NONE, 32), (O.Q_NONE, 128), (O.Q_NONE, 768), (O.Q_F16, 64), (O.Q_F16, 256), (O.Q_BF16, 768), (O.Q_F16, 1536)])
 def test_eight_lane_core_equals_the_oracle_and_the_pair_owned_walk(gpu, monkeypatch, metric, quant, d):
-    """1 / 4 / 24 lines of f32 rows, 1 / 4 / 12 / 24 lines of 2-byte rows; ef below and above the LDS / HBM visited threshold"""
+    """1 / 4 / 24 lines of f32 rows, 1 / 4 / 12 / 24 lines of 2-byte rows; ef below and above the LDS / HBM visited threshold.
+    (COLTT_ROWS8=2: by default only dim >= 256 keeps the copy — short rows do not amortise the core's per-chunk hand-off.)"""
+    monkeypatch.setenv("COLTT_ROWS8", "2")
     monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")          # the one-wave throughput kernels (the latency kernel has its own evaluator)
     n = 4000 if d <= 768 else 1500
     X = O.fill_normal(9000 + d, (n, d)); lv = O.levels(9001 + d, n)
@@ -60,7 +62,7 @@ def test_eight_lane_core_equals_the_oracle_and_the_pair_owned_walk(gpu, monkeypa
 
 def test_tombstones_load_and_bulk_load_keep_the_copy_in_step(gpu, monkeypatch):
     monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
-    n, d = 3000, 128
+    n, d = 3000, 256
     X = O.fill_normal(9100, (n, d)); lv = O.levels(9101, n); Q = O.fill_normal(9102, (30, d))
     gh = _build(gpu, X, lv, O.COSINE, O.Q_NONE, gpu.HnswCfg.default(ef_construction=50))
     db = np.zeros((n + 31) // 32, np.uint32)
@@ -96,13 +98,18 @@ def test_tombstones_load_and_bulk_load_keep_the_copy_in_step(gpu, monkeypatch):
 
 def test_shapes_without_a_copy_and_the_create_time_switch(gpu, monkeypatch):
     X = O.fill_normal(9200, (500, 96)); lv = O.levels(9201, 500)
-    for quant, d, want in ((O.Q_F16, 96, False), (O.Q_NONE, 96, True), (O.Q_F8, 128, False), (O.Q_NONE, 100, False)):
+    for quant, d, want in ((O.Q_F16, 96, False), (O.Q_NONE, 128, False), (O.Q_NONE, 256, True), (O.Q_F16, 320, True), (O.Q_F8, 256, False), (O.Q_NONE, 300, False)):
         gh = _build(gpu, np.ascontiguousarray(O.fill_normal(9202 + d, (500, d))), lv, O.COSINE, quant)
         assert gh.Rows8()[1] == want, (quant, d)
         gh.Search(O.fill_normal(9203, (4, d)), 5, ef=32)
         assert (gh.Rows8()[0] > 0) == want
     monkeypatch.setenv("COLTT_ROWS8", "0")
-    gh = _build(gpu, O.fill_normal(9204, (500, 128)), lv, O.COSINE, O.Q_NONE)
+    gh = _build(gpu, O.fill_normal(9204, (500, 256)), lv, O.COSINE, O.Q_NONE)
     monkeypatch.delenv("COLTT_ROWS8")
-    gh.Search(O.fill_normal(9205, (4, 128)), 5, ef=32)
+    gh.Search(O.fill_normal(9205, (4, 256)), 5, ef=32)
     assert gh.Rows8() == (0, False)
+    monkeypatch.setenv("COLTT_ROWS8", "2")            # ... and the limit lifted: a 128-d f32 index (4 lines per row) keeps the copy
+    gh = _build(gpu, O.fill_normal(9206, (500, 128)), lv, O.COSINE, O.Q_NONE)
+    monkeypatch.delenv("COLTT_ROWS8")
+    gh.Search(O.fill_normal(9207, (4, 128)), 5, ef=32)
+    assert gh.Rows8() == (1, True)

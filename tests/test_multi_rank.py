@@ -127,3 +127,43 @@ def test_shm_exchange_refuses_mismatched_geometry_and_times_out(monkeypatch):
     with pytest.raises(G.ColttError):
         one.allgather(np.zeros((1, 100), np.uint32))     # more bytes than the slot holds
     one.close()
+
+
+def _failing_peer(proc, port, out):
+    sys.path.insert(0, ROOT)
+    import time
+    from coltt_amd import group as GG
+    import coltt_amd as G
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=proc, world_size=2)
+    uid = torch.zeros(GG.UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if proc == 0:
+        uid = torch.frombuffer(bytearray(GG.unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(uid, 0)
+    ex = GG.ShmExchange(bytes(uid.numpy().tobytes()), 2, 1, proc, 256)      # default timeout: 120 s
+    good = np.arange(16, dtype=np.uint32).reshape(1, 16)
+    assert np.array_equal(ex.allgather(good)[proc], good[0])                # generation 0 works
+    dist.barrier()
+    t0 = time.time(); err = ""
+    try:
+        if proc == 0:
+            ex.allgather(np.zeros((1, 200), np.uint32))                     # 800 bytes into a 256-byte slot: refused, and the segment is marked failed
+        else:
+            ex.allgather(good)                                              # the peer is waiting for rank 0's contribution
+    except G.ColttError as e:
+        err = str(e)
+    with open(f"{out}.{proc}.txt", "w") as f:
+        f.write(f"{time.time() - t0:.3f}\n{err}\n")
+    ex.close()
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_a_failing_rank_releases_its_peers_at_once(tmp_path):
+    """a process that fails inside the exchange (here: a contribution larger than its slot) marks the shared segment failed, so
+    the peer that is waiting for it returns an error immediately instead of spinning for COLTT_SHM_TIMEOUT_S (120 s by default)."""
+    out = str(tmp_path / "fail")
+    mp.spawn(_failing_peer, args=(_free_port(), out), nprocs=2, join=True)
+    for p in (0, 1):
+        secs, err = open(f"{out}.{p}.txt").read().split("\n")[:2]
+        assert err, p
+        assert float(secs) < 20.0, (p, secs)

@@ -34,6 +34,30 @@ def test_distance_orders_equal_reference_sources():
             assert np.float32(ns.value).view(np.uint32) == np.float32(p[1] * p[2]).view(np.uint32)
 
 
+def test_manhattan_equals_reference_sources_and_native_order():
+    """Manhattan.Distance (pkg/distance/space.go:77-79): the oracle against the reference's own avx.cpp / sse.cpp (vector part: sqrt of the
+    rounded square, NOT |d|; scalar tail: abs) incl. magnitudes where the two differ, and the native order against a numpy loop."""
+    r = O.ref()
+    rng = np.random.default_rng(11)
+    for t in range(600):
+        d = int(rng.integers(1, 300))
+        a = rng.standard_normal(d).astype(np.float32); b = rng.standard_normal(d).astype(np.float32)
+        if t % 3 == 1: a *= np.float32(1e-25); b *= np.float32(1e-25)       # d * d underflows: sqrt(d * d) != |d|
+        if t % 3 == 2: a *= np.float32(1e25)                                 # d * d overflows to +Inf in the vector part
+        nat = np.float32(0)
+        with np.errstate(over="ignore"):
+            for i in range(d):
+                nat = np.float32(nat + np.float32(abs(np.float32(a[i] - b[i]))))
+        assert bits(O.manhattan(a, b, O.ORDER_NATIVE)) == bits(nat)
+        if r is not None:
+            for order in (O.ORDER_AVX, O.ORDER_SSE):
+                res = C.c_float()
+                r.ref_manhattan(order, C.c_size_t(d), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(res))
+                assert np.float32(res.value).view(np.uint32) == O.manhattan(a, b, order).view(np.uint32), (t, d, order)
+    x = np.array([3e-30] * 8 + [3e-30], np.float32); z = np.zeros(9, np.float32)
+    assert O.manhattan(x, z, O.ORDER_AVX) == np.float32(3e-30) and O.manhattan(x, z, O.ORDER_NATIVE) > np.float32(2.6e-29)   # the vector lanes lost their 8 terms
+
+
 def test_codecs_against_ieee_binary16():
     codes = np.arange(65536, dtype=np.uint16)
     dec = O.f16_decode(codes); ref = codes.view(np.float16).astype(np.float32)

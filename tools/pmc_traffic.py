@@ -42,6 +42,8 @@ def read_counter(path, counter="FETCH_SIZE"):
         elif "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
             q = name.split("hnsw_search_kernel<")[1].split(",")[1].strip() if "hnsw_search_kernel<" in name else "0"   # <METRIC, QUANT, VISG>
             short = ("hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds") + ("" if q == "0" else f"/q{q}")
+        elif "pq_scan_kernel" in name:   # pq.hip: the ADC scan (every query-group / piece-width instance)
+            short = "pq_scan_kernel"
         elif "flat_scan_kernel" in name:   # flat_scan_kernel<METRIC, QUANT, ...>: the calibration launches of each row format apart
             q = name.split("flat_scan_kernel<")[1].split(",")[1].strip() if "flat_scan_kernel<" in name else "0"
             short = "flat_scan_kernel" if q == "0" else f"flat_scan_kernel/q{q}"
@@ -112,9 +114,44 @@ def main_flat(a):
     json.dump(table, open(a.out, "w"), indent=1)
 
 
+def main_pq(a):
+    """`--pq n,dim,m`: HBM bytes of the DOMINANT pq_scan_kernel launch of a single-query search (the launch over the last, largest
+    segment: rows [262144, n) at n = 10 M) in a pass over `bench.py --legs pq` / tools/pq_probe.py.  Those launches are the largest
+    cluster of dispatches whose counter values agree within 3 % among the values above half the maximum of the one-pass launches
+    (the 64-query call streams the codes 64 times in one dispatch and is excluded by its size)."""
+    n, dim, m = (int(v) for v in a.pq.split(","))
+    c = read_counter(a.csv).get("pq_scan_kernel", [])
+    if not c:
+        sys.exit("no pq_scan_kernel dispatches with FETCH_SIZE in " + a.csv)
+    one_pass_cap = 1.5 * n * m / 1024.0 / 2.0           # KiB a one-pass launch can report at most (the counter halves 16 B/lane streams)
+    vals = [v for _, v in c if v <= one_pass_cap]
+    vals = [v for v in vals if v >= 0.5 * max(vals)]
+    best = []
+    for v0 in vals:
+        grp = [v for v in vals if abs(v - v0) <= 0.03 * v0]
+        if len(grp) > len(best):
+            best = grp
+    mean_kib = sum(best) / len(best)
+    s0 = 4096
+    while s0 * 64 < n:
+        s0 *= 64
+    rows = n - s0                                          # pq.hip: segments 4 Ki, x64, ... — the last one starts at the largest 4096 * 64^i below n
+    algorithmic = rows * m
+    traffic = mean_kib * 1024.0 * 2.0
+    table = json.load(open(a.out)) if os.path.exists(a.out) else {}
+    key = f"pq n={n} dim={dim} m={m}"
+    table[key] = {"hbm_bytes_per_launch": traffic, f"FETCH_SIZE_KiB_mean_of_{len(best)}_launches": mean_kib,
+                  "correction": "x2: gfx950 FETCH_SIZE under-counts 16 B/lane streams (factor 1.997 calibrated on flat_scan_kernel in the hnsw passes; the code pieces are 16 B/lane loads)",
+                  "algorithmic_bytes_per_launch": algorithmic, "rows_of_the_launch": rows, "traffic_over_algorithmic": traffic / algorithmic,
+                  "source": os.path.basename(a.csv), "dispatches_used": len(best)}
+    print(key, "->", json.dumps(table[key], indent=1))
+    json.dump(table, open(a.out, "w"), indent=1)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("csv")
+    ap.add_argument("--pq", help="PQ mode: n,dim,m of the product-quantised store whose single-query scans were profiled")
     ap.add_argument("--bench-json", help="file holding the JSON line bench.py printed in the same run (hnsw mode)")
     ap.add_argument("--leg", default="headline", choices=["headline", "op"], help="which HNSW leg of the bench line (hnsw mode)")
     ap.add_argument("--flat", nargs="*", help="FLAT mode: the n,dim,quant,batch cases of the tools/flat_ab.py run that was profiled")
@@ -122,6 +159,8 @@ def main(argv=None):
     a = ap.parse_args(argv)
     if a.flat:
         return main_flat(a)
+    if a.pq:
+        return main_pq(a)
     if not a.bench_json:
         ap.error("--bench-json or --flat is required")
     b = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
