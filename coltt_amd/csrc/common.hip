@@ -139,9 +139,9 @@ int coltt_policy_reload(void) {
 }
 const char* coltt_version(void) {
 #ifdef COLTT_EXPERIMENTS
-  return "coltt_gpu 0.3 (gfx950) +experiments";   // superseded kernel generations compiled in (tools/experiments/)
+  return "coltt_gpu 0.4 (gfx950) +experiments";   // superseded kernel generations compiled in (tools/experiments/)
 #else
-  return "coltt_gpu 0.3 (gfx950)";
+  return "coltt_gpu 0.4 (gfx950)";
 #endif
 }
 
