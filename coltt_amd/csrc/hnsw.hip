@@ -830,6 +830,7 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
   const bool seq = policy().lat_seq;
+  if (x->rows8_on && x->n8done == x->n && QUANT != Q_F8) x->ev8_launches.fetch_add(1);   // hnsw_lat.hpp evaluates rows8 pieces out of their registers
   kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                          k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq ? 1 : 0);
   COLTT_HIP(hipGetLastError());

@@ -254,4 +254,53 @@ class Group {
   coltt_handle_t h_ = 0; uint32_t dim_; int kind_;
 };
 
+
+// Product quantiser (coltt_pq_*).  Parameters = models.ProductQuantizerParameters (pkg/models/hnsw_common.go:20-33);
+// method names follow the call shape of playground/hnswpq_verification.go:90-105,154,190-199 (the package it drives, pkg/hnswpq, is not in
+// the reference's tree).  distance = COLTT_PQ_COSINE / _EUCLIDEAN / _DOT: which pkg/distancepq function fills the query's table.
+struct ProductQuantizerParameters { int NumCentroids = 256; int NumSubVectors = 8; int TriggerThreshold = 10000; };
+class ProductQuantizer {
+ public:
+  ProductQuantizer(uint32_t dim, int distance, const ProductQuantizerParameters& p) : dim_(dim), params_(p) {
+    check(coltt_pq_create(dim, distance, (uint32_t)p.NumSubVectors, (uint32_t)p.NumCentroids, &h_));
+  }
+  ~ProductQuantizer() { if (h_) coltt_pq_destroy(h_); }
+  ProductQuantizer(const ProductQuantizer&) = delete;
+  ProductQuantizer& operator=(const ProductQuantizer&) = delete;
+  // training on a sample of n = sample.size() / dim vectors (n >= NumCentroids), deterministic Lloyd iterations
+  void Fit(const std::vector<float>& sample, unsigned iterations = 8) {
+    if (sample.size() % dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    check(coltt_pq_train(h_, sample.data(), sample.size() / dim_, iterations));
+  }
+  void SetCodebooks(const std::vector<float>& cb) {
+    if (cb.size() != (size_t)params_.NumCentroids * dim_) throw Error(COLTT_E_INVALID, "codebooks: [NumSubVectors][NumCentroids][dim / NumSubVectors] floats expected");
+    check(coltt_pq_set_codebooks(h_, cb.data()));
+  }
+  std::vector<float> Codebooks() const { std::vector<float> cb((size_t)params_.NumCentroids * dim_); check(coltt_pq_get_codebooks(h_, cb.data())); return cb; }
+  std::vector<uint8_t> Encode(const Vector& v) const {
+    if (v.size() != dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    std::vector<uint8_t> c((size_t)params_.NumSubVectors); check(coltt_pq_encode(h_, v.data(), 1, c.data())); return c;
+  }
+  void Insert(uint64_t id, const Vector& v) {
+    if (v.size() != dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    check(coltt_pq_upsert(h_, &id, v.data(), 1));
+  }
+  void InsertMany(const std::vector<uint64_t>& ids, const float* rows) { check(coltt_pq_upsert(h_, ids.data(), rows, ids.size())); }
+  void Remove(const std::vector<uint64_t>& ids) { check(coltt_pq_remove(h_, ids.data(), ids.size())); }
+  uint64_t Len() const { uint64_t n = 0; check(coltt_pq_len(h_, &n)); return n; }
+  // the k nearest by the asymmetric distance, ascending by (score, id)
+  SearchResult Search(const Vector& query, unsigned k) const {
+    if (query.size() != dim_) throw Error(COLTT_E_INVALID, "Dim Length UnmatchdError");
+    std::vector<uint64_t> ids(k); std::vector<float> sc(k); uint32_t n = 0;
+    check(coltt_pq_search(h_, query.data(), 1, k, ids.data(), sc.data(), &n));
+    SearchResult r(n);
+    for (uint32_t i = 0; i < n; i++) r[i] = {ids[i], sc[i]};
+    return r;
+  }
+  coltt_handle_t handle() const { return h_; }
+
+ private:
+  coltt_handle_t h_ = 0; uint32_t dim_; ProductQuantizerParameters params_;
+};
+
 }  // namespace coltt

@@ -141,6 +141,39 @@ int main() {
     grp.Remove({55});
     EXPECT(grp.Len() == (uint64_t)n - 1 && grp.Search(X[5], 1)[0].Id != 55);
   }
+  // ---- the product quantiser (coltt_pq_*): parameters of models.ProductQuantizerParameters, call shape of playground/hnswpq_verification.go
+  {
+    coltt::ProductQuantizerParameters pp; pp.NumSubVectors = 8; pp.NumCentroids = 16;
+    coltt::ProductQuantizer pq(d, COLTT_PQ_EUCLIDEAN, pp);
+    try { pq.Search(X[0], 3); EXPECT(false); } catch (const coltt::Error& e) { EXPECT(e.code == COLTT_E_INVALID); }   // no codebooks yet
+    std::vector<float> sample;
+    for (int i = 0; i < 200; i++) sample.insert(sample.end(), X[i].begin(), X[i].end());
+    pq.Fit(sample, 0);                                       // iteration 0 of the definition: centroid c of sub-space j = sub-vector j of sample vector c
+    auto cb = pq.Codebooks();
+    const int ds = d / 8;
+    bool seeds = true;
+    for (int j = 0; j < 8; j++) for (int c = 0; c < 16; c++) for (int e = 0; e < ds; e++) seeds = seeds && cb[((size_t)j * 16 + c) * ds + e] == X[c][j * ds + e];
+    EXPECT(seeds);
+    pq.Fit(sample, 3);
+    auto c0 = pq.Encode(X[0]);
+    EXPECT(c0.size() == 8 && c0 == pq.Encode(X[0]));
+    for (auto code : c0) EXPECT(code < 16);
+    for (int i = 0; i < n; i++) pq.Insert(7000 + i, X[i]);
+    EXPECT(pq.Len() == (uint64_t)n);
+    try { pq.SetCodebooks(cb); EXPECT(false); } catch (const coltt::Error& e) { EXPECT(e.code == COLTT_E_INVALID); }   // the stored codes belong to the codebooks
+    try { pq.Insert(1, std::vector<float>(d + 1)); EXPECT(false); } catch (const coltt::Error&) {}
+    auto all = pq.Search(X[3], (unsigned)n);
+    EXPECT(all.size() == (size_t)n);
+    std::vector<char> seen(n, 0);
+    for (size_t i = 0; i < all.size(); i++) {
+      EXPECT(all[i].Id >= 7000 && all[i].Id < 7000 + (uint64_t)n && !seen[all[i].Id - 7000]); seen[all[i].Id - 7000] = 1;
+      if (i) EXPECT(all[i - 1].Score < all[i].Score || (all[i - 1].Score == all[i].Score && all[i - 1].Id < all[i].Id));   // ascending by (score, id)
+    }
+    auto top = pq.Search(X[3], 5);
+    for (size_t i = 0; i < top.size(); i++) EXPECT(top[i].Id == all[i].Id && std::memcmp(&top[i].Score, &all[i].Score, 4) == 0);
+    pq.Remove({top[0].Id});
+    EXPECT(pq.Len() == (uint64_t)n - 1 && pq.Search(X[3], 1)[0].Id == all[1].Id);
+  }
   std::printf(fails ? "FAILED %d checks\n" : "mirror ok\n", fails);
   return fails ? 1 : 0;
 }

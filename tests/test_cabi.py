@@ -163,24 +163,29 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
 
 
 def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path):
-    """Round 3: the committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op` -> the HBM traffic bench.py reports for
-    the headline kernel (`hnsw_search2_kernel<.., VIS_LDS>`: 5 template arguments, the last one 1) and for the recall-0.98 kernel
-    (HBM visited map).  Re-derived here from the raw CSV and compared with profiles/pmc_traffic.json."""
+    """The committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op,pq` (round 4: profiles/r04i_*; round 3's pass stays in
+    profiles/ as history) -> the HBM traffic bench.py reports for the headline kernel (`hnsw_search2_kernel<.., VIS_LDS, .., EV8>`: the
+    eight-lane core over the line-transposed rows), for the recall-0.98 kernel (HBM visited map) and for the dominant launch of the
+    product-quantiser scan.  Re-derived here from the raw CSV and compared with profiles/pmc_traffic.json."""
     import json
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import pmc_traffic as T
-    src = os.path.join(root, "profiles", "r03_pmc_fetch_size_raw.csv")
-    bj = os.path.join(root, "profiles", "r03_bench_10m_under_pmc.json")
+    src = os.path.join(root, "profiles", "r04i_pmc_fetch_size_raw.csv")
+    bj = os.path.join(root, "profiles", "r04i_bench_10m_under_pmc.json")
     out = tmp_path / "t.json"
     T.main([src, "--bench-json", bj, "--out", str(out)])
     T.main([src, "--bench-json", bj, "--leg", "op", "--out", str(out)])
+    T.main([src, "--pq", "10000000,768,96", "--out", str(out)])
     t = json.load(open(out))
     committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     head = "hnsw n=10000000 dim=768 quant=0 ef=128 m=16 queries=10000 dataset=normal"
     op = "hnsw n=10000000 dim=768 quant=1 ef=1024 m=16 queries=10000 dataset=lowrank:32:1.0"
-    assert set(t) == {head, op}
+    pq = "pq n=10000000 dim=768 m=96"
+    assert set(t) == {head, op, pq}
+    assert 0.98 <= t[pq]["traffic_over_algorithmic"] <= 1.03 and t[pq]["dispatches_used"] >= 20 and t[pq]["rows_of_the_launch"] == 10_000_000 - 262_144
+    assert abs(committed[pq]["hbm_bytes_per_launch"] - t[pq]["hbm_bytes_per_launch"]) < 1.0
     for key, lo, hi in ((head, 0.97, 1.03), (op, 1.0, 1.05)):
         r = t[key]
         assert lo <= r["traffic_over_algorithmic"] <= hi, (key, r)

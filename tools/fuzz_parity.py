@@ -206,6 +206,66 @@ def fuzz_group(G, O, rng, log):
     grp.close()
 
 
+def fuzz_pq(G, O, rng, log):
+    """product-quantised store (pq.hip): random shape, trained or installed codebooks, vectors / ready codes in, overwrites, removals,
+    searches at random nq / k — codes, ids and score bits against the oracle's definition of the scan"""
+    m = int(rng.choice([2, 4, 6, 8, 12, 16, 32, 48]))
+    dsub = int(rng.choice([1, 2, 4, 5, 8, 16, 32, 40]))
+    c = int(rng.choice([2, 5, 16, 17, 100, 256]))
+    d = m * dsub
+    metric = int(rng.integers(0, 3))
+    pq = G.PQSpace(d, metric, m, c)
+    T = O.fill_normal(int(rng.integers(1, 1 << 30)), (max(c, 64) + int(rng.integers(0, 200)), d))
+    iters = int(rng.integers(0, 4))
+    log(f"pq d={d} m={m} c={c} dsub={dsub} metric={metric} iters={iters}")
+    if rng.random() < 0.5:
+        pq.Fit(T, iters); cb = O.pq_train(T, m, c, iters)
+        assert np.array_equal(pq.Codebooks().view(np.uint32), cb.view(np.uint32)), "trained codebooks"
+    else:
+        cb = O.pq_train(T, m, c, iters)
+        if rng.random() < 0.3: cb[:, 1] = cb[:, 0]          # duplicate centroids: Encode ties
+        pq.SetCodebooks(cb)
+    model = {}
+    nxt = 1
+    for step in range(int(rng.integers(3, 9))):
+        op = rng.choice(["add", "add", "codes", "overwrite", "remove", "search", "search"])
+        if op in ("add", "codes") or not model:
+            n = int(rng.choice([1, 63, 65, 700, 5000, 70000]))
+            ids = (np.arange(nxt, nxt + n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 44); nxt += n
+            if op == "codes":
+                codes = rng.integers(0, c, (n, m), dtype=np.uint8)
+                if n > 5 and rng.random() < 0.3: codes[1:5] = codes[0]
+                pq.InsertCodes(ids, codes)
+            else:
+                X = O.fill_normal(int(rng.integers(1, 1 << 30)), (n, d))
+                if n > 5 and rng.random() < 0.3: X[1:5] = X[0]
+                pq.Insert(ids, X); codes = O.pq_encode(cb, X)
+            for i, r in zip(ids, codes): model[int(i)] = r
+        elif op == "overwrite":
+            ks = np.array(list(model)[:: max(1, len(model) // 40)], dtype=np.uint64)
+            X = O.fill_normal(int(rng.integers(1, 1 << 30)), (len(ks), d))
+            pq.Insert(ks, X)
+            for i, r in zip(ks, O.pq_encode(cb, X)): model[int(i)] = r
+        elif op == "remove":
+            ks = np.array(list(model)[int(rng.integers(0, 5)):: max(2, len(model) // 30)], dtype=np.uint64)
+            if len(ks) == len(model): ks = ks[:-1]
+            if len(ks):
+                pq.Remove(ks)
+                for i in ks: model.pop(int(i))
+        else:
+            fc, fi = pq.FetchCodes()
+            assert len(fi) == len(model) and all(np.array_equal(r, model[int(i)]) for r, i in zip(fc[:: max(1, len(fi) // 200)], fi[:: max(1, len(fi) // 200)])), ("codes", step)
+            nq = int(rng.choice([1, 2, 5, 33])); k = int(rng.choice([1, 10, 64, 200]))
+            Q = O.fill_normal(int(rng.integers(1, 1 << 30)), (nq, d))
+            gi, gs, gc = pq.Search(Q, k)
+            wi, ws, wc, _ = O.pq_search(metric, cb, fc, Q, k, ids=fi, threads=4)
+            for qi in range(nq):
+                n_ = int(wc[qi])
+                assert gc[qi] == n_ and same(gi[qi, :n_], gs[qi, :n_], wi[qi, :n_], ws[qi, :n_]), ("pq search", step, qi, nq, k)
+        assert pq.Len() == len(model), ("pq size", step)
+    pq.close()
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xffffff
@@ -218,7 +278,7 @@ def main():
         rng = np.random.default_rng(rs)
         msgs = []
         try:
-            (fuzz_flat, fuzz_hnsw, fuzz_group, fuzz_hnsw_build)[rounds % 4](G, O, rng, msgs.append)
+            (fuzz_flat, fuzz_hnsw, fuzz_group, fuzz_hnsw_build, fuzz_pq)[rounds % 5](G, O, rng, msgs.append)
         except Exception as e:
             print(f"FUZZ FAILURE seed={rs} {' | '.join(msgs)}: {type(e).__name__}: {e}", flush=True)
             raise
