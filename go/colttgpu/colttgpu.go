@@ -127,6 +127,12 @@ func HnswInsert(h Handle, dim uint32, id uint64, v []float32, level int) error {
 	}
 	return call(func() C.int { return C.coltt_hnsw_insert(h, C.uint64_t(id), fptr(v), C.int32_t(level)) })
 }
+// HnswReserve sizes every device array of the index for nSlots vertices in one allocation (coltt_hnsw_reserve): optional, but a
+// collection whose size is known (a Load, a bulk import) should call it before the inserts — growth re-copies the arrays.
+func HnswReserve(h Handle, nSlots uint64) error {
+	return call(func() C.int { return C.coltt_hnsw_reserve(h, C.uint64_t(nSlots), 0) })
+}
+
 func HnswRemove(h Handle, id uint64) error {
 	return call(func() C.int { return C.coltt_hnsw_remove(h, C.uint64_t(id)) })
 }
