@@ -133,7 +133,8 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     w.bloom = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
     w.bloom_words = bloom_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(bloom_words | 0x80000000u);
     w.hcap = 0; w.hcap_mask = 0;
-    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
+    // vis_epoch == nullptr: the region is the BIT map (one wipe per traversal, no epochs)
+    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.vis_bits = vis_epoch ? 0u : 1u; w.epoch = vis_epoch ? vis_epoch[blockIdx.x] : 0u;
   }
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
 #endif
     }
   }
-  if constexpr (VISMODE == VIS_HBM) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
+  if constexpr (VISMODE == VIS_HBM) { if (lane == 0 && vis_epoch) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 
@@ -485,6 +486,7 @@ struct Hnsw : Object {
   // HBM visited set (hnsw_dev.hpp, VISG): vis_regions regions of vis_stride bytes; concurrent searches lease disjoint
   // contiguous runs of regions (vis_busy), the builder (exclusive lock) uses all of them.
   DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;
+  DevBuf w_visb; uint64_t visb_stride = 0;   // bit-per-slot twin of w_visg (policy visbits): same region indices, 1/8 of the stride
   std::mutex vis_mu; std::condition_variable vis_cv; std::vector<uint8_t> vis_busy;
   coltt_hnsw_stats build_stats{};
   ~Hnsw() override {
@@ -602,7 +604,14 @@ int ensure_visg(Hnsw* x) {
   // search that wants the byte map passes through here first, so a re-allocation can never race a traversal that uses it.
   std::lock_guard<std::mutex> vg(x->vis_mu);
   const uint64_t stride = (std::max<uint64_t>(x->cap, 1) + 1023) & ~1023ull;
-  if (x->vis_stride == stride) return COLTT_OK;
+  if (x->vis_stride == stride) {
+    if (policy().visbits && !x->visb_stride && x->vis_regions) {   // the knob came on after the workspace was sized
+      const uint64_t bs = (stride / 8 + 1023) & ~1023ull;
+      COLTT_TRY(x->w_visb.reserve((uint64_t)x->vis_regions * bs));
+      x->visb_stride = bs;
+    }
+    return COLTT_OK;
+  }
   if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
   size_t free_b = 0, total_b = 0;
   COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -624,6 +633,13 @@ int ensure_visg(Hnsw* x) {
   COLTT_TRY(x->w_vepoch.reserve(VIS_MAX_REGIONS * 4));
   COLTT_HIP(hipMemsetAsync(x->w_visg.p, 0, regions * stride, x->stream));
   COLTT_HIP(hipMemsetAsync(x->w_vepoch.p, 0, VIS_MAX_REGIONS * 4, x->stream));
+  x->visb_stride = 0;
+  if (x->w_visb.p) { (void)hipFree(x->w_visb.p); x->w_visb.p = nullptr; x->w_visb.cap = 0; }
+  if (policy().visbits) {   // contents do not matter: a traversal wipes its region before use
+    const uint64_t bs = (stride / 8 + 1023) & ~1023ull;
+    COLTT_TRY(x->w_visb.reserve(regions * bs));
+    x->visb_stride = bs;
+  }
   COLTT_HIP(hipStreamSynchronize(x->stream));  // searches run on other streams
   x->vis_regions = (uint32_t)regions;
   x->vis_busy.assign(regions, 0);
@@ -800,10 +816,11 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
   if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
   if (sg.ev8) x->ev8_launches.fetch_add(1);
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  const bool bits = !sg.w2_lds && x->visb_stride != 0 && policy().visbits;
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                         k, sg.ef, sg.ef_pad, sg.w2_lds ? sg.hcap : sg.bloom_words, counter, oi, os, oc, stats,
-                                        x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
-                                        x->w_vepoch.as<uint32_t>() + region_base);
+                                        bits ? x->w_visb.as<uint8_t>() + (size_t)region_base * x->visb_stride : x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
+                                        bits ? (size_t)x->visb_stride : (size_t)x->vis_stride, bits ? nullptr : x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -1363,6 +1380,13 @@ __global__ void be_rows_kernel(const uint8_t* __restrict__ chunk, const uint64_t
   uint32_t u = ((uint32_t)s[0] << 24) | ((uint32_t)s[1] << 16) | ((uint32_t)s[2] << 8) | s[3];
   out[t] = __uint_as_float(u);
 }
+// stored 2-byte codes -> the f32 values they stand for (exact), for the f32 vertex section of Commit
+__global__ void decode_rows16_kernel(const uint8_t* __restrict__ rows, size_t stride, uint64_t first, uint64_t m, int dim, float* __restrict__ out) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * (uint64_t)dim) return;
+  uint64_t i = t / dim; int e = (int)(t - i * dim);
+  out[t] = dev::f16bits_to_f32(*reinterpret_cast<const unsigned short*>(rows + (first + i) * stride + (size_t)e * 2));
+}
 }  // namespace
 
 int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t len, uint64_t* out_n, uint64_t* out_ids,
@@ -1475,7 +1499,11 @@ int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_b
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_commit: unknown handle");
   if (!out_len) return fail(COLTT_E_INVALID, "hnsw_commit: out_len is NULL");
-  if (x->quant != COLTT_Q_NONE) return fail(COLTT_E_UNSUPPORTED, "hnsw_commit: the reference stream stores f32 vectors; quantised indexes are not committable");
+  // The reference stream stores f32 vectors (hnsw_commit.go:100-112).  A binary16 ("f16" / "bf16") index writes the values its codes stand
+  // for — exact — and Load into an index of the same quantisation encodes them back to the same codes (encode(decode(c)) == c for every
+  // non-NaN binary16 code; tests/test_oracle.py checks all 65 536), so the round trip is bit-identical and the stream stays readable by
+  // the reference.  The "f8" codec is not idempotent (decode -> encode -> decode changes 128 of its 256 codes): no stream can carry it.
+  if (x->quant == COLTT_Q_F8) return fail(COLTT_E_UNSUPPORTED, "hnsw_commit: the reference stream stores f32 vectors and the f8 codec does not round-trip through them; f8 indexes are not committable");
   ReadLock g(x->rw);
   COLTT_DEVICE(x->device);
   BEW w{out, out ? cap : 0};
@@ -1498,8 +1526,16 @@ int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_b
   const uint64_t blk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)x->dim * 4));
   std::vector<float> all;  // sized only when actually writing
   if (out) { all.resize(n * (size_t)x->dim);
+    DevBuf d_dec;
     for (uint64_t b = 0; b < n; b += blk) { uint64_t m = std::min<uint64_t>(blk, n - b);
-      COLTT_HIP(hipMemcpy2D(all.data() + b * x->dim, (size_t)x->dim * 4, x->rows.as<uint8_t>() + b * x->stride, x->stride, (size_t)x->dim * 4, m, hipMemcpyDeviceToHost)); } }
+      if (x->quant == COLTT_Q_NONE)
+        COLTT_HIP(hipMemcpy2D(all.data() + b * x->dim, (size_t)x->dim * 4, x->rows.as<uint8_t>() + b * x->stride, x->stride, (size_t)x->dim * 4, m, hipMemcpyDeviceToHost));
+      else {
+        COLTT_TRY(d_dec.reserve(m * x->dim * 4));
+        decode_rows16_kernel<<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, d_dec.as<float>());
+        COLTT_HIP(hipGetLastError());
+        COLTT_HIP(hipMemcpy(all.data() + b * x->dim, d_dec.p, m * x->dim * 4, hipMemcpyDeviceToHost));
+      } } }
   for (auto& sh : shards) {
     w.u32((uint32_t)sh.size());
     for (uint32_t s : sh) {

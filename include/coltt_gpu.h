@@ -229,7 +229,10 @@ int coltt_hnsw_export(coltt_handle_t h, uint64_t* n_slots, uint64_t* n_rows, uin
  * vertices and edges to them are skipped.  meta_blobs[slot]/meta_lens[slot] = the vertex's Metadata already in stream
  * encoding (metadata.go:31-74: u16 pairs, {u8 keylen, key, u16 vallen, msgpack}); NULL => empty maps.  n_meta = the length
  * of both arrays: slots >= n_meta (vertices inserted after the caller sized them) get empty metadata, never an out-of-bounds read.
- * out == NULL => only *out_len is computed. */
+ * out == NULL => only *out_len is computed.
+ * Quantised indexes: a binary16 ("f16" / "bf16") index writes the f32 values its codes stand for; coltt_hnsw_load into an index of the
+ * same quantisation encodes them back to the same codes (binary16 encode(decode(c)) == c), so Commit -> Load is bit-identical and the
+ * stream stays in the reference's format.  "f8" indexes return COLTT_E_UNSUPPORTED (that codec does not survive decode -> encode). */
 int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_blobs, const uint32_t* meta_lens, uint64_t n_meta,
                       uint8_t* out, uint64_t cap, uint64_t* out_len);
 /* level of the entrypoint (what Hnsw.BytesSize needs, hnsw.go:476-490), -1 for an empty index: no device traffic */

@@ -147,3 +147,41 @@ def test_f8_rows_go_through_the_matrix_cores(gpu, d):
     g = gpu.FlatSpace(d, gpu.EUCLIDEAN, gpu.Q_F8); g.ChangedVertex(ids[:2000], X[:2000])
     a = g.VertexSearch(Q, k, gpu.SELECT_NEAREST, gpu.MODE_MFMA); b = g.VertexSearch(Q, k, gpu.SELECT_NEAREST, gpu.MODE_EXACT)
     assert g.Stats()["mfma_groups"] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+@pytest.mark.parametrize("quant,d", [(O.Q_F16, 96), (O.Q_BF16, 256)])
+@pytest.mark.parametrize("metric", [O.COSINE, O.L2])
+def test_binary16_index_commits_and_loads_bit_identically(gpu, quant, d, metric):
+    """Hnsw.Commit / Load (core/vectorindex/hnsw_commit.go:69-278) for the C5-shape quantised index (VERDICT r3 missing #5): the f32
+    vertex section carries the values the codes stand for; Load into an index of the same quantisation gives back the same codes, graph,
+    answers and stream; the reference-format stream is readable by the f32 oracle (same graph); f8 is refused with a reason."""
+    import torch
+    n = 1500
+    X = O.fill_normal(9400 + d, (n, d)); lv = O.levels(9401, n); Q = O.fill_normal(9402, (20, d))
+    X[5, :8] = np.float32(3e-6); X[6, :8] = np.float32(-7e-8)          # binary16 subnormals / underflow in the stored codes
+    gh = gpu.Hnsw(d, metric, gpu.HnswCfg.default(ef_construction=40), quantization=quant)
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+    i = 0
+    while i < n:
+        b = int(min(n - i, max(1, min(128, i // 16))))
+        gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i)
+        i += b
+    for i in range(0, n, 11):
+        gh.Remove(i)
+    stream = gh.Commit()
+    g2 = gpu.Hnsw(d, metric, quantization=quant)
+    n_live = g2.Load(stream)
+    assert n_live == n - len(range(0, n, 11))
+    assert g2.Commit() == stream                                         # fixed point
+    # the codes: slot order of a loaded index is the stream's (16 shards), so compare by id
+    a = gh.Search(Q, 10, ef=64); b = g2.Search(Q, 10, ef=64)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    for vid in (1, 5, 6, 17, n - 1):
+        assert np.array_equal(gh.Get(vid)[0], g2.Get(vid)[0]), vid
+    # the reference-format stream loads into the f32 oracle: same vertices, same edges
+    oh = O.Hnsw(d, metric); assert oh.load_stream(stream) == 0
+    assert oh.commit(header=True) == stream
+    f8 = gpu.Hnsw(d, metric, quantization=O.Q_F8)
+    f8.Insert(1, X[0], 0)
+    with pytest.raises(Exception, match="f8"):
+        f8.Commit()
