@@ -75,7 +75,6 @@ Policy read_policy_from_env() {
   bool set = false; long long v;
   p.flat_one = !off("COLTT_FLAT_ONE"); p.staging = !off("COLTT_STAGING"); p.ev8 = !off("COLTT_EV8"); { const char* e = getenv("COLTT_ROWS8"); p.rows8 = (!e || !*e) ? 1 : (*e == '0' ? 0 : (*e == '2' ? 2 : 1)); } p.f8_mfma = !off("COLTT_F8_MFMA");
   v = num("COLTT_VISG", set); p.visg = set ? (int)v : -1;
-  { const char* e = getenv("COLTT_VISBITS"); p.visbits = e && *e == '1'; }
   { const char* e = getenv("COLTT_WALK2"); p.walk2 = (!e || !*e) ? 7 : (!strcmp(e, "off") ? -1 : (atoi(e) & 15)); }
   { const char* e = getenv("COLTT_WALK2_LDS"); if (!e || !*e) p.walk2_lds = 4; else if (!strcmp(e, "off")) p.walk2_lds = -1; else { const int w = atoi(e) & 6; p.walk2_lds = w ? w : -1; } }
   v = num("COLTT_BLOOM_KB", set); p.bloom_kb = set ? (int)std::max<long long>(1, std::min<long long>(64, v)) : 0;

@@ -105,7 +105,6 @@ struct Policy {
   bool f8_mfma = true;         // COLTT_F8_MFMA=0: new "f8" cosine stores keep no binary16 copy: their batches run the exact scan (read at create)
   int rows8 = 1;               // COLTT_ROWS8 (read at create): 0 = new indexes keep no line-transposed row copy, 1 = default (dim >= 256), 2 = any shape rows8 covers
   int visg = -1;               // COLTT_VISG: -1 default (byte map above ef 128), 0 LDS hash, 1 byte map
-  bool visbits = false;        // COLTT_VISBITS=1: the HBM visited set of hnsw_walk2.hpp is a bit map wiped per traversal (read when the workspace is sized)
   int walk2 = 7;               // COLTT_WALK2: -1 off, else OPT bits | 8 deep profile
   int walk2_lds = 4;           // COLTT_WALK2_LDS: -1 off, 2 / 4 / 6
   int bloom_kb = 0;            // COLTT_BLOOM_KB: 0 = sized by the occupancy budget

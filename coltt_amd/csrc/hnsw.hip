@@ -133,8 +133,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     w.bloom = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
     w.bloom_words = bloom_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(bloom_words | 0x80000000u);
     w.hcap = 0; w.hcap_mask = 0;
-    // vis_epoch == nullptr: the region is the BIT map (one wipe per traversal, no epochs)
-    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.vis_bits = vis_epoch ? 0u : 1u; w.epoch = vis_epoch ? vis_epoch[blockIdx.x] : 0u;
+    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
   }
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
 #endif
     }
   }
-  if constexpr (VISMODE == VIS_HBM) { if (lane == 0 && vis_epoch) vis_epoch[blockIdx.x] = w.epoch; }
+  if constexpr (VISMODE == VIS_HBM) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
 }
 
 
@@ -486,7 +485,6 @@ struct Hnsw : Object {
   // HBM visited set (hnsw_dev.hpp, VISG): vis_regions regions of vis_stride bytes; concurrent searches lease disjoint
   // contiguous runs of regions (vis_busy), the builder (exclusive lock) uses all of them.
   DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;
-  DevBuf w_visb; uint64_t visb_stride = 0;   // bit-per-slot twin of w_visg (policy visbits): same region indices, 1/8 of the stride
   std::mutex vis_mu; std::condition_variable vis_cv; std::vector<uint8_t> vis_busy;
   coltt_hnsw_stats build_stats{};
   ~Hnsw() override {
@@ -604,14 +602,7 @@ int ensure_visg(Hnsw* x) {
   // search that wants the byte map passes through here first, so a re-allocation can never race a traversal that uses it.
   std::lock_guard<std::mutex> vg(x->vis_mu);
   const uint64_t stride = (std::max<uint64_t>(x->cap, 1) + 1023) & ~1023ull;
-  if (x->vis_stride == stride) {
-    if (policy().visbits && !x->visb_stride && x->vis_regions) {   // the knob came on after the workspace was sized
-      const uint64_t bs = (stride / 8 + 1023) & ~1023ull;
-      COLTT_TRY(x->w_visb.reserve((uint64_t)x->vis_regions * bs));
-      x->visb_stride = bs;
-    }
-    return COLTT_OK;
-  }
+  if (x->vis_stride == stride) return COLTT_OK;
   if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
   size_t free_b = 0, total_b = 0;
   COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -633,13 +624,6 @@ int ensure_visg(Hnsw* x) {
   COLTT_TRY(x->w_vepoch.reserve(VIS_MAX_REGIONS * 4));
   COLTT_HIP(hipMemsetAsync(x->w_visg.p, 0, regions * stride, x->stream));
   COLTT_HIP(hipMemsetAsync(x->w_vepoch.p, 0, VIS_MAX_REGIONS * 4, x->stream));
-  x->visb_stride = 0;
-  if (x->w_visb.p) { (void)hipFree(x->w_visb.p); x->w_visb.p = nullptr; x->w_visb.cap = 0; }
-  if (policy().visbits) {   // contents do not matter: a traversal wipes its region before use
-    const uint64_t bs = (stride / 8 + 1023) & ~1023ull;
-    COLTT_TRY(x->w_visb.reserve(regions * bs));
-    x->visb_stride = bs;
-  }
   COLTT_HIP(hipStreamSynchronize(x->stream));  // searches run on other streams
   x->vis_regions = (uint32_t)regions;
   x->vis_busy.assign(regions, 0);
@@ -816,11 +800,10 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
   if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
   if (sg.ev8) x->ev8_launches.fetch_add(1);
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  const bool bits = !sg.w2_lds && x->visb_stride != 0 && policy().visbits;
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                         k, sg.ef, sg.ef_pad, sg.w2_lds ? sg.hcap : sg.bloom_words, counter, oi, os, oc, stats,
-                                        bits ? x->w_visb.as<uint8_t>() + (size_t)region_base * x->visb_stride : x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
-                                        bits ? (size_t)x->visb_stride : (size_t)x->vis_stride, bits ? nullptr : x->w_vepoch.as<uint32_t>() + region_base);
+                                        x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride, (size_t)x->vis_stride,
+                                        x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }

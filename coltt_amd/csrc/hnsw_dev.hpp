@@ -50,7 +50,6 @@ struct WaveCtx {
   // counters (wave-uniform)
   uint32_t n_dist, n_exp, n_hops, n_resets;
   uint8_t* visg; size_t vis_bytes; uint32_t epoch;  // VISG: this workgroup's byte-per-slot region, its size, current epoch
-  uint32_t vis_bits = 0;              // hnsw_walk2.hpp: the region is a BIT per slot, wiped at the start of every traversal (no epochs)
   uint32_t* bloom; uint32_t bloom_words, bloom_shift;  // hnsw_walk2.hpp: LDS Bloom filter in front of the byte map (words = 2^(32-shift))
 #ifdef COLTT_PHASE_TIMING
   unsigned long long pt[8], t_last;  // shader-clock ticks per traversal phase (diagnostic build only)

@@ -280,10 +280,10 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   unsigned long long* const res = w.res0;
   uint32_t vis_count = 1;
   if constexpr (VISMODE == VIS_HBM) {
-    if (w.vis_bits) {        // bit map: 1/8 of the byte map's footprint (and of its address translations), paid for with one wipe per traversal
-      for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
-      __threadfence();
-    } else if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
+    // (a BIT per slot instead of a byte — 1/8 of the footprint and of its address translations, paid for with one 1.25 MB wipe per traversal
+    //  and an atomic OR per test — lost: 10 M x 768 f16, ef 1024: 73.7 -> 77.0 ms per 10 k queries, f32 ef 256: 47.5 -> 49.0;
+    //  profiles/r04l_visbits_ab.md.  The byte map with 8-bit epochs stays.)
+    if (++w.epoch > 255u) {  // 8-bit epoch wrapped: wipe the region (once per 255 traversals)
       for (size_t i = (size_t)lane * 16; i < w.vis_bytes; i += 64 * 16) *reinterpret_cast<u32x4v*>(w.visg + i) = u32x4v{0, 0, 0, 0};
       __threadfence();
       w.epoch = 1;
@@ -295,10 +295,8 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   if (lane == 0) res[0] = ((unsigned long long)__float_as_uint(epd) << 32) | ((unsigned long long)ep << 1);
   wave_sync();
   if (lane == 0) {
-    if constexpr (VISMODE == VIS_HBM) {
-      if (w.vis_bits) (void)__hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(w.visg) + (ep >> 5), 1u << (ep & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else vis_insert(w.vis, w.hcap_mask, ep);
+    if constexpr (VISMODE == VIS_HBM) __hip_atomic_store(w.visg + ep, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else vis_insert(w.vis, w.hcap_mask, ep);
     if constexpr (BLOOM) {
       const uint32_t h = ep * 0x9E3779B1u;
       w.bloom[h >> w.bloom_shift] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
@@ -411,14 +409,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
           maybe = (old & bits) == bits;
         }
         if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
-        else if (w.vis_bits) {
-          // two lanes may share a word (never a bit): the set is an atomic OR, whose old value is the test; behind a Bloom "never seen"
-          // the old value is not needed and the wave does not wait for it
-          uint32_t* const wd = reinterpret_cast<uint32_t*>(w.visg) + (nb >> 5);
-          const uint32_t bit = 1u << (nb & 31u);
-          if (maybe) fresh_i = (__hip_atomic_fetch_or(wd, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) ? 0 : 1;
-          else { (void)__hip_atomic_fetch_or(wd, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh_i = 1; }
-        } else {
+        else {
           if (maybe) {
             const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             fresh_i = v != (uint8_t)w.epoch ? 1 : 0;

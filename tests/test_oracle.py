@@ -67,6 +67,10 @@ def test_codecs_against_ieee_binary16():
     x = (rng.standard_normal(300000) * np.exp(rng.uniform(-25, 11, 300000))).astype(np.float32)
     with np.errstate(over="ignore"):
         assert np.array_equal(O.f16_encode(x), x.astype(np.float16).view(np.uint16))
+    # encode(decode(c)) == c for every non-NaN code: what lets a binary16 index travel through the reference's f32 stream (coltt_hnsw_commit)
+    assert np.array_equal(O.f16_encode(dec[m]), codes[m])
+    f8v = O.f8_decode(np.arange(256, dtype=np.uint8))
+    assert not np.array_equal(bits(O.f8_decode(O.f8_encode(f8v))), bits(f8v))           # ... and why an "f8" index cannot
     # "bf16" is binary16 in the reference, "f8" decodes to 8 values (SURVEY.md §0 findings 2-3)
     lut = O.f8_decode(np.arange(256, dtype=np.uint8)).view(np.uint32)
     assert sorted(set(lut.tolist())) == [0, 0x8000, 0x33800000, 0x33808000, 0x34000000, 0x34008000, 0x34400000, 0x34408000]
