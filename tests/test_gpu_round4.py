@@ -191,3 +191,39 @@ def test_binary16_index_commits_and_loads_bit_identically(gpu, quant, d, metric)
     f8.Insert(1, X[0], 0)
     with pytest.raises(Exception, match="f8"):
         f8.Commit()
+
+
+def test_reserve_changes_nothing_but_the_allocations(gpu):
+    """coltt_hnsw_reserve (the collection size is known up front: every array allocated once): an index that reserved its
+    size — exactly, too little (slots and upper rows grow past it), or on top of existing content — holds the same graph and answers the
+    same as one that grew by halves."""
+    import torch
+    n, d = 3000, 256
+    X = O.fill_normal(9500, (n, d)); lv = O.levels(9501, n); Q = O.fill_normal(9502, (16, d))
+    xd = torch.from_numpy(X).cuda(); torch.cuda.synchronize()
+
+    def build(plan):
+        gh = gpu.Hnsw(d, O.COSINE, gpu.HnswCfg.default(ef_construction=40))
+        i = 0
+        while i < n:
+            if i in plan:
+                gh.Reserve(*plan[i])
+            b = int(min(n - i, max(1, min(128, i // 16))))
+            if i < 1000 < i + b:                    # slot 1000 is a batch boundary in every build, so the batches are the same
+                b = 1000 - i
+            gh.InsertBatchDevice(xd.data_ptr() + i * d * 4, b, lv[i:i + b], batch=b, first_id=i)
+            i += b
+        return gh
+    plans = {"grown by halves": {}, "exact": {0: (n,)}, "too little": {0: (500, 1), 1000: (10,)}, "on top of content": {1000: (n, 0)}}
+    ref = None
+    for name, plan in plans.items():
+        gh = build(plan)
+        g = gh.ExportRaw(); rows = gh.FetchRows(); ans = gh.Search(Q, 10, ef=200, with_stats=True)
+        cur = [g["adj0"], g["upper_off"], g["adjU"], np.int64(g["entry"]), rows, ans[0], bits(ans[1]), ans[2]]
+        if ref is None:
+            ref, ref_stats = cur, ans[3]
+        else:
+            for a, b in zip(ref, cur):
+                assert np.array_equal(a, b), name
+            assert ans[3] == ref_stats, name
+        assert gh.Rows8()[1]
