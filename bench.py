@@ -705,7 +705,7 @@ def leg_pq(G, torch, dev, O, args, dim, k):
                         "avg_launch_ms": scan_s * 1e3,
                         "kernel": "pq_scan_kernel<4,1> (table in LDS, one ds_read_b32 per code byte; tile-interleaved codes, 16 B per lane per load)",
                         "bytes_per_launch": int(scan_rows * m),
-                        "lds_note": "one table lookup per code byte: random ds_read_b32 over 32 banks is the second ceiling (~0.7 of the HBM peak)"}}
+                        "lds_note": "one table lookup per code byte: random ds_read_b32 over 32 banks costs 6.29 LDS cycles (2 conflict-free), the LDS array is busy ~92 % of the kernel: its ceiling is ~0.67 of the HBM peak (profiles/r04m_pq_lds.md)"}}
     if O is not None:
         try:
             threads = O.cpu_count(); th = quota_cpus(threads)
