@@ -164,5 +164,95 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
   }
 }
 
+// ---- two-pass form of the same epilogue (flat_mfma3.hpp) ---------------------------------------------------------------------------
+// m2_emit_block pays one global atomic ROUND TRIP per half block that holds a survivor, inside the block loop: a wave with h such half
+// blocks in a tile stalls h x ~2 us, and its workgroup waits for it at the next tile's first barrier.  Behind a loose threshold that is
+// what a segment costs (1 M x 768 f32, batch 64, a 4 Ki-row seed followed by everything else: +0.24 ms for 156 k survivors,
+// profiles/r04n_segment_schedule.md).  Here the tile's blocks are only TESTED first (a 16-bit survivor mask per block, in registers), the
+// lane then reserves its survivors of a whole query column with ONE atomic per column — all columns' atomics in flight together — and a
+// second pass over the blocks that had survivors writes them: one round trip per tile and wave.
+template <int METRIC, bool UNROLLED = true>
+__device__ __forceinline__ uint32_t m2_test_block(const f32x16& acc, const f32x4 (&ir)[4], bool bad, const QCol& qc, int nearest, int nq,
+                                                  uint64_t rbase, uint64_t end, float* ep) {
+  float t[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
+  auto value = [&](float tv) { return METRIC == M_COS ? fabsf(1.0f - tv * qc.iq) : qc.iq + tv; };
+  float mx = t[0], mn = t[0];
+#pragma unroll
+  for (int r = 1; r < 16; r++) mx = __builtin_fmaxf(mx, t[r]);
+  bool hit;
+  if constexpr (METRIC == M_COS) {
+    if (nearest) hit = !(mx < qc.lo);
+    else {
+#pragma unroll
+      for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
+      hit = !(mn > qc.lo) || !(mx < qc.hi);
+    }
+  } else {
+    if (nearest) {
+#pragma unroll
+      for (int r = 1; r < 16; r++) mn = __builtin_fminf(mn, t[r]);
+      hit = !(mn > qc.lo);
+    } else hit = !(mx < qc.hi);
+  }
+  if (!(hit || bad) || qc.qidx >= nq) return 0u;
+  // The element test, UNROLLED in registers: no atomics and no stores here, ~6 VALU per element — the rolled loop over LDS-parked values
+  // that m2_emit_block needs for its instruction-cache footprint cost ~100 dependent cycles per element, which is what a segment behind a
+  // loose threshold (92 % of its blocks hit) was paying.
+  const uint64_t left64 = end > rbase ? end - rbase : 0;
+  const int left = left64 > 64 ? 64 : (int)left64;          // local rows 0 .. 27 of this lane's 16 exist up to `end`
+  uint32_t mask = 0;
+  if constexpr (UNROLLED) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float s = value(t[r]);
+      const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
+      mask |= (pass && ((r & 3) + 8 * (r >> 2)) < left) ? (1u << r) : 0u;
+    }
+  } else {   // (rolled form, not instantiated by the shipped kernels: at batch 256 the unrolled test made the gathered-f32 instances spill and the
+             //  power-bound C3 shape slow from 4.82 to 5.45 ms per batch — those instances stay on m2_emit_block, profiles/r04p_epilogue_ab.md)
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      reinterpret_cast<f32x4*>(ep)[0] = h ? f32x4{t[8], t[9], t[10], t[11]} : f32x4{t[0], t[1], t[2], t[3]};
+      reinterpret_cast<f32x4*>(ep)[1] = h ? f32x4{t[12], t[13], t[14], t[15]} : f32x4{t[4], t[5], t[6], t[7]};
+#pragma unroll 1
+      for (int r8 = 0; r8 < 8; r8++) {
+        const int r = h * 8 + r8;
+        const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
+        const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
+        if (pass && ((r & 3) + 8 * (r >> 2)) < left) mask |= 1u << r;
+      }
+    }
+  }
+  return mask;
+}
+// second pass: the survivors of one block (mask from m2_test_block, same acc / ir / qc) into cand[qidx][idx ...]; returns the next free index
+template <int METRIC>
+__device__ __forceinline__ uint32_t m2_store_block(const f32x16& acc, const f32x4 (&ir)[4], uint32_t mask, const QCol& qc, uint64_t rbase,
+                                                   unsigned long long* __restrict__ cand, uint32_t idx, uint32_t cap, float* ep,
+                                                   const uint32_t* __restrict__ gather) {
+  float t[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
+  auto value = [&](float tv) { return METRIC == M_COS ? fabsf(1.0f - tv * qc.iq) : qc.iq + tv; };
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+    if (!((mask >> (8 * h)) & 0xffu)) continue;
+    reinterpret_cast<f32x4*>(ep)[0] = h ? f32x4{t[8], t[9], t[10], t[11]} : f32x4{t[0], t[1], t[2], t[3]};
+    reinterpret_cast<f32x4*>(ep)[1] = h ? f32x4{t[12], t[13], t[14], t[15]} : f32x4{t[4], t[5], t[6], t[7]};
+#pragma unroll 1
+    for (int r8 = 0; r8 < 8; r8++) {
+      const int r = h * 8 + r8;
+      if (!((mask >> r) & 1u)) continue;
+      const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
+      const uint64_t gr = rbase + (r & 3) + 8 * (r >> 2);
+      if (idx < cap) cand[(size_t)qc.qidx * cap + idx] = ((unsigned long long)score_key(s) << 32) | (gather ? gather[gr] : (uint32_t)gr);
+      idx++;
+    }
+  }
+  return idx;
+}
+
 }  // namespace dev
 }  // namespace coltt

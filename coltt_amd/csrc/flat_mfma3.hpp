@@ -263,14 +263,26 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
     }
     continue;
 #endif
-#pragma unroll
-    for (int tm = 0; tm < TM; tm++) {
-      f32x4 ir[4];
+    auto row_scale = [&](int tm, f32x4 (&ir)[4]) {
 #pragma unroll
       for (int gq = 0; gq < 4; gq++) {
         const f32x4 raw = *reinterpret_cast<const f32x4*>(tn_raw + wm * WROWS + tm * 32 + 8 * gq + 4 * (lane >> 5));
         ir[gq] = METRIC == M_COS ? f32x4{rsqrtf(raw.x), rsqrtf(raw.y), rsqrtf(raw.z), rsqrtf(raw.w)} : raw;   // Euclidean: raw ||row||^2
       }
+    };
+    // Batches up to 128 take the two-pass epilogue (flat_mfma2.hpp: test, one reservation per column, store); the batch-256 instances keep
+    // m2_emit_block: their long segments run behind tight thresholds, and the extra mask bookkeeping cost the power-bound C3 shape 2.4 %
+    // (4.83 -> 4.95 ms per batch; C2 0.650 -> 0.627, filtered batch 64 0.216 -> 0.200: profiles/r04p_epilogue_ab.md).
+    constexpr bool TWO_PASS = BN < 256;
+    // survivor masks of the tile's blocks: 16 bits per block, the TM blocks of a query column packed into one register (TM <= 2)
+    static_assert(TM <= 2, "mask packing: two 16-bit masks per register");
+    uint32_t msk[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) msk[tn] = 0;
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+      f32x4 ir[4];
+      row_scale(tm, ir);
       bool bad;
       if constexpr (METRIC == M_COS) bad = mf_bad_norms(ir);
       else {  // a non-finite norm always takes the element path
@@ -282,7 +294,32 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
       }
       const uint64_t rbase = row0 + wm * WROWS + tm * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int tn = 0; tn < TN; tn++) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep, GATHER ? gather : nullptr);
+      for (int tn = 0; tn < TN; tn++) {
+        if constexpr (SEED || !TWO_PASS) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep, GATHER ? gather : nullptr);
+        else msk[tn] |= m2_test_block<METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, end, ep) << (16 * tm);
+      }
+    }
+    if constexpr (!SEED && TWO_PASS) {   // one reservation per query column and tile (flat_mfma2.hpp: two-pass epilogue), then the blocks that had survivors
+      uint32_t any = 0;
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) any |= msk[tn];
+      if (any) {
+        uint32_t idx[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) idx[tn] = msk[tn] ? atomicAdd(&cnt[qc[tn].qidx], (uint32_t)__builtin_popcount(msk[tn])) : 0u;
+#pragma unroll
+        for (int tm = 0; tm < TM; tm++) {
+          if (!((any >> (16 * tm)) & 0xffffu)) continue;
+          f32x4 ir[4];
+          row_scale(tm, ir);
+          const uint64_t rbase = row0 + wm * WROWS + tm * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int tn = 0; tn < TN; tn++) {
+            const uint32_t m = (msk[tn] >> (16 * tm)) & 0xffffu;
+            if (m) idx[tn] = m2_store_block<METRIC>(acc[tm][tn], ir, m, qc[tn], rbase, cand, idx[tn], cap, ep, GATHER ? gather : nullptr);
+          }
+        }
+      }
     }
   }
   m2_wait_vmcnt<0>();
