@@ -171,9 +171,9 @@ __device__ __forceinline__ void m2_emit_block(const f32x16& acc, const f32x4 (&i
 // profiles/r04n_segment_schedule.md).  Here the tile's blocks are only TESTED first (a 16-bit survivor mask per block, in registers), the
 // lane then reserves its survivors of a whole query column with ONE atomic per column — all columns' atomics in flight together — and a
 // second pass over the blocks that had survivors writes them: one round trip per tile and wave.
-template <int METRIC, bool UNROLLED = true>
+template <int METRIC>
 __device__ __forceinline__ uint32_t m2_test_block(const f32x16& acc, const f32x4 (&ir)[4], bool bad, const QCol& qc, int nearest, int nq,
-                                                  uint64_t rbase, uint64_t end, float* ep) {
+                                                  uint64_t rbase, uint64_t end) {
   float t[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) t[r] = METRIC == M_COS ? acc[r] * ir[r >> 2][r & 3] : ir[r >> 2][r & 3] - 2.0f * acc[r];
@@ -202,28 +202,14 @@ __device__ __forceinline__ uint32_t m2_test_block(const f32x16& acc, const f32x4
   // loose threshold (92 % of its blocks hit) was paying.
   const uint64_t left64 = end > rbase ? end - rbase : 0;
   const int left = left64 > 64 ? 64 : (int)left64;          // local rows 0 .. 27 of this lane's 16 exist up to `end`
+  // (at batch 256 the unrolled test made the gathered-f32 instances spill and the power-bound C3 shape slow from 4.82 to 5.45 ms per batch,
+  //  a rolled one still cost it 2.4 %: those instances stay on m2_emit_block, profiles/r04p_epilogue_ab.md)
   uint32_t mask = 0;
-  if constexpr (UNROLLED) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float s = value(t[r]);
-      const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
-      mask |= (pass && ((r & 3) + 8 * (r >> 2)) < left) ? (1u << r) : 0u;
-    }
-  } else {   // (rolled form, not instantiated by the shipped kernels: at batch 256 the unrolled test made the gathered-f32 instances spill and the
-             //  power-bound C3 shape slow from 4.82 to 5.45 ms per batch — those instances stay on m2_emit_block, profiles/r04p_epilogue_ab.md)
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
-      reinterpret_cast<f32x4*>(ep)[0] = h ? f32x4{t[8], t[9], t[10], t[11]} : f32x4{t[0], t[1], t[2], t[3]};
-      reinterpret_cast<f32x4*>(ep)[1] = h ? f32x4{t[12], t[13], t[14], t[15]} : f32x4{t[4], t[5], t[6], t[7]};
-#pragma unroll 1
-      for (int r8 = 0; r8 < 8; r8++) {
-        const int r = h * 8 + r8;
-        const float s = value(reinterpret_cast<volatile float*>(ep)[r8]);
-        const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
-        if (pass && ((r & 3) + 8 * (r >> 2)) < left) mask |= 1u << r;
-      }
-    }
+  for (int r = 0; r < 16; r++) {
+    const float s = value(t[r]);
+    const bool pass = nearest ? !(s > qc.tf) : !(s < qc.tf);
+    mask |= (pass && ((r & 3) + 8 * (r >> 2)) < left) ? (1u << r) : 0u;
   }
   return mask;
 }

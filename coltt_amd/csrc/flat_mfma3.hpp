@@ -296,7 +296,7 @@ __global__ __launch_bounds__(M2_NT, 2) void flat_mfma3_kernel(
 #pragma unroll
       for (int tn = 0; tn < TN; tn++) {
         if constexpr (SEED || !TWO_PASS) m2_emit_block<SEED, METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, begin, end, cand, cnt, cap, ep, GATHER ? gather : nullptr);
-        else msk[tn] |= m2_test_block<METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, end, ep) << (16 * tm);
+        else msk[tn] |= m2_test_block<METRIC>(acc[tm][tn], ir, bad, qc[tn], nearest, nq, rbase, end) << (16 * tm);
       }
     }
     if constexpr (!SEED && TWO_PASS) {   // one reservation per query column and tile (flat_mfma2.hpp: two-pass epilogue), then the blocks that had survivors
