@@ -513,23 +513,28 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
     // (r04a: 0.32 ms per single-query search of which the dominant scan was 0.18 — the rest was launches)
     uint64_t s0 = std::min<uint64_t>({total, (uint64_t)cap, (std::max<uint64_t>(4096, 4ull * k) + 63) & ~63ull});
     for (uint64_t b = 0, e = s0; b < total; b = e, e = std::min<uint64_t>(total, e * 64)) COLTT_TRY(scan(b, e, e == total));
-    uint32_t h_ovf = 0;
-    COLTT_HIP(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
-    COLTT_HIP(hipStreamSynchronize(c->stream));
-    if (h_ovf) {   // mass ties / adversarial order: segments that cannot overflow (the list holds <= k + segment)
-      pq_init_kernel<<<ceil_div(nq, 256), 256, 0, c->stream>>>(cnt, thr, ovf, (int)nq);
-      const uint64_t seg = (cap - std::min<uint32_t>(k, cap / 2)) & ~63ull;
-      for (uint64_t b = 0; b < total; b += seg) COLTT_TRY(scan(b, std::min<uint64_t>(total, b + seg), false));
+  }
+  // One host round trip per call: the overflow flag travels with the answers; the events bracket the device chain only.
+  auto fetch = [&](uint32_t* h_ovf) -> int {
+    COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+    COLTT_HIP(hipGetLastError());
+    COLTT_HIP(hipMemcpyAsync(h_ovf, ovf, 4, hipMemcpyDeviceToHost, c->stream));
+    if (!out_on_device) {
+      COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
+      COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+      COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    COLTT_HIP(hipStreamSynchronize(c->stream));
+    return COLTT_OK;
+  };
+  uint32_t h_ovf = 0;
+  COLTT_TRY(fetch(&h_ovf));
+  if (h_ovf && total) {   // mass ties / adversarial order: segments that cannot overflow (the list holds <= k + segment)
+    pq_init_kernel<<<ceil_div(nq, 256), 256, 0, c->stream>>>(cnt, thr, ovf, (int)nq);
+    const uint64_t seg = (cap - std::min<uint32_t>(k, cap / 2)) & ~63ull;
+    for (uint64_t b = 0; b < total; b += seg) COLTT_TRY(scan(b, std::min<uint64_t>(total, b + seg), false));
+    COLTT_TRY(fetch(&h_ovf));
   }
-  COLTT_HIP(hipEventRecord(c->ev1, c->stream));
-  COLTT_HIP(hipGetLastError());
-  if (!out_on_device) {
-    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
-    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
-    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
-  }
-  COLTT_HIP(hipStreamSynchronize(c->stream));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   p->last_ms.store(ms);
