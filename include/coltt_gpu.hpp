@@ -170,6 +170,8 @@ class Hnsw {
     return r;
   }
   int Len() const { uint64_t n = 0; check(coltt_hnsw_len(h_, &n)); return (int)n; }
+  // the collection's size is known (bulk import, Load): every array allocated once; never shrinks, never limits an Insert
+  void Reserve(uint64_t vertices, uint64_t upper_rows = 0) { check(coltt_hnsw_reserve(h_, vertices, upper_rows)); }
   // Commit(w, header) / Load(r, header) (hnsw_commit.go:69-278): the reference's big-endian stream (metadata: empty maps)
   std::vector<uint8_t> Commit(bool header = true) const {
     uint64_t n = 0;

@@ -50,6 +50,7 @@ int main() {
   EXPECT(b.Len() == a.Len());
   EXPECT(b.Commit(true).size() == blob.size());
   coltt::Hnsw c(d, COLTT_COSINE);                             // Commit(Load(.)) is a fixed point: c == b slot for slot
+  c.Reserve((uint64_t)n);                                     // sized up front: same index, one allocation
   EXPECT(c.Load(b.Commit(true), true) == (uint64_t)(n - removed));
   std::mt19937 gq(777);
   for (int q = 0; q < 20; q++) {
