@@ -462,3 +462,42 @@ def test_flat_canonical_equals_literal_queue_on_random_configurations():
                 assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])), (trial, n, d, k, metric, quant, mode)
             near = f.search(q, k, nearest=True, mode=2)
             assert len(near[0]) == min(k, len(f)) and np.all(np.diff(near[1]) >= 0)
+
+
+@pytest.mark.parametrize("dim", [128, 384, 768])
+def test_the_reference_codec_loss_property(dim):
+    """pkg/compresshelper/compresshelper_test.go:38-412 (TestF16/BF16/F8Losses{128,384,768,1536}dim): for rand.Float32() vectors,
+    |((d + 1) / 2 * 100)(raw pair) - (the same)(encode -> decode of both)| <= 1 with d = Cosine.Distance.  Restated over the oracle's
+    codecs and AVX-order cosine: binary16 ("f16" and the reference's "bf16") holds it with four decimal places to spare.  The reference's
+    f8 case can never fail there (its failure branch is `assert.Error(t, errors.New(...))`, which passes); restated honestly it does not
+    hold — that codec keeps the low byte of the binary16 code (SURVEY §0 finding 3), so decoded vectors are near-zero noise."""
+    rng = np.random.default_rng(1000 + dim)
+    worst16 = 0.0; f8_fail = 0; pairs = 400
+    for _ in range(pairs):
+        a = rng.random(dim, dtype=np.float32); b = rng.random(dim, dtype=np.float32)
+        raw = (float(O.cosine(a, b)) + 1) / 2 * 100
+        a16 = O.f16_decode(O.f16_encode(a)); b16 = O.f16_decode(O.f16_encode(b))
+        worst16 = max(worst16, abs(raw - (float(O.cosine(a16, b16)) + 1) / 2 * 100))
+        a8 = O.f8_decode(O.f8_encode(a)); b8 = O.f8_decode(O.f8_encode(b))
+        d8 = float(O.cosine(a8, b8))
+        if not np.isfinite(d8) or abs(raw - (d8 + 1) / 2 * 100) > 1:
+            f8_fail += 1
+    assert worst16 < 1e-2, worst16
+    assert f8_fail > pairs // 2, f8_fail
+
+
+def test_the_reference_shard_vertex_cases():
+    """pkg/sharding/shard_test.go:40-63: ShardVertex is a pure function of (id, shards) — the reference checks one id 10 000 times — and
+    snowflake-shaped ids spread over all 16 shards.  Restated: the oracle and the library's host entry point (FNV-1a on the CPU, no device)
+    agree on that id and on 10 000 ids of the snowflake shape (time << 22 | node << 12 | sequence), and every shard is used."""
+    from coltt_amd.group import shard_vertex_host
+    dummy = 128545215
+    want = O.shard_vertex(dummy, 16)
+    assert all(O.shard_vertex(dummy, 16) == want for _ in range(100)) and shard_vertex_host(dummy, 16) == want
+    t0 = 1_700_000_000_000 - 1288834974657
+    ids = [((t0 + i // 7) << 22) | (i % 4096) for i in range(10_000)]
+    sh = [O.shard_vertex(i, 16) for i in ids]
+    assert set(sh) == set(range(16))
+    counts = np.bincount(np.array(sh, np.int64), minlength=16)
+    assert counts.min() > 10_000 // 16 // 2, counts
+    assert [shard_vertex_host(i, 16) for i in ids[:2000]] == sh[:2000]
