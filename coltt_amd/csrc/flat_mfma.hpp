@@ -155,15 +155,34 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
   if (c > cap) { if (tid == 0) atomicOr(overflow, 1u); c = cap; }
   const uint32_t flip = nearest ? 0u : 0xffffffffu;
   uint32_t bound_key = 0xffffffffu;  // in key' space: keep key' <= bound_key
+  // Lists of up to 4096 entries — every list but a pathological one: the seed segment is 1-4 Ki rows, later segments leave a few hundred —
+  // are read from global memory ONCE into registers; the four digit passes and the compaction then run out of them (each used to be its
+  // own trip through L2: 18.8 us for the 4 Ki-entry pick after the seed, profiles/r04w_f3_chain_timeline.txt).
+  constexpr int PK_R = 16;
+  const bool in_regs = c <= 256u * PK_R;
+  unsigned long long ev[PK_R];
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < PK_R; u++) { const uint32_t i = (uint32_t)tid + 256u * u; ev[u] = 0ull; if (256u * u < c) ev[u] = i < c ? src[i] : 0ull; }   // (block-uniform guard: a short list costs its own length)
+  }
   if (c > k) {
     uint32_t prefix = 0, mask = 0, need = k;
     for (int pass = 3; pass >= 0; pass--) {
       const int shift = pass * 8;
       hist[tid] = 0;
       __syncthreads();
-      for (uint32_t i = tid; i < c; i += 256) {
-        uint32_t kp = (uint32_t)(src[i] >> 32) ^ flip;
-        if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
+      if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < PK_R; u++) {
+          if (256u * u >= c) break;
+          const uint32_t kp = (uint32_t)(ev[u] >> 32) ^ flip;
+          if ((uint32_t)tid + 256u * u < c && (kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
+        }
+      } else {
+        for (uint32_t i = tid; i < c; i += 256) {
+          uint32_t kp = (uint32_t)(src[i] >> 32) ^ flip;
+          if ((kp & mask) == prefix) atomicAdd(&hist[(kp >> shift) & 255u], 1u);
+        }
       }
       __syncthreads();
       {  // the digit whose bucket holds the need-th key: inclusive prefix sum of the 256 buckets (a serial walk by one
@@ -193,9 +212,17 @@ __global__ __launch_bounds__(256) void flat_pick_kernel(const unsigned long long
   }
   if (tid == 0) s_n = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < c; i += 256) {
-    unsigned long long e = src[i];
-    if (((uint32_t)(e >> 32) ^ flip) <= bound_key) dst[atomicAdd(&s_n, 1u)] = e;
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < PK_R; u++) {
+      if (256u * u >= c) break;
+      if ((uint32_t)tid + 256u * u < c && ((uint32_t)(ev[u] >> 32) ^ flip) <= bound_key) dst[atomicAdd(&s_n, 1u)] = ev[u];
+    }
+  } else {
+    for (uint32_t i = tid; i < c; i += 256) {
+      unsigned long long e = src[i];
+      if (((uint32_t)(e >> 32) ^ flip) <= bound_key) dst[atomicAdd(&s_n, 1u)] = e;
+    }
   }
   __syncthreads();
   if (tid == 0) { cnt_all[q] = s_n; thr_all[q] = c > k ? (bound_key ^ flip) : (nearest ? 0xffffffffu : 0u); }
