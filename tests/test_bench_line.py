@@ -43,6 +43,24 @@ def test_final_line_of_a_real_record_is_small_and_complete():
     assert "trimmed" not in c
 
 
+def test_final_line_of_this_rounds_record_carries_every_leg():
+    """the round-4 record (all legs incl. the product quantiser and the f8 store): still under the target, nothing trimmed"""
+    res = json.load(open(os.path.join(ROOT, "profiles", "r04aa_bench_10m_full.json")))
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert "trimmed" not in c
+    for leg in ("op", "c1", "c2", "c3", "c3f8", "pq", "f3", "h1"):
+        assert leg in c, leg
+    assert c["pq"]["equals_oracle"] is True and 0 < c["pq"]["frac"] < 1
+    assert c["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], rel=1e-4)
+    # the committed last line of that run is what final_line() produces from the committed full record
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r04aa_bench_10m_line.json")))
+    assert committed["value"] == c["value"] and committed["roofline"] == c["roofline"] and committed["op"] == c["op"]
+
+
 def test_final_line_is_bounded_whatever_the_legs_hold():
     """pathological strings everywhere: the line is trimmed leg by leg, the contract's fields survive"""
     res = _full_record()
