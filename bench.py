@@ -770,25 +770,57 @@ def leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k):
     qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5)     # the SAME query stream on every rank
     nq = args.queries
     q = ds.rows(nq, qgen)
-    out = (np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32))
+    # Streamed: step i begins batch i (every rank searches it on its shard) and ends batch i - 1, whose all-gather, D2H and
+    # host merge ran on the group's exchange thread under this search; drain() ends the last one inside the timed region.  Two output
+    # blocks alternate.  COLTT_BENCH_SHARD_SERIAL=1: one synchronous coltt_group_search_device per step (the round-4 shape, for A/B).
+    out = [(np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32))]   # the most recently ENDED batch's answers
+    serial = os.environ.get("COLTT_BENCH_SHARD_SERIAL", "") not in ("", "0")
+    pending = []
+
+    def end_one():
+        t, o = pending.pop(0)
+        grp.SearchEnd(t)
+        out[0] = o
 
     def step():
-        grp.SearchDevice([q.data_ptr()], nq, k, ef=args.ef, out=out)
-    return grp, member, step, {"shard_rows": int(len(my_ids)), "build_s": build_s, "exchange": grp.info()["exchange"], "world": grp.info()["world"], "n_total": n_total}, out
+        if serial:
+            grp.SearchDevice([q.data_ptr()], nq, k, ef=args.ef, out=out[0])
+            return
+        pending.append(grp.SearchBegin(k, d_queries_per_member=[q.data_ptr()], nq=nq, ef=args.ef))
+        if len(pending) == 2:
+            end_one()
+
+    def drain():
+        while pending:
+            end_one()
+    step.drain = drain
+    step.timing = grp.Timing
+    return grp, member, step, {"shard_rows": int(len(my_ids)), "build_s": build_s, "exchange": grp.info()["exchange"], "world": grp.info()["world"], "n_total": n_total,
+                               "pipelined": not serial}, out
 
 
-def timed(torch, dist, world, cdev, steps, warmup, step):
+def pipeline_timing(t):
+    """per-batch means of the group's three stages (coltt_group_timing): the members' search, the exchange (pack + all-gather + D2H on the
+    comm stream) and the host merge — the last two run under the NEXT batch's search when the leg is streamed"""
+    b = max(1, t["batches"])
+    return {"batches": t["batches"], "search": round(t["search_ms"] / b, 3), "exchange": round(t["exchange_ms"] / b, 3), "merge": round(t["merge_ms"] / b, 3)}
+
+
+def timed(torch, dist, world, cdev, steps, warmup, step, drain=None):
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    drain = drain or getattr(step, "drain", None) or (lambda: None)   # a streamed step leaves its last batch in flight: ended INSIDE the timed region
     for i in range(warmup):
         step(i)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -897,7 +929,7 @@ def compact(res):
     if isinstance(sec.get("lat"), dict):
         out["lat"] = _pick(sec["lat"], "kernel_ms_1", "kernel_ms_128", "cpu_1_thread_ms", "error")
     if isinstance(sec.get("shard"), dict):
-        out["shard"] = _pick(sec["shard"], "value", "exchange", "world", "shard_rows", "n_total", "equals_single_process_group", "error")
+        out["shard"] = _pick(sec["shard"], "value", "exchange", "world", "shard_rows", "n_total", "pipelined", "pipeline_ms_per_batch", "equals_single_process_group", "error")
     if res.get("pcie_inclusive"):
         out["pcie_inclusive_qps"] = res["pcie_inclusive"].get("queries_per_s")
     out["wall_s"] = res.get("wall_s")
@@ -990,9 +1022,11 @@ def main():
             if i >= args.warmup:
                 kernel_ms.append(h.last_kernel_ms())  # hipEvent pair recorded on the library's search stream
                 for kk in stats: stats[kk] += st[kk]
-    dt = timed(torch, dist, world, cdev, args.steps, args.warmup, step)
+    dt = timed(torch, dist, world, cdev, args.steps, args.warmup, step, drain=gstep.drain if shard else None)
+    if shard:
+        shard_info["pipeline_ms_per_batch"] = pipeline_timing(gstep.timing())
     if shard and rank == 0 and shard_info["n_total"] <= 200_000:
-        shard_info["equals_single_process_group"] = verify_shard_leg(G, torch, dev, args, world, local, dim, k, gout)
+        shard_info["equals_single_process_group"] = verify_shard_leg(G, torch, dev, args, world, local, dim, k, gout[0])
     kernel_ms = kernel_ms[-args.steps:]
     total_q = args.steps * nq * (1 if shard else world)
     qps = total_q / dt
@@ -1148,9 +1182,10 @@ def main():
         try:
             grp2, m2, gstep2, info2, gout2 = leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k)
             nst = max(2, min(args.steps, 5))
-            dts = timed(torch, dist, world, cdev, nst, 1, lambda i: gstep2())
+            dts = timed(torch, dist, world, cdev, nst, 1, lambda i: gstep2(), drain=gstep2.drain)
+            info2["pipeline_ms_per_batch"] = pipeline_timing(gstep2.timing())
             if rank == 0 and info2["n_total"] <= 200_000:
-                info2["equals_single_process_group"] = verify_shard_leg(G, torch, dev, args, world, local, dim, k, gout2)
+                info2["equals_single_process_group"] = verify_shard_leg(G, torch, dev, args, world, local, dim, k, gout2[0])
             info2.update({"value": nst * nq / dts, "unit": "queries/s (every query visits every shard)",
                           "workload": f"HNSW {info2['n_total']}x{dim} {QNAME[args.quant]} partitioned {world} ways by ShardVertex, efSearch={args.ef}, "
                                       f"coltt_group_search_device: per-shard search + ONE RCCL all-gather of packed top-k + host merge"})

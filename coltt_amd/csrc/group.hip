@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <deque>
 #include <thread>
 
 #include "common.hpp"
@@ -190,36 +191,65 @@ int shm_allgather(ShmExchange* x, const void* local, uint64_t bytes, void* out) 
 struct Member {
   int device = 0, rank = 0;
   coltt_handle_t h = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // ingest, replica searches
+  hipStream_t cstream = nullptr;   // the exchange of a shard search: pack, all-gather, D2H — never the stream a search runs on
   nccl_comm_t comm = nullptr;
-  DevBuf d_q, d_ids, d_sc, d_cnt, d_pack, d_gather;
+  DevBuf d_q, d_ids, d_sc, d_cnt;  // ingest / replica searches (under call_mu)
 };
+
+// A shard search is a three-stage pipeline ("issued on a comm stream and overlapped with the next batch"):
+//   A  every member searches the batch on its shard                           (the caller's thread, one batch at a time: call_mu)
+//   B  pack + ONE all-gather of the packed top-k + D2H, on the comm streams   (the group's exchange thread, in ticket order)
+//   C  the host-side final merge, split over a few host threads               (same thread, right behind B)
+// Stage A of batch i+1 runs while B and C of batch i are in flight; a batch owns one Slot (answer arrays, packed records, the
+// gathered block, its pinned staging) from A until its merge is done, so nothing is shared between batches in flight.
+// Tickets are handed out in stage-A order and the exchange thread serves them FIFO: in a multi-process group every process makes the
+// same calls in the same order, hence issues the same collectives in the same order.
+struct SlotMember { DevBuf d_q, d_ids, d_sc, d_cnt, d_pack, d_gather; };
+struct Slot {
+  std::vector<std::unique_ptr<SlotMember>> mb;
+  PinnedBuf h_stage;                                  // [world][nq][k] gathered records
+  std::vector<Rec> h_local, h_chunk_in, h_chunk_out;  // SHM transport: this process's records / one chunk of queries in flight
+};
+struct Job {
+  uint64_t ticket = 0; int slot = -1;
+  size_t nq = 0; uint32_t k = 0; int nearest = 1;
+  uint64_t* out_ids = nullptr; float* out_scores = nullptr; uint32_t* out_counts = nullptr;
+  int rc = COLTT_OK; std::string err; bool done = false;
+  double search_ms = 0, exchange_ms = 0, merge_ms = 0;
+};
+constexpr int GROUP_SLOTS = 3;
 
 struct Group : Object {
   int kind = 0, layout = 0, exchange = 0 /* in use: 1 RCCL, 2 host */, world = 0, rank_base = 0;
   uint32_t dim = 0; int metric = 0, quant = 0;
   std::vector<std::unique_ptr<Member>> m;  // DevBuf is neither copyable nor movable
-  std::mutex call_mu;  // one group call at a time (members' own locks still protect them against direct use)
-  Rec* h_stage = nullptr; size_t h_stage_bytes = 0;  // pinned host staging for the gathered records
+  std::mutex call_mu;  // stage A, ingest and remove: one at a time (members' own locks still protect them against direct use)
   std::shared_ptr<ShmExchange> shm;                  // COLTT_EXCHANGE_SHM
-  std::vector<Rec> h_local, h_chunk_in, h_chunk_out; // SHM: this process's packed answers / one chunk of queries in flight
+  // pipeline state
+  Slot slots[GROUP_SLOTS];
+  std::mutex q_mu; std::condition_variable q_cv, done_cv, slot_cv;
+  std::deque<std::shared_ptr<Job>> queue;                       // stage B/C work, FIFO = ticket order
+  std::unordered_map<uint64_t, std::shared_ptr<Job>> jobs;      // begun, not yet ended
+  bool slot_busy[GROUP_SLOTS] = {false, false, false};
+  uint64_t next_ticket = 1; bool stop = false; std::thread worker;
+  // cumulative timing of finished batches (coltt_group_timing)
+  uint64_t t_batches = 0; double t_search = 0, t_exchange = 0, t_merge = 0;
+  void exchange_loop();
+  int exchange_and_merge(Job& j);
   ~Group() override {
+    { std::lock_guard<std::mutex> lk(q_mu); stop = true; }
+    q_cv.notify_all();
+    if (worker.joinable()) worker.join();
     Rccl* r = rccl();
     for (auto& xp : m) {
       Member& x = *xp;
       (void)hipSetDevice(x.device);
       if (x.comm && r) (void)r->CommDestroy(x.comm);
       if (x.stream) (void)hipStreamDestroy(x.stream);
+      if (x.cstream) (void)hipStreamDestroy(x.cstream);
       if (x.h) { if (kind == COLTT_GROUP_FLAT) (void)coltt_flat_destroy(x.h); else (void)coltt_hnsw_destroy(x.h); }
     }
-    if (h_stage) (void)hipHostFree(h_stage);
-  }
-  int stage(size_t bytes) {
-    if (bytes <= h_stage_bytes) return COLTT_OK;
-    if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; h_stage_bytes = 0; }
-    COLTT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_stage), bytes, hipHostMallocDefault));
-    h_stage_bytes = bytes;
-    return COLTT_OK;
   }
 };
 
@@ -243,17 +273,16 @@ inline bool rec_less(const Rec& a, const Rec& b) { return a.score < b.score || (
 
 }  // namespace
 
-// Host-side final merge (exported for the unit tests, which run without a device): recs = [world][nq][k] packed per-shard
-// answers, each shard's valid records ascending by (score, id).  nearest: the k smallest of the union; otherwise (edge
-// SELECT_REFERENCE) the k LARGEST — both returned ascending, as every single store returns them.
-extern "C" int coltt_group_merge_host(const void* recs_v, int world, size_t nq, uint32_t k, int nearest, uint64_t* out_ids,
-                                      float* out_scores, uint32_t* out_counts) {
-  if (!recs_v || world <= 0 || k == 0) return fail(COLTT_E_INVALID, "group_merge_host: bad arguments");
-  const Rec* recs = static_cast<const Rec*>(recs_v);
+// Host-side final merge: recs = [world][nq][k] packed per-shard answers, each shard's valid records ascending by (score, id).
+// nearest: the k smallest of the union; otherwise (edge SELECT_REFERENCE) the k LARGEST — both returned ascending, as every single
+// store returns them.  Queries are independent: [q_lo, q_hi) is one thread's share.
+namespace {
+void merge_range(const Rec* recs, int world, size_t nq, uint32_t k, int nearest, size_t q_lo, size_t q_hi, uint64_t* out_ids, float* out_scores,
+                 uint32_t* out_counts) {
   const size_t per = nq * (size_t)k;
   std::vector<uint32_t> head((size_t)world), len((size_t)world);
   std::vector<Rec> tmp(k);
-  for (size_t q = 0; q < nq; q++) {
+  for (size_t q = q_lo; q < q_hi; q++) {
     size_t total = 0;
     for (int s = 0; s < world; s++) {
       const Rec* r = recs + (size_t)s * per + q * k;
@@ -283,6 +312,29 @@ extern "C" int coltt_group_merge_host(const void* recs_v, int world, size_t nq, 
     }
     out_counts[q] = take;
   }
+}
+// host threads of one merge: COLTT_MERGE_THREADS, else one per 1024 queries, at most 8 (the merge of 10 000 x 8 x 10 records is ~1.5 ms on
+// one thread — it sits behind every exchange, so it is split rather than left on the exchange thread alone)
+int merge_threads(size_t nq) {
+  static const int knob = [] { const char* e = getenv("COLTT_MERGE_THREADS"); return (e && *e) ? std::max(1, atoi(e)) : 0; }();
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int want = knob ? knob : (int)std::min<size_t>(8, (nq + 1023) / 1024);
+  return std::max(1, std::min(want, hw));
+}
+}  // namespace
+
+// exported for the unit tests, which run without a device
+extern "C" int coltt_group_merge_host(const void* recs_v, int world, size_t nq, uint32_t k, int nearest, uint64_t* out_ids,
+                                      float* out_scores, uint32_t* out_counts) {
+  if (!recs_v || world <= 0 || k == 0) return fail(COLTT_E_INVALID, "group_merge_host: bad arguments");
+  const Rec* recs = static_cast<const Rec*>(recs_v);
+  const int T = merge_threads(nq);
+  if (T <= 1) { merge_range(recs, world, nq, k, nearest, 0, nq, out_ids, out_scores, out_counts); return COLTT_OK; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++)
+    th.emplace_back(merge_range, recs, world, nq, k, nearest, nq * (size_t)t / (size_t)T, nq * (size_t)(t + 1) / (size_t)T, out_ids, out_scores, out_counts);
+  merge_range(recs, world, nq, k, nearest, 0, nq / (size_t)T, out_ids, out_scores, out_counts);
+  for (auto& t : th) t.join();
   return COLTT_OK;
 }
 
@@ -354,7 +406,9 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
     if (o.kind == COLTT_GROUP_FLAT) COLTT_TRY(flat_create_on(x.device, dim, metric, quant, &x.h));
     else COLTT_TRY(hnsw_create_on(x.device, dim, metric, quant, cfg, &x.h));
     COLTT_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+    COLTT_HIP(hipStreamCreateWithFlags(&x.cstream, hipStreamNonBlocking));
   }
+  for (auto& sl : g->slots) for (int i = 0; i < n_devices; i++) sl.mb.emplace_back(new SlotMember());
   // exchange transport
   g->exchange = COLTT_EXCHANGE_HOST;
   if (o.exchange == COLTT_EXCHANGE_SHM) {
@@ -393,6 +447,7 @@ int coltt_group_create(const int* devices, int n_devices, uint32_t dim, int metr
     }
   } else if (multi_process) return fail(COLTT_E_UNSUPPORTED, "group_create: shards in several processes exchange through RCCL or shared memory (COLTT_EXCHANGE_SHM), not through one process's host buffer");
   g->device = devices[0];
+  if (g->layout == COLTT_LAYOUT_SHARD) g->worker = std::thread([gp = g.get()] { gp->exchange_loop(); });   // joined by ~Group
   *out = Registry::get().add(g);
   return COLTT_OK;
 }
@@ -512,120 +567,236 @@ int coltt_group_remove(coltt_handle_t h, const uint64_t* ids, size_t n) {
   });
 }
 
-// VertexSearch / Hnsw.Search over the whole collection.  d_queries_per_member != NULL: the batch already lives on every
-// member's device ([n_local] pointers, nq x dim f32 each); otherwise `queries` is a host array broadcast to the members.
-static int group_search_impl(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
-                             int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
-// A process of a shared-memory group that fails ANYWHERE in its search (a member's search, a copy, an argument the peers did not
-// share) marks the segment failed before it returns: its peers, which are or will be waiting for its contribution, stop at once
-// instead of spinning for COLTT_SHM_TIMEOUT_S.  A failed exchange is final — the group has to be re-created.
-static int group_search(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
-                        int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
-  const int rc = group_search_impl(g, queries, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
-  if (rc != COLTT_OK && g->exchange == COLTT_EXCHANGE_SHM && g->shm && g->shm->hdr) g->shm->hdr->failed.store(1, std::memory_order_release);
-  return rc;
-}
-static int group_search_impl(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
-                             int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
-  if (nq == 0) return COLTT_OK;
-  if (k == 0) return fail(COLTT_E_INVALID, "group_search: k must be >= 1");
-  if (g->exchange == COLTT_EXCHANGE_SHM && g->shm && (uint64_t)k * sizeof(Rec) > g->shm->cap)
-    return fail(COLTT_E_INVALID, "group_search: k = %u needs %llu bytes per rank and query, the shared segment holds %llu per rank (COLTT_SHM_MB)", k,
-                (unsigned long long)((uint64_t)k * sizeof(Rec)), (unsigned long long)g->shm->cap);
-  std::lock_guard<std::mutex> lk(g->call_mu);
-  const size_t nm = g->m.size();
-  const bool hn = g->kind == COLTT_GROUP_HNSW;
-  const int nearest = hn ? 1 : (select == COLTT_SELECT_NEAREST);
-  const size_t per = nq * (size_t)k;
-  if (g->layout == COLTT_LAYOUT_REPLICA) {
-    // the batch is split into contiguous slices, one per member; answers land in place — no exchange
-    return for_members(g, [&](size_t j) -> int {
-      const size_t lo = nq * j / nm, hi = nq * (j + 1) / nm;
-      if (hi == lo) return COLTT_OK;
-      Member& x = *g->m[j];
-      if (d_queries_per_member) {
-        COLTT_TRY(x.d_ids.reserve((hi - lo) * k * 8)); COLTT_TRY(x.d_sc.reserve((hi - lo) * k * 4)); COLTT_TRY(x.d_cnt.reserve((hi - lo) * 4));
-        const float* dq = d_queries_per_member[j] + lo * g->dim;
-        if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, hi - lo, k, ef_override, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), nullptr));
-        else COLTT_TRY(coltt_flat_search_device(x.h, dq, hi - lo, k, select, mode, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>()));
-        COLTT_HIP(hipMemcpyAsync(out_ids + lo * k, x.d_ids.p, (hi - lo) * k * 8, hipMemcpyDeviceToHost, x.stream));
-        COLTT_HIP(hipMemcpyAsync(out_scores + lo * k, x.d_sc.p, (hi - lo) * k * 4, hipMemcpyDeviceToHost, x.stream));
-        COLTT_HIP(hipMemcpyAsync(out_counts + lo, x.d_cnt.p, (hi - lo) * 4, hipMemcpyDeviceToHost, x.stream));
-        COLTT_HIP(hipStreamSynchronize(x.stream));
-        return COLTT_OK;
-      }
-      if (hn) return coltt_hnsw_search(x.h, queries + lo * g->dim, hi - lo, k, ef_override, out_ids + lo * k, out_scores + lo * k, out_counts + lo, nullptr);
-      return coltt_flat_search(x.h, queries + lo * g->dim, hi - lo, k, select, mode, out_ids + lo * k, out_scores + lo * k, out_counts + lo);
-    });
-  }
-  // ---- SHARD layout: every member searches the whole batch on its shard ...
-  COLTT_TRY(for_members(g, [&](size_t j) -> int {
-    Member& x = *g->m[j];
-    const float* dq;
-    if (d_queries_per_member) dq = d_queries_per_member[j];
-    else {
-      COLTT_TRY(x.d_q.reserve(nq * g->dim * 4));
-      COLTT_HIP(hipMemcpyAsync(x.d_q.p, queries, nq * g->dim * 4, hipMemcpyHostToDevice, x.stream));
-      COLTT_HIP(hipStreamSynchronize(x.stream));
-      dq = x.d_q.as<float>();
-    }
-    COLTT_TRY(x.d_ids.reserve(per * 8)); COLTT_TRY(x.d_sc.reserve(per * 4)); COLTT_TRY(x.d_cnt.reserve(nq * 4));
-    COLTT_TRY(x.d_pack.reserve(per * sizeof(Rec)));
-    if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, nq, k, ef_override, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), nullptr));
-    else COLTT_TRY(coltt_flat_search_device(x.h, dq, nq, k, select, mode, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>()));
-    pack_topk_kernel<<<ceil_div(per, 256), 256, 0, x.stream>>>(x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), (uint32_t)nq, k, x.d_pack.as<Rec>());
+// ---- VertexSearch / Hnsw.Search over the whole collection ----------------------------------------------------------------------
+}  // extern "C" (the pipeline below is C++; the entry points follow it)
+
+namespace {
+double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+// a failed exchange of a shared-memory group is final: the peers, which are or will be waiting for this process, stop at once
+void poison(Group* g) { if (g->exchange == COLTT_EXCHANGE_SHM && g->shm && g->shm->hdr) g->shm->hdr->failed.store(1, std::memory_order_release); }
+}  // namespace
+
+// stages B + C of one batch, on the exchange thread
+int Group::exchange_and_merge(Job& j) {
+  Slot& sl = slots[j.slot];
+  const size_t nm = m.size(), per = j.nq * (size_t)j.k;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < nm; i++) {   // pack on the comm stream: the search that produced the arrays has completed (stage A is synchronous)
+    Member& x = *m[i]; SlotMember& b = *sl.mb[i];
+    COLTT_TRY(use_device(x.device));
+    pack_topk_kernel<<<ceil_div(per, 256), 256, 0, x.cstream>>>(b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), (uint32_t)j.nq, j.k, b.d_pack.as<Rec>());
     COLTT_HIP(hipGetLastError());
-    if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(x.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
-    return COLTT_OK;
-  }));
-  // ---- ... ONE all-gather of the packed per-shard top-k (RCCL over xGMI), then the host-side final merge
-  if (g->exchange == COLTT_EXCHANGE_SHM) {
+  }
+  if (exchange == COLTT_EXCHANGE_SHM) {
     // the local members' records come to the host, then travel rank-major through the shared segment, a chunk of queries at a
     // time when the batch is larger than a slot; every process merges every chunk itself (an all-gather, like the RCCL path)
-    g->h_local.resize(nm * per);
-    for (size_t j = 0; j < nm; j++) {
-      Member& x = *g->m[j];
-      COLTT_DEVICE(x.device);
-      COLTT_HIP(hipMemcpyAsync(g->h_local.data() + j * per, x.d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.stream));
+    sl.h_local.resize(nm * per);
+    for (size_t i = 0; i < nm; i++) {
+      Member& x = *m[i];
+      COLTT_TRY(use_device(x.device));
+      COLTT_HIP(hipMemcpyAsync(sl.h_local.data() + i * per, sl.mb[i]->d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.cstream));
     }
-    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
-    const size_t q_chunk = std::max<size_t>(1, (size_t)(g->shm->cap / ((size_t)k * sizeof(Rec))));
-    for (size_t q0 = 0; q0 < nq; q0 += q_chunk) {
-      const size_t qn = std::min(q_chunk, nq - q0), cper = qn * (size_t)k;
-      g->h_chunk_in.resize(nm * cper); g->h_chunk_out.resize((size_t)g->world * cper);
-      for (size_t j = 0; j < nm; j++) std::memcpy(g->h_chunk_in.data() + j * cper, g->h_local.data() + j * per + q0 * k, cper * sizeof(Rec));
-      COLTT_TRY(shm_allgather(g->shm.get(), g->h_chunk_in.data(), cper * sizeof(Rec), g->h_chunk_out.data()));
-      COLTT_TRY(coltt_group_merge_host(g->h_chunk_out.data(), g->world, qn, k, nearest, out_ids + q0 * k, out_scores + q0 * k, out_counts + q0));
+    for (auto& xp : m) { COLTT_TRY(use_device(xp->device)); COLTT_HIP(hipStreamSynchronize(xp->cstream)); }
+    const size_t q_chunk = std::max<size_t>(1, (size_t)(shm->cap / ((size_t)j.k * sizeof(Rec))));
+    for (size_t q0 = 0; q0 < j.nq; q0 += q_chunk) {
+      const size_t qn = std::min(q_chunk, j.nq - q0), cper = qn * (size_t)j.k;
+      sl.h_chunk_in.resize(nm * cper); sl.h_chunk_out.resize((size_t)world * cper);
+      for (size_t i = 0; i < nm; i++) std::memcpy(sl.h_chunk_in.data() + i * cper, sl.h_local.data() + i * per + q0 * j.k, cper * sizeof(Rec));
+      const auto te = std::chrono::steady_clock::now();
+      COLTT_TRY(shm_allgather(shm.get(), sl.h_chunk_in.data(), cper * sizeof(Rec), sl.h_chunk_out.data()));
+      j.exchange_ms += ms_since(te);
+      const auto tm = std::chrono::steady_clock::now();
+      COLTT_TRY(coltt_group_merge_host(sl.h_chunk_out.data(), world, qn, j.k, j.nearest, j.out_ids + q0 * j.k, j.out_scores + q0 * j.k, j.out_counts + q0));
+      j.merge_ms += ms_since(tm);
     }
+    j.exchange_ms = ms_since(t0) - j.merge_ms;
     return COLTT_OK;
   }
-  COLTT_TRY(g->stage((size_t)g->world * per * sizeof(Rec)));
-  if (g->exchange == COLTT_EXCHANGE_RCCL) {
+  COLTT_TRY(sl.h_stage.reserve((size_t)world * per * sizeof(Rec)));
+  if (exchange == COLTT_EXCHANGE_RCCL) {
     Rccl* r = rccl();
     COLTT_NCCL(r, r->GroupStart());
     int bad = 0; std::string why;
-    for (auto& xp : g->m) { Member& x = *xp;
+    for (size_t i = 0; i < nm; i++) { Member& x = *m[i]; SlotMember& b = *sl.mb[i];
       if (use_device(x.device) != COLTT_OK) { bad = -1; why = g_last_error; break; }
-      const int e = r->AllGather(x.d_pack.p, x.d_gather.p, per * sizeof(Rec), 0 /*ncclInt8*/, x.comm, x.stream);
+      const int e = r->AllGather(b.d_pack.p, b.d_gather.p, per * sizeof(Rec), 0 /*ncclInt8*/, x.comm, x.cstream);
       if (e != 0) { bad = e; why = std::string("ncclAllGather: ") + r->GetErrorString(e); break; }
     }
     const int ge = r->GroupEnd();   // always closed, also after a failure inside the group
     if (bad) return fail(COLTT_E_DEVICE, "group_search: %s", why.c_str());
     if (ge != 0) return fail(COLTT_E_DEVICE, "group_search: ncclGroupEnd: %s", r->GetErrorString(ge));
-    Member& x0 = *g->m[0];
-    COLTT_DEVICE(x0.device);
-    COLTT_HIP(hipMemcpyAsync(g->h_stage, x0.d_gather.p, (size_t)g->world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.stream));
-    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+    Member& x0 = *m[0];
+    COLTT_TRY(use_device(x0.device));
+    COLTT_HIP(hipMemcpyAsync(sl.h_stage.p, sl.mb[0]->d_gather.p, (size_t)world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.cstream));
+    for (auto& xp : m) { COLTT_TRY(use_device(xp->device)); COLTT_HIP(hipStreamSynchronize(xp->cstream)); }
   } else {
-    for (size_t j = 0; j < nm; j++) {
-      Member& x = *g->m[j];
-      COLTT_DEVICE(x.device);
-      COLTT_HIP(hipMemcpyAsync(g->h_stage + (size_t)x.rank * per, x.d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.stream));
+    for (size_t i = 0; i < nm; i++) {
+      Member& x = *m[i];
+      COLTT_TRY(use_device(x.device));
+      COLTT_HIP(hipMemcpyAsync(sl.h_stage.as<Rec>() + (size_t)x.rank * per, sl.mb[i]->d_pack.p, per * sizeof(Rec), hipMemcpyDeviceToHost, x.cstream));
     }
-    for (auto& xp : g->m) { Member& x = *xp; COLTT_DEVICE(x.device); COLTT_HIP(hipStreamSynchronize(x.stream)); }
+    for (auto& xp : m) { COLTT_TRY(use_device(xp->device)); COLTT_HIP(hipStreamSynchronize(xp->cstream)); }
   }
-  return coltt_group_merge_host(g->h_stage, g->world, nq, k, nearest, out_ids, out_scores, out_counts);
+  j.exchange_ms = ms_since(t0);
+  const auto tm = std::chrono::steady_clock::now();
+  COLTT_TRY(coltt_group_merge_host(sl.h_stage.p, world, j.nq, j.k, j.nearest, j.out_ids, j.out_scores, j.out_counts));
+  j.merge_ms = ms_since(tm);
+  return COLTT_OK;
 }
+
+void Group::exchange_loop() {
+  for (;;) {
+    std::shared_ptr<Job> j;
+    {
+      std::unique_lock<std::mutex> lk(q_mu);
+      q_cv.wait(lk, [&] { return stop || !queue.empty(); });
+      if (queue.empty()) return;   // stop, nothing left in flight
+      j = queue.front(); queue.pop_front();
+    }
+    g_last_error.clear();
+    j->rc = exchange_and_merge(*j);
+    if (j->rc != COLTT_OK) { j->err = g_last_error; poison(this); }
+    {
+      std::lock_guard<std::mutex> lk(q_mu);
+      j->done = true; slot_busy[j->slot] = false;
+      t_batches++; t_search += j->search_ms; t_exchange += j->exchange_ms; t_merge += j->merge_ms;
+    }
+    slot_cv.notify_all(); done_cv.notify_all();
+  }
+}
+
+namespace {
+
+// stage A of a shard search + hand-over to the exchange thread.  d_queries_per_member != NULL: the batch already lives on every
+// member's device ([n_local] pointers, nq x dim f32 each); otherwise `queries` is a host array broadcast to the members.
+int shard_begin(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select, int mode,
+                uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts, uint64_t* out_ticket) {
+  const bool hn = g->kind == COLTT_GROUP_HNSW;
+  const size_t per = nq * (size_t)k;
+  auto job = std::make_shared<Job>();
+  job->nq = nq; job->k = k; job->nearest = hn ? 1 : (select == COLTT_SELECT_NEAREST);
+  job->out_ids = out_ids; job->out_scores = out_scores; job->out_counts = out_counts;
+  std::lock_guard<std::mutex> lk(g->call_mu);   // one stage A at a time; tickets are taken in this order
+  {
+    std::unique_lock<std::mutex> ql(g->q_mu);   // a slot: at most GROUP_SLOTS batches between their search and the end of their merge
+    g->slot_cv.wait(ql, [&] { for (int i = 0; i < GROUP_SLOTS; i++) if (!g->slot_busy[i]) return true; return false; });
+    for (int i = 0; i < GROUP_SLOTS; i++) if (!g->slot_busy[i]) { job->slot = i; g->slot_busy[i] = true; break; }
+  }
+  Slot& sl = g->slots[job->slot];
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = for_members(g, [&](size_t j) -> int {
+    Member& x = *g->m[j]; SlotMember& b = *sl.mb[j];
+    const float* dq;
+    if (d_queries_per_member) dq = d_queries_per_member[j];
+    else {
+      COLTT_TRY(b.d_q.reserve(nq * g->dim * 4));
+      COLTT_HIP(hipMemcpyAsync(b.d_q.p, queries, nq * g->dim * 4, hipMemcpyHostToDevice, x.stream));
+      COLTT_HIP(hipStreamSynchronize(x.stream));
+      dq = b.d_q.as<float>();
+    }
+    COLTT_TRY(b.d_ids.reserve(per * 8)); COLTT_TRY(b.d_sc.reserve(per * 4)); COLTT_TRY(b.d_cnt.reserve(nq * 4));
+    COLTT_TRY(b.d_pack.reserve(per * sizeof(Rec)));
+    if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(b.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
+    if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, nq, k, ef_override, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), nullptr));
+    else COLTT_TRY(coltt_flat_search_device(x.h, dq, nq, k, select, mode, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>()));
+    return COLTT_OK;
+  });
+  job->search_ms = ms_since(t0);
+  std::lock_guard<std::mutex> ql(g->q_mu);
+  if (rc != COLTT_OK) {   // nothing was handed over: the slot goes back, the peers of a shared-memory group are released
+    g->slot_busy[job->slot] = false; g->slot_cv.notify_all();
+    poison(g);
+    return rc;
+  }
+  job->ticket = g->next_ticket++;
+  g->jobs[job->ticket] = job;
+  g->queue.push_back(job);
+  g->q_cv.notify_one();
+  *out_ticket = job->ticket;
+  return COLTT_OK;
+}
+
+int shard_end(Group* g, uint64_t ticket) {
+  std::shared_ptr<Job> j;
+  {
+    std::unique_lock<std::mutex> lk(g->q_mu);
+    auto it = g->jobs.find(ticket);
+    if (it == g->jobs.end()) return fail(COLTT_E_NOT_FOUND, "group_search_end: unknown ticket %llu", (unsigned long long)ticket);
+    j = it->second;
+    g->done_cv.wait(lk, [&] { return j->done; });
+    g->jobs.erase(it);
+  }
+  if (j->rc != COLTT_OK) { g_last_error = j->err; return j->rc; }
+  return COLTT_OK;
+}
+
+// rank-symmetric argument errors are returned BEFORE anything is begun: every process sees the same bad argument, nobody is left
+// waiting, and the shared segment is not poisoned by them
+int check_search_args(Group* g, uint32_t k) {
+  if (k == 0) return fail(COLTT_E_INVALID, "group_search: k must be >= 1");
+  if (g->exchange == COLTT_EXCHANGE_SHM && g->shm && (uint64_t)k * sizeof(Rec) > g->shm->cap)
+    return fail(COLTT_E_INVALID, "group_search: k = %u needs %llu bytes per rank and query, the shared segment holds %llu per rank (COLTT_SHM_MB)", k,
+                (unsigned long long)((uint64_t)k * sizeof(Rec)), (unsigned long long)g->shm->cap);
+  return COLTT_OK;
+}
+
+int replica_search(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select, int mode,
+                   uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  std::lock_guard<std::mutex> lk(g->call_mu);
+  const size_t nm = g->m.size();
+  const bool hn = g->kind == COLTT_GROUP_HNSW;
+  // the batch is split into contiguous slices, one per member; answers land in place — no exchange
+  return for_members(g, [&](size_t j) -> int {
+    const size_t lo = nq * j / nm, hi = nq * (j + 1) / nm;
+    if (hi == lo) return COLTT_OK;
+    Member& x = *g->m[j];
+    if (d_queries_per_member) {
+      COLTT_TRY(x.d_ids.reserve((hi - lo) * k * 8)); COLTT_TRY(x.d_sc.reserve((hi - lo) * k * 4)); COLTT_TRY(x.d_cnt.reserve((hi - lo) * 4));
+      const float* dq = d_queries_per_member[j] + lo * g->dim;
+      if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, hi - lo, k, ef_override, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>(), nullptr));
+      else COLTT_TRY(coltt_flat_search_device(x.h, dq, hi - lo, k, select, mode, x.d_ids.as<uint64_t>(), x.d_sc.as<float>(), x.d_cnt.as<uint32_t>()));
+      COLTT_HIP(hipMemcpyAsync(out_ids + lo * k, x.d_ids.p, (hi - lo) * k * 8, hipMemcpyDeviceToHost, x.stream));
+      COLTT_HIP(hipMemcpyAsync(out_scores + lo * k, x.d_sc.p, (hi - lo) * k * 4, hipMemcpyDeviceToHost, x.stream));
+      COLTT_HIP(hipMemcpyAsync(out_counts + lo, x.d_cnt.p, (hi - lo) * 4, hipMemcpyDeviceToHost, x.stream));
+      COLTT_HIP(hipStreamSynchronize(x.stream));
+      return COLTT_OK;
+    }
+    if (hn) return coltt_hnsw_search(x.h, queries + lo * g->dim, hi - lo, k, ef_override, out_ids + lo * k, out_scores + lo * k, out_counts + lo, nullptr);
+    return coltt_flat_search(x.h, queries + lo * g->dim, hi - lo, k, select, mode, out_ids + lo * k, out_scores + lo * k, out_counts + lo);
+  });
+}
+
+// One synchronous call.  COLTT_GROUP_SUBBATCH=<queries> splits a larger call into sub-batches that go through the pipeline one behind
+// the other (the exchange + merge of sub-batch i under the search of i + 1); default: the call is one batch — callers that stream
+// batches overlap them with coltt_group_search_begin / _end instead, which costs the search kernels no occupancy.
+int group_search(Group* g, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select,
+                 int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+  if (nq == 0) return COLTT_OK;
+  COLTT_TRY(check_search_args(g, k));
+  if (g->layout == COLTT_LAYOUT_REPLICA) return replica_search(g, queries, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
+  static const size_t sub_knob = [] { const char* e = getenv("COLTT_GROUP_SUBBATCH"); return (e && *e) ? (size_t)std::max(1L, atol(e)) : (size_t)0; }();
+  const size_t sub = sub_knob ? sub_knob : nq;
+  std::vector<uint64_t> tickets;
+  std::vector<const float*> dq(g->m.size());
+  int rc = COLTT_OK;
+  for (size_t q0 = 0; q0 < nq && rc == COLTT_OK; q0 += sub) {
+    const size_t qn = std::min(sub, nq - q0);
+    if (d_queries_per_member) for (size_t j = 0; j < dq.size(); j++) dq[j] = d_queries_per_member[j] + q0 * g->dim;
+    uint64_t t = 0;
+    rc = shard_begin(g, queries ? queries + q0 * g->dim : nullptr, d_queries_per_member ? dq.data() : nullptr, qn, k, select, mode, ef_override,
+                     out_ids + q0 * k, out_scores + q0 * k, out_counts + q0, &t);
+    if (rc == COLTT_OK) tickets.push_back(t);
+  }
+  std::string first_err = rc != COLTT_OK ? g_last_error : std::string();
+  for (uint64_t t : tickets) { const int e = shard_end(g, t); if (e != COLTT_OK && rc == COLTT_OK) { rc = e; first_err = g_last_error; } }
+  if (rc != COLTT_OK) g_last_error = first_err;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
 
 int coltt_group_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, int select, int mode, uint32_t ef_override,
                        uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
@@ -643,6 +814,40 @@ int coltt_group_search_device(coltt_handle_t h, const float* const* d_queries_pe
   if (nq && (!d_queries_per_member || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "group_search_device: NULL buffer");
   ReadLock rl(g->rw);
   return group_search(g.get(), nullptr, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts);
+}
+
+// Streaming form of a shard search: _begin returns when every local member has searched the batch (stage A) and the batch's exchange
+// and merge have been queued; _end blocks until the merged answers are in the out arrays handed to _begin (which must stay valid until
+// then).  A caller that keeps one batch begun while it ends the previous one hides the all-gather and the host merge under the next
+// search.  At most 3 batches may be begun and not ended (a fourth _begin waits for a slot).  Multi-process groups: every process makes
+// the same _begin calls in the same order.
+int coltt_group_search_begin(coltt_handle_t h, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k,
+                             int select, int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
+                             uint64_t* out_ticket) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_search_begin: unknown handle");
+  if (!out_ticket) return fail(COLTT_E_INVALID, "group_search_begin: out_ticket is NULL");
+  if (g->layout != COLTT_LAYOUT_SHARD) return fail(COLTT_E_INVALID, "group_search_begin: replicas exchange nothing (use coltt_group_search)");
+  if (nq == 0 || (!queries && !d_queries_per_member) || !out_ids || !out_scores || !out_counts) return fail(COLTT_E_INVALID, "group_search_begin: empty batch or NULL buffer");
+  ReadLock rl(g->rw);
+  COLTT_TRY(check_search_args(g.get(), k));
+  return shard_begin(g.get(), d_queries_per_member ? nullptr : queries, d_queries_per_member, nq, k, select, mode, ef_override, out_ids, out_scores, out_counts, out_ticket);
+}
+
+int coltt_group_search_end(coltt_handle_t h, uint64_t ticket) {
+  auto g = lookup<Group>(h);
+  if (!g) return fail(COLTT_E_NOT_FOUND, "group_search_end: unknown handle");
+  return shard_end(g.get(), ticket);
+}
+
+// cumulative wall-clock of the finished shard-search batches of this group: out = {batches, search_ms, exchange_ms, merge_ms} —
+// search = stage A (every member's search, concurrent), exchange = pack + all-gather + D2H, merge = the host merge
+int coltt_group_timing(coltt_handle_t h, double* out4) {
+  auto g = lookup<Group>(h);
+  if (!g || !out4) return fail(COLTT_E_NOT_FOUND, "group_timing: unknown handle");
+  std::lock_guard<std::mutex> lk(g->q_mu);
+  out4[0] = (double)g->t_batches; out4[1] = g->t_search; out4[2] = g->t_exchange; out4[3] = g->t_merge;
+  return COLTT_OK;
 }
 
 }  // extern "C"

@@ -228,6 +228,22 @@ int coltt_normalize(const float* in, size_t n, uint32_t dim, float* out) {
   return COLTT_OK;
 }
 
+// The same arithmetic on the HOST, for the one-vector-per-RPC callers (vectorindex.Normalize in the Go layer): no device, no stream, no
+// allocation, cannot fail for valid pointers — the reference's Normalize is infallible too.  Sequential f32 sum (mul, then add: the
+// library is built -ffp-contract=off and without fast-math, so neither FMA nor a re-associated reduction can appear), sqrt through
+// float64, one IEEE divide per element; a zero vector comes back as zeros (metadata.go:107-123).
+int coltt_normalize_host(const float* in, uint32_t dim, float* out) {
+  if (dim == 0) return COLTT_OK;
+  if (!in || !out) return fail(COLTT_E_INVALID, "normalize_host: NULL input");
+  volatile float norm = 0.f;   // volatile: keeps the reduction scalar and in source order whatever the host vectoriser is told
+  for (uint32_t i = 0; i < dim; i++) { const float p = in[i] * in[i]; norm = norm + p; }
+  const float nsq = norm;
+  if (nsq == 0.f) { for (uint32_t i = 0; i < dim; i++) out[i] = 0.f; return COLTT_OK; }
+  const float nr = (float)std::sqrt((double)nsq);
+  for (uint32_t i = 0; i < dim; i++) out[i] = in[i] / nr;
+  return COLTT_OK;
+}
+
 int coltt_quant_lower(int quant, const float* in, size_t n, void* out_codes) {
   if (n == 0) return COLTT_OK;
   if (!in || !out_codes) return fail(COLTT_E_INVALID, "quant_lower: NULL input");

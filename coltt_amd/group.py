@@ -152,3 +152,24 @@ class Group:
         L.check(L.lib().coltt_group_search_device(self.h, ptrs, C.c_size_t(nq), C.c_uint32(k), select, mode, C.c_uint32(ef),
                                                   L.vp(out[0]), L.vp(out[1]), L.vp(out[2])))
         return out
+
+    def SearchBegin(self, k, queries=None, d_queries_per_member=None, nq=None, select=L.SELECT_NEAREST, mode=L.MODE_EXACT, ef=0):
+        """coltt_group_search_begin: stage A now, exchange + merge queued; returns (ticket, out arrays) — keep `out` alive until SearchEnd"""
+        if queries is not None:
+            q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim); nq = len(q); qp = L.vp(q); ptrs = None
+        else:
+            q = None; qp = None; ptrs = (C.c_void_p * len(d_queries_per_member))(*d_queries_per_member)
+        out = (np.zeros((nq, k), np.uint64), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32))
+        t = C.c_uint64(0)
+        L.check(L.lib().coltt_group_search_begin(self.h, qp, ptrs, C.c_size_t(nq), C.c_uint32(k), select, mode, C.c_uint32(ef),
+                                                 L.vp(out[0]), L.vp(out[1]), L.vp(out[2]), C.byref(t)))
+        return t.value, out
+
+    def SearchEnd(self, ticket):
+        L.check(L.lib().coltt_group_search_end(self.h, C.c_uint64(int(ticket))))
+
+    def Timing(self):
+        """cumulative ms of the finished shard-search batches: stage A (members' searches), exchange (pack + all-gather + D2H), host merge"""
+        a = (C.c_double * 4)()
+        L.check(L.lib().coltt_group_timing(self.h, a))
+        return {"batches": int(a[0]), "search_ms": a[1], "exchange_ms": a[2], "merge_ms": a[3]}

@@ -96,14 +96,25 @@ func bptr(v []byte) *C.uint8_t {
 
 func Init(device int) error { return call(func() C.int { return C.coltt_init(C.int(device)) }) }
 
-// Normalize — edge.Normalize / vectorindex.Normalize (edge/vectorstore.go:173-189; core/vectorindex/metadata.go:107-123) computed by
-// the library (coltt_normalize); a zero vector comes back as zeros, as in the reference.
-func Normalize(v []float32) ([]float32, error) {
+// Normalize — edge.Normalize / vectorindex.Normalize (edge/vectorstore.go:173-189; core/vectorindex/metadata.go:107-123) through
+// coltt_normalize_host: the library's HOST copy of the arithmetic (sequential f32 sum, float64 sqrt, per-element divide).  It touches no
+// device, stream or allocator, so a call per RPC cannot stall concurrent searches, needs no initialised GPU and — like the reference's
+// function — cannot fail; a zero vector comes back as zeros.  Batches (tests, bulk ingest) use NormalizeBatch.
+func Normalize(v []float32) []float32 {
 	out := make([]float32, len(v))
-	if len(v) == 0 {
+	if len(v) != 0 {
+		C.coltt_normalize_host(fptr(v), C.uint32_t(len(v)), fptr(out))
+	}
+	return out
+}
+
+// NormalizeBatch — n row-major vectors on the device (coltt_normalize); for bulk paths only.
+func NormalizeBatch(v []float32, dim uint32) ([]float32, error) {
+	out := make([]float32, len(v))
+	if len(v) == 0 || dim == 0 {
 		return out, nil
 	}
-	err := call(func() C.int { return C.coltt_normalize(fptr(v), 1, C.uint32_t(len(v)), fptr(out)) })
+	err := call(func() C.int { return C.coltt_normalize(fptr(v), C.size_t(len(v)/int(dim)), C.uint32_t(dim), fptr(out)) })
 	return out, err
 }
 

@@ -167,6 +167,73 @@ func (g *Group) Search(queries []float32, nq int, k uint32, sel, mode int, ef ui
 	return
 }
 
+// PendingSearch is a batch between SearchBegin and End.  The library writes the merged answers AFTER SearchBegin has returned, so
+// the out arrays are C memory (cgo: no Go pointer may be retained by C past the call); End copies them into Go slices and frees them.
+type PendingSearch struct {
+	g      *Group
+	ticket C.uint64_t
+	nq     int
+	k      uint32
+	ids    *C.uint64_t
+	scores *C.float
+	counts *C.uint32_t
+}
+
+// SearchBegin — coltt_group_search_begin: every local member searches the batch now; the exchange (pack + one all-gather + D2H on
+// the comm streams) and the host merge are queued behind the earlier batches'.  A caller that begins batch i+1 before it Ends batch i
+// hides exchange and merge under the next search.  At most 3 batches may be pending.  Multi-process groups: same calls, same order.
+func (g *Group) SearchBegin(queries []float32, nq int, k uint32, sel, mode int, ef uint32) (*PendingSearch, error) {
+	if k == 0 || nq == 0 {
+		return nil, fmt.Errorf("colttgpu: empty batch")
+	}
+	if err := checkDim(queries, g.dim, nq); err != nil {
+		return nil, err
+	}
+	p := &PendingSearch{g: g, nq: nq, k: k,
+		ids:    (*C.uint64_t)(C.malloc(C.size_t(nq * int(k) * 8))),
+		scores: (*C.float)(C.malloc(C.size_t(nq * int(k) * 4))),
+		counts: (*C.uint32_t)(C.malloc(C.size_t(nq * 4)))}
+	err := call(func() C.int {
+		return C.coltt_group_search_begin(g.h, fptr(queries), nil, C.size_t(nq), C.uint32_t(k), C.int(sel), C.int(mode), C.uint32_t(ef),
+			p.ids, p.scores, p.counts, &p.ticket)
+	})
+	if err != nil {
+		p.free()
+		return nil, err
+	}
+	return p, nil
+}
+
+func (p *PendingSearch) free() {
+	C.free(unsafe.Pointer(p.ids))
+	C.free(unsafe.Pointer(p.scores))
+	C.free(unsafe.Pointer(p.counts))
+	p.ids, p.scores, p.counts = nil, nil, nil
+}
+
+// End blocks until the batch's merged answers are complete and returns them (rows ascending by (score, id)).
+func (p *PendingSearch) End() (ids []uint64, scores []float32, counts []uint32, err error) {
+	defer p.free()
+	if err = call(func() C.int { return C.coltt_group_search_end(p.g.h, p.ticket) }); err != nil {
+		return
+	}
+	n := p.nq * int(p.k)
+	ids = make([]uint64, n)
+	scores = make([]float32, n)
+	counts = make([]uint32, p.nq)
+	copy(ids, unsafe.Slice((*uint64)(unsafe.Pointer(p.ids)), n))
+	copy(scores, unsafe.Slice((*float32)(unsafe.Pointer(p.scores)), n))
+	copy(counts, unsafe.Slice((*uint32)(unsafe.Pointer(p.counts)), p.nq))
+	return
+}
+
+// Timing — cumulative ms of the finished shard-search batches: members' searches, exchange (pack + all-gather + D2H), host merge.
+func (g *Group) Timing() (batches uint64, searchMs, exchangeMs, mergeMs float64, err error) {
+	var o [4]C.double
+	err = call(func() C.int { return C.coltt_group_timing(g.h, &o[0]) })
+	return uint64(o[0]), float64(o[1]), float64(o[2]), float64(o[3]), err
+}
+
 // GroupBackend plugs a group under the micro-batcher (batcher.go), so single-query RPCs over a sharded collection ride in batches.
 func GroupBackend(g *Group, sel, mode int, ef uint32) Backend {
 	return func(q []float32, nq int, k uint32) ([]uint64, []float32, []uint32, error) {

@@ -165,17 +165,10 @@ func decodeMetadata(blob []byte) (Metadata, error) {
 	return m, nil
 }
 
-// Normalize — metadata.go:107-123.  Kept as an identifier for callers (core/core_helper.go); the arithmetic lives in the library
-// (coltt_normalize: the same sequential f32 sum, float64 sqrt and per-element divide the reference runs), so there is ONE copy of it.
-// The reference's Normalize cannot fail; a device error here panics, which the RPC goroutine recovers into reply.Error
-// (edge/edge.go:618-624).
-func Normalize(v []float32) []float32 {
-	out, err := colttgpu.Normalize(v)
-	if err != nil {
-		panic(err)
-	}
-	return out
-}
+// Normalize — metadata.go:107-123.  Kept as an identifier for callers (core/core_helper.go).  The arithmetic has ONE copy, in the
+// library, and this calls its host-side entry (coltt_normalize_host): no device work, no allocation beyond the result, infallible — as
+// the reference's.
+func Normalize(v []float32) []float32 { return colttgpu.Normalize(v) }
 
 // ---------------------------------------------------------------------------------------------- results (search.go)
 type SearchResult []SearchResultItem

@@ -66,6 +66,9 @@ int coltt_distance_pairs(int metric, int order, const float* a, const float* b, 
                          float* out);
 /* edge.Normalize / vectorindex.Normalize (edge/vectorstore.go:173-189; core/vectorindex/metadata.go:107-123) */
 int coltt_normalize(const float* in, size_t n, uint32_t dim, float* out);
+/* the same function for ONE vector on the host: no device, no allocation, cannot fail for valid pointers (what the Go layer's
+ * vectorindex.Normalize / edge.Normalize call once per RPC; bit-identical to coltt_normalize and to the reference) */
+int coltt_normalize_host(const float* in, uint32_t dim, float* out);
 /* Quantization.Lower: compresshelper.Fromfloat32 / BF16Fromfloat32 / F8Fromfloat32 per element
  * (edge/f16_quantization.go:47-53; pkg/compresshelper/float16.go:124-126, bf16.go:120-122, float8.go:120-122) */
 int coltt_quant_lower(int quant, const float* in, size_t n_elems, void* out_codes);
@@ -309,6 +312,20 @@ int coltt_group_search(coltt_handle_t h, const float* queries, size_t nq, uint32
 /* same, the query batch already resident on every local member's device: d_queries_per_member[i] -> [nq][dim] f32 */
 int coltt_group_search_device(coltt_handle_t h, const float* const* d_queries_per_member, size_t nq, uint32_t k, int select, int mode,
                               uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
+/* Streaming form of a SHARD-layout search (the exchange "issued on a comm stream and overlapped with the next batch";
+ * the shape of the reference's local-queue-then-merge scan, edge/none_vectorstore.go:148-178, with the merge taken off the critical
+ * path).  _begin returns when every local member has searched the batch and the batch's exchange (pack + ONE all-gather + D2H on the
+ * members' comm streams) and host merge have been queued behind the earlier batches'; _end blocks until the merged answers are in the
+ * out arrays handed to _begin (they must stay valid until then) and returns that batch's status.  Exactly one of queries (host) /
+ * d_queries_per_member (device) is non-NULL.  At most 3 batches may be begun and not ended.  Multi-process groups: every process
+ * makes the same _begin calls in the same order (the collectives are issued in ticket order). */
+int coltt_group_search_begin(coltt_handle_t h, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k,
+                             int select, int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
+                             uint64_t* out_ticket);
+int coltt_group_search_end(coltt_handle_t h, uint64_t ticket);
+/* cumulative wall-clock of this group's finished shard-search batches: out4 = {batches, search_ms (stage A: the members' searches),
+ * exchange_ms (pack + all-gather + D2H), merge_ms (host merge)} */
+int coltt_group_timing(coltt_handle_t h, double* out4);
 /* the host-side final merge on its own (no device needed): recs = [world][nq][k] packed 16-byte records {u64 id, f32 score,
  * u32 valid}, each shard's valid records ascending by (score, id); nearest != 0: the k smallest of the union, else the k
  * largest (edge.PriorityQueue semantics), both returned ascending. */

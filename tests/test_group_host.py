@@ -40,3 +40,40 @@ def test_group_merge_host_equals_sorted_union():
                 want = u[:k] if nearest else u[-k:]
                 assert cnt[q] == len(want)
                 assert [(float(sc[q, j]), int(ids[q, j])) for j in range(cnt[q])] == want, (world, q, nearest)
+
+
+def test_group_merge_host_split_over_threads_equals_sorted_union():
+    """batches above 1024 queries are merged by several host threads (query ranges are independent): same answers, every row filled"""
+    rng = np.random.default_rng(11)
+    world, nq, k = 8, 5000, 10
+    sc = np.sort(rng.random((world, nq, k)).astype(np.float32), axis=2)
+    recs = np.zeros((world, nq, k), GG.REC_DTYPE)
+    recs["score"] = sc
+    recs["id"] = (rng.integers(0, 10**6, (world, nq, k)).astype(np.uint64) * np.uint64(world) + np.arange(world, dtype=np.uint64)[:, None, None])
+    cnt_in = rng.integers(0, k + 1, (world, nq))
+    recs["valid"] = (np.arange(k)[None, None, :] < cnt_in[:, :, None]).astype(np.uint32)
+    for nearest in (True, False):
+        ids, s, cnt = GG.merge_host(recs, world, nq, k, nearest)
+        for q in list(range(0, nq, 97)) + [nq - 1, nq // 8, nq // 8 - 1, nq // 8 + 1]:
+            u = sorted((float(r["score"]), int(r["id"])) for w in range(world) for r in recs[w, q] if r["valid"])
+            want = u[:k] if nearest else u[-k:]
+            assert cnt[q] == len(want)
+            assert [(float(s[q, j]), int(ids[q, j])) for j in range(cnt[q])] == want, (q, nearest)
+        assert np.array_equal(cnt, np.minimum(k, cnt_in.sum(0)))
+
+
+def test_normalize_host_is_the_reference_arithmetic_without_a_device():
+    """coltt_normalize_host (what the Go layer's Normalize calls once per RPC): bit-identical to the oracle's restatement of
+    edge.Normalize (edge/vectorstore.go:173-189), zero vector -> zeros, no HIP device needed"""
+    import ctypes as C
+    from coltt_amd import _lib as L
+    f = L.lib().coltt_normalize_host
+    rng = np.random.default_rng(3)
+    for d in (1, 7, 8, 9, 128, 768, 1536):
+        for scale in (1.0, 1e-20, 1e18):
+            v = (rng.standard_normal(d) * scale).astype(np.float32)
+            out = np.empty(d, np.float32)
+            assert f(L.vp(v), C.c_uint32(d), L.vp(out)) == 0
+            assert np.array_equal(out.view(np.uint32), O.normalize(v).view(np.uint32)), (d, scale)
+    z = np.zeros(33, np.float32); out = np.ones(33, np.float32)
+    assert f(L.vp(z), C.c_uint32(33), L.vp(out)) == 0 and not out.any()
