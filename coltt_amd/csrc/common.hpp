@@ -113,6 +113,7 @@ struct Policy {
   bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
   uint32_t lat_max_nq = 0;     // ... and its value
   long long visg_budget_mb = -1;  // COLTT_VISG_BUDGET_MB (test knob)
+  bool rows8_fail = false;     // COLTT_ROWS8_FAIL=1 (test knob): the allocation of the line-transposed row copy is made to fail
 };
 Policy policy();               // a copy of the current snapshot
 inline bool small_call_staging() { return policy().staging; }
@@ -204,6 +205,12 @@ class DeviceScope {
 // stores / indexes on an explicit device (group.hip places one collection shard per GPU)
 int flat_create_on(int device, uint32_t dim, int metric, int quant, coltt_handle_t* out);
 int hnsw_create_on(int device, uint32_t dim, int metric, int quant, const coltt_hnsw_cfg* cfg, coltt_handle_t* out);
+
+// the product quantiser's kernels for an index that carries row-major codes of its own (pq.hip -> hnsw.hip, product-quantised HNSW)
+struct PqShape { uint32_t dim = 0, m = 0, C = 0, dsub = 0; int metric = 0; };
+int pq_snapshot(coltt_handle_t pq, PqShape* shape, DevBuf* cb_out, hipStream_t s);
+int pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_vecs, uint64_t n, uint8_t* d_codes, uint32_t row_bytes);
+int pq_lut_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, float* d_lut);
 
 inline size_t quant_bytes(int q) { return q == COLTT_Q_NONE ? 4 : (q == COLTT_Q_F8 ? 1 : 2); }
 

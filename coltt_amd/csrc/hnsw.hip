@@ -18,6 +18,7 @@
 #include "hnsw_dev.hpp"
 #include "hnsw_walk2.hpp"
 #include "hnsw_lat.hpp"
+#include "hnsw_pq.hpp"
 #include "prep.hpp"
 
 using namespace coltt;
@@ -279,6 +280,74 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 }
 
 
+
+// Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp): one wave per query, queries pulled from a global counter.
+// OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 / 3 + VIS_HBM: byte map, delta result set, Bloom filter if it fits).
+template <int METRIC, int QUANT, int OPT, int VISMODE>
+__global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
+                                                            const float* __restrict__ qnorms, const float* __restrict__ lut_g,
+                                                            const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t nq, uint32_t k,
+                                                            uint32_t ef, uint32_t ef_pad, uint32_t rerank, uint32_t vis_words,
+                                                            uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
+                                                            float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                            unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
+                                                            size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  WaveCtx w;
+  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  w.qs = reinterpret_cast<float*>(smem); w.qp = nullptr; w.scr = nullptr;
+  w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;
+  w.ef_pad = ef_pad;
+  if constexpr (VISMODE == VIS_LDS) {
+    w.vis = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)vis_words * 4;
+    w.hcap = vis_words; w.hcap_mask = vis_words - 1;
+    w.bloom = nullptr; w.bloom_words = 0; w.bloom_shift = 0;
+    w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0;
+  } else {
+    w.vis = nullptr; w.hcap = 0; w.hcap_mask = 0;
+    w.bloom = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)vis_words * 4;
+    w.bloom_words = vis_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(vis_words | 0x80000000u);
+    w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
+  }
+  float* const lut = reinterpret_cast<float*>(smem + off);
+  const AdcEval ev{codes, row_bytes, lut};
+  for (;;) {
+    const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
+    const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
+    if (qi >= nq) break;
+    w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
+    wave_sync();
+    for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    {  // the query's table: row_bytes x 256 f32, 16 bytes per lane and step
+      const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + (size_t)qi * row_bytes * 256);
+      u32x4v* dst = reinterpret_cast<u32x4v*>(lut);
+      for (uint32_t i = (uint32_t)lane; i < row_bytes * 64u; i += 64) dst[i] = src[i];
+    }
+    w.qnorm = qnorms[qi];
+    wave_sync();
+    uint32_t cur = (uint32_t)entry;
+    float curd = ev.adc(cur);   // minDistance := d(query, entrypoint) (hnsw.go:253), the same value in every lane
+    w.n_dist += 1;
+    for (int l = entry_level; l > 0; l--) greedy_level_adc(g, w, ev, cur, curd, l, lane);  // :254-256
+    w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    uint32_t len;
+    search_level2<M_L2, Q_F16, PROF_SEARCH_HBM, OPT, VISMODE, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259 (M_L2: no norms ride along; Q_F16: the adjacency prefetch)
+    uint32_t r = rerank == 0 ? len : (rerank > k ? rerank : k);
+    r = r < len ? r : len;
+    const uint32_t n = rerank_exact<METRIC, QUANT>(g, w, r, k, qi, out_ids, out_scores, lane);
+    if (lane == 0) {
+      out_counts[qi] = n;
+      atomicAdd(&stats[0], (unsigned long long)w.n_dist);
+      atomicAdd(&stats[1], (unsigned long long)w.n_exp);
+      atomicAdd(&stats[2], (unsigned long long)w.n_hops);
+      atomicAdd(&stats[3], (unsigned long long)r);
+      if (w.err) atomicOr(&stats[4], (unsigned long long)w.err);
+    }
+  }
+  if constexpr (VISMODE == VIS_HBM) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Graph construction (Hnsw.Insert, hnsw.go:104-167) for a batch of new vertices against the frozen graph.
 // Phase A (this kernel, one wave per new vertex): greedy descent above the vertex level (:126-130), then per
@@ -471,6 +540,10 @@ struct Hnsw : Object {
   // COLTT_ROWS8=0, or when the second copy cannot be allocated.
   DevBuf rows8; bool rows8_on = false; uint64_t n8done = 0;
   std::atomic<uint64_t> ev8_launches{0};   // search launches whose level-0 distances came from rows8
+  // hnsw_pq.hpp: a snapshot of a trained product quantiser and one row-major code per slot (derived data, maintained like rows8:
+  // writers encode the slots they added before they release the exclusive lock)
+  bool pq_on = false; PqShape pq_shape; uint32_t pq_row = 0 /* bytes per code row: m rounded up to 16 */; uint64_t pq_done = 0;
+  DevBuf pq_cb, pq_codes, pq_stage;
   bool dense = true; uint64_t dense_base = 0;
   std::unordered_map<uint64_t, uint32_t> id2slot;
   std::vector<uint64_t> h_ids;       // !dense
@@ -507,7 +580,14 @@ struct Hnsw : Object {
     if (slots > cap) {
       uint64_t nc = std::max<uint64_t>({slots, cap + cap / 2, 1024});
       COLTT_TRY(rows.reserve(nc * stride, true, stream));
-      if (rows8_on && rows8.reserve(nc * stride, true, stream) != COLTT_OK) {   // no room for the second copy: the pair-owned walk serves
+      auto rows8_alloc = [&]() -> int {
+        if (policy().rows8_fail) { void* t = nullptr; COLTT_HIP(hipMalloc(&t, (size_t)1 << 60)); }   // test knob: a real, failing allocation
+        return rows8.reserve(nc * stride, true, stream);
+      };
+      if (rows8_on && rows8_alloc() != COLTT_OK) {   // no room for the second copy: the pair-owned walk serves
+        // the failed hipMalloc left HIP's sticky last error behind (ROCm 7: hipGetLastError returns the last REAL error): consume it,
+        // or the next launch check of this very Insert / Reserve would report hipErrorOutOfMemory
+        (void)hipGetLastError();
         rows8_on = false; n8done = 0;
         if (rows8.p) { (void)hipFree(rows8.p); rows8.p = nullptr; rows8.cap = 0; }
         fprintf(stderr, "[coltt_gpu] hnsw: no memory for the line-transposed row copy (%llu B) — searches use the pair-owned rows\n", (unsigned long long)(nc * stride));
@@ -550,7 +630,11 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
 }
 
 // rows8 of the slots added since the last call (rows8.hpp); completes on the device before it returns
-int sync_rows8(Hnsw* x) {
+int sync_pq(Hnsw* x);
+int sync_rows8_only(Hnsw* x);
+// derived per-slot data of the slots a writer added: the line-transposed row copy, then the product-quantiser codes
+int sync_rows8(Hnsw* x) { COLTT_TRY(sync_rows8_only(x)); return sync_pq(x); }
+int sync_rows8_only(Hnsw* x) {
   if (!x->rows8_on || x->n8done >= x->n) { if (x->n8done > x->n) x->n8done = x->n; return COLTT_OK; }
   const uint64_t b = x->n8done, m = x->n - b;
   const uint64_t chunks = (uint64_t)x->stride / 16;
@@ -561,6 +645,34 @@ int sync_rows8(Hnsw* x) {
   COLTT_HIP(hipGetLastError());
   COLTT_HIP(hipStreamSynchronize(x->stream));
   x->n8done = x->n;
+  return COLTT_OK;
+}
+// stored rows [first, first + m) -> the f32 values the index's distance sees (what the quantiser encodes), packed [m][dim]
+template <int QUANT>
+__global__ void rows_to_f32_kernel(const uint8_t* __restrict__ rows, size_t stride, uint64_t first, uint64_t m, int dim, float* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * (uint64_t)dim) return;
+  const uint64_t i = t / dim; const int e = (int)(t - i * dim);
+  out[t] = load1<QUANT>(rows + (first + i) * stride, e);
+}
+// codes of the slots added since the last call (hnsw_pq.hpp); completes on the device before it returns
+int sync_pq(Hnsw* x) {
+  if (!x->pq_on || x->pq_done >= x->n) { if (x->pq_done > x->n) x->pq_done = x->n; return COLTT_OK; }
+  const size_t old = x->pq_codes.cap;
+  COLTT_TRY(x->pq_codes.reserve(std::max<uint64_t>(x->cap, x->n) * x->pq_row, true, x->stream));
+  if (x->pq_codes.cap > old) COLTT_HIP(hipMemsetAsync(x->pq_codes.as<uint8_t>() + old, 0, x->pq_codes.cap - old, x->stream));   // the bytes j >= m of a row read as code 0
+  const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)x->dim * 4));
+  COLTT_TRY(x->pq_stage.reserve(std::min<uint64_t>(chunk, x->n - x->pq_done) * x->dim * 4));
+  for (uint64_t b = x->pq_done; b < x->n; b += chunk) {
+    const uint64_t m = std::min<uint64_t>(chunk, x->n - b);
+#define COLTT_R2F(Q) rows_to_f32_kernel<Q><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>())
+    COLTT_DISPATCH_QUANT(x->quant, COLTT_R2F)
+#undef COLTT_R2F
+    COLTT_HIP(hipGetLastError());
+    COLTT_TRY(pq_encode_rowmajor(x->stream, x->pq_cb.as<float>(), x->pq_shape, x->pq_stage.as<float>(), m, x->pq_codes.as<uint8_t>() + b * x->pq_row, x->pq_row));
+  }
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  x->pq_done = x->n;
   return COLTT_OK;
 }
 // does this shape have a rows8 copy (rows8.hpp: f32 / 2-byte rows whose byte length is a multiple of 128)?
@@ -974,6 +1086,136 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
 }
 
 
+// ---- Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp) --------------------------------------------------------
+struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: LDS hash | 2: byte map + delta | 3: + Bloom */ uint32_t per_cu; };
+bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
+  PqGeom s{};
+  s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
+  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 1024;
+  if (fixed > 160 * 1024) return false;
+  const bool hbm_ok = x->vis_stride != 0 && x->vis_regions > 0;
+  // LDS hash: as search_geom sizes it; it must never need the reset path (err 8 -> the call is re-run over the byte map)
+  uint32_t hcap = std::min<uint32_t>(32768u, std::max<uint32_t>(8192u, next_pow2(ef * 48u)));
+  const bool lds_fits = fixed + (size_t)hcap * 4 <= 160 * 1024;
+  if (!force_hbm && !(wants_visg(ef) && hbm_ok) && lds_fits) { s.variant = 0; s.vis_words = hcap; s.lds = fixed + (size_t)hcap * 4; }
+  else {
+    if (!hbm_ok) return false;
+    // Bloom filter: the largest power of two (2..32 KiB) that does not cost a resident wave
+    const size_t waves = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (fixed + 2048)));
+    const size_t budget = (160 * 1024) / waves;
+    size_t kb = 32; while (kb >= 2 && fixed + kb * 1024 > budget) kb >>= 1;
+    if (kb >= 2) { s.variant = 3; s.vis_words = (uint32_t)(kb * 256); s.lds = fixed + kb * 1024; }
+    else { s.variant = 2; s.vis_words = 0; s.lds = fixed; }
+  }
+  s.per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / s.lds));
+  out = s;
+  return true;
+}
+
+template <int METRIC, int QUANT>
+int launch_pq_search(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t q0, uint32_t nq, uint32_t k,
+                     uint32_t rerank, uint32_t* counter, uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
+  typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, const float*, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                         uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
+  kern_t kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS>
+              : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM>;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  GraphView g = x->view();
+  kern<<<grid, 64, sg.lds, c->stream>>>(g, x->entry, x->entry_level, c->w_qeff.as<float>() + (size_t)q0 * x->dim, c->w_qn.as<float>() + q0, lut,
+                                        x->pq_codes.as<uint8_t>(), x->pq_row, nq, k, sg.ef, sg.ef_pad, rerank, sg.vis_words, counter, oi + (size_t)q0 * k,
+                                        os + (size_t)q0 * k, oc + q0, stats, x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
+                                        (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>() + region_base);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// one attempt; *retry_hbm: the LDS hash would have needed its reset path — the caller runs the same call over the byte map
+int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override, uint32_t rerank,
+                   uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact, bool force_hbm, bool* retry_hbm) {
+  *retry_hbm = false;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (out_n_exact) *out_n_exact = 0;
+  if (nq == 0) return COLTT_OK;
+  if (k == 0) return fail(COLTT_E_INVALID, "hnsw_pq_search: k must be >= 1");
+  if (!x->pq_on) return fail(COLTT_E_INVALID, "hnsw_pq_search: the index carries no product-quantiser codes (coltt_hnsw_pq_attach)");
+  if (x->pq_done != x->n) return fail(COLTT_E_DEVICE, "hnsw_pq_search: codes cover %llu of %llu slots", (unsigned long long)x->pq_done, (unsigned long long)x->n);
+  uint64_t* d_oi = out_ids; float* d_os = out_scores; uint32_t* d_oc = out_counts;
+  if (!on_device) {
+    COLTT_TRY(c->w_out_ids.reserve(nq * k * 8)); COLTT_TRY(c->w_out_sc.reserve(nq * k * 4)); COLTT_TRY(c->w_out_cnt.reserve(nq * 4));
+    d_oi = c->w_out_ids.as<uint64_t>(); d_os = c->w_out_sc.as<float>(); d_oc = c->w_out_cnt.as<uint32_t>();
+  }
+  if (x->entry < 0) {  // empty index => empty result, not an error (hnsw.go:249-251)
+    COLTT_HIP(hipMemsetAsync(d_oc, 0, nq * 4, c->stream));
+    if (!on_device) COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipStreamSynchronize(c->stream));
+    return COLTT_OK;
+  }
+  const uint32_t ef = std::max<uint32_t>(ef_override ? ef_override : (uint32_t)x->cfg.ef, k);  // gomath.MaxInt(ef, k), hnsw.go:258
+  if (ef > 4096) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_search: ef=%u > 4096", ef);
+  if (wants_visg(ef) || force_hbm) COLTT_TRY(ensure_visg(x));
+  PqGeom sg;
+  bool have = pq_geom(x, ef, force_hbm, sg);
+  if (!have && !force_hbm) { COLTT_TRY(ensure_visg(x)); have = pq_geom(x, ef, true, sg); }   // no room for the LDS hash beside the table: the byte map
+  if (!have) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_search: dim %u / ef %u / %u sub-vectors need more than the CU's 160 KiB of LDS", x->dim, ef, x->pq_shape.m);
+  uint32_t grid = (uint32_t)std::min<size_t>(nq, (size_t)256 * sg.per_cu);
+  RegionLease lease;
+  if (sg.variant != 0) { acquire_regions(x, grid, lease); grid = lease.count; }
+  const float* d_q = queries;
+  if (!on_device) {
+    COLTT_TRY(c->w_qraw.reserve(nq * x->dim * 4));
+    COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, queries, nq * x->dim * 4, hipMemcpyHostToDevice, c->stream));
+    d_q = c->w_qraw.as<float>();
+  }
+  COLTT_TRY(prep_queries_any(x, c, d_q, nq));
+  // tables for a group of queries at a time: [group][row_bytes][256] f32 (<= 128 MiB)
+  const size_t lut_q = (size_t)x->pq_row * 1024;
+  const size_t group = std::max<size_t>(1, std::min<size_t>(nq, (128ull << 20) / lut_q));
+  COLTT_TRY(c->w_pack.reserve(group * lut_q));
+  COLTT_TRY(c->w_misc.reserve(256));
+  uint8_t* misc = c->w_misc.as<uint8_t>();
+  uint32_t* counter = reinterpret_cast<uint32_t*>(misc);
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(misc + 16);
+  COLTT_HIP(hipMemsetAsync(misc, 0, 256, c->stream));
+  COLTT_HIP(hipEventRecord(c->ev0, c->stream));
+  for (size_t q0 = 0; q0 < nq; q0 += group) {
+    const size_t gn = std::min(group, nq - q0);
+    COLTT_TRY(pq_lut_batch(c->stream, x->pq_cb.as<float>(), x->pq_shape, c->w_qeff.as<float>() + q0 * x->dim, gn, x->pq_row, c->w_pack.as<float>()));
+    if (q0) COLTT_HIP(hipMemsetAsync(counter, 0, 4, c->stream));
+    int rc;
+#define COLTT_LP_ARGS x, c, sg, (uint32_t)std::min<size_t>(grid, gn), lease.base, c->w_pack.as<float>(), (uint32_t)q0, (uint32_t)gn, k, rerank, counter, d_oi, d_os, d_oc, d_stats
+#define COLTT_LP(Q) rc = x->metric == COLTT_COSINE ? launch_pq_search<M_COS, Q>(COLTT_LP_ARGS) : launch_pq_search<M_L2, Q>(COLTT_LP_ARGS)
+    if (x->quant == COLTT_Q_NONE) { COLTT_LP(Q_NONE); } else { COLTT_LP(Q_F16); }
+#undef COLTT_LP
+#undef COLTT_LP_ARGS
+    COLTT_TRY(rc);
+  }
+  COLTT_HIP(hipEventRecord(c->ev1, c->stream));
+  if (x->dense && x->dense_base) add_base_kernel<<<ceil_div(nq * k, 256), 256, 0, c->stream>>>(d_oi, nq * k, x->dense_base);
+  unsigned long long h_stats[5] = {0, 0, 0, 0, 0};
+  if (!on_device) {
+    COLTT_HIP(hipMemcpyAsync(out_ids, d_oi, nq * k * 8, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
+  COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  x->last_ms.store(ms);
+  if (sg.variant == 0 && (h_stats[4] & 8ull)) { *retry_hbm = true; return COLTT_OK; }
+  if (h_stats[4]) return fail(COLTT_E_DEVICE, "hnsw_pq_search: traversal watchdog tripped (code %llu)", h_stats[4]);
+  if (stats) { stats->n_dist = h_stats[0]; stats->n_exp = h_stats[1]; stats->n_hops = h_stats[2]; stats->n_visit_resets = 0; }
+  if (out_n_exact) *out_n_exact = h_stats[3];
+  return COLTT_OK;
+}
+int pq_search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t nq, uint32_t k, uint32_t ef_override, uint32_t rerank,
+                     uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact) {
+  bool retry = false;
+  COLTT_TRY(pq_search_once(x, c, queries, on_device, nq, k, ef_override, rerank, out_ids, out_scores, out_counts, stats, out_n_exact, false, &retry));
+  if (retry) COLTT_TRY(pq_search_once(x, c, queries, on_device, nq, k, ef_override, rerank, out_ids, out_scores, out_counts, stats, out_n_exact, true, &retry));
+  return COLTT_OK;
+}
+
 // pruneNeighbors as Remove calls it (hnsw.go:234-236): rebuild the row from its non-deleted entries (<= width, so
 // nothing is trimmed).  One thread per (neighbour, level) row.
 __global__ void hnsw_unlink_kernel(GraphView g, const uint32_t* __restrict__ nbs, const int32_t* __restrict__ lvl, uint32_t n) {
@@ -1147,7 +1389,7 @@ int fill_adj_norms(Hnsw* x) {
 
 // A failed (re)load must not leave a half-installed index behind: fall back to the empty index (memory-safe, searchable).
 void make_empty(Hnsw* x) {
-  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false; x->n8done = 0;
+  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false; x->n8done = 0; x->pq_done = 0;
   x->h_levels.clear(); x->h_upper_off.clear(); x->h_del.clear(); x->h_ids.clear(); x->id2slot.clear();
   x->dense = true; x->dense_base = 0;
 }
@@ -1229,7 +1471,7 @@ int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* 
   x->h_del = std::move(h_del);
   x->any_deleted = any_deleted; x->live = live;
   if (!x->dense) { x->h_ids.assign(ids, ids + n); x->id2slot = std::move(id2slot); }
-  x->n = n; x->n_upper = n_upper; x->n8done = 0;   // every row is about to be rewritten (the callers upload the vectors next)
+  x->n = n; x->n_upper = n_upper; x->n8done = 0; x->pq_done = 0;   // every row is about to be rewritten (the callers upload the vectors next)
   x->entry = n ? entry_slot : -1;
   x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
   return COLTT_OK;
@@ -1781,6 +2023,78 @@ int coltt_hnsw_reserve(coltt_handle_t h, uint64_t n_slots, uint64_t n_upper_rows
   return x->reserve(n_slots, n_upper_rows);
 }
 
+// ---- product-quantised HNSW (hnsw_pq.hpp; the reference's call shape: playground/hnswpq_verification.go:69-105) -------------------
+int coltt_hnsw_pq_attach(coltt_handle_t h, coltt_handle_t pq) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_pq_attach: unknown index handle");
+  WriteLock g(x->rw);
+  COLTT_DEVICE(x->device);
+  if (x->quant == COLTT_Q_F8) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: \"f8\" rows hold eight distinct values — nothing to quantise");
+  PqShape sh;
+  COLTT_TRY(pq_snapshot(pq, &sh, &x->pq_stage, x->stream));   // staged first: the index is untouched unless everything checks out
+  if (sh.dim != x->dim) return fail(COLTT_E_INVALID, "hnsw_pq_attach: the quantiser is for dim %u, the index holds dim %u", sh.dim, x->dim);
+  if (sh.metric == COLTT_PQ_DOT) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: dotProductDistance tables are negative — the walk orders distances by their bits (squared L2, or 1 - dot on a cosine index)");
+  if (sh.metric == COLTT_PQ_COSINE && x->metric != COLTT_COSINE) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: cosineDistance tables need a cosine index (normalised rows: every table entry is >= 0)");
+  const uint32_t row = (sh.m + 15u) & ~15u;
+  if (row > 128) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: %u sub-vectors — a query's table (%u KiB) must fit the CU's LDS beside the result set (<= 128)", sh.m, row);
+  const size_t bytes = (size_t)sh.m * sh.C * sh.dsub * 4;
+  COLTT_TRY(x->pq_cb.reserve(bytes));
+  COLTT_HIP(hipMemcpyAsync(x->pq_cb.p, x->pq_stage.p, bytes, hipMemcpyDeviceToDevice, x->stream));
+  COLTT_HIP(hipStreamSynchronize(x->stream));
+  x->pq_shape = sh; x->pq_row = row; x->pq_done = 0; x->pq_on = true;
+  if (x->pq_codes.p) COLTT_HIP(hipMemsetAsync(x->pq_codes.p, 0, x->pq_codes.cap, x->stream));
+  const int rc = sync_pq(x.get());
+  if (rc != COLTT_OK) x->pq_on = false;
+  return rc;
+}
+
+int coltt_hnsw_pq_info(coltt_handle_t h, uint32_t* out_m, uint32_t* out_c, int32_t* out_metric, uint64_t* out_coded) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_pq_info: unknown handle");
+  ReadLock g(x->rw);
+  if (out_m) *out_m = x->pq_on ? x->pq_shape.m : 0;
+  if (out_c) *out_c = x->pq_on ? x->pq_shape.C : 0;
+  if (out_metric) *out_metric = x->pq_on ? x->pq_shape.metric : -1;
+  if (out_coded) *out_coded = x->pq_on ? x->pq_done : 0;
+  return COLTT_OK;
+}
+
+int coltt_hnsw_pq_fetch_codes(coltt_handle_t h, uint64_t first_slot, uint64_t n, uint8_t* out_codes) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_pq_fetch_codes: unknown handle");
+  ReadLock g(x->rw);
+  COLTT_DEVICE(x->device);
+  if (!x->pq_on) return fail(COLTT_E_INVALID, "hnsw_pq_fetch_codes: no quantiser attached");
+  if (first_slot + n > x->pq_done) return fail(COLTT_E_INVALID, "hnsw_pq_fetch_codes: slots [%llu,%llu) outside the %llu coded ones", (unsigned long long)first_slot, (unsigned long long)(first_slot + n), (unsigned long long)x->pq_done);
+  if (n == 0) return COLTT_OK;
+  if (!out_codes) return fail(COLTT_E_INVALID, "hnsw_pq_fetch_codes: NULL out");
+  COLTT_HIP(hipMemcpy2D(out_codes, x->pq_shape.m, x->pq_codes.as<uint8_t>() + first_slot * x->pq_row, x->pq_row, x->pq_shape.m, n, hipMemcpyDeviceToHost));
+  return COLTT_OK;
+}
+
+int coltt_hnsw_pq_search(coltt_handle_t h, const float* queries, size_t nq, uint32_t k, uint32_t ef_override, uint32_t rerank,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_pq_search: unknown handle");
+  if (nq && (!queries || !out_ids || !out_scores || !out_counts)) return fail(COLTT_E_INVALID, "hnsw_pq_search: NULL buffer");
+  ReadLock g(x->rw);
+  COLTT_DEVICE(x->device);
+  CtxLease<HCtx> ctx(x->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return pq_search_common(x.get(), ctx.c, queries, false, nq, k, ef_override, rerank, out_ids, out_scores, out_counts, stats, out_n_exact);
+}
+int coltt_hnsw_pq_search_device(coltt_handle_t h, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override, uint32_t rerank,
+                                uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact) {
+  auto x = lookup<Hnsw>(h);
+  if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_pq_search_device: unknown handle");
+  if (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_counts)) return fail(COLTT_E_INVALID, "hnsw_pq_search_device: NULL buffer");
+  ReadLock g(x->rw);
+  COLTT_DEVICE(x->device);
+  CtxLease<HCtx> ctx(x->pool);
+  if (!ctx.c) return COLTT_E_DEVICE;
+  return pq_search_common(x.get(), ctx.c, d_queries, true, nq, k, ef_override, rerank, d_out_ids, d_out_scores, d_out_counts, stats, out_n_exact);
+}
+
 int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t* out_has_copy) {
   auto x = lookup<Hnsw>(h);
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_rows8_searches: unknown handle");
@@ -1793,7 +2107,6 @@ int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t*
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms) {
   if (!out_ms) return fail(COLTT_E_INVALID, "last_kernel_ms: NULL out");
   if (auto x = lookup<Hnsw>(h)) { *out_ms = x->last_ms.load(); return COLTT_OK; }
-  extern int coltt_last_kernel_ms_flat(coltt_handle_t, float*);
   return coltt_last_kernel_ms_flat(h, out_ms);
 }
 

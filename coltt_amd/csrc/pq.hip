@@ -544,6 +544,60 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
 
 }  // namespace
 
+// ---- the quantiser's kernels for an index that carries codes of its own (hnsw.hip: product-quantised HNSW) -----------------------------
+// a snapshot of a trained quantiser: its shape and a copy of its codebooks on the CURRENT device
+int coltt::pq_snapshot(coltt_handle_t h, PqShape* shape, DevBuf* cb_out, hipStream_t s) {
+  auto p = lookup<Pq>(h);
+  if (!p) return fail(COLTT_E_NOT_FOUND, "pq snapshot: unknown quantiser handle");
+  ReadLock g(p->rw);
+  if (!p->trained) return fail(COLTT_E_INVALID, "pq snapshot: the quantiser has no codebooks yet (coltt_pq_set_codebooks / coltt_pq_train)");
+  shape->dim = p->dim; shape->m = p->m; shape->C = p->C; shape->dsub = p->dsub; shape->metric = p->metric;
+  const size_t bytes = (size_t)p->m * p->C * p->dsub * 4;
+  COLTT_TRY(cb_out->reserve(bytes));
+  COLTT_HIP(hipMemcpyAsync(cb_out->p, p->cb.p, bytes, hipMemcpyDefault, s));
+  COLTT_HIP(hipStreamSynchronize(s));
+  return COLTT_OK;
+}
+
+// Encode of n f32 vectors [n][dim] into ROW-MAJOR codes [n][row_bytes] (row_bytes >= m; the bytes j >= m are left as they are)
+int coltt::pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_vecs, uint64_t n, uint8_t* d_codes, uint32_t row_bytes) {
+  if (n == 0) return COLTT_OK;
+  const size_t cb_bytes = (size_t)sh.C * sh.dsub * 4;
+  const int lds_cb = cb_bytes <= 64 * 1024;
+  const size_t lds = lds_cb ? cb_bytes : 0;
+  dim3 grid(ceil_div(n, 256), sh.m);
+  // code_offset(row, j, T = 1, PB = row_bytes) = row * row_bytes + j: the tile-interleaved address degenerates to row-major
+#define PQ_ENC(DS)                                                                                                               \
+  {                                                                                                                              \
+    auto kern = pq_encode_kernel<DS>;                                                                                            \
+    if (lds > 48 * 1024) COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    kern<<<grid, 256, lds, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_vecs, n, nullptr, 0, lds_cb, d_codes, 1, (int)row_bytes);    \
+  }
+  switch (sh.dsub) {
+    case 4: PQ_ENC(4) break;
+    case 8: PQ_ENC(8) break;
+    case 12: PQ_ENC(12) break;
+    case 16: PQ_ENC(16) break;
+    case 24: PQ_ENC(24) break;
+    case 32: PQ_ENC(32) break;
+    default: PQ_ENC(0) break;
+  }
+#undef PQ_ENC
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+// distance tables of nq queries: d_lut [nq][mp][256] f32, rows j >= m and entries c >= C are +0.0
+int coltt::pq_lut_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, float* d_lut) {
+  if (nq == 0) return COLTT_OK;
+  dim3 grid(mp, (uint32_t)nq);
+  if (sh.metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
+  else if (sh.metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
+  else pq_lut_kernel<2><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
 extern "C" {
 
 int coltt_pq_create(uint32_t dim, int metric, uint32_t num_subvectors, uint32_t num_centroids, coltt_handle_t* out) {

@@ -180,6 +180,40 @@ class Hnsw:
         L.check(L.lib().coltt_hnsw_rows8_searches(self.h, C.byref(a), C.byref(f)))
         return a.value, bool(f.value)
 
+    # -- product-quantised search (coltt_hnsw_pq_*; the reference's call shape: playground/hnswpq_verification.go:69-105)
+    def PqAttach(self, pq):
+        """snapshot the trained quantiser `pq` (a PQSpace) into the index and encode every stored row"""
+        L.check(L.lib().coltt_hnsw_pq_attach(self.h, pq.h))
+
+    def PqInfo(self):
+        m, c, mt, n = C.c_uint32(0), C.c_uint32(0), C.c_int32(0), C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_pq_info(self.h, C.byref(m), C.byref(c), C.byref(mt), C.byref(n)))
+        return {"m": m.value, "C": c.value, "metric": mt.value, "coded": n.value}
+
+    def PqCodes(self, first=0, n=None):
+        info = self.PqInfo()
+        n = info["coded"] - first if n is None else n
+        out = np.empty((n, info["m"]), np.uint8)
+        L.check(L.lib().coltt_hnsw_pq_fetch_codes(self.h, C.c_uint64(first), C.c_uint64(n), L.vp(out)))
+        return out
+
+    def PqSearch(self, queries, k, ef=0, rerank=0, with_stats=False):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32); cnt = np.zeros(nq, np.uint32)
+        st = HnswStats(); nx = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_pq_search(self.h, L.vp(q), C.c_size_t(nq), C.c_uint32(k), C.c_uint32(ef), C.c_uint32(rerank), L.vp(ids), L.vp(sc),
+                                             L.vp(cnt), C.byref(st), C.byref(nx)))
+        if with_stats:
+            return ids, sc, cnt, {"n_dist": st.n_dist, "n_exp": st.n_exp, "n_hops": st.n_hops, "n_exact": nx.value}
+        return ids, sc, cnt
+
+    def PqSearchDevice(self, d_q, nq, k, d_ids, d_scores, d_counts, ef=0, rerank=0):
+        st = HnswStats(); nx = C.c_uint64(0)
+        L.check(L.lib().coltt_hnsw_pq_search_device(self.h, C.c_void_p(d_q), C.c_size_t(nq), C.c_uint32(k), C.c_uint32(ef), C.c_uint32(rerank),
+                                                    C.c_void_p(d_ids), C.c_void_p(d_scores), C.c_void_p(d_counts), C.byref(st), C.byref(nx)))
+        return {"n_dist": st.n_dist, "n_exp": st.n_exp, "n_hops": st.n_hops, "n_exact": nx.value}
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         L.check(L.lib().coltt_last_kernel_ms(self.h, C.byref(ms)))

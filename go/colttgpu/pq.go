@@ -119,3 +119,30 @@ func (p *ProductQuantizer) Search(queries []float32, nq int, k uint32) (ids []ui
 func PQBackend(p *ProductQuantizer) Backend {
 	return func(q []float32, nq int, k uint32) ([]uint64, []float32, []uint32, error) { return p.Search(q, nq, k) }
 }
+
+// ---- product-quantised HNSW (coltt_hnsw_pq_*): the reference's own PQ call shape — hnswpq.NewProductQuantizationHnsw(), m = 32, 256
+// centroids, pre-train, Fit, search on the codes (playground/hnswpq_verification.go:69-105).  The walk runs on table distances over the
+// quantiser's codes; the survivors are re-scored with the index's exact distance, which is what the answers carry.
+
+// HnswPqAttach snapshots the trained quantiser into the index and encodes every stored row; later Inserts are encoded as they arrive.
+func HnswPqAttach(h Handle, p *ProductQuantizer) error {
+	return call(func() C.int { return C.coltt_hnsw_pq_attach(h, p.h) })
+}
+
+// HnswPqSearch: ef = 0 -> the configured efSearch; rerank = 0 -> every survivor of the walk is re-scored exactly.
+func HnswPqSearch(h Handle, dim uint32, queries []float32, nq int, k, ef, rerank uint32) ([]uint64, []float32, []uint32, error) {
+	if nq == 0 || k == 0 {
+		return nil, nil, make([]uint32, nq), nil
+	}
+	if err := checkDim(queries, dim, nq); err != nil {
+		return nil, nil, nil, err
+	}
+	ids := make([]uint64, nq*int(k))
+	sc := make([]float32, nq*int(k))
+	cnt := make([]uint32, nq)
+	err := call(func() C.int {
+		return C.coltt_hnsw_pq_search(h, fptr(queries), C.size_t(nq), C.uint32_t(k), C.uint32_t(ef), C.uint32_t(rerank), uptr(ids), fptr(sc),
+			(*C.uint32_t)(unsafe.Pointer(&cnt[0])), nil, nil)
+	})
+	return ids, sc, cnt, err
+}

@@ -257,6 +257,8 @@ int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_le
 int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, void* out_rows);
 /* last kernel timing of the handle's search stream, measured with hipEvents (milliseconds) */
 int coltt_last_kernel_ms(coltt_handle_t h, float* out_ms);
+/* the FLAT half of the call above (coltt_last_kernel_ms forwards a FLAT store's handle here); exported, hence declared */
+int coltt_last_kernel_ms_flat(coltt_handle_t h, float* out_ms);
 
 /* ---- collection groups: ONE collection partitioned over the GPUs of a node (BASELINE.json north_star) ----
  * The reference has no multi-device code; its sharding rule and merge shape are the ones `highCpu` uses for its 16
@@ -376,6 +378,29 @@ int coltt_pq_search_device(coltt_handle_t h, const float* d_queries, size_t nq, 
 /* hipEvent times of the most recent search of this store: the whole call's kernels, and the scan launch over the last (largest)
  * segment alone — the kernel the roofline of the PQ leg is quoted on — with the number of rows that launch covered */
 int coltt_pq_last_kernel_ms(coltt_handle_t h, float* out_search_ms, float* out_scan_ms, uint64_t* out_scan_rows);
+
+
+/* ---- product-quantised HNSW: Hnsw.Search over the quantiser's codes with an exact re-rank ------------------------------------
+ * The reference's only PQ call shape (playground/hnswpq_verification.go:69-105: hnswpq.NewProductQuantizationHnsw(), m = 32, 256
+ * centroids, pre-train, Fit, search on the codes; UPDATE-LOG.md:190-194) — its package pkg/hnswpq is absent, so this is a DEFINITION
+ * (oracle/coltt_oracle.cpp "Product-quantised HNSW"), assembled from the pinned pieces: the graph and traversal of
+ * core/vectorindex/hnsw.go:243-278,320-389 and the quantiser above (pkg/distancepq/distance.go:30-42):
+ *   codes    Encode(stored row as the index's distance sees it), one row-major code per slot, kept up to date by Insert / Load
+ *   d(q, v)  = sum over j of lut[j][code_v[j]] (f32, j order), lut over the query the index's distance sees (normalised / lowered)
+ *   walk     Hnsw.Search with d in place of Distance() (entrypoint, upper levels, searchLevel(ef)); ties by (d bits, slot)
+ *   re-rank  the min(max(rerank, k), |result set|) nearest by d (rerank = 0: the whole result set) are re-scored with the index's
+ *            exact-order distance; the k smallest by (exact score, slot) are returned with their exact scores.
+ * attach snapshots the (trained) quantiser's codebooks — later changes to `pq` do not reach the index — and encodes every stored row.
+ * Supported: f32 / binary16 rows; euclideanDistance tables on any index, cosineDistance tables on a cosine index; <= 128 sub-vectors. */
+int coltt_hnsw_pq_attach(coltt_handle_t hnsw, coltt_handle_t pq);
+int coltt_hnsw_pq_info(coltt_handle_t hnsw, uint32_t* out_num_subvectors, uint32_t* out_num_centroids, int32_t* out_pq_metric, uint64_t* out_coded_slots);
+/* codes of slots [first_slot, first_slot + n): out_codes [n][num_subvectors] */
+int coltt_hnsw_pq_fetch_codes(coltt_handle_t hnsw, uint64_t first_slot, uint64_t n, uint8_t* out_codes);
+/* stats: n_dist = table-distance evaluations, n_exp / n_hops as Hnsw.Search; *out_n_exact (may be NULL) = exact re-rank evaluations */
+int coltt_hnsw_pq_search(coltt_handle_t hnsw, const float* queries, size_t nq, uint32_t k, uint32_t ef_override_or_0, uint32_t rerank,
+                         uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact);
+int coltt_hnsw_pq_search_device(coltt_handle_t hnsw, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override_or_0, uint32_t rerank,
+                                uint64_t* d_out_ids, float* d_out_scores, uint32_t* d_out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact);
 
 #ifdef __cplusplus
 }

@@ -1744,3 +1744,111 @@ int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub,
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Product-quantised HNSW — a DEFINITION (the reference's pkg/hnswpq, driven by playground/hnswpq_verification.go:69-105, is not in its
+// tree), assembled from restatements that ARE tied to reference code: Hnsw.Search (core/vectorindex/hnsw.go:243-278) in the canonical
+// closed form of csr_search above, and the quantiser's Encode / table / score of "Product quantiser" above
+// (pkg/distancepq/distance.go:30-42):
+//   codes    code_v = Encode(stored row of v as the index's distance sees it: normalised for cosine, lowered and raised for 2-byte rows)
+//   d(q, v)  = pq_adc(lut(q'), code_v), q' = the query as the index's distance sees it, lut over the quantiser's distancepq function
+//   walk     csr_search with d in place of Distance(): entrypoint (hnsw.go:253), greedyClosestNeighbor per upper level (:320-343),
+//            searchLevel(ef) on level 0 (:345-389) — admission rule, canonical neighbour order and (d, slot) ties unchanged
+//   re-rank  r = min(max(rerank, k), |result set|) (rerank = 0: the whole set): the r nearest by d are re-scored with the index's
+//            exact distance; the k smallest by (exact score bits, slot) are returned with the exact scores.
+// Counters: st[0] table-distance evaluations, st[1] expansions, st[2] greedy hops, st[3] exact evaluations.
+// ------------------------------------------------------------------------------------------------
+static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* cb, int m, int C, int dsub, int pq_metric, const float* query, int k, int ef,
+                         int rerank, int32_t* out_slots, float* out_scores, uint64_t* st) {
+  std::vector<float> qn(g.dim), rowbuf(g.dim), lut((size_t)m * C);
+  const float* q = query;
+  if (g.metric == METRIC_COS) { normalize(query, qn.data(), g.dim); q = qn.data(); }
+  if (g.quant != Q_NONE) {
+    std::vector<uint8_t> qlow((size_t)g.dim * quant_bytes(g.quant)); lower(g.quant, q, g.dim, qlow.data());
+    raise(g.quant, qlow.data(), g.dim, qn.data()); q = qn.data();
+  }
+  if (g.entry < 0) return 0;
+  pq_lut(pq_metric, cb, m, C, dsub, q, lut.data());
+  uint64_t n_dist = 0, n_exp = 0, n_hops = 0, n_exact = 0;
+  auto D = [&](uint32_t s) { n_dist++; return pq_adc(lut.data(), m, C, codes + (size_t)s * m); };
+  const size_t rb = (size_t)g.dim * quant_bytes(g.quant);
+  auto X = [&](uint32_t s) {
+    n_exact++;
+    if (g.quant == Q_NONE) return dist(g.metric, g.order, q, (const float*)(g.rows + (size_t)s * rb), g.dim);
+    raise(g.quant, g.rows + (size_t)s * rb, g.dim, rowbuf.data());
+    return dist(g.metric, g.order, q, rowbuf.data(), g.dim);
+  };
+  uint32_t ep = (uint32_t)g.entry; float minD = D(ep);
+  for (int l = g.entry_level; l > 0; l--) {
+    for (;;) {
+      int64_t closest = -1; uint32_t w; const uint32_t* row = csr_row(g, ep, l, w);
+      for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
+        if (csr_deleted(g, row[j])) continue;
+        float d = D(row[j]);
+        if (d < minD) { minD = d; closest = row[j]; }
+      }
+      n_hops++;
+      if (closest < 0) break;
+      ep = (uint32_t)closest;
+    }
+  }
+  std::vector<RItem> res; res.reserve((size_t)ef + g.w0 + 1); res.push_back({D(ep), (int32_t)ep, false});
+  VisitedTable visited; visited.reset((size_t)ef * g.w0); visited.insert(ep);
+  std::vector<RItem> adm;
+  for (;;) {
+    int ci = -1;
+    for (int i = 0; i < (int)res.size(); i++) if (!res[i].expanded) { ci = i; break; }
+    if (ci < 0) break;
+    res[ci].expanded = true;
+    float lowerBound = res.back().d; int free_slots = ef - (int)res.size(); uint32_t c = (uint32_t)res[ci].slot;
+    n_exp++; adm.clear();
+    uint32_t w; const uint32_t* row = csr_row(g, c, 0, w);
+    for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
+      uint32_t nb = row[j];
+      if (csr_deleted(g, nb)) continue;
+      if (!visited.insert(nb)) continue;
+      float d = D(nb);
+      if (free_slots > 0) { adm.push_back({d, (int32_t)nb, false}); free_slots--; }
+      else if (d < lowerBound) adm.push_back({d, (int32_t)nb, false});
+    }
+    for (auto& a : adm) res.insert(std::upper_bound(res.begin(), res.end(), a, ritem_less), a);
+    if ((int)res.size() > ef) res.resize(ef);
+  }
+  int r = rerank == 0 ? (int)res.size() : std::max(rerank, k);
+  r = std::min(r, (int)res.size());
+  std::vector<RItem> ex((size_t)r);
+  for (int i = 0; i < r; i++) ex[(size_t)i] = {X((uint32_t)res[(size_t)i].slot), res[(size_t)i].slot, false};
+  std::sort(ex.begin(), ex.end(), ritem_less);
+  const int n = std::min(k, r);
+  for (int i = 0; i < n; i++) { out_slots[i] = ex[(size_t)i].slot; out_scores[i] = ex[(size_t)i].d; }
+  if (st) { st[0] += n_dist; st[1] += n_exp; st[2] += n_hops; st[3] += n_exact; }
+  return n;
+}
+
+extern "C" {
+
+// codes: [n][m] row-major (slot order); codebooks [m][C][dsub]; stats4 summed over the queries; n_threads native threads (one query each)
+int orc_csr_search_pq_mt(const void* rows, int quant, const uint32_t* adj0, const uint32_t* upper_off, const uint32_t* adjU,
+                         const uint32_t* del_bits, uint32_t w0, uint32_t wu, uint32_t dim, int metric, int order, int32_t entry,
+                         int32_t entry_level, const uint8_t* codes, const float* codebooks, int m, int C, int pq_metric, const float* queries,
+                         size_t nq, int k, int ef, int rerank, int32_t* out_slots, float* out_scores, int32_t* out_counts, uint64_t* stats4,
+                         int n_threads, int pin, double* wall_s) {
+  CsrGraph g{(const uint8_t*)rows, adj0, upper_off, adjU, del_bits, w0, wu, dim, metric, order, entry, entry_level, quant};
+  if (n_threads < 1) n_threads = 1;
+  if (m <= 0 || dim % (uint32_t)m) return -1;
+  const int dsub = (int)(dim / (uint32_t)m);
+  std::atomic<size_t> next{0};
+  std::vector<uint64_t> st((size_t)n_threads * 4, 0);
+  double w = run_threads(n_threads, pin, [&](int t) {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= nq) break;
+      out_counts[i] = csr_search_pq(g, codes, codebooks, m, C, dsub, pq_metric, queries + i * dim, k, ef, rerank, out_slots + i * k, out_scores + i * k, &st[(size_t)t * 4]);
+    }
+  });
+  if (stats4) for (int t = 0; t < n_threads; t++) for (int j = 0; j < 4; j++) stats4[j] += st[(size_t)t * 4 + j];
+  if (wall_s) *wall_s = w;
+  return 0;
+}
+
+}  // extern "C"

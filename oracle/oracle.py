@@ -467,6 +467,26 @@ def csr_search(rows, quant, adj0, upper_off, adjU, dim, metric, entry, entry_lev
     return sl, sc, cn, {"n_dist": st[0], "n_exp": st[1], "n_hops": st[2]}, wall.value
 
 
+def csr_search_pq(rows, quant, adj0, upper_off, adjU, dim, metric, entry, entry_level, codes, codebooks, pq_metric, queries, k, ef, rerank=0,
+                  del_bits=None, threads=1, pin=True, order=ORDER_AVX):
+    """Product-quantised Hnsw.Search (a DEFINITION, coltt_oracle.cpp "Product-quantised HNSW"): the canonical walk with table distances
+    over row-major codes [n, m], then the exact re-rank.  Returns slots, exact scores, counts, {n_dist, n_exp, n_hops, n_exact}, wall s."""
+    q = _f32(queries).reshape(-1, dim); nq = len(q)
+    cb = _f32(codebooks); m, c = cb.shape[0], cb.shape[1]
+    codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, m)
+    sl = np.empty((nq, k), np.int32); sc = np.empty((nq, k), np.float32); cn = np.empty(nq, np.int32)
+    st = (C.c_uint64 * 4)(); wall = C.c_double(0)
+    adj0 = np.ascontiguousarray(adj0, np.uint32); adjU = np.ascontiguousarray(adjU, np.uint32)
+    rc = lib().orc_csr_search_pq_mt(_p(rows), int(quant), _p(adj0), _p(np.ascontiguousarray(upper_off, np.uint32)), _p(adjU),
+                                    _p(del_bits) if del_bits is not None else None, C.c_uint32(adj0.shape[1]), C.c_uint32(adjU.shape[1]),
+                                    C.c_uint32(dim), int(metric), int(order), C.c_int32(int(entry)), C.c_int32(int(entry_level)), _p(codes), _p(cb),
+                                    int(m), int(c), int(pq_metric), _p(q), C.c_size_t(nq), int(k), int(ef), int(rerank), _p(sl), _p(sc), _p(cn), st,
+                                    int(threads), int(bool(pin)), C.byref(wall))
+    if rc != 0:
+        raise ValueError("orc_csr_search_pq_mt: dim is not a multiple of the number of sub-vectors")
+    return sl, sc, cn, {"n_dist": st[0], "n_exp": st[1], "n_hops": st[2], "n_exact": st[3]}, wall.value
+
+
 def flat_scan(rows, quant, dim, metric, queries, k, nearest=True, shape=0, split=1, threads=1, pin=True, order=ORDER_AVX):
     """VertexSearch over contiguous stored rows (orc_flat_scan_mt).  rows: [n, dim] stored codes.  Returns slots, scores,
     counts, wall seconds."""

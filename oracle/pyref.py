@@ -479,3 +479,80 @@ def pq_search(metric, codebooks, vectors, ids, query, k):
     scored.sort(key=lambda t: (t[0], t[1]))
     top = scored[:k]
     return codes, lut, np.array([t[1] for t in top], np.uint64), np.array([t[2] for t in top], np.float32)
+
+
+def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level, codes, codebooks, pq_metric, query_seen, k, ef, rerank=0):
+    """Product-quantised Hnsw.Search as DEFINED in oracle/coltt_oracle.cpp ("Product-quantised HNSW"), restated independently in plain
+    Python over the padded-array graph (adj0 [n][w0], upper_off [n], adj_u [rows][wu], 0xffffffff padded): table distance
+    d = sum_j lut[j][code[j]] (f32, j order) in place of Distance() for the entrypoint (hnsw.go:253), greedyClosestNeighbor (:320-343)
+    and searchLevel(ef) (:345-389, canonical closed form: stale lowerBound per pop, ascending-slot neighbour order, ties by (d, slot));
+    then the r = min(max(rerank, k), len) nearest (rerank = 0: all) re-scored with the exact distance (AVX order) and the k smallest by
+    (score bits, slot) returned.  rows_seen / query_seen: the f32 values the index's distance sees.  Returns slots, scores, counters."""
+    cb = np.asarray(codebooks, f32); m, c, ds = cb.shape
+    q = np.asarray(query_seen, f32)
+    lut = [[pq_fn(pq_metric, q[j * ds:(j + 1) * ds], cb[j, cc]) for cc in range(c)] for j in range(m)]
+    cnt = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
+    NONE = 0xFFFFFFFF
+
+    def d_of(s):
+        cnt["n_dist"] += 1
+        acc = f32(0)
+        for j in range(m):
+            acc = f32(acc + lut[j][int(codes[s][j])])
+        return acc
+
+    def bits(x):
+        return int(f32(x).view(np.uint32))
+
+    def row(s, level):
+        return adj0[s] if level == 0 else adj_u[int(upper_off[s]) + level - 1]
+
+    if entry < 0:
+        return [], [], cnt
+    ep, min_d = int(entry), d_of(int(entry))
+    for level in range(int(entry_level), 0, -1):
+        while True:
+            closest = None
+            for nb in row(ep, level):
+                nb = int(nb)
+                if nb == NONE:
+                    break
+                dd = d_of(nb)
+                if dd < min_d:
+                    min_d, closest = dd, nb
+            cnt["n_hops"] += 1
+            if closest is None:
+                break
+            ep = closest
+    res = [[d_of(ep), ep, False]]          # ascending by (d bits, slot)
+    visited = {ep}
+    while True:
+        ci = next((i for i, e in enumerate(res) if not e[2]), None)
+        if ci is None:
+            break
+        res[ci][2] = True
+        lower_bound = res[-1][0]; free = ef - len(res); cnt["n_exp"] += 1
+        adm = []
+        for nb in row(res[ci][1], 0):
+            nb = int(nb)
+            if nb == NONE:
+                break
+            if nb in visited:
+                continue
+            visited.add(nb)
+            dd = d_of(nb)
+            if free > 0:
+                adm.append([dd, nb, False]); free -= 1
+            elif dd < lower_bound:
+                adm.append([dd, nb, False])
+        res = sorted(res + adm, key=lambda e: (bits(e[0]), e[1]))[:ef]
+    r = len(res) if rerank == 0 else max(rerank, k)
+    r = min(r, len(res))
+    ex = []
+    for e in res[:r]:
+        cnt["n_exact"] += 1
+        v = np.asarray(rows_seen[e[1]], f32)
+        ex.append((bits(cosine(q, v) if metric == 0 else euclidean(q, v)), e[1]))
+    ex.sort()
+    top = ex[:k]
+    return [t[1] for t in top], [np.uint32(t[0]).view(f32) for t in top], cnt

