@@ -396,6 +396,27 @@ def cpu_flat(O, fl, dim, quant, q_dev, k, n_rows, args, gpu_ids=None, gpu_sc=Non
         rows.close()
 
 
+def oracle_full_sample(O, fl, dim, quant, q_dev, k, n_rows, gpu_ids, gpu_sc, nqs=4):
+    """every FLAT leg carries gpu_equals_oracle at FULL size — the first `nqs` queries of the batch scanned by the oracle over
+    ALL rows of the store (copied out of HBM), ids and score bits compared with the GPU's answers of the timed batch."""
+    threads = O.cpu_count()
+    dt = O.QUANT_DTYPE[quant]
+    rows = O.NumaArray((n_rows, dim), dt, threads)
+    try:
+        t0 = time.time()
+        step = max(1, (1 << 30) // (dim * np.dtype(dt).itemsize))
+        for b in range(0, n_rows, step):
+            fl.FetchRows(b, min(step, n_rows - b), out=rows.a[b:b + step])
+        copy_s = time.time() - t0
+        q = q_dev.cpu().numpy()[:nqs]
+        s16 = min(16, threads)
+        r = O.flat_scan(rows.a, quant, dim, O.COSINE, q, k, nearest=True, shape=1, split=s16, threads=s16)   # one query split s16 ways (highCpu), query decoded once
+        eq = bool(np.array_equal(gpu_ids[:len(q)].astype(np.uint64), r[0][:len(q)]) and np.array_equal(gpu_sc[:len(q)].view(np.uint32), r[1][:len(q)].view(np.uint32)))
+        return {"gpu_equals_oracle_full_size": eq, "queries": int(len(q)), "rows": int(n_rows), "copy_s": round(copy_s, 2), "scan_s": round(r[3], 2)}
+    finally:
+        rows.close()
+
+
 # ----------------------------------------------------------------------------------------------- extra legs (N = 1)
 def leg_operating_point(G, torch, dev, O, args, dim, k):
     """north-star point: recall@10 >= 0.98 on 10M x 768 f16 HNSW, structured data; own roofline; CPU baseline at the same ef"""
@@ -589,6 +610,10 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
                         "avg_launch_ms": tm * 1e3, "bytes_per_batch": nbytes,
                         "mfma": {"achieved_TFLOPs": flops / tm / 1e12, "peak_TFLOPs": MFMA_F16_PEAK_TF, "frac": flops / tm / 1e12 / MFMA_F16_PEAK_TF,
                                  "note": "v_mfma_f32_32x32x16_f16 for both row formats (f32 rows are rounded to binary16 on their way into LDS; candidates only)"}}}
+    if quant == 1 and batch >= 128:
+        res["roofline"]["note"] = ("power-bound, not schedule-bound: on one box under tools/power_probe.py (profiles/r05_c3_yardstick.md) the vendor library's f16 GEMM of this very shape "
+                                   "(torch.mm, 10 M x 256 x 768, writing its products instead of testing them) takes 4.41-5.69 ms = 0.28-0.36 of the MFMA peak at the 1 400 W cap; this "
+                                   "whole search chain took 4.78 ms at the same cap")
     if quant == 2:
         res["roofline"]["note"] = ("1-byte rows: the candidate GEMM streams their derived binary16 copy (2 bytes per element, flat.hip f8_expand_kernel), so HBM traffic is "
                                    "2x the algorithmic row bytes this fraction is quoted on; the exact-order scan it replaces is VALU-bound (exact_mode_ms_per_batch)")
@@ -612,6 +637,12 @@ def leg_flat(G, torch, dev, O, args, dim, k, n, quant, batch, tag, cpu_rows):
             if not full:
                 c["sample"] += f"; run on the first {rows_cpu} rows and to be scaled by {n / rows_cpu:.0f}x for the full scan (BASELINE.md §2 allows the slice)"
                 c["value_scaled_to_full_scan"] = c["value"] * rows_cpu / n
+                try:   # the timed legs of the CPU run on a slice; the PARITY sample does not
+                    fs = oracle_full_sample(O, fl, dim, quant, q, k, n, mi, msc)
+                    c["full_size_oracle_sample"] = fs
+                    c["gpu_equals_oracle_on_sample"] = fs["gpu_equals_oracle_full_size"]
+                except Exception as e:
+                    c["full_size_oracle_sample"] = {"error": str(e)}
             res["cpu_baseline"] = c
         except Exception as e:
             res["cpu_baseline"] = {"error": str(e)}
@@ -867,7 +898,7 @@ def compact(res):
     if res.get("per_query"):
         out["per_query"] = _pick(res["per_query"], "n_dist", "n_exp", "bytes")
     roof = res.get("roofline")
-    out["roofline"] = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms") if roof else None
+    out["roofline"] = _pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "avg_launch_ms") if roof else None
     if roof and "traffic" not in out["roofline"]:
         out["roofline"]["traffic"] = None
     cpu = res.get("cpu_baseline")

@@ -310,8 +310,8 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     w.bloom_words = vis_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(vis_words | 0x80000000u);
     w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
   }
-  float* const lut = reinterpret_cast<float*>(smem + off);
-  const AdcEval ev{codes, row_bytes, lut};
+  unsigned short* const lut = reinterpret_cast<unsigned short*>(smem + off);
+  AdcEval ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut;
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
@@ -319,10 +319,13 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
     wave_sync();
     for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
-    {  // the query's table: row_bytes x 256 f32, 16 bytes per lane and step
+    {  // the query's table: row_bytes x 256 entries, f32 in HBM -> binary16 in LDS (round to nearest even: the codec's own integer rounding, exact.hpp)
       const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + (size_t)qi * row_bytes * 256);
-      u32x4v* dst = reinterpret_cast<u32x4v*>(lut);
-      for (uint32_t i = (uint32_t)lane; i < row_bytes * 64u; i += 64) dst[i] = src[i];
+      u32x2e* dst = reinterpret_cast<u32x2e*>(lut);
+      for (uint32_t i = (uint32_t)lane; i < row_bytes * 64u; i += 64) {
+        const u32x4v v = src[i];
+        dst[i] = u32x2e{f32bits_to_f16bits(v.x) | (f32bits_to_f16bits(v.y) << 16), f32bits_to_f16bits(v.z) | (f32bits_to_f16bits(v.w) << 16)};
+      }
     }
     w.qnorm = qnorms[qi];
     wave_sync();
@@ -942,8 +945,10 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
   const bool seq = policy().lat_seq;
-  if (x->rows8_on && x->n8done == x->n && QUANT != Q_F8) x->ev8_launches.fetch_add(1);   // hnsw_lat.hpp evaluates rows8 pieces out of their registers
-  kern<<<grid, 256, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
+  GraphView gv = x->view();
+  if (!ev8_policy()) gv.rows8 = nullptr;   // COLTT_EV8=0 is a per-call switch here too: the pair-owned rows, staged and transposed through LDS
+  if (gv.rows8 && QUANT != Q_F8) x->ev8_launches.fetch_add(1);   // hnsw_lat.hpp evaluates rows8 pieces out of their registers
+  kern<<<grid, 256, sg.lds, c->stream>>>(gv, x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                          k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq ? 1 : 0);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
@@ -1091,7 +1096,7 @@ struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: L
 bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   PqGeom s{};
   s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 1024;
+  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 512;   // query | result set | binary16 table
   if (fixed > 160 * 1024) return false;
   const bool hbm_ok = x->vis_stride != 0 && x->vis_regions > 0;
   // LDS hash: as search_geom sizes it; it must never need the reset path (err 8 -> the call is re-run over the byte map)
@@ -2036,7 +2041,7 @@ int coltt_hnsw_pq_attach(coltt_handle_t h, coltt_handle_t pq) {
   if (sh.metric == COLTT_PQ_DOT) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: dotProductDistance tables are negative — the walk orders distances by their bits (squared L2, or 1 - dot on a cosine index)");
   if (sh.metric == COLTT_PQ_COSINE && x->metric != COLTT_COSINE) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: cosineDistance tables need a cosine index (normalised rows: every table entry is >= 0)");
   const uint32_t row = (sh.m + 15u) & ~15u;
-  if (row > 128) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: %u sub-vectors — a query's table (%u KiB) must fit the CU's LDS beside the result set (<= 128)", sh.m, row);
+  if (row > 128) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: %u sub-vectors — a query's table (%u KiB) must fit the CU's LDS beside the result set (<= 128)", sh.m, row / 2);
   const size_t bytes = (size_t)sh.m * sh.C * sh.dsub * 4;
   COLTT_TRY(x->pq_cb.reserve(bytes));
   COLTT_HIP(hipMemcpyAsync(x->pq_cb.p, x->pq_stage.p, bytes, hipMemcpyDeviceToDevice, x->stream));

@@ -295,6 +295,7 @@ template <int METRIC, int QUANT> struct LatEval {
   static constexpr bool CHUNK_ADJ = true;
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }
+  __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float /*nrm*/, int half, int lane) const {
     const int p = lane >> 1;
     if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = fresh ? 1u : 0u; }

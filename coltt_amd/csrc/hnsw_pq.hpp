@@ -6,8 +6,11 @@
 // and restated here, built from pieces that ARE pinned: the graph and the traversal of core/vectorindex/hnsw.go:243-278, 320-389 (canonical
 // closed form, hnsw_walk2.hpp) and the quantiser of pq.hip (distancepq arithmetic, pkg/distancepq/distance.go:30-42):
 //   codes     one row-major code per stored row: Encode(decode(stored row))          (pq.hip: pq_encode_kernel)
-//   table     lut[j][c] = distFn(q_j, centroid[j][c]) over the query the index's distance sees (normalised / lowered)
-//   distance  d(q, v) = sum over j = 0..m-1 of lut[j][code_v[j]], f32, in j order      (pq.hip: "score")
+//   table     lut[j][c] = binary16(distFn(q_j, centroid[j][c])) over the query the index's distance sees (normalised / lowered): the
+//             quantiser's table entry (pq.hip) ROUNDED TO BINARY16 (round to nearest even, compresshelper.Fromfloat32's rounding,
+//             float16.go:276-321) — d only ranks candidates, the answers carry exact distances, and half the table bytes are twice the
+//             resident traversals (the table is what bounds this kernel's occupancy, see below)
+//   distance  d(q, v) = sum over j = 0..m-1 of float32(lut[j][code_v[j]]), f32 adds, in j order
 //   walk      Hnsw.Search with d in place of Distance(): entrypoint, greedyClosestNeighbor on the upper levels, searchLevel(ef) on
 //             level 0 — same admission rule, same canonical neighbour order, ties by (d bits, slot)
 //   re-rank   the r = min(max(rerank, k), len) nearest survivors by d (rerank = 0: all of them) get the index's EXACT distance
@@ -16,7 +19,9 @@
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
 // One wave per query.  LDS: [query f32, natural order (re-rank) | result set | visited hash or Bloom filter | the query's table].
-// The table is what bounds occupancy: mp16 KiB per resident traversal (m = 32: 32 KiB -> 4 waves per CU; m = 96: 96 KiB -> 1).
+// The table is what bounds occupancy: mp16 / 2 KiB per resident traversal (m = 32: 16 KiB; m = 96: 48 KiB).  Measured with f32 tables
+// (profiles/r05b_hnswpq_probe_10m.jsonl, 10 M x 768 f16): the walk is a chain of dependent round trips (~5 us per expansion), its
+// throughput is resident traversals / latency — 157 k queries/s at 3 waves per CU (m = 32), 49 k at 1 (m = 96) — never HBM bytes.
 #pragma once
 #include "hnsw_walk2.hpp"
 
@@ -27,41 +32,49 @@ namespace dev {
 // first lookup).  The even lane of a pair computes, both lanes of the pair receive (the walk keeps one neighbour per lane pair).
 struct AdcEval {
   const uint8_t* codes; uint32_t row_bytes;   // [n][row_bytes], row_bytes = mp16 (a multiple of 16, <= 128); bytes j >= m are 0
-  const float* lut;                            // LDS: [row_bytes][256] f32, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
+  const unsigned short* lut;                   // LDS: [row_bytes][256] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
+  u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
-  __device__ __forceinline__ float adc(uint32_t slot) const {
+  __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[8]) const {
     const u32x4e* p = reinterpret_cast<const u32x4e*>(codes + (size_t)slot * row_bytes);
     const int np = (int)(row_bytes >> 4);
-    u32x4e raw[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (i < np) raw[i] = p[i];
+    for (int i = 0; i < 8; i++) if (i < np) r[i] = p[i];
+  }
+  __device__ __forceinline__ float sum(const u32x4e (&r)[8]) const {
+    const int np = (int)(row_bytes >> 4);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       if (i < np) {
 #pragma unroll
         for (int wd = 0; wd < 4; wd++) {
-          const uint32_t v = raw[i][wd];
+          const uint32_t v = r[i][wd];
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             const uint32_t c = (v >> (8 * b)) & 0xffu;
-            s = s + lut[(size_t)(i * 16 + wd * 4 + b) * 256 + c];
+            s = s + f16bits_to_f32(lut[(size_t)(i * 16 + wd * 4 + b) * 256 + c]);
           }
         }
       }
     }
     return s;
   }
-  __device__ __forceinline__ float operator()(const GraphView&, const WaveCtx&, uint32_t nb, bool fresh, float, int half, int) const {
+  __device__ __forceinline__ float adc(uint32_t slot) const { u32x4e r[8]; load(slot, r); return sum(r); }
+  // The code row of every LISTED neighbour is requested before the walk knows which of them are fresh: 32-128 bytes each, in flight
+  // under the visited test's own dependent HBM probe instead of behind it (one round trip less per expansion; rows of already visited
+  // neighbours are fetched for nothing — a few KB per expansion against a dependent ~2 us).
+  __device__ __forceinline__ void prefetch(uint32_t nb, bool valid, int half) { if (valid && half == 0) load(nb, raw); }
+  __device__ __forceinline__ float operator()(const GraphView&, const WaveCtx&, uint32_t, bool fresh, float, int half, int) const {
     float r = 0.f;
-    if (fresh && half == 0) r = adc(nb);
+    if (fresh && half == 0) r = sum(raw);
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));   // even lane's value to its pair: quad_perm [0,0,2,2]
   }
 };
 
 // greedyClosestNeighbor (hnsw.go:320-343) with table distances: hnsw_dev.hpp:greedy_level with AdcEval in place of eval_pair
-__device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w, const AdcEval& ev, uint32_t& cur, float& curd, int level, int lane_in) {
+__device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w, AdcEval& ev, uint32_t& cur, float& curd, int level, int lane_in) {
   for (uint32_t hops = 0;; hops++) {
     const int lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;
@@ -74,6 +87,7 @@ __device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w,
       const uint32_t idx = c0 + p;
       const uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+      ev.prefetch(nb, valid, half);
       const float d = ev(g, w, nb, valid, 0.f, half, lane);
       w.n_dist += __popcll(__ballot(valid && half == 0));
       const unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;

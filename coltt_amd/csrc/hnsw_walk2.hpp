@@ -156,6 +156,7 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
 template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
   static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+  __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
     if (!fresh) return 0.f;
     if constexpr (ADJN) return eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
@@ -186,6 +187,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr int G8R = HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS, G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
   static constexpr bool CHUNK_ADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+  __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int lane) const {
     constexpr int ROWS = G8R;
@@ -393,6 +395,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       float nrm = 0.f;
       if constexpr (ADJN) nrm = idx < width ? (pre_hit ? pre_nn_now : nrow[idx]) : 0.f;
       const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
+      ev.prefetch(nb, valid, half);   // evaluators whose per-neighbour input is small (hnsw_pq.hpp: a 32-128 byte code row) request it NOW, under the visited test
 #ifdef COLTT_PHASE_TIMING
       if (__ballot(valid) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the adjacency values to have arrived
 #endif

@@ -34,6 +34,7 @@ using namespace coltt::dev;
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int PQ_LDS_MAX = 152 * 1024;   // LDS a scan workgroup may take (of 160 KiB per CU)
 
 // ---- pkg/distancepq: asm.Dot / asm.SquaredEuclideanDistance by ONE thread (dot.s:7-55, euclidean.s:7-65): acc[8 r + j] is lane j of
@@ -209,6 +210,13 @@ __global__ __launch_bounds__(1024) void pq_scan_kernel(const uint8_t* __restrict
     const f32x4* src = reinterpret_cast<const f32x4*>(lut_g + (size_t)q0 * lq);
     f32x4* dst = reinterpret_cast<f32x4*>(lut);
     for (int i = tid; i < mp * 64; i += blockDim.x) dst[i] = src[i];
+  } else if constexpr (QB == 2) {   // [mp][256][2]: one ds_read_b64 fetches both queries' values of a code
+    for (int i = tid; i < mp * 256; i += blockDim.x) {
+      f32x2 v;
+      v.x = lut_g[(size_t)q0 * lq + i];
+      v.y = q0 + 1 < nq ? lut_g[(size_t)(q0 + 1) * lq + i] : 0.f;
+      reinterpret_cast<f32x2*>(lut)[i] = v;
+    }
   } else {
     for (int i = tid; i < mp * 256; i += blockDim.x) {
       f32x4 v;
@@ -246,9 +254,9 @@ __global__ __launch_bounds__(1024) void pq_scan_kernel(const uint8_t* __restrict
   raw_t cur[R], nxt[R];
 #pragma unroll
   for (int u = 0; u < R; u++) PQ_LOAD(cur[u])
-  typedef typename std::conditional<QB == 1, float, f32x4>::type acc_t;
+  typedef typename std::conditional<QB == 1, float, typename std::conditional<QB == 2, f32x2, f32x4>::type>::type acc_t;
   acc_t acc;
-  if constexpr (QB == 1) acc = 0.f; else acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (QB == 1) acc = 0.f; else if constexpr (QB == 2) acc = f32x2{0.f, 0.f}; else acc = f32x4{0.f, 0.f, 0.f, 0.f};
   while (ctile < tile_end) {
 #pragma unroll
     for (int u = 0; u < R; u++) PQ_LOAD(nxt[u])
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(1024) void pq_scan_kernel(const uint8_t* __restrict
         for (int b = 0; b < 4; b++) {
           const uint32_t code = (wd >> (8 * b)) & 0xffu;
           if constexpr (QB == 1) acc = acc + lp[(d * 4 + b) * 256 + code];
+          else if constexpr (QB == 2) acc = acc + *reinterpret_cast<const f32x2*>(lp + ((size_t)(d * 4 + b) * 256 + code) * 2);
           else acc = acc + *reinterpret_cast<const f32x4*>(lp + ((size_t)(d * 4 + b) * 256 + code) * 4);
         }
       }
@@ -273,14 +282,14 @@ __global__ __launch_bounds__(1024) void pq_scan_kernel(const uint8_t* __restrict
 #pragma unroll
         for (int q = 0; q < QB; q++) {
           float sc;
-          if constexpr (QB == 1) sc = acc; else sc = q == 0 ? acc.x : (q == 1 ? acc.y : (q == 2 ? acc.z : acc.w));
+          if constexpr (QB == 1) sc = acc; else if constexpr (QB == 2) sc = q == 0 ? acc.x : acc.y; else sc = q == 0 ? acc.x : (q == 1 ? acc.y : (q == 2 ? acc.z : acc.w));
           const uint32_t key = score_key(sc);
           if (valid && qv[q] && key <= th[q]) {
             const uint32_t idx = atomicAdd(&cnt[q0 + q], 1u);
             if (idx < cap) cand[(size_t)(q0 + q) * cap + idx] = ((unsigned long long)key << 32) | (uint32_t)row;
           }
         }
-        if constexpr (QB == 1) acc = 0.f; else acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (QB == 1) acc = 0.f; else if constexpr (QB == 2) acc = f32x2{0.f, 0.f}; else acc = f32x4{0.f, 0.f, 0.f, 0.f};
         ct = 0; ctile += tstride;
       }
     }
@@ -440,6 +449,10 @@ int launch_scan_w(Pq* p, PCtx* c, int QBq, uint64_t b, uint64_t e, int nq, const
     auto kern = pq_scan_kernel<W, 1>;
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 1024)));
     kern<<<grid, threads, lds, c->stream>>>(p->codes.as<uint8_t>(), p->T, p->mp, lut, nq, b, e, thr, cand, cnt, cap);
+  } else if (QBq == 2) {
+    auto kern = pq_scan_kernel<W, 2>;
+    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 1024)));
+    kern<<<grid, threads, lds, c->stream>>>(p->codes.as<uint8_t>(), p->T, p->mp, lut, nq, b, e, thr, cand, cnt, cap);
   } else {
     auto kern = pq_scan_kernel<W, 4>;
     COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds, 1024)));
@@ -457,18 +470,18 @@ int launch_scan(Pq* p, PCtx* c, uint64_t b, uint64_t e, int nq, const float* lut
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
   }
-  const int QBq = (nq >= 2 && one * 4 <= (size_t)PQ_LDS_MAX) ? 4 : 1;
+  // queries per pass: four tables when they fit together (mp <= 38), two (mp <= 76: [mp][256][2], ds_read_b64 — the codes of such stores used to be
+  // streamed once per query in a batch), else one
+  const int QBq = nq < 2 ? 1 : (one * 4 <= (size_t)PQ_LDS_MAX ? 4 : (one * 2 <= (size_t)PQ_LDS_MAX ? 2 : 1));
   if (p->PB == 16) return launch_scan_w<4>(p, c, QBq, b, e, nq, lut, thr, cand, cnt, cap);
   if (p->PB == 8) return launch_scan_w<2>(p, c, QBq, b, e, nq, lut, thr, cand, cnt, cap);
   return launch_scan_w<1>(p, c, QBq, b, e, nq, lut, thr, cand, cnt, cap);
 }
 
-int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
-                     uint32_t* out_counts, bool out_on_device) {
-  if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "pq search: k=%u outside [1,%u]", k, K_MAX);
-  if (nq == 0) return COLTT_OK;
-  if (!p->trained) return fail(COLTT_E_INVALID, "pq search: the quantiser has no codebooks yet (coltt_pq_set_codebooks / coltt_pq_train)");
-  if (nq > 65535) return fail(COLTT_E_UNSUPPORTED, "pq search: more than 65535 queries in one call");
+// one group of <= PQ_GROUP queries: tables, candidate lists and the selection's state are sized by the group, not by the call
+constexpr size_t PQ_GROUP = 256;
+int pq_search_group(Pq* p, PCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
+                    uint32_t* out_counts, bool out_on_device) {
   const float* d_q = queries;
   if (!q_on_device) {
     COLTT_TRY(c->w_q.reserve(nq * p->dim * 4));
@@ -537,8 +550,23 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
   }
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-  p->last_ms.store(ms);
+  p->last_ms.store(p->last_ms.load() + ms);
   if (timed_scan) { float sms = 0.f; (void)hipEventElapsedTime(&sms, c->evs0, c->evs1); p->last_scan_ms.store(sms); }
+  return COLTT_OK;
+}
+
+// A call of any size runs group by group (as FLAT does, flat.hip): a 10 000-query call used to reserve 512 KiB of candidate list and mp KiB
+// of table PER QUERY of the whole batch in a pooled context that never shrinks; now the workspaces top out at one group's.
+int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
+                     uint32_t* out_counts, bool out_on_device) {
+  if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "pq search: k=%u outside [1,%u]", k, K_MAX);
+  if (nq == 0) return COLTT_OK;
+  if (!p->trained) return fail(COLTT_E_INVALID, "pq search: the quantiser has no codebooks yet (coltt_pq_set_codebooks / coltt_pq_train)");
+  p->last_ms.store(0.f);
+  for (size_t q0 = 0; q0 < nq; q0 += PQ_GROUP) {
+    const size_t gn = std::min(PQ_GROUP, nq - q0);
+    COLTT_TRY(pq_search_group(p, c, queries + q0 * p->dim, q_on_device, gn, k, out_ids + q0 * k, out_scores + q0 * k, out_counts + q0, out_on_device));
+  }
   return COLTT_OK;
 }
 

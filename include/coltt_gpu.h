@@ -386,7 +386,9 @@ int coltt_pq_last_kernel_ms(coltt_handle_t h, float* out_search_ms, float* out_s
  * (oracle/coltt_oracle.cpp "Product-quantised HNSW"), assembled from the pinned pieces: the graph and traversal of
  * core/vectorindex/hnsw.go:243-278,320-389 and the quantiser above (pkg/distancepq/distance.go:30-42):
  *   codes    Encode(stored row as the index's distance sees it), one row-major code per slot, kept up to date by Insert / Load
- *   d(q, v)  = sum over j of lut[j][code_v[j]] (f32, j order), lut over the query the index's distance sees (normalised / lowered)
+ *   d(q, v)  = sum over j of float32(binary16(lut[j][code_v[j]])) (f32 adds, j order): the quantiser's table over the query the index's
+ *            distance sees (normalised / lowered), every entry rounded to binary16 (nearest even) — d only ranks, and a 2-byte table
+ *            doubles the walk's resident traversals
  *   walk     Hnsw.Search with d in place of Distance() (entrypoint, upper levels, searchLevel(ef)); ties by (d bits, slot)
  *   re-rank  the min(max(rerank, k), |result set|) nearest by d (rerank = 0: the whole result set) are re-scored with the index's
  *            exact-order distance; the k smallest by (exact score, slot) are returned with their exact scores.

@@ -1751,7 +1751,9 @@ int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub,
 // closed form of csr_search above, and the quantiser's Encode / table / score of "Product quantiser" above
 // (pkg/distancepq/distance.go:30-42):
 //   codes    code_v = Encode(stored row of v as the index's distance sees it: normalised for cosine, lowered and raised for 2-byte rows)
-//   d(q, v)  = pq_adc(lut(q'), code_v), q' = the query as the index's distance sees it, lut over the quantiser's distancepq function
+//   d(q, v)  = pq_adc(lut16(q'), code_v), q' = the query as the index's distance sees it, lut16 = the quantiser's table (its distancepq
+//            function) with every entry rounded to binary16 (round to nearest even — the f16 codec's own rounding) and read back as f32:
+//            d only ranks, the answers carry exact distances, and a 2-byte table doubles the GPU kernel's resident traversals
 //   walk     csr_search with d in place of Distance(): entrypoint (hnsw.go:253), greedyClosestNeighbor per upper level (:320-343),
 //            searchLevel(ef) on level 0 (:345-389) — admission rule, canonical neighbour order and (d, slot) ties unchanged
 //   re-rank  r = min(max(rerank, k), |result set|) (rerank = 0: the whole set): the r nearest by d are re-scored with the index's
@@ -1769,6 +1771,7 @@ static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* c
   }
   if (g.entry < 0) return 0;
   pq_lut(pq_metric, cb, m, C, dsub, q, lut.data());
+  for (float& v : lut) v = u2f(f16bits_to_f32bits(f32bits_to_f16bits(f2u(v))));   // the walk's table entries are binary16 (round to nearest even)
   uint64_t n_dist = 0, n_exp = 0, n_hops = 0, n_exact = 0;
   auto D = [&](uint32_t s) { n_dist++; return pq_adc(lut.data(), m, C, codes + (size_t)s * m); };
   const size_t rb = (size_t)g.dim * quant_bytes(g.quant);

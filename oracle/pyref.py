@@ -484,13 +484,13 @@ def pq_search(metric, codebooks, vectors, ids, query, k):
 def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level, codes, codebooks, pq_metric, query_seen, k, ef, rerank=0):
     """Product-quantised Hnsw.Search as DEFINED in oracle/coltt_oracle.cpp ("Product-quantised HNSW"), restated independently in plain
     Python over the padded-array graph (adj0 [n][w0], upper_off [n], adj_u [rows][wu], 0xffffffff padded): table distance
-    d = sum_j lut[j][code[j]] (f32, j order) in place of Distance() for the entrypoint (hnsw.go:253), greedyClosestNeighbor (:320-343)
+    d = sum_j float32(binary16(lut[j][code[j]])) (f32 adds, j order) in place of Distance() for the entrypoint (hnsw.go:253), greedyClosestNeighbor (:320-343)
     and searchLevel(ef) (:345-389, canonical closed form: stale lowerBound per pop, ascending-slot neighbour order, ties by (d, slot));
     then the r = min(max(rerank, k), len) nearest (rerank = 0: all) re-scored with the exact distance (AVX order) and the k smallest by
     (score bits, slot) returned.  rows_seen / query_seen: the f32 values the index's distance sees.  Returns slots, scores, counters."""
     cb = np.asarray(codebooks, f32); m, c, ds = cb.shape
     q = np.asarray(query_seen, f32)
-    lut = [[pq_fn(pq_metric, q[j * ds:(j + 1) * ds], cb[j, cc]) for cc in range(c)] for j in range(m)]
+    lut = [[f32(np.float16(pq_fn(pq_metric, q[j * ds:(j + 1) * ds], cb[j, cc]))) for cc in range(c)] for j in range(m)]   # entries rounded to binary16 (RNE)
     cnt = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
     NONE = 0xFFFFFFFF
 
