@@ -290,8 +290,9 @@ def host_copy_of_index(O, h, dim, quant, threads):
     return rows, adj0, g
 
 
-def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None):
-    """Hnsw.Search on the host cores over the SAME graph: 1 thread (latency), 16 threads, all cores (throughput)."""
+def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None, pq=None):
+    """Hnsw.Search on the host cores over the SAME graph: 1 thread (latency), 16 threads, all cores (throughput).
+    pq = {"cb", "pq_metric", "ef", "rerank"}: also the product-quantised walk (oracle definition) on a sample, timed and compared with the GPU's."""
     import psutil
     threads = O.cpu_count()
     need = h.Len() * dim * QBYTES[quant] * 1.15 + h.Len() * 2 * m * 4 * 2.2
@@ -325,7 +326,21 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None
         same = bool(np.array_equal(gi, res[0].astype(np.int64)) and np.array_equal(gs.view(np.uint32), res[1].view(np.uint32)))
         same_counters = bool(res[3]["n_dist"] == st["n_dist"] and res[3]["n_exp"] == st["n_exp"] and res[3]["n_hops"] == st["n_hops"])
         qps = {str(t): v["queries_per_s"] for t, v in legs.items()}
-        return {"value": best["queries_per_s"], "unit": "queries/s", "cores": best_th, "host_cpus": threads, "kind": "port", "ef": ef,
+        pq_res = None
+        if pq is not None:
+            try:
+                codes = h.PqCodes()
+                ns = int(min(len(q_host), max(best_th, 8 * best_th)))
+                pr = O.csr_search_pq(rows.a, quant, adj0.a, g["upper_off"], g["adjU"], dim, O.COSINE, int(g["entry"]), int(g["entry_level"]), codes, pq["cb"], pq["pq_metric"],
+                                     q_host[:ns], k, pq["ef"], rerank=pq["rerank"], threads=best_th, pin=True)
+                pst = h.PqSearchDevice(q_dev.data_ptr(), ns, k, *out.ptrs(), ef=pq["ef"], rerank=pq["rerank"])
+                pgi = out.ids[:ns].cpu().numpy(); pgs = out.sc[:ns].cpu().numpy()
+                pq_res = {"value": ns / pr[4], "unit": "queries/s", "cores": best_th, "sample": f"{ns} queries, oracle definition of the product-quantised walk on {best_th} pinned threads",
+                          "gpu_equals_oracle_on_sample": bool(np.array_equal(pgi, pr[0].astype(np.int64)) and np.array_equal(pgs.view(np.uint32), pr[1].view(np.uint32))),
+                          "counters_equal": bool(all(pr[3][kk] == pst[kk] for kk in ("n_dist", "n_exp", "n_hops", "n_exact")))}
+            except Exception as e:
+                pq_res = {"error": str(e)}
+        return {"value": best["queries_per_s"], "unit": "queries/s", "cores": best_th, "host_cpus": threads, "kind": "port", "ef": ef, "pq": pq_res,
                 "cpu_model": cpu_model(), "quota_cpus": quota_cpus(threads),
                 "sample_short": f"{sample} of the step's queries on the full {g['n']}x{dim} index, oracle (contiguous arrays, NUMA-interleaved), "
                                 f"best of {sorted(legs)} pinned threads",
@@ -430,6 +445,9 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
     efs = [int(e) for e in args.op_ef_sweep.split(",") if e]
     rq = min(args.recall_queries, nq)
     rec = recall_curve(G, torch, fl, h, q, rq, k, efs)
+    tt = Out(torch, dev, rq, k)
+    fl.VertexSearchDevice(q.data_ptr(), rq, k, *tt.ptrs(), select=G.SELECT_NEAREST)
+    op_truth = tt.ids.cpu().numpy()      # exact nearest-10 of the recall queries (for the product-quantised sweep below)
     fl.close()
     ok = [ef for ef in efs if isinstance(rec[str(ef)], float) and rec[str(ef)] >= args.op_recall]
     ef_op = min(ok) if ok else max(efs)
@@ -449,12 +467,52 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
     qps_curve = {}
     for ef in efs:
         h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef); qps_curve[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
+    # the same index walked on product-quantiser codes with an exact re-rank (coltt_hnsw_pq_*): the quantiser is trained on the first
+    # 65 536 stored rows, every row is encoded on the GPU, the sweep picks the smallest ef that reaches the target recall
+    pqw = None; pq_arg = None
+    try:
+        pm = int(os.environ.get("COLTT_BENCH_PQ_M", "32")); rr = int(os.environ.get("COLTT_BENCH_PQ_RERANK", "0"))
+        sample = h.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
+        pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, pm, 256)
+        t0 = time.perf_counter(); pq.Fit(sample, iterations=6); fit_s = time.perf_counter() - t0
+        t0 = time.perf_counter(); h.PqAttach(pq); attach_s = time.perf_counter() - t0
+        pefs = [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1280,1536,2048").split(",")]
+        pcurve = {}; pqps = {}
+        for ef in pefs:
+            st = h.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef, rerank=rr)
+            pqps[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
+            ids = out.ids[:rq].cpu().numpy()
+            pcurve[str(ef)] = sum(len(set(op_truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
+        pok = [ef for ef in pefs if pcurve[str(ef)] >= args.op_recall]
+        pef = min(pok) if pok else max(pefs)
+        pms = []; pst = None
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            pst = h.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=pef, rerank=rr); pms.append(h.last_kernel_ms())
+        torch.cuda.synchronize(); pdt = time.perf_counter() - t0
+        pnd = pst["n_dist"] / nq; pnx = pst["n_exact"] / nq; pne = pst["n_exp"] / nq
+        pbytes = pnd * ((pm + 15) // 16 * 16) + pne * (2 * args.m) * 4 + pnd * 4 + pnx * dim * 2
+        pqw = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x 256 centroids, {(pm + 15) // 16 * 16} B per row, binary16 tables in LDS) "
+                           f"+ exact re-rank of {'every survivor' if rr == 0 else rr}", "m": pm, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),
+               "value": steps * nq / pdt, "unit": "queries/s", "over_plain_walk": (steps * nq / pdt) / (steps * nq / dt), "recall_vs_ef": pcurve, "qps_vs_ef": pqps,
+               "per_query": {"n_dist": pnd, "n_exp": pne, "n_exact": pnx, "bytes": pbytes}, "fit_s": fit_s, "attach_s": attach_s,
+               "roofline": {"bound": "latency (resident traversals x dependent round trips; LDS holds the tables)", "achieved": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel": "hnsw_pq_search_kernel (hnsw_pq.hpp)",
+                            "avg_launch_ms": float(np.mean(pms))}}
+        pq_arg = {"cb": pq.Codebooks(), "pq_metric": O.PQ_EUCLIDEAN if O is not None else 1, "ef": pef, "rerank": rr}
+        pq.close()
+    except Exception as e:
+        pqw = {"error": str(e)}
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            cpu = cpu_hnsw(G, torch, O, h, args, dim, quant, ef_op, q, k, out, args.m)
+            cpu = cpu_hnsw(G, torch, O, h, args, dim, quant, ef_op, q, k, out, args.m, pq=pq_arg)
         except Exception as e:
             cpu = {"error": str(e)}
+    if isinstance(pqw, dict) and "error" not in pqw and isinstance(cpu, dict) and isinstance(cpu.get("pq"), dict):
+        pqw["cpu_baseline"] = cpu.pop("pq")
+        if pqw["cpu_baseline"].get("value"):
+            pqw["gpu_over_cpu"] = pqw["value"] / pqw["cpu_baseline"]["value"]
     op_ev8 = h.Rows8()[0]
     h.close()
     res = {"workload": f"core/vectorindex HNSW M={args.m} efConstruction={args.efc}, {n}x{dim} f16 codes, cosine, k={k}, dataset {args.op_dataset} "
@@ -469,7 +527,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
                         "kernel": "hnsw_search2_kernel (hnsw_walk2.hpp: HBM visited map behind an LDS Bloom filter, delta result set, 2-byte rows" +
                                   ("; eight lanes per row over rows8)" if op_ev8 > 0 else ")"),
                         "avg_launch_ms": launch_s * 1e3},
-           "cpu_baseline": cpu}
+           "cpu_baseline": cpu, "pq_walk": pqw}
     if cpu and "value" in cpu:
         res["gpu_over_cpu"] = res["value"] / cpu["value"]
     return res
@@ -923,6 +981,10 @@ def compact(res):
                       "traffic_ratio": (r["traffic"] / (r["achieved"] * 1e9 * r["avg_launch_ms"] / 1e3)) if r.get("traffic") and r.get("achieved") else None,
                       "cpu_value": (op.get("cpu_baseline") or {}).get("value"), "cpu_cores": (op.get("cpu_baseline") or {}).get("cores"),
                       "gpu_equals_oracle": (op.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")})
+            pw = op.get("pq_walk")
+            if isinstance(pw, dict):
+                o["pq"] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(_pick(pw, "m", "ef", "recall_at_10", "value", "over_plain_walk", "gpu_over_cpu"),
+                                                                                       gpu_equals_oracle=(pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample"))
             out["op"] = o
     sec = res.get("secondary") or {}
     for tag in ("c1", "c2", "c3", "c3f8", "pq"):

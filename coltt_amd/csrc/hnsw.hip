@@ -295,8 +295,8 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
-  size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
-  w.qs = reinterpret_cast<float*>(smem); w.qp = nullptr; w.scr = nullptr;
+  size_t off = 0;   // no copy of the query in LDS: only the re-rank reads it (a few dozen rows), straight from the prepared batch in HBM / L2
+  w.qs = nullptr; w.qp = nullptr; w.scr = nullptr;
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;
   w.ef_pad = ef_pad;
   if constexpr (VISMODE == VIS_LDS) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     if (qi >= nq) break;
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
     wave_sync();
-    for (int e = lane; e < g.dim; e += 64) w.qs[e] = q_eff[(size_t)qi * g.dim + e];
+    w.qs = const_cast<float*>(q_eff + (size_t)qi * g.dim);
     {  // the query's table: row_bytes x 256 entries, f32 in HBM -> binary16 in LDS (round to nearest even: the codec's own integer rounding, exact.hpp)
       const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + (size_t)qi * row_bytes * 256);
       u32x2e* dst = reinterpret_cast<u32x2e*>(lut);
@@ -1096,7 +1096,7 @@ struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: L
 bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   PqGeom s{};
   s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 512;   // query | result set | binary16 table
+  const size_t fixed = (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 512;   // result set | binary16 table (the query stays in HBM: only the re-rank reads it)
   if (fixed > 160 * 1024) return false;
   const bool hbm_ok = x->vis_stride != 0 && x->vis_regions > 0;
   // LDS hash: as search_geom sizes it; it must never need the reset path (err 8 -> the call is re-run over the byte map)
@@ -2040,6 +2040,7 @@ int coltt_hnsw_pq_attach(coltt_handle_t h, coltt_handle_t pq) {
   if (sh.dim != x->dim) return fail(COLTT_E_INVALID, "hnsw_pq_attach: the quantiser is for dim %u, the index holds dim %u", sh.dim, x->dim);
   if (sh.metric == COLTT_PQ_DOT) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: dotProductDistance tables are negative — the walk orders distances by their bits (squared L2, or 1 - dot on a cosine index)");
   if (sh.metric == COLTT_PQ_COSINE && x->metric != COLTT_COSINE) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: cosineDistance tables need a cosine index (normalised rows: every table entry is >= 0)");
+  if (x->dim % 4) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: dim %u is not a multiple of 4 (the re-rank reads the prepared query rows with 16-byte loads)", x->dim);
   const uint32_t row = (sh.m + 15u) & ~15u;
   if (row > 128) return fail(COLTT_E_UNSUPPORTED, "hnsw_pq_attach: %u sub-vectors — a query's table (%u KiB) must fit the CU's LDS beside the result set (<= 128)", sh.m, row / 2);
   const size_t bytes = (size_t)sh.m * sh.C * sh.dsub * 4;

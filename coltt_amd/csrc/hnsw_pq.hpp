@@ -18,7 +18,7 @@
 // d is a sum of non-negative terms for the supported pairings (squared L2 always; 1 - dot on a cosine index, whose rows, query and
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
-// One wave per query.  LDS: [query f32, natural order (re-rank) | result set | visited hash or Bloom filter | the query's table].
+// One wave per query.  LDS: [result set | visited hash or Bloom filter | the query's table]; the re-rank reads the query from HBM / L2.
 // The table is what bounds occupancy: mp16 / 2 KiB per resident traversal (m = 32: 16 KiB; m = 96: 48 KiB).  Measured with f32 tables
 // (profiles/r05b_hnswpq_probe_10m.jsonl, 10 M x 768 f16): the walk is a chain of dependent round trips (~5 us per expansion), its
 // throughput is resident traversals / latency — 157 k queries/s at 3 waves per CU (m = 32), 49 k at 1 (m = 96) — never HBM bytes.

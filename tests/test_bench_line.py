@@ -58,7 +58,9 @@ def test_final_line_of_this_rounds_record_carries_every_leg():
     assert c["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], rel=1e-4)
     # the committed last line of that run is what final_line() produces from the committed full record
     committed = json.load(open(os.path.join(ROOT, "profiles", "r04aa_bench_10m_line.json")))
-    assert committed["value"] == c["value"] and committed["roofline"] == c["roofline"] and committed["op"] == c["op"]
+    now = {kk: v for kk, v in c["roofline"].items() if kk != "traffic_source"}   # (round 5 carries the PMC file's name in the compact line as well)
+    assert committed["value"] == c["value"] and committed["roofline"] == now and committed["op"] == c["op"]
+    assert c["roofline"]["traffic_source"].startswith("profiles/")
 
 
 def test_final_line_is_bounded_whatever_the_legs_hold():
