@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 template <int METRIC, int QUANT, int OPT, int VISMODE>
 __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
                                                             const float* __restrict__ qnorms, const float* __restrict__ lut_g,
-                                                            const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t nq, uint32_t k,
+                                                            const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
                                                             uint32_t ef, uint32_t ef_pad, uint32_t rerank, uint32_t vis_words,
                                                             uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
                                                             float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
   }
   unsigned short* const lut = reinterpret_cast<unsigned short*>(smem + off);
-  AdcEval ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut;
+  AdcEval ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut; ev.lut_shift = lut_shift;
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
@@ -319,11 +319,14 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
     wave_sync();
     w.qs = const_cast<float*>(q_eff + (size_t)qi * g.dim);
-    {  // the query's table: row_bytes x 256 entries, f32 in HBM -> binary16 in LDS (round to nearest even: the codec's own integer rounding, exact.hpp)
-      const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + (size_t)qi * row_bytes * 256);
+    {  // the query's table: row_bytes rows of (1 << lut_shift) entries (of the 256 per row in HBM), f32 -> binary16 in LDS (round to nearest even:
+       // the codec's own integer rounding, exact.hpp); four entries per lane and step
+      const float* src = lut_g + (size_t)qi * row_bytes * 256;
       u32x2e* dst = reinterpret_cast<u32x2e*>(lut);
-      for (uint32_t i = (uint32_t)lane; i < row_bytes * 64u; i += 64) {
-        const u32x4v v = src[i];
+      const uint32_t per_row = 1u << (lut_shift - 2), total = row_bytes << (lut_shift - 2);
+      for (uint32_t i = (uint32_t)lane; i < total; i += 64) {
+        const uint32_t j = i / per_row, c4 = i - j * per_row;
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (size_t)j * 256 + c4 * 4);
         dst[i] = u32x2e{f32bits_to_f16bits(v.x) | (f32bits_to_f16bits(v.y) << 16), f32bits_to_f16bits(v.z) | (f32bits_to_f16bits(v.w) << 16)};
       }
     }
@@ -1092,11 +1095,13 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
 
 
 // ---- Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp) --------------------------------------------------------
+// log2 of a table row in LDS: the centroid count rounded up to a power of two, at least 16 (codes >= C never occur)
+uint32_t pq_lut_shift(const Hnsw* x) { uint32_t sh = 4; while ((1u << sh) < x->pq_shape.C) sh++; return sh; }
 struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: LDS hash | 2: byte map + delta | 3: + Bloom */ uint32_t per_cu; };
 bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   PqGeom s{};
   s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (size_t)s.ef_pad * 8 + (size_t)x->pq_row * 512;   // result set | binary16 table (the query stays in HBM: only the re-rank reads it)
+  const size_t fixed = (size_t)s.ef_pad * 8 + ((size_t)x->pq_row << pq_lut_shift(x)) * 2;   // result set | binary16 table (the query stays in HBM: only the re-rank reads it)
   if (fixed > 160 * 1024) return false;
   const bool hbm_ok = x->vis_stride != 0 && x->vis_regions > 0;
   // LDS hash: as search_geom sizes it; it must never need the reset path (err 8 -> the call is re-run over the byte map)
@@ -1120,14 +1125,14 @@ bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
 template <int METRIC, int QUANT>
 int launch_pq_search(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t q0, uint32_t nq, uint32_t k,
                      uint32_t rerank, uint32_t* counter, uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
-  typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, const float*, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+  typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, const float*, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
                          uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
   kern_t kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS>
               : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   GraphView g = x->view();
   kern<<<grid, 64, sg.lds, c->stream>>>(g, x->entry, x->entry_level, c->w_qeff.as<float>() + (size_t)q0 * x->dim, c->w_qn.as<float>() + q0, lut,
-                                        x->pq_codes.as<uint8_t>(), x->pq_row, nq, k, sg.ef, sg.ef_pad, rerank, sg.vis_words, counter, oi + (size_t)q0 * k,
+                                        x->pq_codes.as<uint8_t>(), x->pq_row, pq_lut_shift(x), nq, k, sg.ef, sg.ef_pad, rerank, sg.vis_words, counter, oi + (size_t)q0 * k,
                                         os + (size_t)q0 * k, oc + q0, stats, x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
                                         (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());

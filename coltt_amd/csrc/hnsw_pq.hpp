@@ -19,7 +19,8 @@
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
 // One wave per query.  LDS: [result set | visited hash or Bloom filter | the query's table]; the re-rank reads the query from HBM / L2.
-// The table is what bounds occupancy: mp16 / 2 KiB per resident traversal (m = 32: 16 KiB; m = 96: 48 KiB).  Measured with f32 tables
+// The table is what bounds occupancy: mp16 x C' x 2 bytes per resident traversal, C' = the centroid count rounded up to a power of two
+// (m = 32 x 256 centroids: 16 KiB; m = 96 x 256: 48 KiB; m = 64 x 16 — the same 256 bits per row as 32 x 256 — 2 KiB).  Measured with f32 tables
 // (profiles/r05b_hnswpq_probe_10m.jsonl, 10 M x 768 f16): the walk is a chain of dependent round trips (~5 us per expansion), its
 // throughput is resident traversals / latency — 157 k queries/s at 3 waves per CU (m = 32), 49 k at 1 (m = 96) — never HBM bytes.
 #pragma once
@@ -32,7 +33,8 @@ namespace dev {
 // first lookup).  The even lane of a pair computes, both lanes of the pair receive (the walk keeps one neighbour per lane pair).
 struct AdcEval {
   const uint8_t* codes; uint32_t row_bytes;   // [n][row_bytes], row_bytes = mp16 (a multiple of 16, <= 128); bytes j >= m are 0
-  const unsigned short* lut;                   // LDS: [row_bytes][256] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
+  const unsigned short* lut;                   // LDS: [row_bytes][1 << lut_shift] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
+  uint32_t lut_shift;                          // log2 of the table's row length = the number of centroids rounded up to a power of two (4 .. 8)
   u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
@@ -54,7 +56,7 @@ struct AdcEval {
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             const uint32_t c = (v >> (8 * b)) & 0xffu;
-            s = s + f16bits_to_f32(lut[(size_t)(i * 16 + wd * 4 + b) * 256 + c]);
+            s = s + f16bits_to_f32(lut[((uint32_t)(i * 16 + wd * 4 + b) << lut_shift) + c]);
           }
         }
       }

@@ -65,7 +65,7 @@ def _pq_case(gpu, n, d, metric, quant, m, c, seed):
     return h, pq, pqm, rows, seen
 
 
-@pytest.mark.parametrize("metric,quant,d,m,c", [("cos", "f16", 64, 8, 256), ("l2", "f32", 64, 16, 17), ("cos", "f32", 96, 32, 64), ("l2", "f16", 128, 4, 256)])
+@pytest.mark.parametrize("metric,quant,d,m,c", [("cos", "f16", 64, 8, 256), ("l2", "f32", 64, 16, 17), ("cos", "f32", 96, 32, 64), ("l2", "f16", 128, 4, 256), ("cos", "f16", 64, 32, 16)])
 def test_hnsw_over_pq_codes_equals_the_oracle_definition(gpu, metric, quant, d, m, c):
     """VERDICT r4 missing #1: Hnsw.Search over product-quantiser codes with an exact re-rank (hnsw_pq.hpp) against the oracle's
     definition (coltt_oracle.cpp "Product-quantised HNSW"): the codes kept by the index == Encode of the stored rows; ids, EXACT score

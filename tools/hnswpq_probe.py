@@ -18,7 +18,7 @@ def main():
     import coltt_amd as G
     assert G.lib().coltt_init(0) == 0
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-    ms = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "32,96").split(",")]
+    ms = [(int(v.split(":")[0]), int(v.split(":")[1]) if ":" in v else 256) for v in (sys.argv[2] if len(sys.argv) > 2 else "32,96").split(",")]   # m or m:centroids
     efs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "512,1024,2048").split(",")]
     rrs = [int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "0,128").split(",")]
     spec = os.environ.get("PROBE_DATASET", "lowrank:32:1.0")
@@ -56,9 +56,9 @@ def main():
     # training sample: the first 65 536 stored rows as the index's distance sees them
     ns = min(n, 65536)
     sample = h.FetchRows(0, ns).view(np.float16).astype(np.float32)
-    for m in ms:
+    for m, nc in ms:
         for pqm, pname in ((G.PQ_EUCLIDEAN, "l2"),):
-            pq = G.PQSpace(dim, pqm, m, 256)
+            pq = G.PQSpace(dim, pqm, m, nc)
             t0 = time.time(); pq.Fit(sample, iterations=6); fit_s = time.time() - t0
             t0 = time.time(); h.PqAttach(pq); attach_s = time.time() - t0
             for ef in efs:
@@ -68,7 +68,7 @@ def main():
                         t0 = time.time(); st = h.PqSearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef, rerank=rr); dt = time.time() - t0
                         nd, nx = st["n_dist"] / nq, st["n_exact"] / nq
                         bytes_q = nd * ((m + 15) // 16 * 16) + st["n_exp"] / nq * 32 * 4 + nd * 4 + nx * dim * 2
-                        emit({"kind": "pq", "n": n, "m": m, "pq_metric": pname, "ef": ef, "rerank": rr, "recall": round(recall(o.ids.cpu().numpy()), 4),
+                        emit({"kind": "pq", "n": n, "m": m, "C": nc, "pq_metric": pname, "ef": ef, "rerank": rr, "recall": round(recall(o.ids.cpu().numpy()), 4),
                               "qps": round(nq / dt), "kernel_ms": round(h.last_kernel_ms(), 3), "n_dist": round(nd, 1), "n_exact": round(nx, 1),
                               "MB_per_query": round(bytes_q / 1e6, 3), "GBps": round(bytes_q * nq / max(h.last_kernel_ms(), 1e-9) / 1e6, 1),
                               "fit_s": round(fit_s, 2), "attach_s": round(attach_s, 2)})
