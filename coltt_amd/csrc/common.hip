@@ -83,7 +83,6 @@ Policy read_policy_from_env() {
   v = num("COLTT_LAT_MAX_NQ", set); if (!set) v = num("COLTT_MW_MAX_NQ", set);
   p.lat_knob_set = set; p.lat_max_nq = set ? (uint32_t)std::max<long long>(0, v) : 0;
   v = num("COLTT_VISG_BUDGET_MB", set); p.visg_budget_mb = set ? v : -1;
-  { const char* e = getenv("COLTT_ROWS8_FAIL"); p.rows8_fail = e && *e == '1'; }
   return p;
 }
 }  // namespace

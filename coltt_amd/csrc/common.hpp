@@ -101,9 +101,9 @@ constexpr size_t SMALL_CALL_BYTES = 64 * 1024;   // queries and answers up to th
 struct Policy {
   bool flat_one = true;        // COLTT_FLAT_ONE=0: <= 4-query FLAT searches through the scan + select chain
   bool staging = true;         // COLTT_STAGING=0: no page-locked staging of small host-buffer calls
-  bool ev8 = true;             // COLTT_EV8=0: level-0 distances from the pair-owned rows even when rows8 exists
+  bool ev8 = true;             // COLTT_EV8=0: level-0 distances of the throughput kernels from the pair-owned core even over line-transposed rows
   bool f8_mfma = true;         // COLTT_F8_MFMA=0: new "f8" cosine stores keep no binary16 copy: their batches run the exact scan (read at create)
-  int rows8 = 1;               // COLTT_ROWS8 (read at create): 0 = new indexes keep no line-transposed row copy, 1 = default (dim >= 256), 2 = any shape rows8 covers
+  int rows8 = 1;               // COLTT_ROWS8 (read at create): 0 = new indexes store their rows in natural order, 1 = line-transposed for dim >= 256 (default), 2 = for any shape rows8.hpp covers
   int visg = -1;               // COLTT_VISG: -1 default (byte map above ef 128), 0 LDS hash, 1 byte map
   int walk2 = 7;               // COLTT_WALK2: -1 off, else OPT bits | 8 deep profile
   int walk2_lds = 4;           // COLTT_WALK2_LDS: -1 off, 2 / 4 / 6
@@ -113,7 +113,6 @@ struct Policy {
   bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
   uint32_t lat_max_nq = 0;     // ... and its value
   long long visg_budget_mb = -1;  // COLTT_VISG_BUDGET_MB (test knob)
-  bool rows8_fail = false;     // COLTT_ROWS8_FAIL=1 (test knob): the allocation of the line-transposed row copy is made to fail
 };
 Policy policy();               // a copy of the current snapshot
 inline bool small_call_staging() { return policy().staging; }

@@ -284,6 +284,62 @@ __device__ __forceinline__ float pair_distance(const uint8_t* __restrict__ row, 
   else return go_sqrt(s);
 }
 
+// ---- the pair-owned core over LINE-TRANSPOSED rows (rows8.hpp: chunk r of every 128-byte line holds residue r's 4 (f32) / 8 (2-byte)
+// consecutive AVX steps).  Half h of a pair owns residues 4h .. 4h+3 = the chunks 4h .. 4h+3 of a line: 64 CONTIGUOUS bytes per line and
+// lane, the 16-byte chunk of residue r' in register c[r'].  Step t of the line is then (c[0][t], c[1][t], c[2][t], c[3][t]) — register
+// renaming, no data movement — times the query's elements 8 * step + 4h .. + 3 (natural order in LDS, as for pair_distance): the same
+// products added to the same four accumulators in the same order, hence the same bits.  Rows whose byte length is a multiple of 128 only
+// (no scalar tail exists).  U = lines per burst.
+struct Line4 { u32x4e c[4]; };
+template <int METRIC, int QUANT>
+__device__ __forceinline__ void r8_consume(f32x4& acc, const Line4& ln, const float* __restrict__ q, int L, int half) {
+  if constexpr (QUANT == Q_NONE) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * (4 * L + t) + 4 * half);
+      const f32x4 r = {__builtin_bit_cast(float, ln.c[0][t]), __builtin_bit_cast(float, ln.c[1][t]), __builtin_bit_cast(float, ln.c[2][t]), __builtin_bit_cast(float, ln.c[3][t])};
+      if constexpr (METRIC == M_COS) { const f32x4 p = qq * r; acc = acc + p; }
+      else { const f32x4 d = qq - r; const f32x4 p = d * d; acc = acc + p; }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * (8 * L + t) + 4 * half);
+      const int wd = t >> 1, sh = (t & 1) * 16;
+      const f32x4 r = {f16bits_to_f32((ln.c[0][wd] >> sh) & 0xffffu), f16bits_to_f32((ln.c[1][wd] >> sh) & 0xffffu),
+                       f16bits_to_f32((ln.c[2][wd] >> sh) & 0xffffu), f16bits_to_f32((ln.c[3][wd] >> sh) & 0xffffu)};
+      if constexpr (METRIC == M_COS) { const f32x4 p = qq * r; acc = acc + p; }
+      else { const f32x4 d = qq - r; const f32x4 p = d * d; acc = acc + p; }
+    }
+  }
+}
+__device__ __forceinline__ Line4 r8_load(const uint8_t* __restrict__ row, int L, int half) {
+  const u32x4e* p = reinterpret_cast<const u32x4e*>(row + (size_t)L * 128 + (size_t)half * 64);
+  Line4 ln;
+  ln.c[0] = p[0]; ln.c[1] = p[1]; ln.c[2] = p[2]; ln.c[3] = p[3];
+  return ln;
+}
+template <int METRIC, int QUANT, int U = 3>
+__device__ __forceinline__ float pair_distance_r8(const uint8_t* __restrict__ row, const float* __restrict__ q, int dim, float qnorm, float rnorm, int half) {
+  static_assert(QUANT == Q_NONE || QUANT == Q_F16 || QUANT == Q_BF16, "line-transposed rows exist for f32 and 2-byte codes");
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nl = (dim * elem_bytes<QUANT>()) >> 7;
+#define COLTT_LD_(L_) r8_load(row, (L_), half)
+#define COLTT_CS_(RAW, L_) r8_consume<METRIC, QUANT>(acc, RAW, q, (L_), half)
+  COLTT_BURST_WALK(U, Line4, nl, COLTT_LD_, COLTT_CS_)
+#undef COLTT_LD_
+#undef COLTT_CS_
+  const float s = pair_hsum(acc, half);
+  if constexpr (METRIC == M_COS) return cos_epilogue(s, qnorm, rnorm);
+  else return go_sqrt(s);
+}
+// element e of a line-transposed row (host read-backs, the builder's own query): rows8.hpp's index map, restated here for exact.hpp's users
+template <int QUANT> __device__ __host__ __forceinline__ int r8_index(int e) {
+  constexpr int S = QUANT == Q_NONE ? 4 : 8;
+  const int step = e >> 3, r = e & 7;
+  return ((step / S) * 8 + r) * S + (step % S);
+}
+
 // ---- misc --------------------------------------------------------------------------------------------
 // sharding.ShardVertex (pkg/sharding/shard.go:34-41): FNV-1a-64 over the 8 LE bytes of the id
 __device__ __host__ __forceinline__ uint64_t shard_vertex(uint64_t x, uint64_t c) {

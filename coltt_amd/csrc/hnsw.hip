@@ -27,7 +27,7 @@ using namespace coltt::dev;
 namespace {
 
 // Hnsw.Search (hnsw.go:243-278) for a batch: one wave per query, queries pulled from a global counter.
-template <int METRIC, int QUANT, bool VISG>
+template <int METRIC, int QUANT, bool VISG, bool R8 = false>   // R8: the index's ONE row array is line-transposed (rows8.hpp)
 __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                         const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                         uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
@@ -64,15 +64,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
     wave_sync();
     // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253)
     uint32_t cur = (uint32_t)entry;
-    float curd = eval_pair<METRIC, QUANT, PROF>(g, w, cur, lane & 1);
+    float curd = eval_pair<METRIC, QUANT, PROF, R8>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
-    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF>(g, w, cur, curd, l, lane);  // :254-256
+    for (int l = entry_level; l > 0; l--) greedy_level<METRIC, QUANT, PROF, R8>(g, w, cur, curd, l, lane);  // :254-256
     COLTT_PT(w, 5)  // query load + entry distance + upper levels
     // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     w.n_dist += 1;
     uint32_t len; int buf;
-    search_level<METRIC, QUANT, VISG, PROF>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
+    search_level<METRIC, QUANT, VISG, PROF, R8>(g, w, cur, curd, ef, 0, lane, len, buf);  // :258-259
     // selectNeighbors + pop into result[n-1..0] (:261-277) == the k smallest, ascending
     uint32_t n = len < k ? len : k;
     const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 // of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
 // EV8: the level-0 distances come from the eight-lanes-per-row core over GraphView::rows8 (rows8.hpp); the upper levels and the
 // entrypoint (a few dozen evaluations) stay on the pair-owned rows.
-template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false, bool EV8 = false>   // APREF: adjacency prefetch for f32 rows too (small batches)
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false, bool EV8 = false, bool R8 = false>   // APREF: adjacency prefetch for f32 rows too (small batches); R8 (without EV8): the pair-owned core over line-transposed rows
 __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                          const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                          uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t bloom_words,
@@ -156,18 +156,18 @@ __global__ __launch_bounds__(64) void hnsw_search2_kernel(GraphView g, int32_t e
     float curd;
     constexpr bool H16 = EV8 && QUANT != Q_NONE && VISMODE == VIS_HBM;   // Group8Eval: rows x burst depth of the HBM-visited 2-byte kernels
     if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false, H16>().one(g, w, cur, lane);
-    else curd = eval_pair<METRIC, QUANT, PROFILE>(g, w, cur, lane & 1);  // hnsw.go:253
+    else curd = eval_pair<METRIC, QUANT, PROFILE, R8>(g, w, cur, lane & 1);  // hnsw.go:253
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
     for (int l = entry_level; l > 0; l--) {  // :254-256
       if constexpr (EV8) greedy_level8<METRIC, QUANT, H16>(g, w, cur, curd, l, lane);
-      else greedy_level<METRIC, QUANT, PROFILE>(g, w, cur, curd, l, lane);
+      else greedy_level<METRIC, QUANT, PROFILE, R8>(g, w, cur, curd, l, lane);
     }
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
     if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS, H16>());
-    else search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len);  // :258-259
+    else search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, PairEval<METRIC, QUANT, PROFILE, (OPT & W2_ADJN) != 0 && METRIC == M_COS, R8>());  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {
       const unsigned long long e = w.res0[i];
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 
 // Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp): one wave per query, queries pulled from a global counter.
 // OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 / 3 + VIS_HBM: byte map, delta result set, Bloom filter if it fits).
-template <int METRIC, int QUANT, int OPT, int VISMODE>
+template <int METRIC, int QUANT, int OPT, int VISMODE, bool R8 = false>
 __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
                                                             const float* __restrict__ qnorms, const float* __restrict__ lut_g,
                                                             const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
     search_level2<M_L2, Q_F16, PROF_SEARCH_HBM, OPT, VISMODE, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259 (M_L2: no norms ride along; Q_F16: the adjacency prefetch)
     uint32_t r = rerank == 0 ? len : (rerank > k ? rerank : k);
     r = r < len ? r : len;
-    const uint32_t n = rerank_exact<METRIC, QUANT>(g, w, r, k, qi, out_ids, out_scores, lane);
+    const uint32_t n = rerank_exact<METRIC, QUANT, R8>(g, w, r, k, qi, out_ids, out_scores, lane);
     if (lane == 0) {
       out_counts[qi] = n;
       atomicAdd(&stats[0], (unsigned long long)w.n_dist);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t
 // ---------------------------------------------------------------------------------------------------
 struct BuildReq { uint32_t rid, from; float d; uint32_t next; };
 
-template <int METRIC, int QUANT, bool VISG>
+template <int METRIC, int QUANT, bool VISG, bool R8 = false>
 __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int32_t entry, int32_t entry_level, uint32_t base,
                                                               uint32_t count, const int32_t* __restrict__ levels, uint32_t M,
                                                               uint32_t efc, uint32_t ef_pad, uint32_t hcap, uint64_t cap_slots,
@@ -392,19 +392,21 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
     wave_sync();
     {  // the query is the vertex's own stored row, decoded to f32
       const uint8_t* row = g.rows + (size_t)vi * g.stride;
-      for (int e = lane; e < g.dim; e += 64) w.qs[e] = load1<QUANT>(row, e);
+      for (int e = lane; e < g.dim; e += 64) {
+        if constexpr (R8) w.qs[e] = load1<QUANT>(row, r8_index<QUANT>(e)); else w.qs[e] = load1<QUANT>(row, e);
+      }
     }
     w.qnorm = METRIC == M_COS ? g.norms[vi] : 0.f;
     wave_sync();
     uint32_t cur = (uint32_t)entry;
-    float curd = eval_pair<METRIC, QUANT, PROF_BUILD>(g, w, cur, lane & 1);
+    float curd = eval_pair<METRIC, QUANT, PROF_BUILD, R8>(g, w, cur, lane & 1);
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
-    for (int l = entry_level; l > lv; l--) greedy_level<METRIC, QUANT, PROF_BUILD>(g, w, cur, curd, l, lane);
+    for (int l = entry_level; l > lv; l--) greedy_level<METRIC, QUANT, PROF_BUILD, R8>(g, w, cur, curd, l, lane);
     for (int l = entry_level < lv ? entry_level : lv; l >= 0; l--) {
       uint32_t len; int buf;
       w.n_dist += 1;
-      search_level<METRIC, QUANT, VISG, PROF_BUILD>(g, w, cur, curd, efc, l, lane, len, buf);
+      search_level<METRIC, QUANT, VISG, PROF_BUILD, R8>(g, w, cur, curd, efc, l, lane, len, buf);
       const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
       const uint32_t m = len < M ? len : M;
       // the m nearest, re-ordered by slot (canonical row order)
@@ -540,11 +542,13 @@ struct Hnsw : Object {
   int32_t entry = -1, entry_level = 0;
   bool any_deleted = false;
   DevBuf rows, norms, ids, adj0, adj0_d, adj0_n, upper_off, adjU, adjU_d, del_bits;
-  // rows8.hpp: line-transposed copy of `rows` for the eight-lanes-per-row distance core.  Derived data: writers permute the slots they
-  // added before they release the exclusive lock (sync_rows8); slots are never rewritten (Insert refuses an existing id, Remove
-  // is a tombstone), so [0, n8done) stays valid until the index is replaced.  Off for shapes rows8 does not cover, with
-  // COLTT_ROWS8=0, or when the second copy cannot be allocated.
-  DevBuf rows8; bool rows8_on = false; uint64_t n8done = 0;
+  // rows8.hpp (round 5: ONE row array).  r8: `rows` itself is stored LINE-TRANSPOSED — every 128-byte line rewritten so that its 16-byte chunk r
+  // holds residue r's consecutive AVX steps — for the shapes the eight-lanes-per-row core covers (f32 / 2-byte rows whose byte length is a
+  // multiple of 128, dim >= 256 unless COLTT_ROWS8=2; never with COLTT_ROWS8=0).  Every reader knows the layout: the eight-lane core reads whole
+  // lines, the pair-owned core reads its four chunks of a line (exact.hpp: pair_distance_r8 — same values, same order, same bits), the builder,
+  // Commit / Get / fetch and the quantiser's Encode un-permute element indices (r8_index).  Writers go through a natural-order staging block.
+  bool r8 = false;
+  DevBuf w_stage;   // natural-order rows of the batch being ingested (r8 indexes)
   std::atomic<uint64_t> ev8_launches{0};   // search launches whose level-0 distances came from rows8
   // hnsw_pq.hpp: a snapshot of a trained product quantiser and one row-major code per slot (derived data, maintained like rows8:
   // writers encode the slots they added before they release the exclusive lock)
@@ -573,7 +577,7 @@ struct Hnsw : Object {
   GraphView view() const {
     GraphView g;
     g.rows = rows.as<uint8_t>(); g.stride = stride; g.norms = norms.as<float>();
-    g.rows8 = (rows8_on && n8done == n) ? rows8.as<uint8_t>() : nullptr;
+    g.rows8 = r8 ? rows.as<uint8_t>() : nullptr;   // the same array: which core reads it is the kernel's choice
     g.ids = dense ? nullptr : ids.as<uint64_t>();
     g.adj0 = adj0.as<uint32_t>(); g.adj0_d = adj0_d.as<float>(); g.upper_off = upper_off.as<uint32_t>();
     g.adj0_n = metric == COLTT_COSINE ? adj0_n.as<float>() : nullptr;
@@ -586,18 +590,6 @@ struct Hnsw : Object {
     if (slots > cap) {
       uint64_t nc = std::max<uint64_t>({slots, cap + cap / 2, 1024});
       COLTT_TRY(rows.reserve(nc * stride, true, stream));
-      auto rows8_alloc = [&]() -> int {
-        if (policy().rows8_fail) { void* t = nullptr; COLTT_HIP(hipMalloc(&t, (size_t)1 << 60)); }   // test knob: a real, failing allocation
-        return rows8.reserve(nc * stride, true, stream);
-      };
-      if (rows8_on && rows8_alloc() != COLTT_OK) {   // no room for the second copy: the pair-owned walk serves
-        // the failed hipMalloc left HIP's sticky last error behind (ROCm 7: hipGetLastError returns the last REAL error): consume it,
-        // or the next launch check of this very Insert / Reserve would report hipErrorOutOfMemory
-        (void)hipGetLastError();
-        rows8_on = false; n8done = 0;
-        if (rows8.p) { (void)hipFree(rows8.p); rows8.p = nullptr; rows8.cap = 0; }
-        fprintf(stderr, "[coltt_gpu] hnsw: no memory for the line-transposed row copy (%llu B) — searches use the pair-owned rows\n", (unsigned long long)(nc * stride));
-      }
       COLTT_TRY(norms.reserve(nc * 4, true, stream));
       if (!dense) COLTT_TRY(ids.reserve(nc * 8, true, stream));
       COLTT_TRY(adj0.reserve(nc * cfg.m_max0 * 4, true, stream));
@@ -624,6 +616,22 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
   int nrm = normalize ? 1 : 0;
   uint8_t* R = x->rows.as<uint8_t>();
   float* N = x->norms.as<float>();
+  if (x->r8) {   // Normalize + Lower into a natural-order staging block, norms from it (AVX order), then the line transposition into the row array
+    COLTT_TRY(x->w_stage.reserve(n * x->stride));
+    uint8_t* S = x->w_stage.as<uint8_t>();
+    const uint64_t chunks = (uint64_t)x->stride / 16;
+    if (x->quant == COLTT_Q_NONE) {
+      launch_prep_rows<Q_NONE>(x->stream, d_raw, n, (int)x->dim, nrm, nullptr, 0, S, x->stride);
+      row_norms_kernel<Q_NONE><<<ceil_div(n * 2, 256), 256, 0, x->stream>>>(S, x->stride, nullptr, 0, n, (int)x->dim, N + slot_base);
+      rows8_permute_kernel<Q_NONE><<<ceil_div(n * chunks, 256), 256, 0, x->stream>>>(S, R + slot_base * x->stride, x->stride, (int)x->dim, n);
+    } else {
+      launch_prep_rows<Q_F16>(x->stream, d_raw, n, (int)x->dim, nrm, nullptr, 0, S, x->stride);
+      row_norms_kernel<Q_F16><<<ceil_div(n * 2, 256), 256, 0, x->stream>>>(S, x->stride, nullptr, 0, n, (int)x->dim, N + slot_base);
+      rows8_permute_kernel<Q_F16><<<ceil_div(n * chunks, 256), 256, 0, x->stream>>>(S, R + slot_base * x->stride, x->stride, (int)x->dim, n);
+    }
+    COLTT_HIP(hipGetLastError());
+    return COLTT_OK;
+  }
 #define COLTT_PREP(Q)                                                                                                  \
   do {                                                                                                                 \
     launch_prep_rows<Q>(x->stream, d_raw, n, (int)x->dim, nrm, nullptr, slot_base, R, x->stride);                     \
@@ -635,31 +643,29 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
   return COLTT_OK;
 }
 
-// rows8 of the slots added since the last call (rows8.hpp); completes on the device before it returns
+// derived per-slot data of the slots a writer added (the product quantiser's codes); completes on the device before it returns
 int sync_pq(Hnsw* x);
-int sync_rows8_only(Hnsw* x);
-// derived per-slot data of the slots a writer added: the line-transposed row copy, then the product-quantiser codes
-int sync_rows8(Hnsw* x) { COLTT_TRY(sync_rows8_only(x)); return sync_pq(x); }
-int sync_rows8_only(Hnsw* x) {
-  if (!x->rows8_on || x->n8done >= x->n) { if (x->n8done > x->n) x->n8done = x->n; return COLTT_OK; }
-  const uint64_t b = x->n8done, m = x->n - b;
-  const uint64_t chunks = (uint64_t)x->stride / 16;
-  if (x->quant == COLTT_Q_NONE)
-    rows8_permute_kernel<Q_NONE><<<ceil_div(m * chunks, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->rows8.as<uint8_t>(), x->stride, (int)x->dim, b, m);
-  else
-    rows8_permute_kernel<Q_F16><<<ceil_div(m * chunks, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->rows8.as<uint8_t>(), x->stride, (int)x->dim, b, m);
-  COLTT_HIP(hipGetLastError());
-  COLTT_HIP(hipStreamSynchronize(x->stream));
-  x->n8done = x->n;
-  return COLTT_OK;
-}
+int sync_rows8(Hnsw* x) { return sync_pq(x); }
 // stored rows [first, first + m) -> the f32 values the index's distance sees (what the quantiser encodes), packed [m][dim]
-template <int QUANT>
+template <int QUANT, bool R8>
 __global__ void rows_to_f32_kernel(const uint8_t* __restrict__ rows, size_t stride, uint64_t first, uint64_t m, int dim, float* __restrict__ out) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= m * (uint64_t)dim) return;
   const uint64_t i = t / dim; const int e = (int)(t - i * dim);
-  out[t] = load1<QUANT>(rows + (first + i) * stride, e);
+  int pos = e;
+  if constexpr (R8) pos = r8_index<QUANT>(e);
+  out[t] = load1<QUANT>(rows + (first + i) * stride, pos);
+}
+// the stored codes of rows [first, first + m) in NATURAL element order, packed [m][dim * elem bytes] (read-backs of a line-transposed index)
+template <int QUANT>
+__global__ void rows_natural_kernel(const uint8_t* __restrict__ rows, size_t stride, uint64_t first, uint64_t m, int dim, uint8_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * (uint64_t)dim) return;
+  const uint64_t i = t / dim; const int e = (int)(t - i * dim);
+  const uint8_t* row = rows + (first + i) * stride;
+  const int pos = r8_index<QUANT>(e);
+  if constexpr (QUANT == Q_NONE) reinterpret_cast<uint32_t*>(out)[t] = reinterpret_cast<const uint32_t*>(row)[pos];
+  else reinterpret_cast<unsigned short*>(out)[t] = reinterpret_cast<const unsigned short*>(row)[pos];
 }
 // codes of the slots added since the last call (hnsw_pq.hpp); completes on the device before it returns
 int sync_pq(Hnsw* x) {
@@ -671,9 +677,13 @@ int sync_pq(Hnsw* x) {
   COLTT_TRY(x->pq_stage.reserve(std::min<uint64_t>(chunk, x->n - x->pq_done) * x->dim * 4));
   for (uint64_t b = x->pq_done; b < x->n; b += chunk) {
     const uint64_t m = std::min<uint64_t>(chunk, x->n - b);
-#define COLTT_R2F(Q) rows_to_f32_kernel<Q><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>())
-    COLTT_DISPATCH_QUANT(x->quant, COLTT_R2F)
-#undef COLTT_R2F
+    if (x->quant == COLTT_Q_NONE) {
+      if (x->r8) rows_to_f32_kernel<Q_NONE, true><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>());
+      else rows_to_f32_kernel<Q_NONE, false><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>());
+    } else {   // (attach refuses "f8" rows)
+      if (x->r8) rows_to_f32_kernel<Q_F16, true><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>());
+      else rows_to_f32_kernel<Q_F16, false><<<ceil_div(m * x->dim, 256), 256, 0, x->stream>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, x->pq_stage.as<float>());
+    }
     COLTT_HIP(hipGetLastError());
     COLTT_TRY(pq_encode_rowmajor(x->stream, x->pq_cb.as<float>(), x->pq_shape, x->pq_stage.as<float>(), m, x->pq_codes.as<uint8_t>() + b * x->pq_row, x->pq_row));
   }
@@ -824,7 +834,7 @@ SearchGeom search_geom(Hnsw* x, uint32_t ef, bool for_search = false, bool no_w2
   // eight lanes per row (rows8.hpp): a second, permuted copy of the query and 96 words of scratch per wave.  Served by the shipped
   // walk2 variants only (LDS hash: 4; HBM map: 6 / 7).
   const bool vis_hbm = wants_visg(ef) && x->vis_stride != 0 && x->vis_regions > 0;
-  const bool want8 = for_search && x->rows8_on && x->n8done == x->n && x->n > 0 && ev8_policy() && x->cfg.m_max0 <= 1024 &&
+  const bool want8 = for_search && x->r8 && x->n > 0 && ev8_policy() && x->cfg.m_max0 <= 1024 &&
                      (vis_hbm ? (walk2_policy() == 6 || walk2_policy() == 7) : (!no_w2_lds && walk2_lds_policy() == 4));
   const size_t fixed = qbytes + (want8 ? 96 * 4 : 0) + (size_t)s.ef_pad * 8;   // query (+ the eight-lane core's scratch) + result set (merged in place)
   // LDS visited set: sized so that a typical traversal (a few dozen evaluations per result slot) never resets
@@ -888,7 +898,10 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
 #endif
       case 4:
         kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>;
-        if constexpr (QUANT != Q_F8) { if (sg.ev8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true>; }
+        if constexpr (QUANT != Q_F8) {
+          if (sg.ev8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true>;
+          else if (x->r8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, false, true>;   // the pair-owned core over the line-transposed rows
+        }
         break;   // (adjacency prefetch for f32 rows in small batches: measured, no gain — 1 M x 128, ef 20, one query 105 vs 111 us)
       default: break;
     }
@@ -912,10 +925,14 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
     if constexpr (QUANT != Q_F8) {
       if (sg.ev8 && sg.w2 == 6) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, true>;
       if (sg.ev8 && sg.w2 == 7) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, true>;
+      if (!sg.ev8 && x->r8 && sg.w2 == 6) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, false, true>;
+      if (!sg.ev8 && x->r8 && sg.w2 == 7) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, false, true>;
     }
   }
 #undef COLTT_W2
   if (!kern) return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d is not compiled into this build (COLTT_WALK2)", sg.w2);
+  if (x->r8 && !sg.ev8 && !(sg.w2_lds ? sg.w2 == 4 : (sg.w2 == 6 || sg.w2 == 7)))
+    return fail(COLTT_E_UNSUPPORTED, "hnsw_search: walk variant %d has no instance for line-transposed rows (create the index with COLTT_ROWS8=0 for this experiment)", sg.w2);
   if (sg.ev8) x->ev8_launches.fetch_add(1);
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
@@ -930,6 +947,7 @@ template <int METRIC, int QUANT>
 int launch_search(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
                   uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_search_kernel<METRIC, QUANT, true> : hnsw_search_kernel<METRIC, QUANT, false>;
+  if constexpr (QUANT != Q_F8) { if (x->r8) kern = sg.visg ? hnsw_search_kernel<METRIC, QUANT, true, true> : hnsw_search_kernel<METRIC, QUANT, false, true>; }
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats,
@@ -948,9 +966,11 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
   const bool seq = policy().lat_seq;
+  // the latency kernel reads the index's ONE row array in the layout it has (line-transposed: pieces evaluated out of their registers; natural:
+  // staged and transposed through LDS).  COLTT_EV8 chooses between distance cores over the same bytes in the THROUGHPUT kernels; here the layout
+  // alone decides (the A/B partner is an index created with COLTT_ROWS8=0).
   GraphView gv = x->view();
-  if (!ev8_policy()) gv.rows8 = nullptr;   // COLTT_EV8=0 is a per-call switch here too: the pair-owned rows, staged and transposed through LDS
-  if (gv.rows8 && QUANT != Q_F8) x->ev8_launches.fetch_add(1);   // hnsw_lat.hpp evaluates rows8 pieces out of their registers
+  if (gv.rows8 && QUANT != Q_F8) x->ev8_launches.fetch_add(1);
   kern<<<grid, 256, sg.lds, c->stream>>>(gv, x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
                                          k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq ? 1 : 0);
   COLTT_HIP(hipGetLastError());
@@ -1129,6 +1149,8 @@ int launch_pq_search(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t
                          uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
   kern_t kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS>
               : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM>;
+  if (x->r8) kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS, true>
+                  : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM, true> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM, true>;   // the re-rank reads line-transposed rows
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   GraphView g = x->view();
   kern<<<grid, 64, sg.lds, c->stream>>>(g, x->entry, x->entry_level, c->w_qeff.as<float>() + (size_t)q0 * x->dim, c->w_qn.as<float>() + q0, lut,
@@ -1262,6 +1284,7 @@ template <int METRIC, int QUANT>
 int launch_build(Hnsw* x, const SearchGeom& sg, uint32_t base, uint32_t count, const int32_t* d_levels, uint32_t* counter,
                  uint32_t* req_count, BuildReq* req, uint32_t* head, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true> : hnsw_build_search_kernel<METRIC, QUANT, false>;
+  if constexpr (QUANT != Q_F8) { if (x->r8) kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true, true> : hnsw_build_search_kernel<METRIC, QUANT, false, true>; }
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / sg.lds));
   uint32_t grid = std::min<uint32_t>({count, 256u * per_cu, sg.max_grid});
@@ -1399,7 +1422,7 @@ int fill_adj_norms(Hnsw* x) {
 
 // A failed (re)load must not leave a half-installed index behind: fall back to the empty index (memory-safe, searchable).
 void make_empty(Hnsw* x) {
-  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false; x->n8done = 0; x->pq_done = 0;
+  x->n = 0; x->live = 0; x->n_upper = 0; x->entry = -1; x->entry_level = 0; x->any_deleted = false; x->pq_done = 0;
   x->h_levels.clear(); x->h_upper_off.clear(); x->h_del.clear(); x->h_ids.clear(); x->id2slot.clear();
   x->dense = true; x->dense_base = 0;
 }
@@ -1481,7 +1504,7 @@ int graph_install(Hnsw* x, const coltt_hnsw_cfg& c, uint64_t n, const uint64_t* 
   x->h_del = std::move(h_del);
   x->any_deleted = any_deleted; x->live = live;
   if (!x->dense) { x->h_ids.assign(ids, ids + n); x->id2slot = std::move(id2slot); }
-  x->n = n; x->n_upper = n_upper; x->n8done = 0; x->pq_done = 0;   // every row is about to be rewritten (the callers upload the vectors next)
+  x->n = n; x->n_upper = n_upper; x->pq_done = 0;   // every row is about to be rewritten (the callers upload the vectors next)
   x->entry = n ? entry_slot : -1;
   x->entry_level = x->entry >= 0 ? levels[x->entry] : 0;
   return COLTT_OK;
@@ -1519,7 +1542,7 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
   if (c.ef <= 0 || c.ef_construction <= 0) return fail(COLTT_E_INVALID, "hnsw_create: ef and efConstruction must be > 0");
   x->cfg = c;
-  x->rows8_on = rows8_shape(dim, quant);
+  x->r8 = rows8_shape(dim, quant);
   COLTT_DEVICE(device); device = coltt_dev_scope_.device();
   x->device = device;
   COLTT_HIP(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
@@ -1763,11 +1786,13 @@ int coltt_hnsw_commit(coltt_handle_t h, int header, const uint8_t* const* meta_b
   if (out) { all.resize(n * (size_t)x->dim);
     DevBuf d_dec;
     for (uint64_t b = 0; b < n; b += blk) { uint64_t m = std::min<uint64_t>(blk, n - b);
-      if (x->quant == COLTT_Q_NONE)
+      if (x->quant == COLTT_Q_NONE && !x->r8)
         COLTT_HIP(hipMemcpy2D(all.data() + b * x->dim, (size_t)x->dim * 4, x->rows.as<uint8_t>() + b * x->stride, x->stride, (size_t)x->dim * 4, m, hipMemcpyDeviceToHost));
       else {
         COLTT_TRY(d_dec.reserve(m * x->dim * 4));
-        decode_rows16_kernel<<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, d_dec.as<float>());
+        if (x->quant == COLTT_Q_NONE) rows_to_f32_kernel<Q_NONE, true><<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, d_dec.as<float>());
+        else if (x->r8) rows_to_f32_kernel<Q_F16, true><<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, d_dec.as<float>());
+        else decode_rows16_kernel<<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, b, m, (int)x->dim, d_dec.as<float>());
         COLTT_HIP(hipGetLastError());
         COLTT_HIP(hipMemcpy(all.data() + b * x->dim, d_dec.p, m * x->dim * 4, hipMemcpyDeviceToHost));
       } } }
@@ -1998,6 +2023,19 @@ int coltt_hnsw_fetch_rows(coltt_handle_t h, uint64_t first_slot, uint64_t n, voi
   if (!out_rows || first_slot + n > x->n) return fail(COLTT_E_INVALID, "hnsw_fetch_rows: range outside [0,%llu)", (unsigned long long)x->n);
   COLTT_DEVICE(x->device);
   const size_t rb = (size_t)x->dim * quant_bytes(x->quant);
+  if (x->r8) {   // line-transposed rows: natural element order is restored on the device, block by block
+    DevBuf d_nat;
+    const uint64_t blk = std::max<uint64_t>(1, (256ull << 20) / rb);
+    COLTT_TRY(d_nat.reserve(std::min<uint64_t>(blk, n) * rb));
+    for (uint64_t b = 0; b < n; b += blk) {
+      const uint64_t m = std::min<uint64_t>(blk, n - b);
+      if (x->quant == COLTT_Q_NONE) rows_natural_kernel<Q_NONE><<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, first_slot + b, m, (int)x->dim, d_nat.as<uint8_t>());
+      else rows_natural_kernel<Q_F16><<<ceil_div(m * x->dim, 256), 256, 0, nullptr>>>(x->rows.as<uint8_t>(), x->stride, first_slot + b, m, (int)x->dim, d_nat.as<uint8_t>());
+      COLTT_HIP(hipGetLastError());
+      COLTT_HIP(hipMemcpy(static_cast<uint8_t*>(out_rows) + b * rb, d_nat.p, m * rb, hipMemcpyDeviceToHost));
+    }
+    return COLTT_OK;
+  }
   COLTT_HIP(hipMemcpy2D(out_rows, rb, x->rows.as<uint8_t>() + first_slot * x->stride, x->stride, rb, n, hipMemcpyDeviceToHost));
   return COLTT_OK;
 }
@@ -2017,7 +2055,12 @@ int coltt_hnsw_get(coltt_handle_t h, uint64_t id, void* out_row, int32_t* out_le
     if (it == x->id2slot.end()) return fail(COLTT_E_NOT_FOUND, "Item not found");  // ItemNotFoundError (hnsw.go:177,188)
     slot = it->second;
   }
-  if (out_row) COLTT_HIP(hipMemcpy(out_row, x->rows.as<uint8_t>() + slot * x->stride, (size_t)x->dim * quant_bytes(x->quant), hipMemcpyDeviceToHost));
+  if (out_row && x->r8) {   // one line-transposed row: copied as stored, natural element order restored on the host
+    std::vector<uint8_t> raw(x->stride);
+    COLTT_HIP(hipMemcpy(raw.data(), x->rows.as<uint8_t>() + slot * x->stride, x->stride, hipMemcpyDeviceToHost));
+    if (x->quant == COLTT_Q_NONE) for (uint32_t e = 0; e < x->dim; e++) static_cast<uint32_t*>(out_row)[e] = reinterpret_cast<const uint32_t*>(raw.data())[r8_index<Q_NONE>((int)e)];
+    else for (uint32_t e = 0; e < x->dim; e++) static_cast<uint16_t*>(out_row)[e] = reinterpret_cast<const uint16_t*>(raw.data())[r8_index<Q_F16>((int)e)];
+  } else if (out_row) COLTT_HIP(hipMemcpy(out_row, x->rows.as<uint8_t>() + slot * x->stride, (size_t)x->dim * quant_bytes(x->quant), hipMemcpyDeviceToHost));
   if (out_level) *out_level = x->h_levels[slot];
   return COLTT_OK;
 }
@@ -2111,7 +2154,7 @@ int coltt_hnsw_rows8_searches(coltt_handle_t h, uint64_t* out_launches, int32_t*
   if (!x) return fail(COLTT_E_NOT_FOUND, "hnsw_rows8_searches: unknown handle");
   ReadLock g(x->rw);
   if (out_launches) *out_launches = x->ev8_launches.load();
-  if (out_has_copy) *out_has_copy = (x->rows8_on && x->n8done == x->n) ? 1 : 0;
+  if (out_has_copy) *out_has_copy = x->r8 ? 1 : 0;
   return COLTT_OK;
 }
 

@@ -141,16 +141,18 @@ template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst
   if (PROFILE == PROF_SEARCH_HBM_DEEP) return 48;   // one wave per SIMD: a whole 2-byte row in flight
   return PROFILE == PROF_SEARCH_LDS ? 48 : 24;
 }
-template <int METRIC, int QUANT, int PROFILE>
+// R8: GraphView::rows is line-transposed (rows8.hpp; the index keeps ONE row array in that layout) — same values, same order, same bits
+template <int METRIC, int QUANT, int PROFILE, bool R8 = false>
 __device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
   float rn = 0.f;
   if constexpr (METRIC == M_COS) rn = g.norms[slot];
   constexpr int U = burst_depth<QUANT, PROFILE>();
-  return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  if constexpr (R8) return pair_distance_r8<METRIC, QUANT, U / (QUANT == Q_NONE ? 4 : 8)>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
 // greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.
-template <int METRIC, int QUANT, int PROFILE>
+template <int METRIC, int QUANT, int PROFILE, bool R8 = false>
 __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level,
                                              int lane_in) {
   for (uint32_t hops = 0;; hops++) {
@@ -166,7 +168,7 @@ __device__ __forceinline__ void greedy_level(const GraphView& g, WaveCtx& w, uin
       uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       float d = 0.f;
-      if (valid) d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+      if (valid) d = eval_pair<METRIC, QUANT, PROFILE, R8>(g, w, nb, half);
       w.n_dist += __popcll(__ballot(valid && half == 0));
       unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;
       unsigned long long km = wave_min_u64(key);
@@ -193,7 +195,7 @@ __device__ __forceinline__ void vis_reset(WaveCtx& w, const unsigned long long* 
 
 // searchLevel (hnsw.go:345-389).  On return w.res[buf][0..len) holds the result set ascending by (d, slot).
 // The wave must be the only one in its workgroup (wave_sync is a wave-level LDS fence).
-template <int METRIC, int QUANT, bool VISG, int PROFILE>
+template <int METRIC, int QUANT, bool VISG, int PROFILE, bool R8 = false>
 __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uint32_t ep, float epd, uint32_t ef,
                                              int level, int lane_in, uint32_t& out_len, int& out_buf) {
   int lane = lane_in;
@@ -323,7 +325,7 @@ __device__ __forceinline__ void search_level(const GraphView& g, WaveCtx& w, uin
       if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT() } continue; }
       vis_count += nfresh; w.n_dist += nfresh;
       float d = 0.f;
-      if (fresh) d = eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+      if (fresh) d = eval_pair<METRIC, QUANT, PROFILE, R8>(g, w, nb, half);
       uint32_t rank = __popcll(E & lt_mask);
       bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
 #ifdef COLTT_PHASE_TIMING

@@ -109,7 +109,7 @@ __device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w,
 
 // The k best of res[0, r) by their EXACT distance: res[i] <- (exact bits << 32 | slot << 1), then k rounds of "smallest key not yet
 // taken" (r <= 4096: at most 64 LDS reads per lane and round).  Returns how many were written (min(k, r)).
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, bool R8 = false>
 __device__ __forceinline__ uint32_t rerank_exact(const GraphView& g, WaveCtx& w, uint32_t r, uint32_t k, uint32_t qi, uint64_t* __restrict__ out_ids,
                                                  float* __restrict__ out_scores, int lane_in) {
   unsigned long long* const res = w.res0;
@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t rerank_exact(const GraphView& g, WaveCtx& w,
     const bool valid = i < r;
     const uint32_t slot = valid ? ((uint32_t)res[i] >> 1) : 0u;
     float d = 0.f;
-    if (valid) d = eval_pair<METRIC, QUANT, PROF_SEARCH_HBM>(g, w, slot, half);   // the shallower burst profile: the walk's registers decide the occupancy
+    if (valid) d = eval_pair<METRIC, QUANT, PROF_SEARCH_HBM, R8>(g, w, slot, half);   // the shallower burst profile: the walk's registers decide the occupancy
     wave_sync();
     if (valid && half == 0) res[i] = ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)slot << 1);
   }

@@ -75,10 +75,11 @@ __device__ __forceinline__ int wave_argmax_key(bool valid, uint32_t hi, uint32_t
   return L;
 }
 
-template <int METRIC, int QUANT, int PROFILE>
+template <int METRIC, int QUANT, int PROFILE, bool R8 = false>
 __device__ __forceinline__ float eval_pair_n(const GraphView& g, const WaveCtx& w, uint32_t slot, int half, float rn) {
   constexpr int U = burst_depth<QUANT, PROFILE>();
-  return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  if constexpr (R8) return pair_distance_r8<METRIC, QUANT, U / (QUANT == Q_NONE ? 4 : 8)>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
 // The delta: one (hi, lo) key per lane, lanes [0, n) valid, bit 0 of lo = expanded; `mx` = the largest key with bit 0 cleared
@@ -153,14 +154,14 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
 
 // Where the distances of a chunk come from.  The throughput kernels evaluate them in place (one lane pair per row, exact.hpp); the
 // latency kernel (hnsw_lat.hpp) hands the chunk to all four waves of its workgroup.  Called by every lane of the walking wave.
-template <int METRIC, int QUANT, int PROFILE, bool ADJN> struct PairEval {
+template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct PairEval {
   static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
     if (!fresh) return 0.f;
-    if constexpr (ADJN) return eval_pair_n<METRIC, QUANT, PROFILE>(g, w, nb, half, nrm);
-    else return eval_pair<METRIC, QUANT, PROFILE>(g, w, nb, half);
+    if constexpr (ADJN) return eval_pair_n<METRIC, QUANT, PROFILE, R8>(g, w, nb, half, nrm);
+    else return eval_pair<METRIC, QUANT, PROFILE, R8>(g, w, nb, half);
   }
 };
 // Eight lanes per row over the line-transposed copy (rows8.hpp).  The fresh neighbours of the chunk are compacted through LDS (slot

@@ -26,16 +26,16 @@ namespace dev {
 
 template <int QUANT> __device__ __host__ __forceinline__ constexpr int rows8_steps() { return QUANT == Q_NONE ? 4 : 8; }   // AVX steps per 128-byte line
 
-// canonical rows [slot_begin, slot_begin + n) -> rows8 (same stride).  One thread per 16-byte destination chunk.
+// n natural-order rows at `rows` -> their line-transposed form at `rows8` (same stride; row i of the source is row i of the destination).
+// One thread per 16-byte destination chunk.
 template <int QUANT>
-__global__ __launch_bounds__(256) void rows8_permute_kernel(const uint8_t* __restrict__ rows, uint8_t* __restrict__ rows8, size_t stride, int dim,
-                                                            uint64_t slot_begin, uint64_t n) {
+__global__ __launch_bounds__(256) void rows8_permute_kernel(const uint8_t* __restrict__ rows, uint8_t* __restrict__ rows8, size_t stride, int dim, uint64_t n) {
   constexpr int S = rows8_steps<QUANT>();
   constexpr int EB = 16 / S;                    // bytes per element (4 | 2)
   const int chunks = dim * EB / 16;             // 16-byte chunks per row (dim * EB is a multiple of 128)
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * (uint64_t)chunks) return;
-  const uint64_t row = slot_begin + t / chunks;
+  const uint64_t row = t / chunks;
   const int c = (int)(t % chunks), l = c >> 3, r = c & 7;
   const uint8_t* src = rows + row * stride;
   uint8_t* dst = rows8 + row * stride + (size_t)c * 16;

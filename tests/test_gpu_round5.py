@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from util import bits
 
 pytestmark = pytest.mark.gpu
 
@@ -132,24 +133,38 @@ def test_hnsw_pq_attach_refuses_what_the_walk_cannot_order(gpu):
     assert np.array_equal(ids[:, 0], np.arange(4, dtype=np.uint64)) and not sc[:, 0].any()   # a stored row finds itself at exact distance 0
 
 
-def test_rows8_allocation_failure_falls_back_without_a_sticky_error(gpu):
-    """when the line-transposed row copy cannot be allocated (COLTT_ROWS8_FAIL=1 forces a real failing hipMalloc) the index
-    keeps the pair-owned walk AND the Insert that hit the failure succeeds — the failed allocation's sticky HIP error is consumed."""
-    import os
+def test_one_row_array_serves_every_reader(gpu, monkeypatch):
+    """Round 5: an index whose shape the eight-lane core covers keeps ONE row array, stored line-transposed.
+    Every reader must see the same values: the builder (graph == the graph of an index created with COLTT_ROWS8=0, natural layout), Get /
+    FetchRows / Commit (natural element order restored), the pair-owned walk (COLTT_EV8=0) and the round-2 walk (COLTT_WALK2=off /
+    COLTT_WALK2_LDS=off) over the transposed rows, the latency kernel, the product-quantiser's Encode."""
     import torch
-    n, d = 600, 256
-    X = O.fill_normal(88, (n, d)); lv = O.levels(89, n)
-    os.environ["COLTT_ROWS8_FAIL"] = "1"; gpu.lib().coltt_policy_reload()
-    try:
-        h = gpu.Hnsw(d, gpu.COSINE, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=gpu.Q_F16)
-        xd = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
-        h.InsertBatchDevice(xd.data_ptr(), n, lv, batch=32)
-    finally:
-        del os.environ["COLTT_ROWS8_FAIL"]; gpu.lib().coltt_policy_reload()
-    assert h.Rows8()[1] is False
-    ref = gpu.Hnsw(d, gpu.COSINE, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=gpu.Q_F16)
-    ref.InsertBatchDevice(xd.data_ptr(), n, lv, batch=32)
-    assert ref.Rows8()[1] is True
-    Q = O.fill_normal(90, (16, d))
-    a = h.Search(Q, 10, ef=64); b = ref.Search(Q, 10, ef=64)
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    n, d = 2500, 256
+    X = O.fill_normal(9500, (n, d)); lv = O.levels(9501, n); Q = O.fill_normal(9502, (33, d))
+    xd = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
+    for quant in (gpu.Q_NONE, gpu.Q_F16):
+        cfg = gpu.HnswCfg.default(m=8, ef=32, ef_construction=60)
+        a = gpu.Hnsw(d, gpu.COSINE, cfg, quantization=quant); a.InsertBatchDevice(xd.data_ptr(), n, lv, batch=64)
+        monkeypatch.setenv("COLTT_ROWS8", "0")
+        b = gpu.Hnsw(d, gpu.COSINE, cfg, quantization=quant); b.InsertBatchDevice(xd.data_ptr(), n, lv, batch=64)
+        monkeypatch.delenv("COLTT_ROWS8")
+        assert a.Rows8()[1] is True and b.Rows8()[1] is False
+        ga, gb = a.ExportRaw(), b.ExportRaw()
+        assert np.array_equal(ga["adj0"], gb["adj0"]) and np.array_equal(ga["adjU"], gb["adjU"]) and ga["entry"] == gb["entry"]     # the builder read the same values
+        assert np.array_equal(a.FetchRows(), b.FetchRows())                                                                         # natural order out of both layouts
+        for i in (0, 7, n - 1):
+            assert np.array_equal(a.Get(i)[0], b.Get(i)[0])
+        assert a.Commit() == b.Commit()                                                                                             # the reference's stream, byte for byte
+        for ef in (24, 300):
+            want = b.Search(Q, 10, ef=ef, with_stats=True)
+            for env in ({}, {"COLTT_EV8": "0"}, {"COLTT_WALK2": "off", "COLTT_WALK2_LDS": "off"}, {"COLTT_MW_MAX_NQ": "0"}, {"COLTT_MW_MAX_NQ": "0", "COLTT_EV8": "0"}):
+                for kk, vv in env.items(): monkeypatch.setenv(kk, vv)
+                got = a.Search(Q, 10, ef=ef, with_stats=True)
+                for kk in env: monkeypatch.delenv(kk)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1])) and np.array_equal(got[2], want[2]), (quant, ef, env)
+                assert all(got[3][c] == want[3][c] for c in ("n_dist", "n_exp", "n_hops")), (quant, ef, env, got[3], want[3])
+        pq = gpu.PQSpace(d, gpu.PQ_EUCLIDEAN, 16, 32); pq.Fit(O.fill_normal(9503, (600, d)), iterations=2)
+        a.PqAttach(pq); b.PqAttach(pq)
+        assert np.array_equal(a.PqCodes(), b.PqCodes())
+        pa = a.PqSearch(Q, 10, ef=64, with_stats=True); pb = b.PqSearch(Q, 10, ef=64, with_stats=True)
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(bits(pa[1]), bits(pb[1])) and pa[3] == pb[3]
