@@ -471,9 +471,11 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
     # 65 536 stored rows, every row is encoded on the GPU, the sweep picks the smallest ef that reaches the target recall
     pqw = None; pq_arg = None
     try:
-        pm = int(os.environ.get("COLTT_BENCH_PQ_M", "32")); rr = int(os.environ.get("COLTT_BENCH_PQ_RERANK", "0"))
+        # 64 sub-vectors x 32 centroids (5 bits per 12 dimensions; 64 B per row, a 4 KiB binary16 table): the best of the shapes swept on this
+        # collection (profiles/r05h_hnswpq_probe_10m.jsonl) — the table is what bounds the walk's resident traversals
+        pm = int(os.environ.get("COLTT_BENCH_PQ_M", "64")); pc = int(os.environ.get("COLTT_BENCH_PQ_C", "32")); rr = int(os.environ.get("COLTT_BENCH_PQ_RERANK", "0"))
         sample = h.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
-        pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, pm, 256)
+        pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, pm, pc)
         t0 = time.perf_counter(); pq.Fit(sample, iterations=6); fit_s = time.perf_counter() - t0
         t0 = time.perf_counter(); h.PqAttach(pq); attach_s = time.perf_counter() - t0
         pefs = [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1280,1536,2048").split(",")]
@@ -492,8 +494,8 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
         torch.cuda.synchronize(); pdt = time.perf_counter() - t0
         pnd = pst["n_dist"] / nq; pnx = pst["n_exact"] / nq; pne = pst["n_exp"] / nq
         pbytes = pnd * ((pm + 15) // 16 * 16) + pne * (2 * args.m) * 4 + pnd * 4 + pnx * dim * 2
-        pqw = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x 256 centroids, {(pm + 15) // 16 * 16} B per row, binary16 tables in LDS) "
-                           f"+ exact re-rank of {'every survivor' if rr == 0 else rr}", "m": pm, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),
+        pqw = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x {pc} centroids, {(pm + 15) // 16 * 16} B per row, binary16 tables in LDS) "
+                           f"+ exact re-rank of {'every survivor' if rr == 0 else rr}", "m": pm, "centroids": pc, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),
                "value": steps * nq / pdt, "unit": "queries/s", "over_plain_walk": (steps * nq / pdt) / (steps * nq / dt), "recall_vs_ef": pcurve, "qps_vs_ef": pqps,
                "per_query": {"n_dist": pnd, "n_exp": pne, "n_exact": pnx, "bytes": pbytes}, "fit_s": fit_s, "attach_s": attach_s,
                "roofline": {"bound": "latency (resident traversals x dependent round trips; LDS holds the tables)", "achieved": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -983,7 +985,7 @@ def compact(res):
                       "gpu_equals_oracle": (op.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")})
             pw = op.get("pq_walk")
             if isinstance(pw, dict):
-                o["pq"] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(_pick(pw, "m", "ef", "recall_at_10", "value", "over_plain_walk", "gpu_over_cpu"),
+                o["pq"] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(_pick(pw, "m", "centroids", "ef", "recall_at_10", "value", "over_plain_walk", "gpu_over_cpu"),
                                                                                        gpu_equals_oracle=(pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample"))
             out["op"] = o
     sec = res.get("secondary") or {}

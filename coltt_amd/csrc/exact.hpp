@@ -294,10 +294,11 @@ struct Line4 { u32x4e c[4]; };
 template <int METRIC, int QUANT>
 __device__ __forceinline__ void r8_consume(f32x4& acc, const Line4& ln, const float* __restrict__ q, int L, int half) {
   if constexpr (QUANT == Q_NONE) {
+    const f32x4 c0 = __builtin_bit_cast(f32x4, ln.c[0]), c1 = __builtin_bit_cast(f32x4, ln.c[1]), c2 = __builtin_bit_cast(f32x4, ln.c[2]), c3 = __builtin_bit_cast(f32x4, ln.c[3]);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const f32x4 qq = *reinterpret_cast<const f32x4*>(q + 8 * (4 * L + t) + 4 * half);
-      const f32x4 r = {__builtin_bit_cast(float, ln.c[0][t]), __builtin_bit_cast(float, ln.c[1][t]), __builtin_bit_cast(float, ln.c[2][t]), __builtin_bit_cast(float, ln.c[3][t])};
+      const f32x4 r = {c0[t], c1[t], c2[t], c3[t]};
       if constexpr (METRIC == M_COS) { const f32x4 p = qq * r; acc = acc + p; }
       else { const f32x4 d = qq - r; const f32x4 p = d * d; acc = acc + p; }
     }

@@ -721,7 +721,7 @@ struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t m
 #ifndef COLTT_VISG_MIN_EF
 #define COLTT_VISG_MIN_EF 128
 #endif
-constexpr uint32_t VIS_MAX_REGIONS = 2048;  // 8 waves on each of 256 CUs
+constexpr uint32_t VIS_MAX_REGIONS = 3072;  // 12 waves on each of 256 CUs (the row walks keep 8; the product-quantised walk fits 3 per SIMD)
 
 // (Re)allocate the HBM visited set for the current slot capacity: one byte per slot and workgroup, zeroed, epochs reset.
 // Sized against a quarter of the device memory; if that buys fewer than one region per CU the LDS hash is used instead.
@@ -1131,13 +1131,13 @@ bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   else {
     if (!hbm_ok) return false;
     // Bloom filter: the largest power of two (2..32 KiB) that does not cost a resident wave
-    const size_t waves = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (fixed + 2048)));
+    const size_t waves = std::max<size_t>(1, std::min<size_t>(12, (160 * 1024) / (fixed + 2048)));   // <= 168 VGPRs: three waves per SIMD
     const size_t budget = (160 * 1024) / waves;
     size_t kb = 32; while (kb >= 2 && fixed + kb * 1024 > budget) kb >>= 1;
     if (kb >= 2) { s.variant = 3; s.vis_words = (uint32_t)(kb * 256); s.lds = fixed + kb * 1024; }
     else { s.variant = 2; s.vis_words = 0; s.lds = fixed; }
   }
-  s.per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / s.lds));
+  s.per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(12, (160 * 1024) / s.lds));
   out = s;
   return true;
 }

@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t rerank_exact(const GraphView& g, WaveCtx& w,
     const bool valid = i < r;
     const uint32_t slot = valid ? ((uint32_t)res[i] >> 1) : 0u;
     float d = 0.f;
-    if (valid) d = eval_pair<METRIC, QUANT, PROF_SEARCH_HBM, R8>(g, w, slot, half);   // the shallower burst profile: the walk's registers decide the occupancy
+    if (valid) d = eval_pair<METRIC, QUANT, PROF_RERANK, R8>(g, w, slot, half);   // shallow bursts: the walk's register count decides the occupancy
     wave_sync();
     if (valid && half == 0) res[i] = ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)slot << 1);
   }
