@@ -580,7 +580,7 @@ def leg_filtered(G, torch, dev, O, args, dim, k):
     """SURVEY §8 f3, reported separately: FilterableVertexSearch (edge/none_vectorstore.go:182-253) — the inverted index hands over
     an ascending id list (roaring ToArray), the library translates ids to slots on the host and scans those rows only: <= 4 queries
     per call (the reference's RPC shape is one) through the one-launch exact-order GATHER scan (flat_one_kernel), batches through the matrix cores' gather mode
-    (flat_mfma3.hpp: candidates from the gathered rows + exact re-score; answers equal exact mode's, checked here).
+    (flat_mfma.hpp: candidates from the gathered rows + exact re-score; answers equal exact mode's, checked here).
     1 M x 768 f32; every 10th id a candidate (100 k rows, 30 KB apart), and every id (1 M candidates)."""
     n = 1_000_000
     ds = Dataset(torch, dev, dim, "normal")

@@ -16,7 +16,7 @@
 #include "common.hpp"
 #include "exact.hpp"
 #include "prep.hpp"
-#include "flat_mfma3.hpp"
+#include "flat_mfma.hpp"
 #ifdef COLTT_EXPERIMENTS   // superseded kernel generations, A/B only (tools/flat_ab.py, COLTT_MFMA_GEN)
 #include "../../tools/experiments/flat_mfma_gen1.hpp"
 #include "../../tools/experiments/flat_mfma_gen2.hpp"
@@ -419,7 +419,7 @@ struct Flat : Object {
     uint64_t ncap = std::max<uint64_t>(rows_needed, cap + cap / 2);
     ncap = std::max<uint64_t>(ncap, 1024);
     // ROW_SLACK rows (and norms) behind the capacity: the matrix-core scan fetches whole 256/384-row tiles without clamping
-    // the last one (flat_mfma3.hpp); what it reads there is never scored
+    // the last one (flat_mfma.hpp); what it reads there is never scored
     // ... and everything behind the stored rows is ZERO: for dim % 32 != 0 the last K step of a row reads into its (zeroed)
     // padding and the head of the next row, against zero query columns — finite garbage is harmless there, NaN bits are not
     const size_t old_bytes = rows.cap;
@@ -605,7 +605,7 @@ int search_group_one(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest
   return rc;
 }
 
-// The FLAT matrix-core kernel is flat_mfma3.hpp (split LDS-DMA rings).  A -DCOLTT_EXPERIMENTS build also carries generations 1, 2
+// The FLAT matrix-core kernel is flat_mfma.hpp (split LDS-DMA rings).  A -DCOLTT_EXPERIMENTS build also carries generations 1, 2
 // and 4 (tools/experiments/), selectable with COLTT_MFMA_GEN for A/B measurements; the default library has exactly one.
 static int mfma_generation() {
 #ifdef COLTT_EXPERIMENTS
@@ -627,7 +627,7 @@ template <int BN, bool AF32>
 int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16* q16, const float* qn, int g, const uint32_t* thr, int nearest,
                        unsigned long long* cand, uint32_t* cnt, uint32_t cap, bool seed, int kdim, const uint32_t* d_gather) {
   const RowSrc src = mfma_rows(f);
-  if (d_gather) {   // rows[gather[pos]] for pos in [b, e): FilterableVertexSearch through the matrix cores (flat_mfma3.hpp, GATHER)
+  if (d_gather) {   // rows[gather[pos]] for pos in [b, e): FilterableVertexSearch through the matrix cores (flat_mfma.hpp, GATHER)
     auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_COS, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_COS, true>)
                                           : (seed ? flat_mfma3_kernel<BN, AF32, true, M2_BM, M_L2, true> : flat_mfma3_kernel<BN, AF32, false, M2_BM, M_L2, true>);
     const size_t lds = M3Geom<BN, AF32, M2_BM, true>::LDS;

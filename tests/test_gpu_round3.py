@@ -134,7 +134,7 @@ def test_cosine_mfma_is_closed_for_rows_of_odd_norm(gpu):
                                               (O.L2, O.Q_NONE, 12000, 768)])
 def test_filtered_search_through_the_matrix_cores(gpu, metric, quant, n, d):
     """FilterableVertexSearch (edge/none_vectorstore.go:182-253) with COLTT_MODE_MFMA: the gathered rows feed the matrix-core candidate
-    kernel (flat_mfma3.hpp, GATHER), survivors are re-scored in exact order — ids, ranks and score bits equal exact mode and the
+    kernel (flat_mfma.hpp, GATHER), survivors are re-scored in exact order — ids, ranks and score bits equal exact mode and the
     oracle's scan over exactly the candidate rows.  Candidate lists: strided, random, tiny (< one tile), with unknown and removed ids
     (skipped, :201) and repeated ids (scored once)."""
     X = O.fill_normal(5000 + d + quant, (n, d)); X[300:310] = X[4]

@@ -3,7 +3,7 @@
 // 4 x 32 KB stages.  C3 5.63 ms; superseded by the split-ring kernel (coltt_amd/csrc/flat_mfma3.hpp), which reuses this
 // generation's DMA / epilogue helpers (they stay in coltt_amd/csrc/flat_mfma2.hpp).
 #pragma once
-#include "../../coltt_amd/csrc/flat_mfma2.hpp"
+#include "../../coltt_amd/csrc/flat_mfma.hpp"
 
 namespace coltt {
 namespace dev {

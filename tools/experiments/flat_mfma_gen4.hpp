@@ -22,7 +22,7 @@
 // Everything else (256 x BN tile, 4 x 2 waves, XOR-swizzled lane-linear DMA image, saddr-form DMA, seed segment in place, one
 // atomic per half block) is flat_mfma3.hpp's.  The raw-norm parity buffers require dim >= 128 (flat.hip checks).
 #pragma once
-#include "../../coltt_amd/csrc/flat_mfma3.hpp"
+#include "../../coltt_amd/csrc/flat_mfma.hpp"
 
 namespace coltt {
 namespace dev {
