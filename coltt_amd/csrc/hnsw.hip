@@ -1199,9 +1199,11 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
     d_q = c->w_qraw.as<float>();
   }
   COLTT_TRY(prep_queries_any(x, c, d_q, nq));
-  // tables for a group of queries at a time: [group][row_bytes][256] f32 (<= 128 MiB)
+  // tables for a group of queries at a time: [group][row_bytes][256] f32, up to 1 GiB of them — a launch should hold several queries per resident
+  // wave so that the work counter balances the tail (with 128 MiB a 10 000-query call ran as five 2 048-query launches on 2 048 waves: every launch
+  // as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv)
   const size_t lut_q = (size_t)x->pq_row * 1024;
-  const size_t group = std::max<size_t>(1, std::min<size_t>(nq, (128ull << 20) / lut_q));
+  const size_t group = std::max<size_t>(1, std::min<size_t>(nq, (1024ull << 20) / lut_q));
   COLTT_TRY(c->w_pack.reserve(group * lut_q));
   COLTT_TRY(c->w_misc.reserve(256));
   uint8_t* misc = c->w_misc.as<uint8_t>();

@@ -116,6 +116,26 @@ def fuzz_hnsw(G, O, rng, log):
                 assert same(gi[qi, :gc[qi]], gs[qi, :gc[qi]], want, sc[qi, :cn[qi]]), ("hnsw search", qi, ef, k, visg, n, d, metric, quant, m, efc, algo, len(removed))
             assert st["n_dist"] == ost["n_dist"] and st["n_exp"] == ost["n_exp"], ("counters", ef, k, visg, st, ost)
     os.environ.pop("COLTT_VISG", None)
+    # the product-quantised walk over the same graph (hnsw_pq.hpp; oracle definition coltt_oracle.cpp "Product-quantised HNSW"): tombstones, both
+    # visited sets, partial re-ranks, every supported table metric
+    if quant != O.Q_F8 and d % 4 == 0 and d >= 8 and n >= 60:
+        seen = rows if quant == O.Q_NONE else O.f16_decode(rows)
+        pm = int(rng.choice([v for v in (2, 4, 8, 16, 32, 64, 96, 128) if d % v == 0 and v <= d]))
+        pc = int(rng.choice([c for c in (5, 16, 64, 256) if c <= n]))
+        pqm = int(rng.choice([G.PQ_EUCLIDEAN, G.PQ_COSINE])) if metric == O.COSINE else G.PQ_EUCLIDEAN
+        pq = G.PQSpace(d, pqm, pm, pc); pq.Fit(seen[: max(pc, min(n, 1500))], iterations=int(rng.integers(1, 4)))
+        gh.PqAttach(pq); cb = pq.Codebooks(); codes = gh.PqCodes()
+        assert np.array_equal(codes, O.pq_encode(cb, seen)), ("pq codes", n, d, pm, pc)
+        for ef in (int(rng.choice([3, 20, 100])), int(rng.choice([129, 400, 1500]))):
+            k = int(rng.choice([1, 10, min(ef, 40)])); rr = int(rng.choice([0, 0, k, 2 * k + 1, ef]))
+            gi, gs, gc, st = gh.PqSearch(Q, k, ef=ef, rerank=rr, with_stats=True)
+            sl, sc, cn, ost, _ = O.csr_search_pq(rows, quant, g["adj0"], g["upper_off"], g["adjU"], d, metric, g["entry"], g["entry_level"], codes, cb, pqm, Q, k, max(ef, k),
+                                                 rerank=rr, del_bits=del_bits, threads=2)
+            for qi in range(len(Q)):
+                want = ids[sl[qi, :cn[qi]].astype(np.int64)]
+                assert same(gi[qi, :gc[qi]], gs[qi, :gc[qi]], want, sc[qi, :cn[qi]]), ("pq walk", qi, ef, k, rr, n, d, metric, quant, pm, pc, pqm, len(removed))
+            assert st == ost, ("pq counters", ef, k, rr, st, ost)
+        pq.close()
     # Commit -> Load round trip keeps answers (the reference stream stores f32 vectors: f32 indexes only)
     if quant == O.Q_NONE:
         # (Load renumbers the slots in stream order — tombstoned vertices are not stored — so the canonical neighbour order, and with
