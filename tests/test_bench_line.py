@@ -121,3 +121,24 @@ def test_gpus_2_launches_two_ranks_on_one_device(gpu):
     assert c["shard"]["equals_single_process_group"] is True
     full = json.load(open(os.path.join(ROOT, "bench_full.json")))
     assert full["secondary"]["shard"]["n_total"] == 20000
+
+
+def test_final_line_of_round_5_carries_the_pq_walk_and_the_traffic_source():
+    """the round-5 record (call I): every leg, the product-quantised walk next to the operating point, the PMC file's name, full-size parity of C3 / c3f8"""
+    res = json.load(open(os.path.join(ROOT, "profiles", "r05i_bench_10m_full.json")))
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert "trimmed" not in c
+    for leg in ("op", "c1", "c2", "c3", "c3f8", "pq", "f3", "h1"):
+        assert leg in c, leg
+    assert c["roofline"]["traffic_source"].startswith("profiles/") and 0.7 < c["roofline"]["frac"] < 1
+    pq = c["op"]["pq"]
+    assert pq["recall_at_10"] >= 0.98 and pq["gpu_equals_oracle"] is True and pq["over_plain_walk"] > 1.0 and pq["value"] > c["op"]["value"]
+    assert c["op"]["recall_at_10"] >= 0.98 and c["op"]["gpu_equals_oracle"] is True
+    for leg in ("c3", "c3f8"):     # the parity sample of these legs is full size now (cpu_baseline.full_size_oracle_sample)
+        assert c[leg]["gpu_equals_oracle"] is True and res["secondary"][leg]["cpu_baseline"]["full_size_oracle_sample"]["rows"] == 10_000_000
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r05i_bench_10m_line.json")))
+    assert committed["value"] == c["value"] and committed["op"]["pq"]["value"] == pq["value"]
