@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 // Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp): one wave per query, queries pulled from a global counter.
 // OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 / 3 + VIS_HBM: byte map, delta result set, Bloom filter if it fits).
 template <int METRIC, int QUANT, int OPT, int VISMODE, bool R8 = false>
-__global__ __launch_bounds__(64) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
+// amdgpu_waves_per_eu(3): <= 168 VGPRs, three waves per SIMD — the walk is latency-bound, resident traversals are its throughput
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
                                                             const float* __restrict__ qnorms, const float* __restrict__ lut_g,
                                                             const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
                                                             uint32_t ef, uint32_t ef_pad, uint32_t rerank, uint32_t vis_words,

@@ -293,6 +293,7 @@ __device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w,
 // chosen (search_level2: CHUNK_ADJ); the runner-up's row is requested at pop time.
 template <int METRIC, int QUANT> struct LatEval {
   static constexpr bool CHUNK_ADJ = true;
+  static constexpr bool SPEC = false;
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}

@@ -37,6 +37,13 @@ struct AdcEval {
   uint32_t lut_shift;                          // log2 of the table's row length = the number of centroids rounded up to a power of two (4 .. 8)
   u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
+  // hnsw_walk2.hpp SPEC: visited bytes + code rows of the predicted next candidate's (the runner-up's) neighbours requested one expansion ahead.
+  // Exact (tests + 246 randomised rounds with it on), but measured SLOWER — an A/B knob (-DCOLTT_PQ_SPEC=1), off in the shipped library
+  // (profiles/r05m_pq_spec_ab.md)
+#ifndef COLTT_PQ_SPEC
+#define COLTT_PQ_SPEC 0
+#endif
+  static constexpr bool SPEC = COLTT_PQ_SPEC != 0;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[8]) const {
     const u32x4e* p = reinterpret_cast<const u32x4e*>(codes + (size_t)slot * row_bytes);

@@ -156,6 +156,7 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
 // latency kernel (hnsw_lat.hpp) hands the chunk to all four waves of its workgroup.  Called by every lane of the walking wave.
 template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct PairEval {
   static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
+  static constexpr bool SPEC = false;        // no speculation on the next expansion's inputs (see AdcEval, hnsw_pq.hpp)
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
@@ -187,6 +188,7 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
 template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eval {
   static constexpr int G8R = HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS, G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
   static constexpr bool CHUNK_ADJ = false;
+  static constexpr bool SPEC = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
@@ -309,6 +311,12 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   uint32_t scan_lo = 0;   // every main-array member before this index is expanded (pop scans start at its 64-entry chunk)
   Delta dl; dl.hi = dl.lo = 0xffffffffu; dl.n = 0; dl.mx = 0ull; dl.mx_lane = -1;
   uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE; float pre_nn = 0.f;
+  // SPEC evaluators (small per-neighbour inputs: hnsw_pq.hpp): when the next candidate is predicted to be the runner-up — whose adjacency row was
+  // requested at pop time and has arrived by the end of the expansion — the visited bytes and the evaluator's inputs of ITS neighbours are requested
+  // one expansion ahead (spec_slot = that candidate; spec_vis = the byte-map values).  The probe is issued after every visited mark of the current
+  // expansion (program order, agent-scope accesses served by L2) and nothing marks in between, so the values are exactly what the probe of the
+  // next expansion would read.
+  uint32_t spec_slot = NBR_NONE; uint32_t spec_vis = 0;
   const uint32_t width = g.mMax0;
   wave_sync();
   for (uint32_t iters = 0;; iters++) {
@@ -356,7 +364,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     // needed next and is not on chip then is the runner-up's — requested now, it flies during the whole expansion
     typedef typename std::remove_reference<EVAL>::type eval_t;
     uint32_t runner_nb = NBR_NONE;
-    if constexpr (eval_t::CHUNK_ADJ && PREF) {
+    if constexpr ((eval_t::CHUNK_ADJ || eval_t::SPEC) && PREF) {
       if (runner_key != ~0ull && (uint32_t)p < g.mMax0) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * g.mMax0 + p];
     }
     int best_src = -1;   // lane of the smallest key admitted in this expansion's (single) chunk
@@ -376,17 +384,27 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     const float* nrow = ADJN ? g.adj0_n + (size_t)cslot * width : nullptr;
     const bool use_pre = pre_slot == cslot;
     const uint32_t pre_now = pre_nb; const float pre_nn_now = pre_nn;
-    pre_slot = NBR_NONE;
+    const uint32_t spec_now = spec_slot, spec_vis_now = spec_vis;
+    pre_slot = NBR_NONE; spec_slot = NBR_NONE;
     unsigned long long best_new = ~0ull;
 #define COLTT_PREFETCH_NEXT2()                                                                       \
     if constexpr (PREF) {                                                                            \
       const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
       if (nk_ != ~0ull) {                                                                            \
         pre_slot = (uint32_t)nk_ >> 1;                                                               \
-        if (eval_t::CHUNK_ADJ && width <= 32 && runner_key < best_new) pre_nb = runner_nb;           \
+        if ((eval_t::CHUNK_ADJ || eval_t::SPEC) && width <= 32 && runner_key < best_new) pre_nb = runner_nb;           \
         else if (eval_t::CHUNK_ADJ && width <= 32 && best_src >= 0) pre_nb = (uint32_t)p < width ? ev.chunk_adj(best_src >> 1, p) : NBR_NONE; \
         else pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;        \
         if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \
+        if constexpr (eval_t::SPEC) {                                                                \
+          spec_slot = NBR_NONE;                                                                      \
+          if (width <= 32 && runner_key < best_new) {   /* pre_nb is in registers (requested at pop time) */ \
+            spec_slot = pre_slot;                                                                    \
+            const bool sv_ = pre_nb != NBR_NONE;                                                     \
+            if constexpr (VISMODE == VIS_HBM) { spec_vis = 0; if (sv_ && half == 0) spec_vis = __hip_atomic_load(w.visg + pre_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } \
+            ev.prefetch(pre_nb, sv_, half);                                                          \
+          }                                                                                          \
+        }                                                                                            \
       }                                                                                              \
     }
     for (uint32_t c0 = 0; c0 < width; c0 += 32) {
@@ -396,7 +414,9 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       float nrm = 0.f;
       if constexpr (ADJN) nrm = idx < width ? (pre_hit ? pre_nn_now : nrow[idx]) : 0.f;
       const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
-      ev.prefetch(nb, valid, half);   // evaluators whose per-neighbour input is small (hnsw_pq.hpp: a 32-128 byte code row) request it NOW, under the visited test
+      bool spec_hit = false;
+      if constexpr (eval_t::SPEC) spec_hit = pre_hit && spec_now == cslot;   // this expansion's inputs were requested during the previous one
+      if (!spec_hit) ev.prefetch(nb, valid, half);   // evaluators whose per-neighbour input is small (hnsw_pq.hpp: a 32-128 byte code row) request it NOW, under the visited test
 #ifdef COLTT_PHASE_TIMING
       if (__ballot(valid) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the adjacency values to have arrived
 #endif
@@ -415,7 +435,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
         else {
           if (maybe) {
-            const uint8_t v = __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint8_t v = spec_hit ? (uint8_t)spec_vis_now : __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
           } else fresh_i = 1;
           if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
