@@ -150,7 +150,7 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import pmc_traffic as T
-    src = os.path.join(root, "profiles", "r02_pmc_flat_fetch_size_raw.csv")
+    src = os.path.join(root, "profiles", "r05i_pmc_flat_fetch_size_raw.csv")   # re-taken on the round-5 library (one header, same kernels)
     out = tmp_path / "t.json"
     T.main([src, "--flat", "1000000,768,0,64", "10000000,768,1,256", "--out", str(out)])
     t = json.load(open(out))
@@ -159,12 +159,12 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
         assert r["algorithmic_bytes_per_batch"] == alg and r["searches_used"] >= 3
         assert 1.0 <= r["traffic_over_algorithmic"] < 1.1, r
     committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
-    assert all(k in committed for k in t)
+    assert all(k in committed and abs(committed[k]["hbm_bytes_per_batch"] - t[k]["hbm_bytes_per_batch"]) < 1.0 and committed[k]["source"] == "r05i_pmc_flat_fetch_size_raw.csv" for k in t)
 
 
 def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path):
-    """The committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op,pq` (round 4: profiles/r04i_*; round 3's pass stays in
-    profiles/ as history) -> the HBM traffic bench.py reports for the headline kernel (`hnsw_search2_kernel<.., VIS_LDS, .., EV8>`: the
+    """The committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op,pq` (round 5: profiles/r05i_*, taken on the round's final kernels;
+    earlier rounds' passes stay in profiles/ as history) -> the HBM traffic bench.py reports for the headline kernel (`hnsw_search2_kernel<.., VIS_LDS, .., EV8>`: the
     eight-lane core over the line-transposed rows), for the recall-0.98 kernel (HBM visited map) and for the dominant launch of the
     product-quantiser scan.  Re-derived here from the raw CSV and compared with profiles/pmc_traffic.json."""
     import json
@@ -172,8 +172,8 @@ def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import pmc_traffic as T
-    src = os.path.join(root, "profiles", "r04i_pmc_fetch_size_raw.csv")
-    bj = os.path.join(root, "profiles", "r04i_bench_10m_under_pmc.json")
+    src = os.path.join(root, "profiles", "r05i_pmc_fetch_size_raw.csv")
+    bj = os.path.join(root, "profiles", "r05i_bench_10m_under_pmc.json")
     out = tmp_path / "t.json"
     T.main([src, "--bench-json", bj, "--out", str(out)])
     T.main([src, "--bench-json", bj, "--leg", "op", "--out", str(out)])
