@@ -75,7 +75,7 @@ def parse():
                     help="normal = iid N(0,1) (BASELINE.json's synthetic random-normal); lowrank:R[:sigma[:clusters]] = "
                          "x = mu_c + A z + sigma*eps, z ~ N(0, I_R), c uniform over `clusters` centres in the same R-dim subspace")
     ap.add_argument("--ef-curve", default="256,512,1024", help="extra efSearch values for the recall/ef curve")
-    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,c3f8,f3,pq ('auto' = all at the default size, none otherwise; 'none')")
+    ap.add_argument("--legs", default="auto", help="comma list of extra legs at N=1: op,h1,c1,c2,c3,c3f8,f3,pq,g8 ('auto' = all at the default size, none otherwise; 'none')")
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
@@ -822,6 +822,53 @@ def leg_pq(G, torch, dev, O, args, dim, k):
     return res
 
 
+def leg_group8(G, torch, dev, args, dim, k, local=0):
+    """SURVEY §8e on ONE device (what an N = 1 run can show of the multi-GPU path): a 2 M x 768 "bf16" collection partitioned 8 ways by
+    sharding.ShardVertex (BASELINE.json configs[4]'s layout and ef 256), eight members on this GPU (the packed per-shard top-k travel through
+    pinned host memory — RCCL refuses one device twice), 10 000 queries per batch.  Serial calls against the streamed form
+    (coltt_group_search_begin / _end: exchange and merge of batch i under the search of batch i + 1): same answers, and where a batch's time goes."""
+    from coltt_amd import group as GG
+    n_total, world, nq, ef, quant = 2_000_000, 8, args.queries, 256, 3
+    L = G.lib()
+    grp = GG.Group([local] * world, dim, G.COSINE, quant, kind=GG.GROUP_HNSW, layout=GG.LAYOUT_SHARD,
+                   cfg=G.HnswCfg.default(m=args.m, ef=ef, ef_construction=args.efc))
+    ds = Dataset(torch, dev, dim, "normal")
+    t0 = time.time(); rows = 0
+    for r in range(world):
+        ids = shard_ids(G, n_total, world, r)
+        member = G.Hnsw.from_handle(grp.member(r), dim, G.COSINE, quant)
+        build_index(G, torch, dev, ds, len(ids), dim, args, args.seed + 7919 * (r + 1), quant, ids=ids, h=member)
+        rows += len(ids)
+    build_s = time.time() - t0
+    qgen = torch.Generator(device=dev); qgen.manual_seed(0x5EED5 + 23)
+    qs = [ds.rows(nq, qgen) for _ in range(2)]
+    reps = 6
+    grp.SearchDevice([qs[0].data_ptr()] * world, nq, k, ef=ef)        # warm-up (workspaces, visited sets)
+    t0 = time.perf_counter()
+    serial = [grp.SearchDevice([qs[i & 1].data_ptr()] * world, nq, k, ef=ef) for i in range(reps)]
+    serial_ms = (time.perf_counter() - t0) / reps * 1e3
+    tm0 = grp.Timing()
+    t0 = time.perf_counter(); pend = []; outs = []
+    for i in range(reps):
+        pend.append(grp.SearchBegin(k, d_queries_per_member=[qs[i & 1].data_ptr()] * world, nq=nq, ef=ef))
+        if len(pend) == 2:
+            t, o = pend.pop(0); grp.SearchEnd(t); outs.append(o)
+    while pend:
+        t, o = pend.pop(0); grp.SearchEnd(t); outs.append(o)
+    streamed_ms = (time.perf_counter() - t0) / reps * 1e3
+    tm1 = grp.Timing(); nb = max(1, tm1["batches"] - tm0["batches"])
+    same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2]) for a, b in zip(serial, outs))
+    stage = {kk: round((tm1[kk] - tm0[kk]) / nb, 3) for kk in ("search_ms", "exchange_ms", "merge_ms")}
+    res = {"workload": f"HNSW {n_total}x{dim} {QNAME[quant]} partitioned {world} ways by ShardVertex, {world} members on ONE device (host-staged exchange), efSearch={ef}, "
+                       f"{nq} queries per batch, k={k}", "members": world, "rows": rows, "build_s": build_s,
+           "serial_ms_per_batch": serial_ms, "streamed_ms_per_batch": streamed_ms, "value": nq / (streamed_ms / 1e3), "unit": "queries/s (every query visits every shard)",
+           "stage_ms_per_batch": stage, "exposed_frac_of_a_streamed_batch": max(0.0, streamed_ms - stage["search_ms"]) / streamed_ms,
+           "streamed_equals_serial": bool(same),
+           "note": "one device: the eight members' searches share this GPU, so queries/s says nothing about scaling; the record is the pipeline — exchange + merge against the search stage"}
+    grp.close()
+    return res
+
+
 def leg_shard(G, torch, dist, dev, cdev, args, rank, world, local, dim, k):
     """north-star layout: ShardVertex partition, per-shard HNSW, ONE RCCL all-gather of packed top-k inside the library
     (coltt_group_*), host merge.  Each rank generates only its own shard's vectors."""
@@ -1023,6 +1070,8 @@ def compact(res):
         out["h1"] = _pick(sec["h1"], "single_query_call_ms_median", "single_query_kernel_ms_median", "batch_of_10000_queries_per_s", "error")
     if isinstance(sec.get("lat"), dict):
         out["lat"] = _pick(sec["lat"], "kernel_ms_1", "kernel_ms_128", "cpu_1_thread_ms", "error")
+    if isinstance(sec.get("g8"), dict):
+        out["g8"] = _pick(sec["g8"], "members", "serial_ms_per_batch", "streamed_ms_per_batch", "stage_ms_per_batch", "exposed_frac_of_a_streamed_batch", "streamed_equals_serial", "error")
     if isinstance(sec.get("shard"), dict):
         out["shard"] = _pick(sec["shard"], "value", "exchange", "world", "shard_rows", "n_total", "pipelined", "pipeline_ms_per_batch", "equals_single_process_group", "error")
     if res.get("pcie_inclusive"):
@@ -1036,7 +1085,7 @@ def final_line(res):
     """json of compact(res), trimmed leg by leg if it ever outgrew the hard bound (never observed; the CPU test pins the size)"""
     c = compact(res)
     line = json.dumps(c, separators=(",", ":"))
-    for k in ("f3", "h1", "lat", "c1", "pcie_inclusive_qps", "shard", "c3f8", "pq", "c2", "c3", "op"):
+    for k in ("f3", "h1", "lat", "c1", "pcie_inclusive_qps", "g8", "shard", "c3f8", "pq", "c2", "c3", "op"):
         if len(line) <= LINE_HARD:
             break
         c.pop(k, None); c["trimmed"] = c.get("trimmed", []) + [k]
@@ -1093,7 +1142,7 @@ def main():
     n_total, dim, k, nq = args.n, args.dim, args.k, args.queries
     shard = args.mode == "shard" and world > 1
     default_size = (args.n == 10_000_000 and args.dim == 768 and args.quant == 0 and args.dataset == "normal")
-    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "c3f8", "f3", "pq"] if (args.legs == "auto" and default_size) else
+    legs = [] if world > 1 else (["op", "h1", "c1", "c2", "c3", "c3f8", "f3", "pq", "g8"] if (args.legs == "auto" and default_size) else
                                  [] if args.legs in ("auto", "none") else [x for x in args.legs.split(",") if x])
     ds = Dataset(torch, dev, dim, args.dataset)
     kernel_ms = []; stats = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_visit_resets": 0}
@@ -1197,6 +1246,11 @@ def main():
                 secondary["pq"] = leg_pq(G, torch, dev, O, args, dim, k)
             except Exception as e:
                 secondary["pq"] = {"error": str(e)}
+        if "g8" in legs:
+            try:
+                secondary["g8"] = leg_group8(G, torch, dev, args, dim, k, local)
+            except Exception as e:
+                secondary["g8"] = {"error": str(e)}
         if "h1" in legs:
             try:
                 secondary["h1"] = leg_published_hnsw_point(G, torch, dev, O, args, k)
