@@ -198,8 +198,8 @@ struct Member {
 };
 
 // A shard search is a three-stage pipeline ("issued on a comm stream and overlapped with the next batch"):
-//   A  every member searches the batch on its shard                           (the caller's thread, one batch at a time: call_mu)
-//   B  pack + ONE all-gather of the packed top-k + D2H, on the comm streams   (the group's exchange thread, in ticket order)
+//   A  every member searches the batch on its shard and packs its top-k       (the caller's thread, one batch at a time: call_mu)
+//   B  ONE all-gather of the packed top-k + D2H, on the comm streams          (the group's exchange thread, in ticket order)
 //   C  the host-side final merge, split over a few host threads               (same thread, right behind B)
 // Stage A of batch i+1 runs while B and C of batch i are in flight; a batch owns one Slot (answer arrays, packed records, the
 // gathered block, its pinned staging) from A until its merge is done, so nothing is shared between batches in flight.
@@ -582,12 +582,9 @@ int Group::exchange_and_merge(Job& j) {
   Slot& sl = slots[j.slot];
   const size_t nm = m.size(), per = j.nq * (size_t)j.k;
   const auto t0 = std::chrono::steady_clock::now();
-  for (size_t i = 0; i < nm; i++) {   // pack on the comm stream: the search that produced the arrays has completed (stage A is synchronous)
-    Member& x = *m[i]; SlotMember& b = *sl.mb[i];
-    COLTT_TRY(use_device(x.device));
-    pack_topk_kernel<<<ceil_div(per, 256), 256, 0, x.cstream>>>(b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), (uint32_t)j.nq, j.k, b.d_pack.as<Rec>());
-    COLTT_HIP(hipGetLastError());
-  }
+  // (the records were packed at the end of stage A, on the member's own stream: with the host and shared-memory transports this stage is pure DMA and
+  //  proceeds while the NEXT batch's search kernel holds every CU — a pack kernel on the comm stream would queue behind that persistent grid: call N
+  //  measured a 19 ms "exchange" that was 18.5 ms of waiting for a CU.  The RCCL all-gather is a kernel and still waits its turn; it is overlapped either way.)
   if (exchange == COLTT_EXCHANGE_SHM) {
     // the local members' records come to the host, then travel rank-major through the shared segment, a chunk of queries at a
     // time when the batch is larger than a slot; every process merges every chunk itself (an all-gather, like the RCCL path)
@@ -700,6 +697,10 @@ int shard_begin(Group* g, const float* queries, const float* const* d_queries_pe
     if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(b.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
     if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, nq, k, ef_override, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), nullptr));
     else COLTT_TRY(coltt_flat_search_device(x.h, dq, nq, k, select, mode, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>()));
+    // the packed {id, score, valid} records of this member: a ~10 us kernel right behind its search, while the device is still this batch's
+    pack_topk_kernel<<<ceil_div(per, 256), 256, 0, x.stream>>>(b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), (uint32_t)nq, k, b.d_pack.as<Rec>());
+    COLTT_HIP(hipGetLastError());
+    COLTT_HIP(hipStreamSynchronize(x.stream));
     return COLTT_OK;
   });
   job->search_ms = ms_since(t0);
