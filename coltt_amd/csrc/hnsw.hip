@@ -283,20 +283,21 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 
 // Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp): one wave per query, queries pulled from a global counter.
 // OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 / 3 + VIS_HBM: byte map, delta result set, Bloom filter if it fits).
-template <int METRIC, int QUANT, int OPT, int VISMODE, bool R8 = false>
+// The walk touches no stored row: its survivors (slots, nearest first by table distance) go to HBM and the exact re-rank is two small kernels of its
+// own (below) — inside the walk kernel it was 19 % of the time (one 128-byte line per row in flight, the burst depth the walk's register budget left:
+// profiles/r05p_phase_breakdown.txt) and tied 24 instances of this kernel to the row format.
+template <int OPT, int VISMODE>
 // amdgpu_waves_per_eu(3): <= 168 VGPRs, three waves per SIMD — the walk is latency-bound, resident traversals are its throughput
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ q_eff,
-                                                            const float* __restrict__ qnorms, const float* __restrict__ lut_g,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ lut_g,
                                                             const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
                                                             uint32_t ef, uint32_t ef_pad, uint32_t rerank, uint32_t vis_words,
-                                                            uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
-                                                            float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
+                                                            uint32_t* __restrict__ counter, uint32_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt,
                                                             unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
                                                             size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
-  size_t off = 0;   // no copy of the query in LDS: only the re-rank reads it (a few dozen rows), straight from the prepared batch in HBM / L2
+  size_t off = 0;   // no copy of the query in LDS: the walk only needs its table
   w.qs = nullptr; w.qp = nullptr; w.scr = nullptr;
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;
   w.ef_pad = ef_pad;
@@ -318,8 +319,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
     if (qi >= nq) break;
     w.n_dist = w.n_exp = w.n_hops = w.n_resets = 0; w.err = 0;
+#ifdef COLTT_PHASE_TIMING
+    for (int i_ = 0; i_ < 8; i_++) w.pt[i_] = 0;
+    w.t_last = __builtin_amdgcn_s_memtime();
+#endif
     wave_sync();
-    w.qs = const_cast<float*>(q_eff + (size_t)qi * g.dim);
     {  // the query's table: row_bytes rows of (1 << lut_shift) entries (of the 256 per row in HBM), f32 -> binary16 in LDS (round to nearest even:
        // the codec's own integer rounding, exact.hpp); four entries per lane and step
       const float* src = lut_g + (size_t)qi * row_bytes * 256;
@@ -331,20 +335,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
         dst[i] = u32x2e{f32bits_to_f16bits(v.x) | (f32bits_to_f16bits(v.y) << 16), f32bits_to_f16bits(v.z) | (f32bits_to_f16bits(v.w) << 16)};
       }
     }
-    w.qnorm = qnorms[qi];
+    w.qnorm = 0.f;
     wave_sync();
     uint32_t cur = (uint32_t)entry;
     float curd = ev.adc(cur);   // minDistance := d(query, entrypoint) (hnsw.go:253), the same value in every lane
     w.n_dist += 1;
     for (int l = entry_level; l > 0; l--) greedy_level_adc(g, w, ev, cur, curd, l, lane);  // :254-256
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
+    COLTT_PT(w, 5)  // table load + entry + upper levels
     uint32_t len;
     search_level2<M_L2, Q_F16, PROF_SEARCH_HBM, OPT, VISMODE, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259 (M_L2: no norms ride along; Q_F16: the adjacency prefetch)
     uint32_t r = rerank == 0 ? len : (rerank > k ? rerank : k);
     r = r < len ? r : len;
-    const uint32_t n = rerank_exact<METRIC, QUANT, R8>(g, w, r, k, qi, out_ids, out_scores, lane);
+    for (uint32_t i = (uint32_t)lane; i < r; i += 64) surv[(size_t)qi * ef_pad + i] = (uint32_t)w.res0[i] >> 1;   // the r nearest by table distance, in that order
+    COLTT_PT(w, 6)  // final delta flush + survivors' write-out
     if (lane == 0) {
-      out_counts[qi] = n;
+#ifdef COLTT_PHASE_TIMING
+      for (int i_ = 0; i_ < 8; i_++) atomicAdd(&stats[8 + i_], w.pt[i_]);
+#endif
+      surv_cnt[qi] = r;
       atomicAdd(&stats[0], (unsigned long long)w.n_dist);
       atomicAdd(&stats[1], (unsigned long long)w.n_exp);
       atomicAdd(&stats[2], (unsigned long long)w.n_hops);
@@ -353,6 +362,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     }
   }
   if constexpr (VISMODE == VIS_HBM) { if (lane == 0) vis_epoch[blockIdx.x] = w.epoch; }
+}
+
+// Exact re-rank, step 1: the index's distance (reference summation order, exact.hpp) of every survivor.  One wave per (query, 32 survivors): lane pair p
+// owns survivor 32 * chunk + p; key = exact score bits << 32 | slot << 1, the walk's own key layout.  The query is read from the prepared batch.
+template <int METRIC, int QUANT, bool R8>
+__global__ __launch_bounds__(64) void hnsw_pq_rerank_kernel(GraphView g, const float* __restrict__ q_eff, const float* __restrict__ qnorms, const uint32_t* __restrict__ surv,
+                                                            const uint32_t* __restrict__ surv_cnt, uint32_t ef_pad, unsigned long long* __restrict__ keys) {
+  const uint32_t qi = blockIdx.y, r = surv_cnt[qi];
+  if (blockIdx.x * 32u >= r) return;   // wave-uniform
+  const int lane = threadIdx.x, half = lane & 1, p = lane >> 1;
+  WaveCtx w;
+  w.qs = const_cast<float*>(q_eff + (size_t)qi * g.dim); w.qnorm = qnorms[qi];
+  const uint32_t i = blockIdx.x * 32u + (uint32_t)p;
+  const bool valid = i < r;
+  const uint32_t slot = surv[(size_t)qi * ef_pad + (valid ? i : blockIdx.x * 32u)];   // an idle pair re-evaluates a live survivor (DPP partners stay active)
+  const float d = eval_pair<METRIC, QUANT, PROF_SEARCH_HBM, R8>(g, w, slot, half);
+  if (valid && half == 0) keys[(size_t)qi * ef_pad + i] = ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)slot << 1);
+}
+// step 2: the k smallest keys of a query — (exact score bits, slot) order — by k rounds of a wave minimum over the keys staged in LDS
+__global__ __launch_bounds__(64) void hnsw_pq_select_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ surv_cnt, uint32_t ef_pad, uint32_t k,
+                                                            const uint64_t* __restrict__ ids, uint64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                            uint32_t* __restrict__ out_counts) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  unsigned long long* const res = reinterpret_cast<unsigned long long*>(smem);
+  const uint32_t qi = blockIdx.x, r = surv_cnt[qi];
+  const int lane_in = threadIdx.x;
+  for (uint32_t i = (uint32_t)lane_in; i < r; i += 64) res[i] = keys[(size_t)qi * ef_pad + i];
+  wave_sync();
+  const uint32_t n = r < k ? r : k;
+  for (uint32_t t = 0; t < n; t++) {
+    const int lane = opaque_lane(lane_in);
+    unsigned long long best = ~0ull; uint32_t bi = 0;
+    for (uint32_t i = (uint32_t)lane; i < r; i += 64) { const unsigned long long e = res[i]; if (e < best) { best = e; bi = i; } }
+    const unsigned long long km = wave_min_u64(best);
+    if (best == km && km != ~0ull) {   // keys are distinct (a slot appears once): exactly one lane
+      const uint32_t slot = (uint32_t)km >> 1;
+      out_ids[(size_t)qi * k + t] = ids ? ids[slot] : (uint64_t)slot;
+      out_scores[(size_t)qi * k + t] = __uint_as_float((uint32_t)(km >> 32));
+      res[bi] = ~0ull;
+    }
+    wave_sync();
+  }
+  if (lane_in == 0) out_counts[qi] = n;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -522,6 +574,7 @@ struct HCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc, w_pack;
+  DevBuf w_surv, w_scnt, w_keys;   // product-quantised walk: survivors (slots), their count, their exact keys
   PinnedBuf h_in, h_out;   // small calls: see PinnedBuf
   int init() {  // the caller has selected the index's device
     COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -1143,21 +1196,27 @@ bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   return true;
 }
 
-template <int METRIC, int QUANT>
-int launch_pq_search(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t q0, uint32_t nq, uint32_t k,
-                     uint32_t rerank, uint32_t* counter, uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
-  typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, const float*, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                         uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
-  kern_t kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS>
-              : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM>;
-  if (x->r8) kern = sg.variant == 0 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 0, VIS_LDS, true>
-                  : sg.variant == 3 ? (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 3, VIS_HBM, true> : (kern_t)hnsw_pq_search_kernel<METRIC, QUANT, 2, VIS_HBM, true>;   // the re-rank reads line-transposed rows
+int launch_pq_walk(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t nq, uint32_t k,
+                   uint32_t rerank, uint32_t* counter, uint32_t* surv, uint32_t* surv_cnt, unsigned long long* stats) {
+  auto kern = sg.variant == 0 ? hnsw_pq_search_kernel<0, VIS_LDS> : sg.variant == 3 ? hnsw_pq_search_kernel<3, VIS_HBM> : hnsw_pq_search_kernel<2, VIS_HBM>;
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  GraphView g = x->view();
-  kern<<<grid, 64, sg.lds, c->stream>>>(g, x->entry, x->entry_level, c->w_qeff.as<float>() + (size_t)q0 * x->dim, c->w_qn.as<float>() + q0, lut,
-                                        x->pq_codes.as<uint8_t>(), x->pq_row, pq_lut_shift(x), nq, k, sg.ef, sg.ef_pad, rerank, sg.vis_words, counter, oi + (size_t)q0 * k,
-                                        os + (size_t)q0 * k, oc + q0, stats, x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
+  kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, lut, x->pq_codes.as<uint8_t>(), x->pq_row, pq_lut_shift(x), nq, k, sg.ef, sg.ef_pad, rerank,
+                                        sg.vis_words, counter, surv, surv_cnt, stats, x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
                                         (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>() + region_base);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+template <int METRIC, int QUANT>
+int launch_pq_rerank(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t q0, uint32_t nq, uint32_t k, const uint32_t* surv, const uint32_t* surv_cnt,
+                     unsigned long long* keys, uint64_t* oi, float* os, uint32_t* oc) {
+  const dim3 grid(ceil_div(sg.ef_pad, 32), nq);
+  const GraphView g = x->view();
+  const float* qe = c->w_qeff.as<float>() + (size_t)q0 * x->dim; const float* qn = c->w_qn.as<float>() + q0;
+  if (x->r8) hnsw_pq_rerank_kernel<METRIC, QUANT, true><<<grid, 64, 0, c->stream>>>(g, qe, qn, surv, surv_cnt, sg.ef_pad, keys);
+  else hnsw_pq_rerank_kernel<METRIC, QUANT, false><<<grid, 64, 0, c->stream>>>(g, qe, qn, surv, surv_cnt, sg.ef_pad, keys);
+  const size_t lds = (size_t)sg.ef_pad * 8;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hnsw_pq_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hnsw_pq_select_kernel<<<nq, 64, lds, c->stream>>>(keys, surv_cnt, sg.ef_pad, k, g.ids, oi + (size_t)q0 * k, os + (size_t)q0 * k, oc + q0);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -1202,10 +1261,11 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
   COLTT_TRY(prep_queries_any(x, c, d_q, nq));
   // tables for a group of queries at a time: [group][row_bytes][256] f32, up to 1 GiB of them — a launch should hold several queries per resident
   // wave so that the work counter balances the tail (with 128 MiB a 10 000-query call ran as five 2 048-query launches on 2 048 waves: every launch
-  // as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv)
+  // as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv); at most 32 768 queries (the re-rank's grid.y)
   const size_t lut_q = (size_t)x->pq_row * 1024;
-  const size_t group = std::max<size_t>(1, std::min<size_t>(nq, (1024ull << 20) / lut_q));
+  const size_t group = std::max<size_t>(1, std::min<size_t>({nq, (1024ull << 20) / lut_q, (size_t)32768}));
   COLTT_TRY(c->w_pack.reserve(group * lut_q));
+  COLTT_TRY(c->w_surv.reserve(group * sg.ef_pad * 4)); COLTT_TRY(c->w_scnt.reserve(group * 4)); COLTT_TRY(c->w_keys.reserve(group * sg.ef_pad * 8));
   COLTT_TRY(c->w_misc.reserve(256));
   uint8_t* misc = c->w_misc.as<uint8_t>();
   uint32_t* counter = reinterpret_cast<uint32_t*>(misc);
@@ -1216,9 +1276,11 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
     const size_t gn = std::min(group, nq - q0);
     COLTT_TRY(pq_lut_batch(c->stream, x->pq_cb.as<float>(), x->pq_shape, c->w_qeff.as<float>() + q0 * x->dim, gn, x->pq_row, c->w_pack.as<float>()));
     if (q0) COLTT_HIP(hipMemsetAsync(counter, 0, 4, c->stream));
+    COLTT_TRY(launch_pq_walk(x, c, sg, (uint32_t)std::min<size_t>(grid, gn), lease.base, c->w_pack.as<float>(), (uint32_t)gn, k, rerank, counter, c->w_surv.as<uint32_t>(),
+                             c->w_scnt.as<uint32_t>(), d_stats));
     int rc;
-#define COLTT_LP_ARGS x, c, sg, (uint32_t)std::min<size_t>(grid, gn), lease.base, c->w_pack.as<float>(), (uint32_t)q0, (uint32_t)gn, k, rerank, counter, d_oi, d_os, d_oc, d_stats
-#define COLTT_LP(Q) rc = x->metric == COLTT_COSINE ? launch_pq_search<M_COS, Q>(COLTT_LP_ARGS) : launch_pq_search<M_L2, Q>(COLTT_LP_ARGS)
+#define COLTT_LP_ARGS x, c, sg, (uint32_t)q0, (uint32_t)gn, k, c->w_surv.as<uint32_t>(), c->w_scnt.as<uint32_t>(), c->w_keys.as<unsigned long long>(), d_oi, d_os, d_oc
+#define COLTT_LP(Q) rc = x->metric == COLTT_COSINE ? launch_pq_rerank<M_COS, Q>(COLTT_LP_ARGS) : launch_pq_rerank<M_L2, Q>(COLTT_LP_ARGS)
     if (x->quant == COLTT_Q_NONE) { COLTT_LP(Q_NONE); } else { COLTT_LP(Q_F16); }
 #undef COLTT_LP
 #undef COLTT_LP_ARGS
@@ -1233,7 +1295,20 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
     COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
   }
   COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
+#ifdef COLTT_PHASE_TIMING
+  unsigned long long h_pt[8] = {0};
+  COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, c->stream));
+#endif
   COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
+#ifdef COLTT_PHASE_TIMING
+  {
+    static const char* nm[8] = {"pop", "adjacency", "visited", "codes+table sum", "admission/evict/flush", "prologue(table, upper levels)", "flush+re-rank+writeout", "-"};
+    double tot = 0; for (int i = 0; i < 7; i++) tot += (double)h_pt[i];
+    fprintf(stderr, "[phase pq] nq=%zu ef=%u variant=%d per_cu=%u:", nq, sg.ef, sg.variant, sg.per_cu);
+    for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h_pt[i] / tot);
+    fprintf(stderr, "  | ticks/query %.0f, per expansion %.0f\n", tot / (double)nq, tot / (double)std::max<unsigned long long>(1, h_stats[1]));
+  }
+#endif
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   x->last_ms.store(ms);

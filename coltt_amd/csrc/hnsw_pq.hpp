@@ -18,7 +18,8 @@
 // d is a sum of non-negative terms for the supported pairings (squared L2 always; 1 - dot on a cosine index, whose rows, query and
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
-// One wave per query.  LDS: [result set | visited hash or Bloom filter | the query's table]; the re-rank reads the query from HBM / L2.
+// One wave per query.  LDS: [result set | visited hash or Bloom filter | the query's table].  The walk writes its survivors to HBM; the exact re-rank is
+// two kernels of its own (hnsw.hip: hnsw_pq_rerank_kernel — one wave per 32 survivors, deep bursts — and hnsw_pq_select_kernel).
 // The table is what bounds occupancy: mp16 x C' x 2 bytes per resident traversal, C' = the centroid count rounded up to a power of two
 // (m = 32 x 256 centroids: 16 KiB; m = 96 x 256: 48 KiB; m = 64 x 16 — the same 256 bits per row as 32 x 256 — 2 KiB).  Measured with f32 tables
 // (profiles/r05b_hnswpq_probe_10m.jsonl, 10 M x 768 f16): the walk is a chain of dependent round trips (~5 us per expansion), its
@@ -112,41 +113,6 @@ __device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w,
     if (best != ~0ull && bd < curd) { cur = best_slot; curd = bd; }
     else break;
   }
-}
-
-// The k best of res[0, r) by their EXACT distance: res[i] <- (exact bits << 32 | slot << 1), then k rounds of "smallest key not yet
-// taken" (r <= 4096: at most 64 LDS reads per lane and round).  Returns how many were written (min(k, r)).
-template <int METRIC, int QUANT, bool R8 = false>
-__device__ __forceinline__ uint32_t rerank_exact(const GraphView& g, WaveCtx& w, uint32_t r, uint32_t k, uint32_t qi, uint64_t* __restrict__ out_ids,
-                                                 float* __restrict__ out_scores, int lane_in) {
-  unsigned long long* const res = w.res0;
-  for (uint32_t i0 = 0; i0 < r; i0 += 32) {
-    const int lane = opaque_lane(lane_in);
-    const int half = lane & 1, p = lane >> 1;
-    const uint32_t i = i0 + (uint32_t)p;
-    const bool valid = i < r;
-    const uint32_t slot = valid ? ((uint32_t)res[i] >> 1) : 0u;
-    float d = 0.f;
-    if (valid) d = eval_pair<METRIC, QUANT, PROF_RERANK, R8>(g, w, slot, half);   // shallow bursts: the walk's register count decides the occupancy
-    wave_sync();
-    if (valid && half == 0) res[i] = ((unsigned long long)__float_as_uint(d) << 32) | ((unsigned long long)slot << 1);
-  }
-  wave_sync();
-  const uint32_t n = r < k ? r : k;
-  for (uint32_t t = 0; t < n; t++) {
-    const int lane = opaque_lane(lane_in);
-    unsigned long long best = ~0ull; uint32_t bi = 0;
-    for (uint32_t i = (uint32_t)lane; i < r; i += 64) { const unsigned long long e = res[i]; if (e < best) { best = e; bi = i; } }
-    const unsigned long long km = wave_min_u64(best);
-    if (best == km && km != ~0ull) {   // keys are distinct (a slot appears once): exactly one lane
-      const uint32_t slot = (uint32_t)km >> 1;
-      out_ids[(size_t)qi * k + t] = g.ids ? g.ids[slot] : (uint64_t)slot;
-      out_scores[(size_t)qi * k + t] = __uint_as_float((uint32_t)(km >> 32));
-      res[bi] = ~0ull;
-    }
-    wave_sync();
-  }
-  return n;
 }
 
 }  // namespace dev
