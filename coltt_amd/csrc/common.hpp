@@ -109,6 +109,7 @@ struct Policy {
   int walk2_lds = 4;           // COLTT_WALK2_LDS: -1 off, 2 / 4 / 6
   int bloom_kb = 0;            // COLTT_BLOOM_KB: 0 = sized by the occupancy budget
   int waves_per_cu = 0;        // COLTT_WAVES_PER_CU: 0 = per row format
+  int pq_waves = 0;            // COLTT_PQ_WAVES: resident traversals per CU of the product-quantised walk, 0 = the default cap
   bool lat_seq = false;        // COLTT_LAT_SEQ=1
   bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
   uint32_t lat_max_nq = 0;     // ... and its value

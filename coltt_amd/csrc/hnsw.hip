@@ -282,11 +282,12 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 
 
 // Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp): one wave per query, queries pulled from a global counter.
-// OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 / 3 + VIS_HBM: byte map, delta result set, Bloom filter if it fits).
+// OPT / VISMODE as hnsw_search2_kernel (0 + VIS_LDS: the LDS hash; 2 + VIS_HBM: byte map, delta result set; no Bloom filter — see pq_geom).
 // The walk touches no stored row: its survivors (slots, nearest first by table distance) go to HBM and the exact re-rank is two small kernels of its
 // own (below) — inside the walk kernel it was 19 % of the time (one 128-byte line per row in flight, the burst depth the walk's register budget left:
 // profiles/r05p_phase_breakdown.txt) and tied 24 instances of this kernel to the row format.
-template <int OPT, int VISMODE>
+// LS: the table's row length (log2) when it is one of the common ones (16, 32, 256 centroids), 0 = any (hnsw_pq.hpp: AdcEval<LS>).
+template <int OPT, int VISMODE, int LS>
 // amdgpu_waves_per_eu(3): <= 168 VGPRs, three waves per SIMD — the walk is latency-bound, resident traversals are its throughput
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ lut_g,
                                                             const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
@@ -297,7 +298,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
-  size_t off = 0;   // no copy of the query in LDS: the walk only needs its table
+  // LDS: [table | result set | visited hash or Bloom filter] — the table first: its lookups address it by immediate offsets (AdcEval<LS>).
+  // No copy of the query: the walk only needs its table.
+  unsigned short* const lut = reinterpret_cast<unsigned short*>(smem);
+  size_t off = ((size_t)row_bytes << lut_shift) * 2;   // a multiple of 512
   w.qs = nullptr; w.qp = nullptr; w.scr = nullptr;
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;
   w.ef_pad = ef_pad;
@@ -312,8 +316,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     w.bloom_words = vis_words; w.bloom_shift = 32u - (uint32_t)__builtin_ctz(vis_words | 0x80000000u);
     w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
   }
-  unsigned short* const lut = reinterpret_cast<unsigned short*>(smem + off);
-  AdcEval ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut; ev.lut_shift = lut_shift;
+  AdcEval<LS> ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut; ev.lut_shift = lut_shift;
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
@@ -1171,7 +1174,15 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
 // ---- Hnsw.Search over product-quantiser codes + exact re-rank (hnsw_pq.hpp) --------------------------------------------------------
 // log2 of a table row in LDS: the centroid count rounded up to a power of two, at least 16 (codes >= C never occur)
 uint32_t pq_lut_shift(const Hnsw* x) { uint32_t sh = 4; while ((1u << sh) < x->pq_shape.C) sh++; return sh; }
-struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: LDS hash | 2: byte map + delta | 3: + Bloom */ uint32_t per_cu; };
+// Resident traversals per CU of the product-quantised walk (120 VGPRs: four waves per SIMD would fit; the LDS decides below that — 16 instead of 12
+// measured nothing, profiles/r05s_pq_ab.md).
+// The walk over the byte map carries NO Bloom filter (the row walks do, hnsw_walk2.hpp): the probe of the byte map is one wave-wide load that is
+// issued whenever ANY lane's filter bits are set — and some ~10 of an expansion's 32 neighbours have been visited, so it is issued practically
+// always; what the filter saves is probing lanes (HBM sectors), which this walk has to spare, and what it costs is an LDS atomic round trip in
+// front of every probe plus 2-4 KiB of LDS per traversal (one resident wave per CU at ef 1 408).  Same box, 10 M x 768 f16, 64 x 32 quantiser
+// (profiles/r05s_pq_ab.md): ef 1 024 410 -> 440 k queries/s, ef 1 408 277 -> 316 k.
+constexpr size_t PQ_WAVES_CAP = 12;
+struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: LDS hash | 2: byte map + delta result set */ uint32_t per_cu; };
 bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   PqGeom s{};
   s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
@@ -1184,23 +1195,25 @@ bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   if (!force_hbm && !(wants_visg(ef) && hbm_ok) && lds_fits) { s.variant = 0; s.vis_words = hcap; s.lds = fixed + (size_t)hcap * 4; }
   else {
     if (!hbm_ok) return false;
-    // Bloom filter: the largest power of two (2..32 KiB) that does not cost a resident wave
-    const size_t waves = std::max<size_t>(1, std::min<size_t>(12, (160 * 1024) / (fixed + 2048)));   // <= 168 VGPRs: three waves per SIMD
-    const size_t budget = (160 * 1024) / waves;
-    size_t kb = 32; while (kb >= 2 && fixed + kb * 1024 > budget) kb >>= 1;
-    if (kb >= 2) { s.variant = 3; s.vis_words = (uint32_t)(kb * 256); s.lds = fixed + kb * 1024; }
-    else { s.variant = 2; s.vis_words = 0; s.lds = fixed; }
+    s.variant = 2; s.vis_words = 0; s.lds = fixed;
   }
-  s.per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(12, (160 * 1024) / s.lds));
+  {
+    const Policy pol = policy();
+    const size_t cap = pol.pq_waves > 0 ? (size_t)pol.pq_waves : PQ_WAVES_CAP;
+    s.per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(cap, (160 * 1024) / s.lds));
+  }
   out = s;
   return true;
 }
 
 int launch_pq_walk(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t nq, uint32_t k,
                    uint32_t rerank, uint32_t* counter, uint32_t* surv, uint32_t* surv_cnt, unsigned long long* stats) {
-  auto kern = sg.variant == 0 ? hnsw_pq_search_kernel<0, VIS_LDS> : sg.variant == 3 ? hnsw_pq_search_kernel<3, VIS_HBM> : hnsw_pq_search_kernel<2, VIS_HBM>;
+  const uint32_t sh = pq_lut_shift(x);
+#define COLTT_PQK(LS) (sg.variant == 0 ? hnsw_pq_search_kernel<0, VIS_LDS, LS> : hnsw_pq_search_kernel<2, VIS_HBM, LS>)
+  auto kern = sh == 4 ? COLTT_PQK(4) : sh == 5 ? COLTT_PQK(5) : sh == 8 ? COLTT_PQK(8) : COLTT_PQK(0);
+#undef COLTT_PQK
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, lut, x->pq_codes.as<uint8_t>(), x->pq_row, pq_lut_shift(x), nq, k, sg.ef, sg.ef_pad, rerank,
+  kern<<<grid, 64, sg.lds, c->stream>>>(x->view(), x->entry, x->entry_level, lut, x->pq_codes.as<uint8_t>(), x->pq_row, sh, nq, k, sg.ef, sg.ef_pad, rerank,
                                         sg.vis_words, counter, surv, surv_cnt, stats, x->w_visg.as<uint8_t>() + (size_t)region_base * x->vis_stride,
                                         (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>() + region_base);
   COLTT_HIP(hipGetLastError());

@@ -294,6 +294,7 @@ __device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w,
 template <int METRIC, int QUANT> struct LatEval {
   static constexpr bool CHUNK_ADJ = true;
   static constexpr bool SPEC = false;
+  static constexpr bool RADJ = true;    // the runner-up's adjacency row is requested at pop time (the chunk's rows come along with its vectors)
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}

@@ -18,7 +18,7 @@
 // d is a sum of non-negative terms for the supported pairings (squared L2 always; 1 - dot on a cosine index, whose rows, query and
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
-// One wave per query.  LDS: [result set | visited hash or Bloom filter | the query's table].  The walk writes its survivors to HBM; the exact re-rank is
+// One wave per query.  LDS: [the query's table | result set | visited hash (small ef; above it the byte map in HBM, no Bloom filter)].  The walk writes its survivors to HBM; the exact re-rank is
 // two kernels of its own (hnsw.hip: hnsw_pq_rerank_kernel — one wave per 32 survivors, deep bursts — and hnsw_pq_select_kernel).
 // The table is what bounds occupancy: mp16 x C' x 2 bytes per resident traversal, C' = the centroid count rounded up to a power of two
 // (m = 32 x 256 centroids: 16 KiB; m = 96 x 256: 48 KiB; m = 64 x 16 — the same 256 bits per row as 32 x 256 — 2 KiB).  Measured with f32 tables
@@ -32,10 +32,33 @@ namespace dev {
 
 // Where the walk's distances come from: the table in LDS, the code row of the neighbour (16-byte pieces, all requested before the
 // first lookup).  The even lane of a pair computes, both lanes of the pair receive (the walk keeps one neighbour per lane pair).
-struct AdcEval {
+// LS: the table's row length as a compile-time constant (log2; 0 = read lut_shift at run time).  With LS known and the table at the START of the
+// workgroup's LDS, lookup j is `ds_read_u16 v, (code byte << 1) offset: j << (LS + 1)`: no per-lookup address arithmetic beyond the byte extraction
+// (the run-time form keeps 128 row bases, which the compiler parks in VGPR lanes and fetches back one v_readlane + hazard nop at a time).
+template <int LS = 0> struct AdcEval {
   const uint8_t* codes; uint32_t row_bytes;   // [n][row_bytes], row_bytes = mp16 (a multiple of 16, <= 128); bytes j >= m are 0
   const unsigned short* lut;                   // LDS: [row_bytes][1 << lut_shift] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
   uint32_t lut_shift;                          // log2 of the table's row length = the number of centroids rounded up to a power of two (4 .. 8)
+  // s + float32(h), h = a binary16 in the low half of a register.  v_fma_mix_f32 computes fma(float32(h), 1.0f, s) with ONE rounding; float32(h) * 1.0f
+  // is exact, so the result is the IEEE sum of the converted entry — the bits of v_cvt_f32_f16 + v_add_f32 (the definition) in one issue slot.
+  static __device__ __forceinline__ float acc(float s, uint32_t h) {
+    float r; const float one = 1.0f;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(one), "v"(s));
+    return r;
+  }
+  // byte B of v, times two (the byte offset of a binary16 entry in its table row): one SDWA shift instead of v_bfe + v_lshl
+  template <int B> static __device__ __forceinline__ uint32_t byte2(uint32_t v) {
+    uint32_t r; const uint32_t one = 1u;
+    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(one), "v"(v));
+    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(one), "v"(v));
+    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(one), "v"(v));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(one), "v"(v));
+    return r;
+  }
+  // table entry (row j, code byte B of v), as the 16 bits the LDS read returns
+  template <int B> __device__ __forceinline__ uint32_t entry(uint32_t j, uint32_t sh, uint32_t v) const {
+    return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)j << (sh + 1)) + byte2<B>(v));
+  }
   u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
   // hnsw_walk2.hpp SPEC: visited bytes + code rows of the predicted next candidate's (the runner-up's) neighbours requested one expansion ahead.
@@ -45,6 +68,10 @@ struct AdcEval {
 #define COLTT_PQ_SPEC 0
 #endif
   static constexpr bool SPEC = COLTT_PQ_SPEC != 0;
+  // hnsw_walk2.hpp RADJ: the runner-up's adjacency row requested at pop time (it is the next candidate unless this expansion admits a nearer
+  // vertex).  On its own, without the speculation above: 1 % slower (profiles/r05s_pq_ab.md) — the exact prefetch at the end of the expansion already
+  // flies under the admission and the next pop.
+  static constexpr bool RADJ = SPEC;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[8]) const {
     const u32x4e* p = reinterpret_cast<const u32x4e*>(codes + (size_t)slot * row_bytes);
@@ -54,6 +81,7 @@ struct AdcEval {
   }
   __device__ __forceinline__ float sum(const u32x4e (&r)[8]) const {
     const int np = (int)(row_bytes >> 4);
+    const uint32_t sh = LS ? (uint32_t)LS : lut_shift;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -61,11 +89,8 @@ struct AdcEval {
 #pragma unroll
         for (int wd = 0; wd < 4; wd++) {
           const uint32_t v = r[i][wd];
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const uint32_t c = (v >> (8 * b)) & 0xffu;
-            s = s + f16bits_to_f32(lut[((uint32_t)(i * 16 + wd * 4 + b) << lut_shift) + c]);
-          }
+          const uint32_t j = (uint32_t)(i * 16 + wd * 4);
+          s = acc(s, entry<0>(j, sh, v)); s = acc(s, entry<1>(j + 1, sh, v)); s = acc(s, entry<2>(j + 2, sh, v)); s = acc(s, entry<3>(j + 3, sh, v));
         }
       }
     }
@@ -84,7 +109,8 @@ struct AdcEval {
 };
 
 // greedyClosestNeighbor (hnsw.go:320-343) with table distances: hnsw_dev.hpp:greedy_level with AdcEval in place of eval_pair
-__device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w, AdcEval& ev, uint32_t& cur, float& curd, int level, int lane_in) {
+template <class EV>
+__device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w, EV& ev, uint32_t& cur, float& curd, int level, int lane_in) {
   for (uint32_t hops = 0;; hops++) {
     const int lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;

@@ -157,6 +157,7 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
 template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct PairEval {
   static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
   static constexpr bool SPEC = false;        // no speculation on the next expansion's inputs (see AdcEval, hnsw_pq.hpp)
+  static constexpr bool RADJ = false;        // the runner-up's adjacency row is not requested at pop time
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
@@ -189,6 +190,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr int G8R = HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS, G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
   static constexpr bool CHUNK_ADJ = false;
   static constexpr bool SPEC = false;
+  static constexpr bool RADJ = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
@@ -364,7 +366,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     // needed next and is not on chip then is the runner-up's — requested now, it flies during the whole expansion
     typedef typename std::remove_reference<EVAL>::type eval_t;
     uint32_t runner_nb = NBR_NONE;
-    if constexpr ((eval_t::CHUNK_ADJ || eval_t::SPEC) && PREF) {
+    if constexpr (eval_t::RADJ && PREF) {
       if (runner_key != ~0ull && (uint32_t)p < g.mMax0) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * g.mMax0 + p];
     }
     int best_src = -1;   // lane of the smallest key admitted in this expansion's (single) chunk
@@ -392,7 +394,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
       if (nk_ != ~0ull) {                                                                            \
         pre_slot = (uint32_t)nk_ >> 1;                                                               \
-        if ((eval_t::CHUNK_ADJ || eval_t::SPEC) && width <= 32 && runner_key < best_new) pre_nb = runner_nb;           \
+        if (eval_t::RADJ && width <= 32 && runner_key < best_new) pre_nb = runner_nb;                \
         else if (eval_t::CHUNK_ADJ && width <= 32 && best_src >= 0) pre_nb = (uint32_t)p < width ? ev.chunk_adj(best_src >> 1, p) : NBR_NONE; \
         else pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;        \
         if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \

@@ -70,8 +70,8 @@ def _pq_case(gpu, n, d, metric, quant, m, c, seed):
 def test_hnsw_over_pq_codes_equals_the_oracle_definition(gpu, metric, quant, d, m, c):
     """VERDICT r4 missing #1: Hnsw.Search over product-quantiser codes with an exact re-rank (hnsw_pq.hpp) against the oracle's
     definition (coltt_oracle.cpp "Product-quantised HNSW"): the codes kept by the index == Encode of the stored rows; ids, EXACT score
-    bits, table-distance / expansion / hop / re-rank counters equal for the LDS-hash walk (ef 48), the byte-map walk (ef 300, Bloom +
-    delta result set) and partial re-ranks; inserts after the attach are encoded too."""
+    bits, table-distance / expansion / hop / re-rank counters equal for the LDS-hash walk (ef 48), the byte-map walk (ef 300, delta
+    result set) and partial re-ranks; inserts after the attach are encoded too."""
     import torch
     M = gpu.COSINE if metric == "cos" else gpu.EUCLIDEAN
     Qn = gpu.Q_NONE if quant == "f32" else gpu.Q_F16

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Product-quantised HNSW at the operating-point shape: recall@10 and queries/s of coltt_hnsw_pq_search (table-distance walk + exact
 re-rank) against the plain walk on the same index.  `python tools/hnswpq_probe.py [n] [m,m,..] [ef,ef,..] [rerank,..]`; one JSON line per
-configuration, appended to $PROBE_OUT."""
+configuration, appended to $PROBE_OUT.  $PROBE_KNOBS = "K=V;K=V|K=V|" runs every product-quantised search once per knob setting (an empty
+setting = the defaults) on the same index; $PROBE_PLAIN=0 skips the plain walk."""
 import json
 import os
 import sys
@@ -48,7 +49,8 @@ def main():
     def recall(ids):
         return sum(len(set(truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
 
-    for ef in efs:   # the plain walk on this box, for the ratio
+    knob_sets = [dict(kv.split("=") for kv in ks.split(";") if kv) for ks in os.environ.get("PROBE_KNOBS", "").split("|")]
+    for ef in (efs if os.environ.get("PROBE_PLAIN", "1") != "0" else []):   # the plain walk on this box, for the ratio
         h.SearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef)
         t0 = time.time(); st = h.SearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef); dt = time.time() - t0
         emit({"kind": "plain", "n": n, "ef": ef, "recall": round(recall(o.ids.cpu().numpy()), 4), "qps": round(nq / dt), "kernel_ms": round(h.last_kernel_ms(), 3),
@@ -61,14 +63,16 @@ def main():
             pq = G.PQSpace(dim, pqm, m, nc)
             t0 = time.time(); pq.Fit(sample, iterations=6); fit_s = time.time() - t0
             t0 = time.time(); h.PqAttach(pq); attach_s = time.time() - t0
-            for ef in efs:
-                for rr in rrs:
+            for ef, rr, knobs in [(e_, r_, k_) for e_ in efs for r_ in rrs for k_ in knob_sets]:
                     try:
+                        for kk in [kk for ks in knob_sets for kk in ks]:
+                            os.environ.pop(kk, None)
+                        os.environ.update(knobs)
                         h.PqSearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef, rerank=rr)
                         t0 = time.time(); st = h.PqSearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef, rerank=rr); dt = time.time() - t0
                         nd, nx = st["n_dist"] / nq, st["n_exact"] / nq
                         bytes_q = nd * ((m + 15) // 16 * 16) + st["n_exp"] / nq * 32 * 4 + nd * 4 + nx * dim * 2
-                        emit({"kind": "pq", "n": n, "m": m, "C": nc, "pq_metric": pname, "ef": ef, "rerank": rr, "recall": round(recall(o.ids.cpu().numpy()), 4),
+                        emit({"kind": "pq", "knobs": knobs, "n": n, "m": m, "C": nc, "pq_metric": pname, "ef": ef, "rerank": rr, "recall": round(recall(o.ids.cpu().numpy()), 4),
                               "qps": round(nq / dt), "kernel_ms": round(h.last_kernel_ms(), 3), "n_dist": round(nd, 1), "n_exact": round(nx, 1),
                               "MB_per_query": round(bytes_q / 1e6, 3), "GBps": round(bytes_q * nq / max(h.last_kernel_ms(), 1e-9) / 1e6, 1),
                               "fit_s": round(fit_s, 2), "attach_s": round(attach_s, 2)})
