@@ -27,27 +27,30 @@ namespace dev {
 enum { W2_BLOOM = 1, W2_DELTA = 2, W2_ADJN = 4 };
 
 // ---- wave64 reductions through DPP (no LDS crossbar): quad_perm, row_shr, row_bcast — the result lands in lane 63 -------------
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_keep(uint32_t v) {  // lanes without a source keep their value
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+// One reduction step = ONE v_min_u32_dpp / v_max_u32_dpp: the DPP move is given the operation's identity as its `old` value (lanes without a source,
+// rows outside ROW_MASK), which is the form the compiler's DPP combine folds into the arithmetic instruction (old == the value itself compiled to
+// v_mov + v_mov_dpp + v_min: three issue slots and a longer hazard stall per step, six steps per reduction, five to eight reductions per expansion).
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_or(uint32_t v, uint32_t ident) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  v = umin32(v, dpp_keep<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
-  v = umin32(v, dpp_keep<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
-  v = umin32(v, dpp_keep<0x114, 0xf>(v));   // row_shr:4
-  v = umin32(v, dpp_keep<0x118, 0xf>(v));   // row_shr:8   -> lane 15 of every row holds the row's minimum
-  v = umin32(v, dpp_keep<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3
-  v = umin32(v, dpp_keep<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+  v = umin32(dpp_or<0xB1, 0xf>(v, 0xffffffffu), v);    // quad_perm [1,0,3,2]
+  v = umin32(dpp_or<0x4E, 0xf>(v, 0xffffffffu), v);    // quad_perm [2,3,0,1]
+  v = umin32(dpp_or<0x114, 0xf>(v, 0xffffffffu), v);   // row_shr:4
+  v = umin32(dpp_or<0x118, 0xf>(v, 0xffffffffu), v);   // row_shr:8   -> lane 15 of every row holds the row's minimum
+  v = umin32(dpp_or<0x142, 0xa>(v, 0xffffffffu), v);   // row_bcast:15 into rows 1 and 3
+  v = umin32(dpp_or<0x143, 0xc>(v, 0xffffffffu), v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  v = umax32(v, dpp_keep<0xB1, 0xf>(v));
-  v = umax32(v, dpp_keep<0x4E, 0xf>(v));
-  v = umax32(v, dpp_keep<0x114, 0xf>(v));
-  v = umax32(v, dpp_keep<0x118, 0xf>(v));
-  v = umax32(v, dpp_keep<0x142, 0xa>(v));
-  v = umax32(v, dpp_keep<0x143, 0xc>(v));
+  v = umax32(dpp_or<0xB1, 0xf>(v, 0u), v);
+  v = umax32(dpp_or<0x4E, 0xf>(v, 0u), v);
+  v = umax32(dpp_or<0x114, 0xf>(v, 0u), v);
+  v = umax32(dpp_or<0x118, 0xf>(v, 0u), v);
+  v = umax32(dpp_or<0x142, 0xa>(v, 0u), v);
+  v = umax32(dpp_or<0x143, 0xc>(v, 0u), v);
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // lane holding the smallest / largest 64-bit key (hi:lo) among the lanes with `valid` (wave-uniform; -1 when there is none).
