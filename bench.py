@@ -478,7 +478,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
         pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, pm, pc)
         t0 = time.perf_counter(); pq.Fit(sample, iterations=6); fit_s = time.perf_counter() - t0
         t0 = time.perf_counter(); h.PqAttach(pq); attach_s = time.perf_counter() - t0
-        pefs = [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1152,1280,1408,1536,2048").split(",")]
+        pefs = [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1152,1280,1344,1408,1536,2048").split(",")]
         pcurve = {}; pqps = {}
         for ef in pefs:
             st = h.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef, rerank=rr)

@@ -301,6 +301,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
   // LDS: [table | result set | visited hash or Bloom filter] — the table first: its lookups address it by immediate offsets (AdcEval<LS>).
   // No copy of the query: the walk only needs its table.
   unsigned short* const lut = reinterpret_cast<unsigned short*>(smem);
+  if constexpr (LS != 0) {   // AdcEval<LS> addresses the table by absolute LDS offsets: this kernel has no static LDS, so its dynamic LDS starts at 0
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem != 0u) { if (lane == 0) atomicOr(&stats[4], 128ull); return; }
+  }
   size_t off = ((size_t)row_bytes << lut_shift) * 2;   // a multiple of 512
   w.qs = nullptr; w.qp = nullptr; w.scr = nullptr;
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;

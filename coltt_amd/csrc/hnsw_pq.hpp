@@ -55,9 +55,16 @@ template <int LS = 0> struct AdcEval {
     else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(one), "v"(v));
     return r;
   }
-  // table entry (row j, code byte B of v), as the 16 bits the LDS read returns
+  // table entry (row j, code byte B of v), as the 16 bits the LDS read returns.  LS != 0: the table starts at LDS address 0 (the kernel checks it), so
+  // the read is addressed by the shifted code byte alone, the row in the instruction's offset field — through the generic pointer the compiler adds
+  // the (zero) base symbol to every address: one v_add per lookup.
   template <int B> __device__ __forceinline__ uint32_t entry(uint32_t j, uint32_t sh, uint32_t v) const {
-    return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)j << (sh + 1)) + byte2<B>(v));
+    if constexpr (LS != 0) {
+      typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+      return *reinterpret_cast<lds_u16*>((uint32_t)((j << (LS + 1)) + byte2<B>(v)));
+    } else {
+      return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)j << (sh + 1)) + byte2<B>(v));
+    }
   }
   u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;

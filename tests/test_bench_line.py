@@ -142,3 +142,25 @@ def test_final_line_of_round_5_carries_the_pq_walk_and_the_traffic_source():
         assert c[leg]["gpu_equals_oracle"] is True and res["secondary"][leg]["cpu_baseline"]["full_size_oracle_sample"]["rows"] == 10_000_000
     committed = json.load(open(os.path.join(ROOT, "profiles", "r05i_bench_10m_line.json")))
     assert committed["value"] == c["value"] and committed["op"]["pq"]["value"] == pq["value"]
+
+
+def test_last_record_of_round_5_is_the_last_library():
+    """the round's last full run of the driver's command (call V, the shipped library): every leg incl. the 8-member pipeline; the product-quantised
+    walk answers the recall >= 0.98 point at more than twice the plain walk's rate; the line is what final_line() makes of the full record"""
+    res = json.load(open(os.path.join(ROOT, "profiles", "r05v_bench_10m_full.json")))
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert "trimmed" not in c
+    for leg in ("op", "c1", "c2", "c3", "c3f8", "pq", "f3", "h1", "g8"):
+        assert leg in c, leg
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r05v_bench_10m_line.json")))
+    assert committed["value"] == c["value"] and committed["roofline"]["frac"] == c["roofline"]["frac"]
+    assert c["cpu_baseline"]["gpu_equals_oracle_on_sample"] is True and c["cpu_baseline"]["counters_equal"] is True
+    op = c["op"]; pq = op["pq"]
+    assert op["recall_at_10"] >= 0.98 and pq["recall_at_10"] >= 0.98 and op["gpu_equals_oracle"] is True and pq["gpu_equals_oracle"] is True
+    assert pq["value"] > 2.0 * op["value"] and committed["op"]["pq"]["value"] == pq["value"]
+    g8 = c["g8"]
+    assert g8["streamed_equals_serial"] is True and g8["exposed_frac_of_a_streamed_batch"] < 0.05
