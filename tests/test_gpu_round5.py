@@ -51,10 +51,10 @@ def test_batched_build_matches_sequential_recall(gpu):
         assert nb <= 1.10 * ns, (ef, nb, ns)
 
 
-def _pq_case(gpu, n, d, metric, quant, m, c, seed):
+def _pq_case(gpu, n, d, metric, quant, m, c, seed, scale=1.0):
     """index (graph built on the GPU, batch 1 == the reference's sequential Insert) + a quantiser trained on its stored rows"""
     import torch
-    X = O.fill_normal(seed, (n, d)); lv = O.levels(seed + 1, n)
+    X = (O.fill_normal(seed, (n, d)) * np.float32(scale)).astype(np.float32); lv = O.levels(seed + 1, n)
     h = gpu.Hnsw(d, metric, gpu.HnswCfg.default(m=8, ef=32, ef_construction=40), quantization=quant)
     xd = torch.from_numpy(X).to("cuda:0"); torch.cuda.synchronize()
     h.InsertBatchDevice(xd.data_ptr(), n, lv, batch=64)
@@ -114,6 +114,29 @@ def test_hnsw_over_pq_codes_equals_the_oracle_definition(gpu, metric, quant, d, 
     for qi in range(8):
         assert np.array_equal(gi[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64)) and np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32))
     assert st == ost
+
+
+@pytest.mark.parametrize("c", [16, 32, 64, 256])
+def test_hnsw_pq_tables_of_binary16_denormals(gpu, c):
+    """The walk's table entries are binary16 and its distance is their f32 sum — in the kernel one v_fma_mix_f32 per entry (hnsw_pq.hpp: AdcEval::acc).
+    Rows scaled to ~2^-9 put the squared sub-vector distances around 2^-14 … 2^-17: most table entries are binary16 DENORMALS, the rest tiny normals.
+    A flushed denormal would change the table distances, hence the walk: ids, exact score bits and all four counters must still equal the oracle's,
+    for every table shape the kernel is instantiated for (16 / 32 / 256 centroids) and the run-time one (64)."""
+    d, m, n, k = 64, 16, 2000, 10
+    h, pq, pqm, rows, seen = _pq_case(gpu, n, d, gpu.EUCLIDEAN, gpu.Q_NONE, m, c, 4100 + c, scale=2.0 ** -9)
+    h.PqAttach(pq)
+    cb = pq.Codebooks(); codes = h.PqCodes(); g = h.ExportRaw()
+    Q = (O.fill_normal(4177 + c, (24, d)) * np.float32(2.0 ** -9)).astype(np.float32)
+    h16 = np.concatenate([O.pq_lut(O.PQ_EUCLIDEAN, cb, Q[i]).ravel() for i in range(4)]).astype(np.float16)
+    assert (np.abs(h16[h16 != 0]) < 6.2e-5).mean() > 0.3, "the case no longer produces denormal table entries"
+    for ef, rr in ((40, 0), (300, 0), (300, 32)):
+        gi, gs, gc, st = h.PqSearch(Q, k, ef=ef, rerank=rr, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search_pq(rows, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], codes, cb, pqm, Q, k, ef, rerank=rr)
+        assert np.array_equal(gc, cn.astype(np.uint32)), (ef, rr)
+        for qi in range(len(Q)):
+            assert np.array_equal(gi[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64)), (ef, rr, qi)
+            assert np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32)), (ef, rr, qi)
+        assert st == ost, (ef, rr, st, ost)
 
 
 def test_hnsw_pq_attach_refuses_what_the_walk_cannot_order(gpu):

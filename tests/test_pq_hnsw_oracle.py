@@ -30,10 +30,11 @@ def _padded(g, w0, wu):
     return adj0, upper_off, adjU
 
 
-@pytest.mark.parametrize("metric,quant,pqm", [(O.COSINE, O.Q_NONE, O.PQ_COSINE), (O.L2, O.Q_F16, O.PQ_EUCLIDEAN), (O.COSINE, O.Q_F16, O.PQ_EUCLIDEAN)])
-def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant, pqm):
+@pytest.mark.parametrize("metric,quant,pqm,scale", [(O.COSINE, O.Q_NONE, O.PQ_COSINE, 1.0), (O.L2, O.Q_F16, O.PQ_EUCLIDEAN, 1.0), (O.COSINE, O.Q_F16, O.PQ_EUCLIDEAN, 1.0),
+                                                         (O.L2, O.Q_NONE, O.PQ_EUCLIDEAN, 2.0 ** -9)])   # the last one: table entries that are binary16 denormals
+def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant, pqm, scale):
     n, d, m, c, k = 260, 32, 8, 16, 5
-    X = O.fill_normal(4100 + metric + 3 * quant, (n, d)); lv = O.levels(4200, n)
+    X = (O.fill_normal(4100 + metric + 3 * quant, (n, d)) * np.float32(scale)).astype(np.float32); lv = O.levels(4200, n)
     stored_f32 = np.array([O.normalize(x) for x in X]) if metric == O.COSINE else X
     rows = O.lower(quant, stored_f32) if quant != O.Q_NONE else stored_f32       # what the index stores
     seen = O.f16_decode(rows) if quant != O.Q_NONE else rows                      # ... as its distance sees it
@@ -44,7 +45,10 @@ def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant,
     entry = int(g["entry"]); entry_level = int(g["levels"][entry])
     cb = O.pq_train(seen[:120], m, c, iters=3)
     codes = O.pq_encode(cb, seen)
-    Q = O.fill_normal(4300, (5, d))
+    Q = (O.fill_normal(4300, (5, d)) * np.float32(scale)).astype(np.float32)
+    if scale != 1.0:
+        h16 = np.concatenate([O.pq_lut(pqm, cb, Q[i]).ravel() for i in range(len(Q))]).astype(np.float16)
+        assert (np.abs(h16[h16 != 0]) < 6.2e-5).mean() > 0.3
     for ef, rr in ((12, 0), (40, 7), (5, 2)):
         sl, sc, cn, st, _ = O.csr_search_pq(rows, quant, adj0, upper_off, adjU, d, metric, entry, entry_level, codes, cb, pqm, Q, k, ef, rerank=rr)
         tot = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
