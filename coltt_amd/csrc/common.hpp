@@ -210,7 +210,8 @@ int hnsw_create_on(int device, uint32_t dim, int metric, int quant, const coltt_
 struct PqShape { uint32_t dim = 0, m = 0, C = 0, dsub = 0; int metric = 0; };
 int pq_snapshot(coltt_handle_t pq, PqShape* shape, DevBuf* cb_out, hipStream_t s);
 int pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_vecs, uint64_t n, uint8_t* d_codes, uint32_t row_bytes);
-int pq_lut_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, float* d_lut);
+// the walk's tables: [nq][mp][1 << shift] binary16 (round to nearest even: the f16 codec's rounding), rows j >= m and entries c >= C are +0.0
+int pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, unsigned short* d_lut);
 
 inline size_t quant_bytes(int q) { return q == COLTT_Q_NONE ? 4 : (q == COLTT_Q_F8 ? 1 : 2); }
 

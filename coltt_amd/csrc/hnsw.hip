@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
 // LS: the table's row length (log2) when it is one of the common ones (16, 32, 256 centroids), 0 = any (hnsw_pq.hpp: AdcEval<LS>).
 template <int OPT, int VISMODE, int LS>
 // amdgpu_waves_per_eu(3): <= 168 VGPRs, three waves per SIMD — the walk is latency-bound, resident traversals are its throughput
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const float* __restrict__ lut_g,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hnsw_pq_search_kernel(GraphView g, int32_t entry, int32_t entry_level, const unsigned short* __restrict__ lut_g,
                                                             const uint8_t* __restrict__ codes, uint32_t row_bytes, uint32_t lut_shift, uint32_t nq, uint32_t k,
                                                             uint32_t ef, uint32_t ef_pad, uint32_t rerank, uint32_t vis_words,
                                                             uint32_t* __restrict__ counter, uint32_t* __restrict__ surv, uint32_t* __restrict__ surv_cnt,
@@ -330,16 +330,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     w.t_last = __builtin_amdgcn_s_memtime();
 #endif
     wave_sync();
-    {  // the query's table: row_bytes rows of (1 << lut_shift) entries (of the 256 per row in HBM), f32 -> binary16 in LDS (round to nearest even:
-       // the codec's own integer rounding, exact.hpp); four entries per lane and step
-      const float* src = lut_g + (size_t)qi * row_bytes * 256;
-      u32x2e* dst = reinterpret_cast<u32x2e*>(lut);
-      const uint32_t per_row = 1u << (lut_shift - 2), total = row_bytes << (lut_shift - 2);
-      for (uint32_t i = (uint32_t)lane; i < total; i += 64) {
-        const uint32_t j = i / per_row, c4 = i - j * per_row;
-        const u32x4v v = *reinterpret_cast<const u32x4v*>(src + (size_t)j * 256 + c4 * 4);
-        dst[i] = u32x2e{f32bits_to_f16bits(v.x) | (f32bits_to_f16bits(v.y) << 16), f32bits_to_f16bits(v.z) | (f32bits_to_f16bits(v.w) << 16)};
-      }
+    {  // the query's table as pq_lut16_kernel wrote it: row_bytes rows of (1 << lut_shift) binary16 entries, copied 16 bytes per lane and step
+      const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + ((size_t)qi * row_bytes << lut_shift));
+      u32x4v* dst = reinterpret_cast<u32x4v*>(lut);
+      const uint32_t total = row_bytes << (lut_shift - 3);   // 16-byte pieces (row_bytes is a multiple of 16, lut_shift >= 4)
+      for (uint32_t i = (uint32_t)lane; i < total; i += 64) dst[i] = src[i];
     }
     w.qnorm = 0.f;
     wave_sync();
@@ -1209,7 +1204,7 @@ bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   return true;
 }
 
-int launch_pq_walk(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const float* lut, uint32_t nq, uint32_t k,
+int launch_pq_walk(Hnsw* x, HCtx* c, const PqGeom& sg, uint32_t grid, uint32_t region_base, const unsigned short* lut, uint32_t nq, uint32_t k,
                    uint32_t rerank, uint32_t* counter, uint32_t* surv, uint32_t* surv_cnt, unsigned long long* stats) {
   const uint32_t sh = pq_lut_shift(x);
 #define COLTT_PQK(LS) (sg.variant == 0 ? hnsw_pq_search_kernel<0, VIS_LDS, LS> : hnsw_pq_search_kernel<2, VIS_HBM, LS>)
@@ -1275,11 +1270,12 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
     d_q = c->w_qraw.as<float>();
   }
   COLTT_TRY(prep_queries_any(x, c, d_q, nq));
-  // tables for a group of queries at a time: [group][row_bytes][256] f32, up to 1 GiB of them — a launch should hold several queries per resident
-  // wave so that the work counter balances the tail (with 128 MiB a 10 000-query call ran as five 2 048-query launches on 2 048 waves: every launch
-  // as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv); at most 32 768 queries (the re-rank's grid.y)
-  const size_t lut_q = (size_t)x->pq_row * 1024;
-  const size_t group = std::max<size_t>(1, std::min<size_t>({nq, (1024ull << 20) / lut_q, (size_t)32768}));
+  // tables for a group of queries at a time: [group][row_bytes][1 << shift] binary16 (4 KiB per query for 64 x 32), up to 256 MiB of them — a launch should
+  // hold several queries per resident wave so that the work counter balances the tail (a 10 000-query call once ran as five 2 048-query launches on
+  // 2 048 waves: every launch as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv); at most 32 768 queries (the re-rank's grid.y)
+  const uint32_t lsh = pq_lut_shift(x);
+  const size_t lut_q = ((size_t)x->pq_row << lsh) * 2;
+  const size_t group = std::max<size_t>(1, std::min<size_t>({nq, (256ull << 20) / lut_q, (size_t)32768}));
   COLTT_TRY(c->w_pack.reserve(group * lut_q));
   COLTT_TRY(c->w_surv.reserve(group * sg.ef_pad * 4)); COLTT_TRY(c->w_scnt.reserve(group * 4)); COLTT_TRY(c->w_keys.reserve(group * sg.ef_pad * 8));
   COLTT_TRY(c->w_misc.reserve(256));
@@ -1290,9 +1286,9 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   for (size_t q0 = 0; q0 < nq; q0 += group) {
     const size_t gn = std::min(group, nq - q0);
-    COLTT_TRY(pq_lut_batch(c->stream, x->pq_cb.as<float>(), x->pq_shape, c->w_qeff.as<float>() + q0 * x->dim, gn, x->pq_row, c->w_pack.as<float>()));
+    COLTT_TRY(pq_lut16_batch(c->stream, x->pq_cb.as<float>(), x->pq_shape, c->w_qeff.as<float>() + q0 * x->dim, gn, x->pq_row, lsh, c->w_pack.as<unsigned short>()));
     if (q0) COLTT_HIP(hipMemsetAsync(counter, 0, 4, c->stream));
-    COLTT_TRY(launch_pq_walk(x, c, sg, (uint32_t)std::min<size_t>(grid, gn), lease.base, c->w_pack.as<float>(), (uint32_t)gn, k, rerank, counter, c->w_surv.as<uint32_t>(),
+    COLTT_TRY(launch_pq_walk(x, c, sg, (uint32_t)std::min<size_t>(grid, gn), lease.base, c->w_pack.as<unsigned short>(), (uint32_t)gn, k, rerank, counter, c->w_surv.as<uint32_t>(),
                              c->w_scnt.as<uint32_t>(), d_stats));
     int rc;
 #define COLTT_LP_ARGS x, c, sg, (uint32_t)q0, (uint32_t)gn, k, c->w_surv.as<uint32_t>(), c->w_scnt.as<uint32_t>(), c->w_keys.as<unsigned long long>(), d_oi, d_os, d_oc

@@ -99,6 +99,19 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ c
   lut[((size_t)q * mp + j) * 256 + c] = v;
 }
 
+// the product-quantised HNSW's table (hnsw_pq.hpp): the same entries, rounded to binary16, rows as long as the centroid count rounded up to a power
+// of two (1 << shift, 16 .. 256) — what the walk kernel copies into its LDS as it is: 4 KiB per query for 64 x 32 instead of 64 KiB of f32
+template <int KIND>
+__global__ __launch_bounds__(256) void pq_lut16_kernel(const float* __restrict__ cb, int m, int C, int dsub, const float* __restrict__ queries,
+                                                       int mp, int shift, unsigned short* __restrict__ lut) {
+  const int per = 256 >> shift;                                  // table rows per workgroup
+  const int j = blockIdx.x * per + ((int)threadIdx.x >> shift), c = (int)threadIdx.x & ((1 << shift) - 1), q = blockIdx.y;
+  if (j >= mp) return;
+  float v = 0.f;
+  if (j < m && c < C) v = pq_dist<KIND>(queries + ((size_t)q * m + j) * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
+  lut[(((size_t)q * mp + j) << shift) + c] = (unsigned short)f32bits_to_f16bits(__float_as_uint(v));
+}
+
 // ---- Encode.  One thread per (row, sub-space): the sub-vector sits in registers (DS compile-time) or is re-read (DS == 0), the
 // sub-space's centroids are broadcast from LDS when they fit (lds_cb) or read through the caches.
 __device__ __forceinline__ size_t code_offset(uint64_t row, int j, int T, int PB) {
@@ -615,13 +628,14 @@ int coltt::pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& s
   return COLTT_OK;
 }
 
-// distance tables of nq queries: d_lut [nq][mp][256] f32, rows j >= m and entries c >= C are +0.0
-int coltt::pq_lut_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, float* d_lut) {
+// distance tables of nq queries for the product-quantised HNSW: d_lut [nq][mp][1 << shift] binary16
+int coltt::pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, unsigned short* d_lut) {
   if (nq == 0) return COLTT_OK;
-  dim3 grid(mp, (uint32_t)nq);
-  if (sh.metric == COLTT_PQ_COSINE) pq_lut_kernel<0><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
-  else if (sh.metric == COLTT_PQ_EUCLIDEAN) pq_lut_kernel<1><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
-  else pq_lut_kernel<2><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, d_lut, nullptr, nullptr, nullptr);
+  if (shift < 4 || shift > 8 || (1u << shift) < sh.C) return fail(COLTT_E_INVALID, "pq_lut16: %u centroids do not fit rows of %u entries", sh.C, 1u << shift);
+  dim3 grid(ceil_div(mp, 256u >> shift), (uint32_t)nq);
+  if (sh.metric == COLTT_PQ_COSINE) pq_lut16_kernel<0><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
+  else if (sh.metric == COLTT_PQ_EUCLIDEAN) pq_lut16_kernel<1><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
+  else pq_lut16_kernel<2><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
