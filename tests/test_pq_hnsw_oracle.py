@@ -61,3 +61,38 @@ def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant,
             assert np.array_equal(sc[qi, :cn[qi]].view(np.uint32), np.array(wsc, np.float32).view(np.uint32)), (ef, rr, qi)
             for kk in tot: tot[kk] += cnt[kk]
         assert st == tot, (ef, rr, st, tot)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_oracle_pq_walk_equals_the_python_restatement_on_random_shapes(seed):
+    """the same double entry over random shapes: sub-vector counts that leave padding rows in the table (m not a multiple of 16), centroid counts that are
+    not powers of two (the table's row is as long as the next power of two), tombstone-free graphs of random degree, ef below / at / above k"""
+    rng = np.random.default_rng(seed)
+    m = int(rng.choice([2, 4, 6, 8, 12])); dsub = int(rng.choice([2, 3, 4])); d = m * dsub
+    c = int(rng.choice([5, 16, 17, 33, 64])); n = int(rng.integers(150, 320)); k = int(rng.choice([1, 3, 7]))
+    metric = int(rng.choice([O.COSINE, O.L2])); quant = int(rng.choice([O.Q_NONE, O.Q_F16]))
+    pqm = O.PQ_COSINE if (metric == O.COSINE and rng.random() < 0.5) else O.PQ_EUCLIDEAN
+    X = O.fill_normal(7000 + seed, (n, d)); lv = O.levels(7100 + seed, n)
+    stored_f32 = np.array([O.normalize(x) for x in X]) if metric == O.COSINE else X
+    rows = O.lower(quant, stored_f32) if quant != O.Q_NONE else stored_f32
+    seen = O.f16_decode(rows) if quant != O.Q_NONE else rows
+    h = O.Hnsw(d, metric, cfg=O.default_cfg(m=int(rng.choice([4, 6, 8])), ef=16, efConstruction=24))
+    h.insert_many(np.arange(n, dtype=np.uint64), X, lv)
+    g = h.export(with_vectors=False)
+    adj0, upper_off, adjU = _padded(g, h.cfg.mMax0, h.cfg.mMax)
+    entry = int(g["entry"]); entry_level = int(g["levels"][entry])
+    cb = O.pq_train(seen[: max(c, 100)], m, c, iters=2)
+    codes = O.pq_encode(cb, seen)
+    Q = O.fill_normal(7200 + seed, (4, d))
+    for ef, rr in ((max(1, k - 1), 0), (k, k), (4 * k + 9, 0), (30, 5)):
+        sl, sc, cn, st, _ = O.csr_search_pq(rows, quant, adj0, upper_off, adjU, d, metric, entry, entry_level, codes, cb, pqm, Q, k, ef, rerank=rr)
+        tot = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
+        for qi in range(len(Q)):
+            q = O.normalize(Q[qi]) if metric == O.COSINE else Q[qi]
+            if quant != O.Q_NONE:
+                q = O.f16_decode(O.lower(quant, q))
+            ws, wsc, cnt = P.csr_search_pq(seen, adj0, upper_off, adjU, 0 if metric == O.COSINE else 1, entry, entry_level, codes, cb, pqm, q, k, ef, rr)
+            assert list(sl[qi, :cn[qi]]) == ws, (seed, ef, rr, qi)
+            assert np.array_equal(sc[qi, :cn[qi]].view(np.uint32), np.array(wsc, np.float32).view(np.uint32)), (seed, ef, rr, qi)
+            for kk in tot: tot[kk] += cnt[kk]
+        assert st == tot, (seed, ef, rr, st, tot)
