@@ -110,6 +110,7 @@ struct Policy {
   int bloom_kb = 0;            // COLTT_BLOOM_KB: 0 = sized by the occupancy budget
   int waves_per_cu = 0;        // COLTT_WAVES_PER_CU: 0 = per row format
   int pq_waves = 0;            // COLTT_PQ_WAVES: resident traversals per CU of the product-quantised walk, 0 = the default cap
+  bool pq_nbr = true;          // COLTT_PQ_NBR=0: the product-quantised walk gathers its code rows by neighbour slot (round 5) instead of reading the neighbourhood blocks
   bool lat_seq = false;        // COLTT_LAT_SEQ=1
   bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
   uint32_t lat_max_nq = 0;     // ... and its value
@@ -211,7 +212,8 @@ struct PqShape { uint32_t dim = 0, m = 0, C = 0, dsub = 0; int metric = 0; };
 int pq_snapshot(coltt_handle_t pq, PqShape* shape, DevBuf* cb_out, hipStream_t s);
 int pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_vecs, uint64_t n, uint8_t* d_codes, uint32_t row_bytes);
 // the walk's tables: [nq][mp][1 << shift] binary16 (round to nearest even: the f16 codec's rounding), rows j >= m and entries c >= C are +0.0
-int pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, unsigned short* d_lut);
+int pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, uint32_t* d_qmax, unsigned short* d_lut);
+int pq_centroid_norm_max(hipStream_t s, const float* d_cb, const PqShape& sh, uint32_t* d_scratch, float* out);
 
 inline size_t quant_bytes(int q) { return q == COLTT_Q_NONE ? 4 : (q == COLTT_Q_F8 ? 1 : 2); }
 

@@ -295,6 +295,8 @@ template <int METRIC, int QUANT> struct LatEval {
   static constexpr bool CHUNK_ADJ = true;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = true;    // the runner-up's adjacency row is requested at pop time (the chunk's rows come along with its vectors)
+  static constexpr bool ROWPF = false;
+  static constexpr bool EARLY = false;
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
@@ -344,7 +346,7 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
   for (uint32_t i = tid; i < w.hcap; i += 256) w.vis[i] = VIS_EMPTY;
   __syncthreads();
   uint32_t len = 1, vis_count = 1, scan_lo = 1;
-  Delta dl; dl.hi = dl.lo = 0xffffffffu; dl.n = 0; dl.mx = 0ull; dl.mx_lane = -1;
+  Delta dl; dl.clear();
   float lower_bound = epd; uint32_t free_slots = ef - 1;
   unsigned long long runner_key = ~0ull; uint32_t runner_nb = NBR_NONE; int runner_idx = -1, runner_dlane = -1;
   uint32_t nb = NBR_NONE; bool fresh = false;       // the expansion in flight (wave 0, lane pair p <-> neighbour p)
@@ -353,15 +355,12 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
   auto absorb = [&]() {   // the admitted keys of the previous expansion: into the delta, then keep the ef smallest
     if (!pm) return;
     if (dl.n + pm > 64u) delta_flush(res, len, dl, scan_lo, lane);
-    unsigned long long am = pA; uint32_t t = dl.n;
+    unsigned long long am = pA;
     while (am) {
       const int jj = __builtin_ctzll(am); am &= am - 1;
-      const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)pkhi, jj), vl = (uint32_t)__builtin_amdgcn_readlane((int)pklo, jj);
-      if ((uint32_t)lane == t) { dl.hi = vh; dl.lo = vl; }
-      t++;
+      dl.insert((uint32_t)__builtin_amdgcn_readlane((int)pkhi, jj), (uint32_t)__builtin_amdgcn_readlane((int)pklo, jj), lane);
     }
-    dl.n += pm; pm = 0;
-    dl.refresh_max(lane);
+    pm = 0;
     const uint32_t total = len + dl.n;
     if (total > ef) evict_largest(res, len, dl, total - ef, lane);
   };
@@ -371,7 +370,7 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
     if (!locate) return;
     locate = false;
     unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
-    worst = dl.mx > worst ? dl.mx : worst;
+    { const unsigned long long dmx = dl.max_key(); worst = dmx > worst ? dmx : worst; }
     if (pnext > worst) { dead = true; return; }   // the candidate in flight was truncated away: the canonical loop ends here
     w.n_exp++;
     lower_bound = __uint_as_float((uint32_t)(worst >> 32));
@@ -386,8 +385,8 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
     }
     scan_lo = ci >= 0 ? (uint32_t)ci : len;
     const unsigned long long kci = ci >= 0 ? res[ci] : ~0ull;
-    unsigned long long kd;
-    const int dlane = wave_argmin_key((uint32_t)lane < dl.n && !(dl.lo & 1u), dl.hi, dl.lo, kd);
+    unsigned long long kd = ~0ull; int dlane = -1;
+    { const unsigned long long u = dl.unexpanded(lane); if (u) { dlane = __builtin_ctzll(u); kd = dl.key_at(dlane); } }
     if (kd < kci) { runner_key = kd; runner_dlane = dlane; runner_idx = -1; }
     else { runner_key = kci; runner_idx = ci; runner_dlane = -1; }
     runner_nb = NBR_NONE;

@@ -35,10 +35,21 @@ namespace dev {
 // LS: the table's row length as a compile-time constant (log2; 0 = read lut_shift at run time).  With LS known and the table at the START of the
 // workgroup's LDS, lookup j is `ds_read_u16 v, (code byte << 1) offset: j << (LS + 1)`: no per-lookup address arithmetic beyond the byte extraction
 // (the run-time form keeps 128 row bases, which the compiler parks in VGPR lanes and fetches back one v_readlane + hazard nop at a time).
-template <int LS = 0> struct AdcEval {
+// NP: 16-byte pieces per code row as a compile-time constant (0 = read row_bytes at run time): the row's registers and the lookups are then straight-line
+// code — the run-time form tests `piece < row_bytes / 16` in front of every piece and carries all 8 x 4 row registers through every loop of the walk
+// (32 v_mov_b64 per expansion at the loop's back edge, round 5's ISA).
+// NBR: the walk's code rows come from the NEIGHBOURHOOD BLOCKS (round 6) — nbrc[slot][p][row_bytes] = the code row of slot's p-th level-0 neighbour, the
+// same bytes as codes[adj0[slot][p]] laid beside the adjacency row's order — addressed by (candidate, position) instead of by the neighbour's slot:
+// they are requested TOGETHER with the candidate's adjacency row at the end of the previous expansion (search_level2: ROWPF), one contiguous
+// mMax0 x row_bytes block (2 KiB for 32 x 64) instead of 32 gathers of 64 bytes (each a whole 128-byte line of HBM traffic) behind the adjacency row's
+// own round trip; the table sums of ALL listed neighbours then run under the visited probe's round trip (EARLY) instead of behind it.  One dependent
+// round trip per expansion (the probe) instead of three.  Derived data like adj0_n (hnsw.hip: sync_pq_nbr); the upper levels gather from `codes`.
+template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   const uint8_t* codes; uint32_t row_bytes;   // [n][row_bytes], row_bytes = mp16 (a multiple of 16, <= 128); bytes j >= m are 0
   const unsigned short* lut;                   // LDS: [row_bytes][1 << lut_shift] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
   uint32_t lut_shift;                          // log2 of the table's row length = the number of centroids rounded up to a power of two (4 .. 8)
+  const uint8_t* nbrc; uint32_t nbr_stride;    // NBR: [n][mMax0][row_bytes], nbr_stride = mMax0 * row_bytes
+  static constexpr int NR = NP ? NP : 8;       // row registers (16-byte pieces)
   // s + float32(h), h = a binary16 in the low half of a register.  v_fma_mix_f32 computes fma(float32(h), 1.0f, s) with ONE rounding; float32(h) * 1.0f
   // is exact, so the result is the IEEE sum of the converted entry — the bits of v_cvt_f32_f16 + v_add_f32 (the definition) in one issue slot.
   static __device__ __forceinline__ float acc(float s, uint32_t h) {
@@ -66,7 +77,7 @@ template <int LS = 0> struct AdcEval {
       return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)j << (sh + 1)) + byte2<B>(v));
     }
   }
-  u32x4e raw[8];                               // the code row requested by prefetch() for this lane pair's neighbour
+  u32x4e raw[NR];                              // the code row requested by prefetch() / prefetch_at() for this lane pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
   // hnsw_walk2.hpp SPEC: visited bytes + code rows of the predicted next candidate's (the runner-up's) neighbours requested one expansion ahead.
   // Exact (tests + 246 randomised rounds with it on), but measured SLOWER — an A/B knob (-DCOLTT_PQ_SPEC=1), off in the shipped library
@@ -74,44 +85,119 @@ template <int LS = 0> struct AdcEval {
 #ifndef COLTT_PQ_SPEC
 #define COLTT_PQ_SPEC 0
 #endif
-  static constexpr bool SPEC = COLTT_PQ_SPEC != 0;
+  static constexpr bool SPEC = COLTT_PQ_SPEC != 0 && !NBR;
   // hnsw_walk2.hpp RADJ: the runner-up's adjacency row requested at pop time (it is the next candidate unless this expansion admits a nearer
   // vertex).  On its own, without the speculation above: 1 % slower (profiles/r05s_pq_ab.md) — the exact prefetch at the end of the expansion already
   // flies under the admission and the next pop.
   static constexpr bool RADJ = SPEC;
+  static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
+  static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
-  __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[8]) const {
-    const u32x4e* p = reinterpret_cast<const u32x4e*>(codes + (size_t)slot * row_bytes);
-    const int np = (int)(row_bytes >> 4);
+  __device__ __forceinline__ void load_from(const uint8_t* row, u32x4e (&r)[NR]) const {
+    const u32x4e* p = reinterpret_cast<const u32x4e*>(row);
+    const int np = NP ? NP : (int)(row_bytes >> 4);
 #pragma unroll
-    for (int i = 0; i < 8; i++) if (i < np) r[i] = p[i];
+    for (int i = 0; i < NR; i++) if (i < np) r[i] = p[i];
   }
-  __device__ __forceinline__ float sum(const u32x4e (&r)[8]) const {
-    const int np = (int)(row_bytes >> 4);
-    const uint32_t sh = LS ? (uint32_t)LS : lut_shift;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      if (i < np) {
-#pragma unroll
-        for (int wd = 0; wd < 4; wd++) {
-          const uint32_t v = r[i][wd];
-          const uint32_t j = (uint32_t)(i * 16 + wd * 4);
-          s = acc(s, entry<0>(j, sh, v)); s = acc(s, entry<1>(j + 1, sh, v)); s = acc(s, entry<2>(j + 2, sh, v)); s = acc(s, entry<3>(j + 3, sh, v));
-        }
-      }
-    }
+  __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[NR]) const { load_from(codes + (size_t)slot * row_bytes, r); }
+  // Eight lookups at a time, as ONE instruction block (LS known): the eight byte extractions, then the eight LDS reads, then the eight adds — each add
+  // behind `s_waitcnt lgkmcnt(7 - t)`, i.e. as soon as ITS read is back (LDS returns in order).  The adds are one dependent chain (the definition sums in
+  // j order), so what can overlap is the reads' latency: left to the scheduler, hipcc 7.2 emits read / wait lgkmcnt(0) / add per lookup (64 x ~64 cycles of
+  // exposed LDS latency per expansion; three reads in flight at best in round 5's form).  The block only ever lowers the outstanding-LDS count it raised
+  // itself, so the compiler's own wait counts around it stay conservative-correct.
+  template <int J> static __device__ __forceinline__ float sum8(float s, uint32_t v0, uint32_t v1) {
+    static_assert(LS != 0, "sum8 needs the table's row length at compile time");
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
+    const uint32_t one = 1u; const float onef = 1.0f;
+    constexpr int R = 1 << (LS + 1);   // bytes per table row
+    asm volatile(
+        "v_lshlrev_b32_sdwa %1, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %2, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %3, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %4, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_lshlrev_b32_sdwa %5, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %6, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %7, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %8, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "ds_read_u16 %1, %1 offset:%13\n\t"
+        "ds_read_u16 %2, %2 offset:%14\n\t"
+        "ds_read_u16 %3, %3 offset:%15\n\t"
+        "ds_read_u16 %4, %4 offset:%16\n\t"
+        "ds_read_u16 %5, %5 offset:%17\n\t"
+        "ds_read_u16 %6, %6 offset:%18\n\t"
+        "ds_read_u16 %7, %7 offset:%19\n\t"
+        "ds_read_u16 %8, %8 offset:%20\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t" "v_fma_mix_f32 %0, %1, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t" "v_fma_mix_f32 %0, %2, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(5)\n\t" "v_fma_mix_f32 %0, %3, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t" "v_fma_mix_f32 %0, %4, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t" "v_fma_mix_f32 %0, %5, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t" "v_fma_mix_f32 %0, %6, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t" "v_fma_mix_f32 %0, %7, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t" "v_fma_mix_f32 %0, %8, %12, %0 op_sel_hi:[1,0,0]"
+        : "+v"(s), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(v0), "v"(v1), "v"(one), "v"(onef),
+          "n"((J + 0) * R), "n"((J + 1) * R), "n"((J + 2) * R), "n"((J + 3) * R), "n"((J + 4) * R), "n"((J + 5) * R), "n"((J + 6) * R), "n"((J + 7) * R)
+        : "memory");
     return s;
   }
-  __device__ __forceinline__ float adc(uint32_t slot) const { u32x4e r[8]; load(slot, r); return sum(r); }
+  template <int I> __device__ __forceinline__ float sum_piece(float s, const u32x4e& r) const {   // the 16 lookups of piece I
+    s = sum8<I * 16>(s, r[0], r[1]);
+    return sum8<I * 16 + 8>(s, r[2], r[3]);
+  }
+  __device__ __forceinline__ float sum(const u32x4e (&r)[NR]) const {
+    const int np = NP ? NP : (int)(row_bytes >> 4);
+    float s = 0.f;
+    if constexpr (LS != 0) {
+      if (0 < np) s = sum_piece<0>(s, r[0]);
+      if constexpr (NR > 1) { if (1 < np) s = sum_piece<1>(s, r[1]); }
+      if constexpr (NR > 2) { if (2 < np) s = sum_piece<2>(s, r[2]); }
+      if constexpr (NR > 3) { if (3 < np) s = sum_piece<3>(s, r[3]); }
+      if constexpr (NR > 4) { if (4 < np) s = sum_piece<4>(s, r[4]); }
+      if constexpr (NR > 5) { if (5 < np) s = sum_piece<5>(s, r[5]); }
+      if constexpr (NR > 6) { if (6 < np) s = sum_piece<6>(s, r[6]); }
+      if constexpr (NR > 7) { if (7 < np) s = sum_piece<7>(s, r[7]); }
+      return s;
+    } else {
+      const uint32_t sh = lut_shift;
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        if (i < np) {
+#pragma unroll
+          for (int wd = 0; wd < 4; wd++) {
+            const uint32_t v = r[i][wd];
+            const uint32_t j = (uint32_t)(i * 16 + wd * 4);
+            s = acc(s, entry<0>(j, sh, v)); s = acc(s, entry<1>(j + 1, sh, v)); s = acc(s, entry<2>(j + 2, sh, v)); s = acc(s, entry<3>(j + 3, sh, v));
+          }
+        }
+      }
+      return s;
+    }
+  }
+  __device__ __forceinline__ float adc(uint32_t slot) const { u32x4e r[NR]; load(slot, r); return sum(r); }
   // The code row of every LISTED neighbour is requested before the walk knows which of them are fresh: 32-128 bytes each, in flight
   // under the visited test's own dependent HBM probe instead of behind it (one round trip less per expansion; rows of already visited
   // neighbours are fetched for nothing — a few KB per expansion against a dependent ~2 us).
   __device__ __forceinline__ void prefetch(uint32_t nb, bool valid, int half) { if (valid && half == 0) load(nb, raw); }
-  __device__ __forceinline__ float operator()(const GraphView&, const WaveCtx&, uint32_t, bool fresh, float, int half, int) const {
+  // NBR: the code row of candidate `cand`'s neighbour at position idx of its level-0 row (in_row: idx < mMax0)
+  __device__ __forceinline__ void prefetch_at(uint32_t cand, uint32_t idx, bool in_row, int half) {
+    if (in_row && half == 0) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, raw);
+  }
+  float pre_d;   // EARLY: the table sum of this lane pair's neighbour, computed under the visited probe
+  __device__ __forceinline__ void early(bool valid, int half) { pre_d = 0.f; if (valid && half == 0) pre_d = sum(raw); }
+  // ties a value loaded before early() to early()'s result: the compiler may not use (hence wait for) it before the sums are computed
+  __device__ __forceinline__ void after_early(uint32_t& x) { asm volatile("" : "+v"(x), "+v"(pre_d)); }
+  // the table sum over the code row prefetch() requested (greedy descent: every valid neighbour is evaluated at once)
+  __device__ __forceinline__ float eval_now(bool fresh, int half) const {
     float r = 0.f;
     if (fresh && half == 0) r = sum(raw);
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));   // even lane's value to its pair: quad_perm [0,0,2,2]
+  }
+  __device__ __forceinline__ float operator()(const GraphView&, const WaveCtx&, uint32_t, bool fresh, float, int half, int) const {
+    if constexpr (EARLY) {
+      const float r = fresh ? pre_d : 0.f;   // (pre_d lives in the even lanes)
+      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));
+    } else return eval_now(fresh, half);
   }
 };
 
@@ -131,7 +217,7 @@ __device__ __forceinline__ void greedy_level_adc(const GraphView& g, WaveCtx& w,
       const uint32_t nb = idx < width ? row[idx] : NBR_NONE;
       const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       ev.prefetch(nb, valid, half);
-      const float d = ev(g, w, nb, valid, 0.f, half, lane);
+      const float d = ev.eval_now(valid, half);
       w.n_dist += __popcll(__ballot(valid && half == 0));
       const unsigned long long key = valid ? (((unsigned long long)__float_as_uint(d) << 32) | idx) : ~0ull;
       const unsigned long long km = wave_min_u64(key);

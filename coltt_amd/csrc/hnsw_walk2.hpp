@@ -4,11 +4,14 @@
 // neighbour order, ties by (distance, slot), the ef smallest kept) and the same exact-order distances — ids, score bits and the
 // traversal counters stay equal to the oracle's — but the three things that made the large-ef walk slow are restructured:
 //
-//  W2_DELTA  result set = a SORTED main array in LDS + an UNSORTED delta of <= 64 entries held in registers (one per lane).
-//            An admission is a register move; the eviction of the largest member compares the main array's tail (one LDS read per
-//            neighbour chunk) with the delta maximum (DPP reductions); the delta is merged into the main array only when it is full —
-//            one pass over the array per 64 admissions instead of a binary search + partial shift per admission.  The set is the
-//            same set at every step, so pop order, lowerBound and the final order are unchanged.
+//  W2_DELTA  result set = a SORTED main array in LDS + a SORTED delta of <= 64 entries held in registers (one per lane, ascending).
+//            An admission is a one-lane shift of the delta's tail (DPP wave_shr:1) behind one 64-bit compare; the largest member is
+//            the larger of the main array's tail and the delta's last lane (two v_readlane), the smallest unexpanded member of the
+//            delta is the first set bit of one ballot — no cross-lane reductions anywhere on the expansion chain (round 6; rounds 4-5
+//            kept the delta UNSORTED and paid a 6-step DPP arg-max per admission batch and per eviction, a DPP arg-min or two per pop
+//            and a rank loop per flush).  The delta is merged into the main array only when it is full — one pass over the array per
+//            64 admissions instead of a binary search + partial shift per admission.  The set is the same set at every step, so pop
+//            order, lowerBound and the final order are unchanged.
 //  W2_BLOOM  a blocked Bloom filter in LDS (2 bits in one 32-bit word, one ds_or_rtn per test) in front of the HBM byte-per-slot
 //            visited map: a negative answer is definite ("never tested in this traversal"), so only positives pay the dependent
 //            HBM probe; every fresh vertex is still recorded in the byte map, which stays the exact set.
@@ -85,13 +88,39 @@ __device__ __forceinline__ float eval_pair_n(const GraphView& g, const WaveCtx& 
   else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
-// The delta: one (hi, lo) key per lane, lanes [0, n) valid, bit 0 of lo = expanded; `mx` = the largest key with bit 0 cleared
-// (0 when n == 0) and `mx_lane` its lane.  All members wave-uniform except hi / lo.
+// The delta: one (hi, lo) key per lane, lanes [0, n) valid and ASCENDING by key (bit 0 of lo = expanded; slots are distinct, so bit 0 never
+// decides an order); lanes >= n hold stale values.  n is wave-uniform.  Every member function is called by all 64 lanes.
 struct Delta {
   uint32_t hi, lo;
   uint32_t n;
-  unsigned long long mx; int mx_lane;
-  __device__ __forceinline__ void refresh_max(int lane) { mx_lane = wave_argmax_key((uint32_t)lane < n, hi, lo & ~1u, mx); }
+  __device__ __forceinline__ void clear() { hi = lo = 0xffffffffu; n = 0; }
+  // the largest key, bit 0 cleared (0 when empty)
+  __device__ __forceinline__ unsigned long long max_key() const {
+    const int L = (int)n - 1;   // n == 0: lane 63's stale value, discarded
+    const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)hi, L), ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, L);
+    return n ? ((((unsigned long long)mh) << 32) | (ml & ~1u)) : 0ull;
+  }
+  // ballot of the unexpanded members (ascending: the first set bit is the smallest)
+  __device__ __forceinline__ unsigned long long unexpanded(int lane) const {
+    const unsigned long long live = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    (void)lane;
+    return __ballot(!(lo & 1u)) & live;
+  }
+  __device__ __forceinline__ unsigned long long key_at(int L) const {
+    const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)hi, L), ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, L);
+    return (((unsigned long long)mh) << 32) | ml;
+  }
+  // insert the wave-uniform key (vh, vl) (n < 64): members behind its position move up one lane
+  __device__ __forceinline__ void insert(uint32_t vh, uint32_t vl, int lane) {
+    const unsigned long long live = (1ull << n) - 1ull;
+    const unsigned long long mine = (((unsigned long long)hi) << 32) | lo, key = (((unsigned long long)vh) << 32) | vl;
+    const uint32_t pos = (uint32_t)__popcll(__ballot(mine < key) & live);   // a prefix of the live lanes
+    const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, 0x138, 0xf, 0xf, false);   // wave_shr:1 — lane i takes lane i - 1
+    const uint32_t sl = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, 0x138, 0xf, 0xf, false);
+    if ((uint32_t)lane > pos) { hi = sh; lo = sl; }
+    if ((uint32_t)lane == pos) { hi = vh; lo = vl; }
+    n++;
+  }
 };
 
 // Merge the delta into the sorted main array res[0, len), in place (len + delta.n <= ef_pad).  scan_lo: see search_level2.
@@ -105,12 +134,8 @@ __device__ __forceinline__ void delta_flush(unsigned long long* res, uint32_t& l
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (res[mid] < key) lo = mid + 1; else hi = mid; }
     pos = lo;
   }
-  uint32_t r = 0;  // rank among the delta keys
-  for (uint32_t j = 0; j < dl.n; j++) {
-    const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)dl.hi, (int)j), kl = (uint32_t)__builtin_amdgcn_readlane((int)dl.lo, (int)j);
-    r += (kh < dl.hi || (kh == dl.hi && kl < dl.lo)) ? 1u : 0u;
-  }
-  const uint32_t minpos = wave_min_u32(pos);
+  const uint32_t r = (uint32_t)lane;  // rank among the delta keys: the delta is sorted
+  const uint32_t minpos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);   // lane 0 holds the smallest key, hence the smallest insertion point
   scan_lo = minpos < scan_lo ? minpos : scan_lo;  // flushed keys may be unexpanded
   wave_sync();
   if (len) {
@@ -133,7 +158,7 @@ __device__ __forceinline__ void delta_flush(unsigned long long* res, uint32_t& l
   wave_sync();
   if (valid) res[pos + r] = key;
   len += dl.n;
-  dl.n = 0; dl.hi = dl.lo = 0xffffffffu; dl.mx = 0ull; dl.mx_lane = -1;
+  dl.clear();
   wave_sync();
 }
 
@@ -144,14 +169,8 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
   const unsigned long long treg = tb + (uint32_t)lane < len ? res[tb + lane] : 0ull;
   for (uint32_t t = 0; t < e; t++) {
     const unsigned long long mt = len ? (readlane_u64(treg, (int)(len - 1u - tb)) & ~1ull) : 0ull;
-    if (dl.n && (!len || dl.mx > mt)) {  // the largest member sits in the delta: the last delta entry takes its lane
-      const int last = (int)dl.n - 1;
-      const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)dl.hi, last), vl = (uint32_t)__builtin_amdgcn_readlane((int)dl.lo, last);
-      if (lane == dl.mx_lane) { dl.hi = vh; dl.lo = vl; }
-      if (lane == last) { dl.hi = 0xffffffffu; dl.lo = 0xffffffffu; }
-      dl.n--;
-      dl.refresh_max(lane);
-    } else len--;
+    if (dl.n && (!len || dl.max_key() > mt)) dl.n--;   // the largest member is the delta's last lane
+    else len--;
   }
 }
 
@@ -161,6 +180,8 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
   static constexpr bool CHUNK_ADJ = false;   // the evaluator does not bring the neighbours' adjacency rows along
   static constexpr bool SPEC = false;        // no speculation on the next expansion's inputs (see AdcEval, hnsw_pq.hpp)
   static constexpr bool RADJ = false;        // the runner-up's adjacency row is not requested at pop time
+  static constexpr bool ROWPF = false;       // no per-neighbour input addressed by (candidate, position) (see AdcEval<.., NBR>, hnsw_pq.hpp)
+  static constexpr bool EARLY = false;       // distances are computed for the fresh neighbours only, after the visited test
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
@@ -194,6 +215,8 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr bool CHUNK_ADJ = false;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = false;
+  static constexpr bool ROWPF = false;
+  static constexpr bool EARLY = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
@@ -314,7 +337,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   }
   uint32_t len = 1;
   uint32_t scan_lo = 0;   // every main-array member before this index is expanded (pop scans start at its 64-entry chunk)
-  Delta dl; dl.hi = dl.lo = 0xffffffffu; dl.n = 0; dl.mx = 0ull; dl.mx_lane = -1;
+  Delta dl; dl.clear();
   uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE; float pre_nn = 0.f;
   // SPEC evaluators (small per-neighbour inputs: hnsw_pq.hpp): when the next candidate is predicted to be the runner-up — whose adjacency row was
   // requested at pop time and has arrived by the end of the expansion — the visited bytes and the evaluator's inputs of ITS neighbours are requested
@@ -328,26 +351,27 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     if (iters > (1u << 22)) { w.err |= 2u; break; }
     lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    // ---- pop: the smallest unexpanded member of main ∪ delta (cj = the unexpanded main member after the first one)
+    // ---- pop: the smallest unexpanded member of main ∪ delta (cj = the unexpanded main member after the first one).  The keys come out of
+    // the registers the scan loaded its chunk into (v_readlane), not out of a second, dependent LDS read.
     int ci = -1, cj = -1;
+    unsigned long long kci = ~0ull, kcj = ~0ull;
     for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
       const uint32_t i = base + lane;
-      const bool un = i < len && !(res[i] & 1ull);
-      unsigned long long m = __ballot(un);
+      const unsigned long long e = i < len ? res[i] : 1ull;
+      unsigned long long m = __ballot(!(e & 1ull));
       if (m) {
-        ci = (int)base + __builtin_ctzll(m);
+        const int l0 = __builtin_ctzll(m);
+        ci = (int)base + l0; kci = readlane_u64(e, l0);
         m &= m - 1;
-        if (m) cj = (int)base + __builtin_ctzll(m);
+        if (m) { const int l1 = __builtin_ctzll(m); cj = (int)base + l1; kcj = readlane_u64(e, l1); }
         break;
       }
     }
-    const unsigned long long kci = ci >= 0 ? res[ci] : ~0ull;
     unsigned long long kd = ~0ull; int dlane = -1;
-    bool d_un = false;
+    unsigned long long d_un = 0ull;   // the delta's unexpanded members (ballot; ascending lanes = ascending keys)
     if constexpr (DELTA) {
-      d_un = (uint32_t)lane < dl.n && !(dl.lo & 1u);
-      dlane = wave_argmin_key(d_un, dl.hi, dl.lo, kd);
+      d_un = dl.unexpanded(lane);
+      if (d_un) { dlane = __builtin_ctzll(d_un); kd = dl.key_at(dlane); }
     }
     if (ci < 0 && dlane < 0) break;
     if constexpr (VISMODE == VIS_LDS) {
@@ -358,10 +382,10 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     unsigned long long runner_key = ~0ull;
     if constexpr (PREF) {
       if (from_delta) {
-        unsigned long long kd2; (void)wave_argmin_key(d_un && lane != dlane, dl.hi, dl.lo, kd2);
+        const unsigned long long u2 = d_un & (d_un - 1ull);   // the delta's second unexpanded member
+        const unsigned long long kd2 = u2 ? dl.key_at(__builtin_ctzll(u2)) : ~0ull;
         runner_key = kci < kd2 ? kci : kd2;
       } else {
-        const unsigned long long kcj = cj >= 0 ? res[cj] : ~0ull;
         runner_key = kcj < kd ? kcj : kd;
       }
     }
@@ -376,7 +400,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     COLTT_PT(w, 0)  // pop
     // lowerBound: the distance of the largest member, sampled once per pop (hnsw.go:357)
     unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
-    if constexpr (DELTA) worst = dl.mx > worst ? dl.mx : worst;
+    if constexpr (DELTA) { const unsigned long long dmx = dl.max_key(); worst = dmx > worst ? dmx : worst; }
     const float lower_bound = __uint_as_float((uint32_t)(worst >> 32));
     wave_sync();
     if (from_delta) { if (lane == dlane) dl.lo |= 1u; }
@@ -401,6 +425,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         else if (eval_t::CHUNK_ADJ && width <= 32 && best_src >= 0) pre_nb = (uint32_t)p < width ? ev.chunk_adj(best_src >> 1, p) : NBR_NONE; \
         else pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;        \
         if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \
+        if constexpr (eval_t::ROWPF) ev.prefetch_at(pre_slot, (uint32_t)p, (uint32_t)p < width, half); /* the next candidate's neighbours' inputs fly with its adjacency row */ \
         if constexpr (eval_t::SPEC) {                                                                \
           spec_slot = NBR_NONE;                                                                      \
           if (width <= 32 && runner_key < best_new) {   /* pre_nb is in registers (requested at pop time) */ \
@@ -421,29 +446,49 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       const bool valid = nb != NBR_NONE && !is_deleted(g, nb);
       bool spec_hit = false;
       if constexpr (eval_t::SPEC) spec_hit = pre_hit && spec_now == cslot;   // this expansion's inputs were requested during the previous one
-      if (!spec_hit) ev.prefetch(nb, valid, half);   // evaluators whose per-neighbour input is small (hnsw_pq.hpp: a 32-128 byte code row) request it NOW, under the visited test
+      if constexpr (eval_t::ROWPF) { if (!pre_hit) ev.prefetch_at(cslot, idx, idx < width, half); }   // (requested with the adjacency row when that was prefetched)
+      else { if (!spec_hit) ev.prefetch(nb, valid, half); }   // evaluators whose per-neighbour input is small (hnsw_pq.hpp: a 32-128 byte code row) request it NOW, under the visited test
 #ifdef COLTT_PHASE_TIMING
       if (__ballot(valid) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the adjacency values to have arrived
 #endif
       COLTT_PT(w, 1)  // adjacency row
       int fresh_i = 0;
-      if (valid && half == 0) {
-        // Test-and-set.  No two lanes hold the same slot (a row lists a neighbour once), so load + store on the byte map is
-        // race-free; agent-scope atomics are served by L2, never by a stale L1 line.
-        bool maybe = true;
-        if constexpr (BLOOM) {
-          const uint32_t h = nb * 0x9E3779B1u;
-          const uint32_t bits = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
-          const uint32_t old = atomicOr(&w.bloom[h >> w.bloom_shift], bits);
-          maybe = (old & bits) == bits;
-        }
-        if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
-        else {
-          if (maybe) {
-            const uint8_t v = spec_hit ? (uint8_t)spec_vis_now : __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
-          } else fresh_i = 1;
-          if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (eval_t::EARLY && VISMODE == VIS_HBM && !BLOOM) {
+        // The probe of the byte map is ISSUED, the evaluator computes the distances of all listed neighbours out of inputs that are already on chip
+        // (AdcEval<.., NBR>: the code rows came with the adjacency row), and only then is the probe's answer looked at: its round trip runs under
+        // ~200 issue slots of table lookups instead of in front of them.  Test-and-set as below.
+        static_assert(!eval_t::SPEC, "EARLY evaluators take no speculative visited bytes");
+        const bool probe = valid && half == 0;
+        // The aligned 32-bit word around the byte is loaded (no zero-extension for the compiler to place — with its s_waitcnt vmcnt — right behind the
+        // load) and the byte is taken out of it after early().  The region is this wave's own and its size a multiple of 16; agent scope: served by L2.
+        // EVERY lane loads (the others word 0 of the region: one more address in the same request): a load under a divergent branch would leave the
+        // compiler two paths with different numbers of loads in flight, and it then waits for all of them (vmcnt(0)) in front of the sums.
+        uint32_t vw = __hip_atomic_load(reinterpret_cast<const uint32_t*>(w.visg + (probe ? (nb & ~3u) : 0u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ev.early(valid, half);
+        ev.after_early(vw);   // the probe's value is not looked at (no s_waitcnt vmcnt for it) before the table sums are there
+        const uint32_t v = (vw >> ((nb & 3u) * 8u)) & 0xffu;
+        fresh_i = probe && v != (w.epoch & 0xffu) ? 1 : 0;
+        if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if constexpr (eval_t::EARLY) ev.early(valid, half);
+        if (valid && half == 0) {
+          // Test-and-set.  No two lanes hold the same slot (a row lists a neighbour once), so load + store on the byte map is
+          // race-free; agent-scope atomics are served by L2, never by a stale L1 line.
+          bool maybe = true;
+          if constexpr (BLOOM) {
+            const uint32_t h = nb * 0x9E3779B1u;
+            const uint32_t bits = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+            const uint32_t old = atomicOr(&w.bloom[h >> w.bloom_shift], bits);
+            maybe = (old & bits) == bits;
+          }
+          if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
+          else {
+            if (maybe) {
+              const uint8_t v = spec_hit ? (uint8_t)spec_vis_now : __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
+            } else fresh_i = 1;
+            if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       fresh_i = __builtin_amdgcn_mov_dpp(fresh_i, 0xA0, 0xf, 0xf, true);  // even lane's verdict to its pair: quad_perm [0,0,2,2]
@@ -455,7 +500,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT2() } continue; }
       w.n_dist += nfresh; vis_count += nfresh;
       const float d = ev(g, w, nb, fresh, nrm, half, lane);
-      const uint32_t rank = __popcll(E & lt_mask);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u));   // fresh neighbours in front of this lane
       const bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
 #ifdef COLTT_PHASE_TIMING
       if (__ballot(adm) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the distances
@@ -468,22 +513,30 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       const unsigned long long mykey = adm ? (((unsigned long long)khi << 32) | klo) : ~0ull;
       if constexpr (DELTA) {
         if (m) {
-          if constexpr (PREF) { unsigned long long mn; const int bl = wave_argmin_key(adm, khi, klo, mn); if (mn < best_new) { best_new = mn; best_src = bl; } }
+          if constexpr (PREF) {   // the smallest admitted key: a scalar minimum over a handful of lanes, a DPP arg-min when the set is still filling up
+            unsigned long long mn; int bl;
+            if (m <= 4u) {
+              mn = ~0ull; bl = -1;
+              unsigned long long am = A;
+              while (am) {
+                const int j = __builtin_ctzll(am); am &= am - 1;
+                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+                if (kj < mn) { mn = kj; bl = j; }
+              }
+            } else bl = wave_argmin_key(adm, khi, klo, mn);
+            if (mn < best_new) { best_new = mn; best_src = bl; }
+          }
         }
         if (last_chunk) { COLTT_PREFETCH_NEXT2() }
         if (m == 0) continue;
         if (dl.n + m > 64u) delta_flush(res, len, dl, scan_lo, lane);
         {
-          unsigned long long am = A; uint32_t t = dl.n;
+          unsigned long long am = A;
           while (am) {
             const int j = __builtin_ctzll(am); am &= am - 1;
-            const uint32_t vh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j), vl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
-            if ((uint32_t)lane == t) { dl.hi = vh; dl.lo = vl; }
-            t++;
+            dl.insert((uint32_t)__builtin_amdgcn_readlane((int)khi, j), (uint32_t)__builtin_amdgcn_readlane((int)klo, j), lane);
           }
-          dl.n += m;
         }
-        dl.refresh_max(lane);
         const uint32_t total = len + dl.n;
         if (total > ef) evict_largest(res, len, dl, total - ef, lane);
         COLTT_PT(w, 4)  // admission + eviction (+ the occasional flush)

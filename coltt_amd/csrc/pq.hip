@@ -101,15 +101,46 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ c
 
 // the product-quantised HNSW's table (hnsw_pq.hpp): the same entries, rounded to binary16, rows as long as the centroid count rounded up to a power
 // of two (1 << shift, 16 .. 256) — what the walk kernel copies into its LDS as it is: 4 KiB per query for 64 x 32 instead of 64 KiB of f32
+// Table scale (round 6, ADVICE r5: un-normalised Euclidean data — SIFT-like values 0..255 — puts most entries above binary16's 65504, i.e. at +Inf, and the
+// walk collapses).  Part of the DEFINITION (oracle/coltt_oracle.cpp: pq_table_scale): k = the smallest integer >= 0 with M * 2^-k <= 32768, M = the
+// largest entry of the query's f32 table; every entry is multiplied by 2^-k (exact) before the binary16 rounding.  k = 0 for every table whose entries stay
+// under 32768 — every table of rounds 4-5.  A power-of-two scale keeps the ranking; the answers carry exact distances.
+// qmax[q] = the bits of max(entry, 0) over the query's table (non-negative floats order as their bits; zeroed by the caller)
+template <int KIND>
+__global__ __launch_bounds__(256) void pq_lut16_max_kernel(const float* __restrict__ cb, int m, int C, int dsub, const float* __restrict__ queries,
+                                                           int mp, int shift, uint32_t* __restrict__ qmax) {
+  const int per = 256 >> shift;
+  const int j = blockIdx.x * per + ((int)threadIdx.x >> shift), c = (int)threadIdx.x & ((1 << shift) - 1), q = blockIdx.y;
+  float v = 0.f;
+  if (j < m && c < C) v = pq_dist<KIND>(queries + ((size_t)q * m + j) * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
+  uint32_t b = v > 0.f ? __float_as_uint(v) : 0u;   // (NaN compares false: 0)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)b, o, 64); b = t > b ? t : b; }
+  if ((threadIdx.x & 63) == 0 && b) atomicMax(&qmax[q], b);
+}
+__device__ __forceinline__ float pq_table_scale(uint32_t max_bits) {
+  const float M = __uint_as_float(max_bits);
+  float s = 1.0f;
+  if (M == M && M < __uint_as_float(0x7f800000u)) { while (M * s > 32768.0f) s *= 0.5f; }   // at most 113 halvings; products by a power of two are exact
+  return s;
+}
 template <int KIND>
 __global__ __launch_bounds__(256) void pq_lut16_kernel(const float* __restrict__ cb, int m, int C, int dsub, const float* __restrict__ queries,
-                                                       int mp, int shift, unsigned short* __restrict__ lut) {
+                                                       int mp, int shift, const uint32_t* __restrict__ qmax, unsigned short* __restrict__ lut) {
   const int per = 256 >> shift;                                  // table rows per workgroup
   const int j = blockIdx.x * per + ((int)threadIdx.x >> shift), c = (int)threadIdx.x & ((1 << shift) - 1), q = blockIdx.y;
   if (j >= mp) return;
   float v = 0.f;
   if (j < m && c < C) v = pq_dist<KIND>(queries + ((size_t)q * m + j) * dsub, cb + ((size_t)j * C + c) * dsub, dsub);
+  v = v * pq_table_scale(qmax[q]);
   lut[(((size_t)q * mp + j) << shift) + c] = (unsigned short)f32bits_to_f16bits(__float_as_uint(v));
+}
+// max over the centroids of ||centroid||^2 (bits), for coltt_hnsw_pq_attach's range check of cosineDistance tables
+__global__ void pq_centroid_norm_max_kernel(const float* __restrict__ cb, uint32_t n_centroids, int dsub, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  if (i < n_centroids) for (int e = 0; e < dsub; e++) { const float x = cb[(size_t)i * dsub + e]; s = __builtin_fmaf(x, x, s); }
+  if (i < n_centroids) atomicMax(out, s == s ? __float_as_uint(s) : 0x7fc00000u);
 }
 
 // ---- Encode.  One thread per (row, sub-space): the sub-vector sits in registers (DS compile-time) or is re-read (DS == 0), the
@@ -629,14 +660,34 @@ int coltt::pq_encode_rowmajor(hipStream_t s, const float* d_cb, const PqShape& s
 }
 
 // distance tables of nq queries for the product-quantised HNSW: d_lut [nq][mp][1 << shift] binary16
-int coltt::pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, unsigned short* d_lut) {
+// d_qmax: nq words of scratch (the per-query table maxima the scale is derived from)
+int coltt::pq_lut16_batch(hipStream_t s, const float* d_cb, const PqShape& sh, const float* d_queries, size_t nq, uint32_t mp, uint32_t shift, uint32_t* d_qmax, unsigned short* d_lut) {
   if (nq == 0) return COLTT_OK;
   if (shift < 4 || shift > 8 || (1u << shift) < sh.C) return fail(COLTT_E_INVALID, "pq_lut16: %u centroids do not fit rows of %u entries", sh.C, 1u << shift);
   dim3 grid(ceil_div(mp, 256u >> shift), (uint32_t)nq);
-  if (sh.metric == COLTT_PQ_COSINE) pq_lut16_kernel<0><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
-  else if (sh.metric == COLTT_PQ_EUCLIDEAN) pq_lut16_kernel<1><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
-  else pq_lut16_kernel<2><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_lut);
+  COLTT_HIP(hipMemsetAsync(d_qmax, 0, nq * 4, s));
+#define COLTT_L16(K)                                                                                                                        \
+  do {                                                                                                                                      \
+    pq_lut16_max_kernel<K><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_qmax);          \
+    pq_lut16_kernel<K><<<grid, 256, 0, s>>>(d_cb, (int)sh.m, (int)sh.C, (int)sh.dsub, d_queries, (int)mp, (int)shift, d_qmax, d_lut);        \
+  } while (0)
+  if (sh.metric == COLTT_PQ_COSINE) COLTT_L16(0);
+  else if (sh.metric == COLTT_PQ_EUCLIDEAN) COLTT_L16(1);
+  else COLTT_L16(2);
+#undef COLTT_L16
   COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+// the largest ||centroid||^2 of a codebook on the device (synchronises the stream)
+int coltt::pq_centroid_norm_max(hipStream_t s, const float* d_cb, const PqShape& sh, uint32_t* d_scratch, float* out) {
+  COLTT_HIP(hipMemsetAsync(d_scratch, 0, 4, s));
+  const uint32_t nc = sh.m * sh.C;
+  pq_centroid_norm_max_kernel<<<ceil_div(nc, 256u), 256, 0, s>>>(d_cb, nc, (int)sh.dsub, d_scratch);
+  COLTT_HIP(hipGetLastError());
+  uint32_t bits = 0;
+  COLTT_HIP(hipMemcpyAsync(&bits, d_scratch, 4, hipMemcpyDeviceToHost, s));
+  COLTT_HIP(hipStreamSynchronize(s));
+  std::memcpy(out, &bits, 4);
   return COLTT_OK;
 }
 

@@ -19,6 +19,7 @@
 // summation order as pkg/distance/simd/avx/AVX_amd64.s).
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1753,7 +1754,9 @@ int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub,
 //   codes    code_v = Encode(stored row of v as the index's distance sees it: normalised for cosine, lowered and raised for 2-byte rows)
 //   d(q, v)  = pq_adc(lut16(q'), code_v), q' = the query as the index's distance sees it, lut16 = the quantiser's table (its distancepq
 //            function) with every entry rounded to binary16 (round to nearest even — the f16 codec's own rounding) and read back as f32:
-//            d only ranks, the answers carry exact distances, and a 2-byte table doubles the GPU kernel's resident traversals
+//            d only ranks, the answers carry exact distances, and a 2-byte table doubles the GPU kernel's resident traversals.  Before the
+//            rounding every entry is multiplied by 2^-k, k = the smallest integer >= 0 with (largest entry) * 2^-k <= 32768 (exact; k = 0 for
+//            unit-scale data): un-normalised Euclidean data would otherwise round to +Inf and every vertex would be equally far (round 6)
 //   walk     csr_search with d in place of Distance(): entrypoint (hnsw.go:253), greedyClosestNeighbor per upper level (:320-343),
 //            searchLevel(ef) on level 0 (:345-389) — admission rule, canonical neighbour order and (d, slot) ties unchanged
 //   re-rank  r = min(max(rerank, k), |result set|) (rerank = 0: the whole set): the r nearest by d are re-scored with the index's
@@ -1771,6 +1774,13 @@ static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* c
   }
   if (g.entry < 0) return 0;
   pq_lut(pq_metric, cb, m, C, dsub, q, lut.data());
+  {  // table scale: k = the smallest integer >= 0 with M * 2^-k <= 32768, M = the largest entry (k = 0 for unit-scale data); entries * 2^-k are exact
+    float M = 0.f;
+    for (float v : lut) if (v > M) M = v;
+    float sc = 1.0f;
+    if (M == M && M < std::numeric_limits<float>::infinity()) while (M * sc > 32768.0f) sc *= 0.5f;
+    for (float& v : lut) v = v * sc;
+  }
   for (float& v : lut) v = u2f(f16bits_to_f32bits(f32bits_to_f16bits(f2u(v))));   // the walk's table entries are binary16 (round to nearest even)
   uint64_t n_dist = 0, n_exp = 0, n_hops = 0, n_exact = 0;
   auto D = [&](uint32_t s) { n_dist++; return pq_adc(lut.data(), m, C, codes + (size_t)s * m); };

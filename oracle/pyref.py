@@ -490,7 +490,14 @@ def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level,
     (score bits, slot) returned.  rows_seen / query_seen: the f32 values the index's distance sees.  Returns slots, scores, counters."""
     cb = np.asarray(codebooks, f32); m, c, ds = cb.shape
     q = np.asarray(query_seen, f32)
-    lut = [[f32(np.float16(pq_fn(pq_metric, q[j * ds:(j + 1) * ds], cb[j, cc]))) for cc in range(c)] for j in range(m)]   # entries rounded to binary16 (RNE)
+    lut32 = [[f32(pq_fn(pq_metric, q[j * ds:(j + 1) * ds], cb[j, cc])) for cc in range(c)] for j in range(m)]
+    big = max([v for r_ in lut32 for v in r_ if v > 0] or [f32(0)])
+    sc = f32(1)
+    if np.isfinite(big):
+        while f32(big * sc) > f32(32768):   # table scale (coltt_oracle.cpp): a power of two, exact
+            sc = f32(sc * f32(0.5))
+    with np.errstate(over="ignore"):
+        lut = [[f32(np.float16(f32(v * sc))) for v in r_] for r_ in lut32]   # entries rounded to binary16 (RNE)
     cnt = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
     NONE = 0xFFFFFFFF
 

@@ -139,6 +139,35 @@ def test_hnsw_pq_tables_of_binary16_denormals(gpu, c):
         assert st == ost, (ef, rr, st, ost)
 
 
+@pytest.mark.parametrize("scale,c", [(2.0 ** 8, 32), (2.0 ** 8, 256), (181.0, 16)])
+def test_hnsw_pq_tables_of_unnormalised_rows_are_scaled_not_infinite(gpu, scale, c):
+    """a Euclidean index over un-normalised data (SIFT-like magnitudes) has squared sub-vector distances far above binary16's
+    65504 — unscaled, the walk's table is mostly +Inf, every vertex is equally far, the greedy descent stops at once and recall collapses silently.
+    The definition (oracle: "table scale") multiplies the query's table by 2^-k, k the smallest integer with max * 2^-k <= 32768, before the binary16
+    rounding: GPU == oracle (ids, exact score bits, all four counters), the table distances are finite, and a stored row finds itself."""
+    d, m, n, k = 64, 16, 2500, 10
+    h, pq, pqm, rows, seen = _pq_case(gpu, n, d, gpu.EUCLIDEAN, gpu.Q_NONE, m, c, 5200 + c, scale=scale)
+    h.PqAttach(pq)
+    cb = pq.Codebooks(); codes = h.PqCodes(); g = h.ExportRaw()
+    Q = (O.fill_normal(5277 + c, (24, d)) * np.float32(scale)).astype(np.float32)
+    big = max(float(O.pq_lut(O.PQ_EUCLIDEAN, cb, Q[i]).max()) for i in range(4))
+    assert big > 65504.0, "the case no longer overflows binary16 without the scale"
+    for ef, rr in ((40, 0), (300, 0), (300, 32)):
+        gi, gs, gc, st = h.PqSearch(Q, k, ef=ef, rerank=rr, with_stats=True)
+        sl, sc, cn, ost, _ = O.csr_search_pq(rows, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], codes, cb, pqm, Q, k, ef, rerank=rr)
+        assert np.array_equal(gc, cn.astype(np.uint32)), (ef, rr)
+        for qi in range(len(Q)):
+            assert np.array_equal(gi[qi, :gc[qi]], sl[qi, :cn[qi]].astype(np.uint64)), (ef, rr, qi)
+            assert np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32)), (ef, rr, qi)
+        assert st == ost, (ef, rr, st, ost)
+        assert st["n_hops"] > len(Q), "the greedy descent never moved: the table distances carry no information"
+    ids, sc_, _ = h.PqSearch(seen[:6], 5, ef=64)
+    assert np.array_equal(ids[:, 0], np.arange(6, dtype=np.uint64)) and not sc_[:, 0].any()
+    pi, _, _ = h.Search(Q, k, ef=300)
+    gi, _, _ = h.PqSearch(Q, k, ef=300)
+    assert np.mean([len(set(gi[q].tolist()) & set(pi[q].tolist())) / k for q in range(len(Q))]) > 0.8
+
+
 def test_hnsw_pq_attach_refuses_what_the_walk_cannot_order(gpu):
     d = 32
     h = gpu.Hnsw(d, gpu.EUCLIDEAN)
@@ -151,6 +180,10 @@ def test_hnsw_pq_attach_refuses_what_the_walk_cannot_order(gpu):
     pq3 = gpu.PQSpace(d, gpu.PQ_EUCLIDEAN, 4, 16)
     with pytest.raises(gpu.ColttError): h.PqAttach(pq3)                      # untrained
     with pytest.raises(gpu.ColttError): h.PqSearch(X[:2], 5)                 # nothing attached
+    hc = gpu.Hnsw(d, gpu.COSINE)                                             # a cosineDistance quantiser trained on RAW vectors, attached to a cosine index
+    for i in range(300): hc.Insert(i, X[i], 0)
+    with pytest.raises(gpu.ColttError): hc.PqAttach(pq2)                     # ||centroid|| > 1: 1 - dot(unit query piece, centroid) can be negative
+    pq4 = gpu.PQSpace(d, gpu.PQ_COSINE, 4, 16); pq4.Fit(hc.FetchRows(), iterations=2); hc.PqAttach(pq4)   # trained on the index's normalised rows: fine
     pq3.Fit(X, iterations=2); h.PqAttach(pq3)
     ids, sc, cnt = h.PqSearch(X[:4], 5, ef=40)
     assert np.array_equal(ids[:, 0], np.arange(4, dtype=np.uint64)) and not sc[:, 0].any()   # a stored row finds itself at exact distance 0

@@ -31,7 +31,8 @@ def _padded(g, w0, wu):
 
 
 @pytest.mark.parametrize("metric,quant,pqm,scale", [(O.COSINE, O.Q_NONE, O.PQ_COSINE, 1.0), (O.L2, O.Q_F16, O.PQ_EUCLIDEAN, 1.0), (O.COSINE, O.Q_F16, O.PQ_EUCLIDEAN, 1.0),
-                                                         (O.L2, O.Q_NONE, O.PQ_EUCLIDEAN, 2.0 ** -9)])   # the last one: table entries that are binary16 denormals
+                                                         (O.L2, O.Q_NONE, O.PQ_EUCLIDEAN, 2.0 ** -9),    # table entries that are binary16 denormals
+                                                         (O.L2, O.Q_NONE, O.PQ_EUCLIDEAN, 300.0)])       # entries beyond binary16's 65504: the table scale (round 6)
 def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant, pqm, scale):
     n, d, m, c, k = 260, 32, 8, 16, 5
     X = (O.fill_normal(4100 + metric + 3 * quant, (n, d)) * np.float32(scale)).astype(np.float32); lv = O.levels(4200, n)
@@ -46,9 +47,11 @@ def test_oracle_pq_walk_equals_the_independent_python_restatement(metric, quant,
     cb = O.pq_train(seen[:120], m, c, iters=3)
     codes = O.pq_encode(cb, seen)
     Q = (O.fill_normal(4300, (5, d)) * np.float32(scale)).astype(np.float32)
-    if scale != 1.0:
+    if scale < 1.0:
         h16 = np.concatenate([O.pq_lut(pqm, cb, Q[i]).ravel() for i in range(len(Q))]).astype(np.float16)
         assert (np.abs(h16[h16 != 0]) < 6.2e-5).mean() > 0.3
+    if scale > 1.0:
+        assert max(float(O.pq_lut(pqm, cb, Q[i]).max()) for i in range(len(Q))) > 65504.0, "the case no longer overflows binary16 without the scale"
     for ef, rr in ((12, 0), (40, 7), (5, 2)):
         sl, sc, cn, st, _ = O.csr_search_pq(rows, quant, adj0, upper_off, adjU, d, metric, entry, entry_level, codes, cb, pqm, Q, k, ef, rerank=rr)
         tot = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
