@@ -469,16 +469,18 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
         h.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef); qps_curve[str(ef)] = nq / (h.last_kernel_ms() / 1e3)
     # the same index walked on product-quantiser codes with an exact re-rank (coltt_hnsw_pq_*): the quantiser is trained on the first
     # 65 536 stored rows, every row is encoded on the GPU, the sweep picks the smallest ef that reaches the target recall
-    pqw = None; pq_arg = None
-    try:
-        # 64 sub-vectors x 32 centroids (5 bits per 12 dimensions; 64 B per row, a 4 KiB binary16 table): the best of the shapes swept on this
-        # collection (profiles/r05h_hnswpq_probe_10m.jsonl) — the table is what bounds the walk's resident traversals
-        pm = int(os.environ.get("COLTT_BENCH_PQ_M", "64")); pc = int(os.environ.get("COLTT_BENCH_PQ_C", "32")); rr = int(os.environ.get("COLTT_BENCH_PQ_RERANK", "0"))
+    def one_query_ms(fn, reps=60):
+        """median kernel time of single-query calls (the reference's RPC shape, core/core.go:633-667): hipEvent pair on the search stream"""
+        o1 = Out(torch, dev, 1, k); km = []
+        for i in range(reps):
+            fn(q.data_ptr() + (i % nq) * dim * 4, o1); km.append(h.last_kernel_ms())
+        return float(np.median(km[5:]))
+
+    def pq_walk(pm, pc, rr, pefs):
         sample = h.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
         pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, pm, pc)
         t0 = time.perf_counter(); pq.Fit(sample, iterations=6); fit_s = time.perf_counter() - t0
         t0 = time.perf_counter(); h.PqAttach(pq); attach_s = time.perf_counter() - t0
-        pefs = [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1152,1280,1344,1408,1536,2048").split(",")]
         pcurve = {}; pqps = {}
         for ef in pefs:
             st = h.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef, rerank=rr)
@@ -493,16 +495,41 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
             pst = h.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=pef, rerank=rr); pms.append(h.last_kernel_ms())
         torch.cuda.synchronize(); pdt = time.perf_counter() - t0
         pnd = pst["n_dist"] / nq; pnx = pst["n_exact"] / nq; pne = pst["n_exp"] / nq
-        pbytes = pnd * ((pm + 15) // 16 * 16) + pne * (2 * args.m) * 4 + pnd * 4 + pnx * dim * 2
-        pqw = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x {pc} centroids, {(pm + 15) // 16 * 16} B per row, binary16 tables in LDS) "
-                           f"+ exact re-rank of {'every survivor' if rr == 0 else rr}", "m": pm, "centroids": pc, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),
-               "value": steps * nq / pdt, "unit": "queries/s", "over_plain_walk": (steps * nq / pdt) / (steps * nq / dt), "recall_vs_ef": pcurve, "qps_vs_ef": pqps,
-               "per_query": {"n_dist": pnd, "n_exp": pne, "n_exact": pnx, "bytes": pbytes}, "fit_s": fit_s, "attach_s": attach_s,
-               "roofline": {"bound": "latency (resident traversals x dependent round trips; LDS holds the tables)", "achieved": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel": "hnsw_pq_search_kernel (hnsw_pq.hpp)",
-                            "avg_launch_ms": float(np.mean(pms))}}
-        pq_arg = {"cb": pq.Codebooks(), "pq_metric": O.PQ_EUCLIDEAN if O is not None else 1, "ef": pef, "rerank": rr}
+        row = (pm + 15) // 16 * 16
+        # algorithmic bytes: one code row + one visited byte per table distance, the adjacency row per expansion, the stored row per exact distance
+        pbytes = pnd * row + pne * (2 * args.m) * 4 + pnd * 4 + pnx * dim * 2
+        w = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x {pc} centroids, {row} B per row, binary16 tables in LDS; code rows read from "
+                         f"neighbourhood blocks beside the adjacency rows) + exact re-rank of {'every survivor' if rr == 0 else 'the ' + str(rr) + ' nearest survivors'}",
+             "m": pm, "centroids": pc, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),
+             "value": steps * nq / pdt, "unit": "queries/s", "over_plain_walk": (steps * nq / pdt) / (steps * nq / dt), "recall_vs_ef": pcurve, "qps_vs_ef": pqps,
+             "per_query": {"n_dist": pnd, "n_exp": pne, "n_exact": pnx, "bytes": pbytes}, "fit_s": fit_s, "attach_s": attach_s,
+             "single_query_kernel_ms": one_query_ms(lambda p, o1: h.PqSearchDevice(p, 1, k, *o1.ptrs(), ef=pef, rerank=rr)),
+             "roofline": {"bound": "latency (resident traversals x dependent round trips; LDS holds the tables)", "achieved": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel": "hnsw_pq_search_kernel (hnsw_pq.hpp)",
+                          "avg_launch_ms": float(np.mean(pms))}}
+        arg = {"cb": pq.Codebooks(), "pq_metric": O.PQ_EUCLIDEAN if O is not None else 1, "ef": pef, "rerank": rr}
         pq.close()
+        return w, arg
+
+    pqw = None; pq_arg = None; pqw_ref = None
+    single_ms = None
+    try:
+        single_ms = one_query_ms(lambda p, o1: h.SearchDevice(p, 1, k, *o1.ptrs(), ef=ef_op))
+    except Exception as e:
+        single_ms = f"failed: {e}"
+    try:
+        # the reference's own quantiser shape first (playground/hnswpq_verification.go:69-73: 32 sub-vectors x 256 centroids; 32 B per row, a 16 KiB binary16
+        # table per traversal), reported beside the shape that serves this collection best — the LAST attach is the one the CPU baseline re-runs
+        rr_ref = int(os.environ.get("COLTT_BENCH_PQ_REF_RERANK", "0"))
+        pqw_ref, _ = pq_walk(32, 256, rr_ref, [int(e) for e in os.environ.get("COLTT_BENCH_PQ_REF_EFS", "1536,2048,2560,3072").split(",")])
+    except Exception as e:
+        pqw_ref = {"error": str(e)}
+    try:
+        # 64 sub-vectors x 32 centroids (5 bits per 12 dimensions; 64 B per row, a 4 KiB binary16 table): the best of the shapes swept on this
+        # collection (profiles/r05h_hnswpq_probe_10m.jsonl) — the table is what bounds the walk's resident traversals.  The exact re-rank takes the 768
+        # nearest survivors (profiles/r06b_pq_occupancy_rerank.jsonl: recall -0.0006 against re-ranking all ~1 350, +7 % queries/s)
+        pm = int(os.environ.get("COLTT_BENCH_PQ_M", "64")); pc = int(os.environ.get("COLTT_BENCH_PQ_C", "32")); rr = int(os.environ.get("COLTT_BENCH_PQ_RERANK", "768"))
+        pqw, pq_arg = pq_walk(pm, pc, rr, [int(e) for e in os.environ.get("COLTT_BENCH_PQ_EFS", "1024,1152,1280,1344,1408,1536,2048").split(",")])
     except Exception as e:
         pqw = {"error": str(e)}
     cpu = None
@@ -529,7 +556,8 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
                         "kernel": "hnsw_search2_kernel (hnsw_walk2.hpp: HBM visited map behind an LDS Bloom filter, delta result set, 2-byte rows" +
                                   ("; eight lanes per row over rows8)" if op_ev8 > 0 else ")"),
                         "avg_launch_ms": launch_s * 1e3},
-           "cpu_baseline": cpu, "pq_walk": pqw}
+           "single_query_kernel_ms": single_ms,
+           "cpu_baseline": cpu, "pq_walk": pqw, "pq_walk_reference_shape": pqw_ref}
     if cpu and "value" in cpu:
         res["gpu_over_cpu"] = res["value"] / cpu["value"]
     return res
@@ -1030,10 +1058,14 @@ def compact(res):
                       "traffic_ratio": (r["traffic"] / (r["achieved"] * 1e9 * r["avg_launch_ms"] / 1e3)) if r.get("traffic") and r.get("achieved") else None,
                       "cpu_value": (op.get("cpu_baseline") or {}).get("value"), "cpu_cores": (op.get("cpu_baseline") or {}).get("cores"),
                       "gpu_equals_oracle": (op.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")})
-            pw = op.get("pq_walk")
-            if isinstance(pw, dict):
-                o["pq"] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(_pick(pw, "m", "centroids", "ef", "recall_at_10", "value", "over_plain_walk", "gpu_over_cpu"),
-                                                                                       gpu_equals_oracle=(pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample"))
+            if op.get("single_query_kernel_ms") is not None:
+                o["lat_ms"] = op.get("single_query_kernel_ms")
+            for key, short in (("pq_walk", "pq"), ("pq_walk_reference_shape", "pq_ref")):
+                pw = op.get(key)
+                if isinstance(pw, dict):
+                    o[short] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(
+                        _pick(pw, "m", "centroids", "ef", "rerank", "recall_at_10", "reached", "value", "over_plain_walk", "gpu_over_cpu"), lat_ms=pw.get("single_query_kernel_ms"),
+                        **({"gpu_equals_oracle": (pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")} if pw.get("cpu_baseline") else {}))
             out["op"] = o
     sec = res.get("secondary") or {}
     for tag in ("c1", "c2", "c3", "c3f8", "pq"):
@@ -1069,7 +1101,7 @@ def compact(res):
     if isinstance(sec.get("h1"), dict):
         out["h1"] = _pick(sec["h1"], "single_query_call_ms_median", "single_query_kernel_ms_median", "batch_of_10000_queries_per_s", "error")
     if isinstance(sec.get("lat"), dict):
-        out["lat"] = _pick(sec["lat"], "kernel_ms_1", "kernel_ms_128", "cpu_1_thread_ms", "error")
+        out["lat"] = _pick(sec["lat"], "kernel_ms_1", "call_ms_1", "kernel_ms_16", "ef", "error")
     if isinstance(sec.get("g8"), dict):
         out["g8"] = _pick(sec["g8"], "members", "serial_ms_per_batch", "streamed_ms_per_batch", "stage_ms_per_batch", "exposed_frac_of_a_streamed_batch", "streamed_equals_serial", "error")
     if isinstance(sec.get("shard"), dict):
@@ -1217,6 +1249,21 @@ def main():
                     cpu = cpu_hnsw(G, torch, O, h, args, dim, args.quant, args.ef, queries[0], k, out, args.m)
                 except Exception as e:
                     cpu = {"error": str(e)}
+        if not shard:
+            # ONE query per call on the headline index — the reference's RPC shape (core/core.go:633-667, edge/edge.go:610-690): kernel time (hipEvent pair on
+            # the search stream) and wall time of the C-ABI call with device buffers, medians
+            try:
+                o1 = Out(torch, dev, 16, k); lk = {1: [], 16: []}; lw = []
+                for b in (1, 16):
+                    for i in range(70):
+                        t0 = time.perf_counter()
+                        h.SearchDevice(queries[0].data_ptr() + ((i * b) % (nq - b)) * dim * 4, b, k, *o1.ptrs(), ef=args.ef)
+                        if b == 1: lw.append((time.perf_counter() - t0) * 1e3)
+                        lk[b].append(h.last_kernel_ms())
+                secondary["lat"] = {"kernel_ms_1": float(np.median(lk[1][10:])), "call_ms_1": float(np.median(lw[10:])), "kernel_ms_16": float(np.median(lk[16][10:])), "ef": args.ef,
+                                    "kernel": "hnsw_search_lat_kernel (hnsw_lat.hpp): one 256-thread workgroup per query, rows evaluated out of the registers they land in"}
+            except Exception as e:
+                secondary["lat"] = {"error": str(e)}
         launch_s = float(np.mean(kernel_ms)) / 1e3
         ev8_launches = h.Rows8()[0]
         roof = None

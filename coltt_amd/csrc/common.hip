@@ -140,11 +140,7 @@ int coltt_policy_reload(void) {
   return COLTT_OK;
 }
 const char* coltt_version(void) {
-#ifdef COLTT_EXPERIMENTS
-  return "coltt_gpu 0.4 (gfx950) +experiments";   // superseded kernel generations compiled in (tools/experiments/)
-#else
-  return "coltt_gpu 0.4 (gfx950)";
-#endif
+  return "coltt_gpu 0.6 (gfx950)";
 }
 
 }  // extern "C"

@@ -17,11 +17,6 @@
 #include "exact.hpp"
 #include "prep.hpp"
 #include "flat_mfma.hpp"
-#ifdef COLTT_EXPERIMENTS   // superseded kernel generations, A/B only (tools/flat_ab.py, COLTT_MFMA_GEN)
-#include "../../tools/experiments/flat_mfma_gen1.hpp"
-#include "../../tools/experiments/flat_mfma_gen2.hpp"
-#include "../../tools/experiments/flat_mfma_gen4.hpp"
-#endif
 #include "select.hpp"
 
 using namespace coltt;
@@ -605,16 +600,8 @@ int search_group_one(Flat* f, FCtx* c, size_t q0, int g, uint32_t k, int nearest
   return rc;
 }
 
-// The FLAT matrix-core kernel is flat_mfma.hpp (split LDS-DMA rings).  A -DCOLTT_EXPERIMENTS build also carries generations 1, 2
-// and 4 (tools/experiments/), selectable with COLTT_MFMA_GEN for A/B measurements; the default library has exactly one.
-static int mfma_generation() {
-#ifdef COLTT_EXPERIMENTS
-  static const int v = [] { const char* e = getenv("COLTT_MFMA_GEN"); return e && *e ? atoi(e) : 3; }();
-  return v;
-#else
-  return 3;
-#endif
-}
+// The FLAT matrix-core kernel is flat_mfma.hpp (split LDS-DMA rings) — the third generation; the superseded ones (rounds 1-2, and the round-3
+// experiment that lost) were A/B material until round 5 and live in the history only.
 
 // what the candidate GEMM streams: the stored rows, or — "f8" stores — their derived binary16 copy (f8_expand_kernel)
 struct RowSrc { const uint8_t* rows; size_t stride; const float* norms; };
@@ -639,43 +626,6 @@ int launch_mfma_scan_t(Flat* f, FCtx* c, uint64_t b, uint64_t e, const _Float16*
     COLTT_HIP(hipGetLastError());
     return COLTT_OK;
   }
-#ifdef COLTT_EXPERIMENTS
-  if (mfma_generation() >= 4 && !(seed && BN == 256)) {   // (the batch-256 seed instance would spill: it stays on generation 3)
-    auto kern = f->metric == COLTT_COSINE ? (seed ? flat_mfma4_kernel<BN, AF32, true, M_COS> : flat_mfma4_kernel<BN, AF32, false, M_COS>)
-                                          : (seed ? flat_mfma4_kernel<BN, AF32, true, M_L2> : flat_mfma4_kernel<BN, AF32, false, M_L2>);
-    const size_t lds = M3Geom<BN, AF32, M2_BM>::LDS;
-    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);
-    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
-                                          nearest, cand, cnt, cap);
-    COLTT_HIP(hipGetLastError());
-    return COLTT_OK;
-  }
-  if (mfma_generation() == 2) {
-    // seed = the first, unfiltered segment (every score passes, e - b <= cap): candidates are written in place, no atomics
-    auto kern = seed ? flat_mfma2_kernel<BN, AF32, true> : flat_mfma2_kernel<BN, AF32, false>;
-    const size_t lds = M2Geom<BN, AF32>::LDS;
-    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t tiles = (e - b + M2_BM - 1) / M2_BM;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256);  // one persistent workgroup (8 waves, ~147 KB of LDS) per CU
-    kern<<<grid, M2_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
-                                          nearest, cand, cnt, cap);
-    COLTT_HIP(hipGetLastError());
-    return COLTT_OK;
-  }
-  if (mfma_generation() == 1) {
-    auto kern = flat_mfma_cos_kernel<BN, AF32>;
-    const size_t lds = mfma_lds_bytes<BN>();
-    COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint64_t tiles = (e - b + MF_BM - 1) / MF_BM;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, 256 * (MF_BM <= 64 ? 3 : 2));
-    kern<<<grid, MF_NT, lds, c->stream>>>(src.rows, src.stride, src.norms, b, e, q16, qn, g, kdim, thr,
-                                        nearest, cand, cnt, cap);
-    COLTT_HIP(hipGetLastError());
-    return COLTT_OK;
-  }
-#endif
   {
 #ifdef COLTT_M3_BM
     constexpr int BM = (!AF32 && BN == 256) ? COLTT_M3_BM : M2_BM;
@@ -783,7 +733,7 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // the third-generation kernel, as long as every stored norm is finite (max_norm bounds the margin)
   // (f32 rows are rounded to binary16 for candidate generation: ||row||^2 <= 4e9 keeps every element inside its range)
   const float max_norm = f->max_norm(), min_norm = f->min_norm();
-  const bool l2_ok = f->metric == COLTT_EUCLIDEAN && mfma_generation() >= 3 && max_norm == max_norm &&
+  const bool l2_ok = f->metric == COLTT_EUCLIDEAN && max_norm == max_norm &&
                      max_norm <= (f->quant == COLTT_Q_NONE ? 4.0e9f : 3.0e38f);
   // Cosine: the candidate margin (flat_mfma.hpp: MF_MARGIN / MF_MARGIN_F32) is proved for rows of norm ~1 — f32 rows are rounded to
   // binary16 on their way into the fragments, which is a RELATIVE perturbation only while the elements stay in binary16's normal
@@ -795,10 +745,10 @@ int search_prepared(Flat* f, FCtx* c, size_t nq, uint32_t k, int select, int mod
   // (padding, head of the next row — all finite as long as no stored norm ever was non-finite; Flat::reserve zeroes the rest)
   // multiplies zeros.  dim >= 128: the raw-norm parity buffers assume >= 4 K steps per tile.
   const bool finite_rows = max_norm == max_norm && max_norm < 3.0e38f;
-  const bool k_ok = (f->dim % MF_BK == 0 && f->dim >= 4 * MF_BK) || (mfma_generation() >= 3 && finite_rows);
+  const bool k_ok = (f->dim % MF_BK == 0 && f->dim >= 4 * MF_BK) || (finite_rows);
   // (a filtered search — d_gather: positions of a slot list — takes the matrix cores too, through the kernel's gather mode; the
   //  superseded experiment generations have none)
-  const bool mfma = mode == COLTT_MODE_MFMA && (!d_gather || mfma_generation() == 3) && (cos_ok || l2_ok) &&
+  const bool mfma = mode == COLTT_MODE_MFMA && (cos_ok || l2_ok) &&
                     (f->quant == COLTT_Q_NONE || f->quant == COLTT_Q_F16 || f->quant == COLTT_Q_BF16 || (f->quant == COLTT_Q_F8 && f->f8x && f->metric == COLTT_COSINE)) &&
                     k_ok && f->dim >= 8 && f->dim <= 4096 && total > 0;
   // small batches: the whole search in one launch, whatever the mode asked for (exact-order scores either way)

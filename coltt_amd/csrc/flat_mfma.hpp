@@ -5,7 +5,7 @@
 //   [1] contract, margins, query preparation, the per-column constants, pick and exact re-score           (round 1)
 //   [2] tile geometry, the LDS-DMA primitives, counted vmcnt waits, the one- and two-pass epilogues        (round 2)
 //   [3] flat_mfma3_kernel: split row / query rings with specialised loader waves, gather mode             (round 3-4)
-// The superseded kernels themselves live in tools/experiments/ (-DCOLTT_EXPERIMENTS builds only).
+// (The superseded kernels were kept under tools/experiments/ for A/B builds until round 5; they are in the history only.)
 //
 // ---- [1] ----------------------------------------------------------------------------------------------------------------------------------
 // The reference scores one (query, vector) pair at a time (edge/none_vectorstore.go:136-147); a GPU serving a batch of B

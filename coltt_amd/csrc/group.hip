@@ -41,6 +41,7 @@ struct Rccl {
   int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
   int (*CommInitRank)(nccl_comm_t*, int, NcclId, int) = nullptr;
   int (*CommDestroy)(nccl_comm_t) = nullptr;
+  int (*CommAbort)(nccl_comm_t) = nullptr;   // optional: tears a communicator down without waiting for its peers (after an exchange timeout)
   int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, nccl_comm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -61,6 +62,7 @@ Rccl* rccl() {
     COLTT_SYM(CommDestroy, "ncclCommDestroy") COLTT_SYM(AllGather, "ncclAllGather") COLTT_SYM(GroupStart, "ncclGroupStart")
     COLTT_SYM(GroupEnd, "ncclGroupEnd") COLTT_SYM(GetErrorString, "ncclGetErrorString")
 #undef COLTT_SYM
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.so, "ncclCommAbort"));
   });
   return r.so ? &r : nullptr;
 }
@@ -68,8 +70,13 @@ Rccl* rccl() {
   do { int _e = (expr); if (_e != 0) return fail(COLTT_E_DEVICE, "%s: %s", #expr, (R)->GetErrorString(_e)); } while (0)
 
 // ---- packed per-shard answers ---------------------------------------------------------------------------------------------
+// valid: bit 0 = the record holds an answer; bits 8..31 = the STATUS of the rank that packed it (0 = its shard search succeeded), the same in every
+// record of the rank's block.  A rank whose stage A failed still takes part in the exchange — with a block of status records — so that no peer is left
+// waiting in an all-gather that never comes and every rank returns the same error for the batch (round 6; core shape: edge/none_vectorstore.go:148-178,
+// where a failing shard goroutine still signals its WaitGroup).
 struct Rec { uint64_t id; float score; uint32_t valid; };  // 16 bytes
 static_assert(sizeof(Rec) == 16, "Rec");
+constexpr uint32_t REC_STATUS_SHIFT = 8;
 
 __global__ void pack_topk_kernel(const uint64_t* __restrict__ ids, const float* __restrict__ sc, const uint32_t* __restrict__ cnt,
                                  uint32_t nq, uint32_t k, Rec* __restrict__ out) {
@@ -78,6 +85,11 @@ __global__ void pack_topk_kernel(const uint64_t* __restrict__ ids, const float* 
   const uint32_t q = (uint32_t)(i / k), j = (uint32_t)(i - (size_t)q * k);
   const bool v = j < cnt[q];
   out[i] = Rec{v ? ids[i] : 0ull, v ? sc[i] : 0.f, v ? 1u : 0u};
+}
+// the block of a rank whose shard search failed: no answers, its status in every record
+__global__ void pack_status_kernel(size_t n, uint32_t status, Rec* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = Rec{0ull, 0.f, status << REC_STATUS_SHIFT};
 }
 
 // ---- all-gather between the processes of one box through POSIX shared memory -------------------------------------------------
@@ -216,6 +228,8 @@ struct Job {
   size_t nq = 0; uint32_t k = 0; int nearest = 1;
   uint64_t* out_ids = nullptr; float* out_scores = nullptr; uint32_t* out_counts = nullptr;
   int rc = COLTT_OK; std::string err; bool done = false;
+  int local_rc = COLTT_OK; std::string local_err;   // stage A failed HERE: the exchange still runs (status records), the error is returned at the end
+  bool clean_failure = false;                         // a rank's status said so: the transport itself is intact (nothing to poison)
   double search_ms = 0, exchange_ms = 0, merge_ms = 0;
 };
 constexpr int GROUP_SLOTS = 3;
@@ -233,6 +247,7 @@ struct Group : Object {
   std::unordered_map<uint64_t, std::shared_ptr<Job>> jobs;      // begun, not yet ended
   bool slot_busy[GROUP_SLOTS] = {false, false, false};
   uint64_t next_ticket = 1; bool stop = false; std::thread worker;
+  std::atomic<bool> broken{false};   // an exchange timed out: the communicator's state is unknown, every later shard search fails at once
   // cumulative timing of finished batches (coltt_group_timing)
   uint64_t t_batches = 0; double t_search = 0, t_exchange = 0, t_merge = 0;
   void exchange_loop();
@@ -286,7 +301,7 @@ void merge_range(const Rec* recs, int world, size_t nq, uint32_t k, int nearest,
     size_t total = 0;
     for (int s = 0; s < world; s++) {
       const Rec* r = recs + (size_t)s * per + q * k;
-      uint32_t c = 0; while (c < k && r[c].valid) c++;
+      uint32_t c = 0; while (c < k && (r[c].valid & 1u)) c++;
       len[s] = c; head[s] = 0; total += c;
     }
     const uint32_t take = (uint32_t)std::min<size_t>(k, total);
@@ -575,7 +590,48 @@ double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::
 
 // a failed exchange of a shared-memory group is final: the peers, which are or will be waiting for this process, stop at once
 void poison(Group* g) { if (g->exchange == COLTT_EXCHANGE_SHM && g->shm && g->shm->hdr) g->shm->hdr->failed.store(1, std::memory_order_release); }
+
+// seconds an exchange may take before it is given up (COLTT_EXCHANGE_TIMEOUT_S, default 120): a peer that died, or never made the call, must not
+// hold this process in hipStreamSynchronize for ever
+double exchange_timeout_s() {
+  static const double v = [] { const char* e = getenv("COLTT_EXCHANGE_TIMEOUT_S"); return (e && *e) ? std::max(0.05, atof(e)) : 120.0; }();
+  return v;
+}
+// hipStreamSynchronize with a deadline: polls hipStreamQuery
+int stream_wait(hipStream_t s, double timeout_s, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; spin++) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return COLTT_OK;
+    if (e != hipErrorNotReady) return fail(COLTT_E_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    if (spin < 4000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 127u) == 127u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      return fail(COLTT_E_DEVICE, "%s: not finished after %.1f s (COLTT_EXCHANGE_TIMEOUT_S) — a peer died or never made this call", what, timeout_s);
+  }
+}
+// the first rank whose block carries a status (record 0 of every rank's block of `per` records), or -1
+int first_failed_rank(const Rec* recs, int world, size_t per, uint32_t* status) {
+  for (int r = 0; r < world; r++) {
+    const uint32_t st = recs[(size_t)r * per].valid >> REC_STATUS_SHIFT;
+    if (st) { *status = st; return r; }
+  }
+  return -1;
+}
+int fail_for_rank(Job& j, int rank, uint32_t status) {
+  j.clean_failure = true;
+  if (j.local_rc != COLTT_OK) return fail(j.local_rc, "group_search: this process's shard search failed (every rank of the group returns an error for this batch): %s", j.local_err.c_str());
+  return fail(COLTT_E_DEVICE, "group_search: rank %d failed its shard search (status %u); every rank of the group returns an error for this batch", rank, status);
+}
 }  // namespace
+
+// exported for the unit tests, which run without a device: the rank whose block of `per` 16-byte records carries a status, or -1
+extern "C" int coltt_group_first_failed_rank_host(const void* recs, int world, size_t per, uint32_t* out_status) {
+  uint32_t st = 0;
+  if (!recs || world <= 0 || per == 0) return -1;
+  const int r = first_failed_rank(static_cast<const Rec*>(recs), world, per, &st);
+  if (out_status) *out_status = st;
+  return r;
+}
 
 // stages B + C of one batch, on the exchange thread
 int Group::exchange_and_merge(Job& j) {
@@ -603,6 +659,7 @@ int Group::exchange_and_merge(Job& j) {
       const auto te = std::chrono::steady_clock::now();
       COLTT_TRY(shm_allgather(shm.get(), sl.h_chunk_in.data(), cper * sizeof(Rec), sl.h_chunk_out.data()));
       j.exchange_ms += ms_since(te);
+      { uint32_t st = 0; const int bad = first_failed_rank(sl.h_chunk_out.data(), world, cper, &st); if (bad >= 0) return fail_for_rank(j, bad, st); }   // (every chunk carries it: all ranks stop at the first)
       const auto tm = std::chrono::steady_clock::now();
       COLTT_TRY(coltt_group_merge_host(sl.h_chunk_out.data(), world, qn, j.k, j.nearest, j.out_ids + q0 * j.k, j.out_scores + q0 * j.k, j.out_counts + q0));
       j.merge_ms += ms_since(tm);
@@ -626,7 +683,16 @@ int Group::exchange_and_merge(Job& j) {
     Member& x0 = *m[0];
     COLTT_TRY(use_device(x0.device));
     COLTT_HIP(hipMemcpyAsync(sl.h_stage.p, sl.mb[0]->d_gather.p, (size_t)world * per * sizeof(Rec), hipMemcpyDeviceToHost, x0.cstream));
-    for (auto& xp : m) { COLTT_TRY(use_device(xp->device)); COLTT_HIP(hipStreamSynchronize(xp->cstream)); }
+    // bounded: a peer that never issues its all-gather (it died, or it never made this call) must not hold this process for ever
+    for (auto& xp : m) {
+      COLTT_TRY(use_device(xp->device));
+      if (stream_wait(xp->cstream, exchange_timeout_s(), "group_search: RCCL all-gather") != COLTT_OK) {
+        broken.store(true);
+        const std::string why = g_last_error;
+        if (r->CommAbort) for (auto& yp : m) if (yp->comm) { (void)use_device(yp->device); (void)r->CommAbort(yp->comm); yp->comm = nullptr; }
+        return fail(COLTT_E_DEVICE, "%s", why.c_str());
+      }
+    }
   } else {
     for (size_t i = 0; i < nm; i++) {
       Member& x = *m[i];
@@ -636,6 +702,7 @@ int Group::exchange_and_merge(Job& j) {
     for (auto& xp : m) { COLTT_TRY(use_device(xp->device)); COLTT_HIP(hipStreamSynchronize(xp->cstream)); }
   }
   j.exchange_ms = ms_since(t0);
+  { uint32_t st = 0; const int bad = first_failed_rank(sl.h_stage.as<Rec>(), world, per, &st); if (bad >= 0) return fail_for_rank(j, bad, st); }
   const auto tm = std::chrono::steady_clock::now();
   COLTT_TRY(coltt_group_merge_host(sl.h_stage.p, world, j.nq, j.k, j.nearest, j.out_ids, j.out_scores, j.out_counts));
   j.merge_ms = ms_since(tm);
@@ -653,7 +720,7 @@ void Group::exchange_loop() {
     }
     g_last_error.clear();
     j->rc = exchange_and_merge(*j);
-    if (j->rc != COLTT_OK) { j->err = g_last_error; poison(this); }
+    if (j->rc != COLTT_OK) { j->err = g_last_error; if (!j->clean_failure) poison(this); }   // (a rank's status record is a CLEAN failure: the transport is intact, the next batch may run)
     {
       std::lock_guard<std::mutex> lk(q_mu);
       j->done = true; slot_busy[j->slot] = false;
@@ -674,6 +741,10 @@ int shard_begin(Group* g, const float* queries, const float* const* d_queries_pe
   auto job = std::make_shared<Job>();
   job->nq = nq; job->k = k; job->nearest = hn ? 1 : (select == COLTT_SELECT_NEAREST);
   job->out_ids = out_ids; job->out_scores = out_scores; job->out_counts = out_counts;
+  if (g->broken.load()) return fail(COLTT_E_DEVICE, "group_search: an earlier exchange of this group timed out — its communicator is gone (destroy the group)");
+  // test hook: COLTT_TEST_FAIL_STAGE_A=<rank> makes that rank's shard search fail before anything is searched (tests/test_gpu_group.py)
+  int inject_rank = -1;
+  if (const char* e = getenv("COLTT_TEST_FAIL_STAGE_A")) { if (*e) inject_rank = atoi(e); }
   std::lock_guard<std::mutex> lk(g->call_mu);   // one stage A at a time; tickets are taken in this order
   {
     std::unique_lock<std::mutex> ql(g->q_mu);   // a slot: at most GROUP_SLOTS batches between their search and the end of their merge
@@ -695,6 +766,7 @@ int shard_begin(Group* g, const float* queries, const float* const* d_queries_pe
     COLTT_TRY(b.d_ids.reserve(per * 8)); COLTT_TRY(b.d_sc.reserve(per * 4)); COLTT_TRY(b.d_cnt.reserve(nq * 4));
     COLTT_TRY(b.d_pack.reserve(per * sizeof(Rec)));
     if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(b.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
+    if (x.rank == inject_rank) return fail(COLTT_E_DEVICE, "injected stage-A failure on rank %d (COLTT_TEST_FAIL_STAGE_A)", x.rank);
     if (hn) COLTT_TRY(coltt_hnsw_search_device(x.h, dq, nq, k, ef_override, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>(), nullptr));
     else COLTT_TRY(coltt_flat_search_device(x.h, dq, nq, k, select, mode, b.d_ids.as<uint64_t>(), b.d_sc.as<float>(), b.d_cnt.as<uint32_t>()));
     // the packed {id, score, valid} records of this member: a ~10 us kernel right behind its search, while the device is still this batch's
@@ -704,12 +776,30 @@ int shard_begin(Group* g, const float* queries, const float* const* d_queries_pe
     return COLTT_OK;
   });
   job->search_ms = ms_since(t0);
-  std::lock_guard<std::mutex> ql(g->q_mu);
-  if (rc != COLTT_OK) {   // nothing was handed over: the slot goes back, the peers of a shared-memory group are released
-    g->slot_busy[job->slot] = false; g->slot_cv.notify_all();
-    poison(g);
-    return rc;
+  if (rc != COLTT_OK) {
+    // This rank's shard search failed.  Its peers are (or will be) in the all-gather of this batch: the exchange still happens, with a block of STATUS
+    // records from every local member, and every rank returns an error for the batch.  Only if even that cannot be done (no memory for the records, a
+    // dead device) is the batch dropped here — the peers' bounded wait (RCCL) / the poisoned segment (shared memory) releases them.
+    job->local_rc = rc; job->local_err = g_last_error;
+    const uint32_t status = (uint32_t)(rc < 0 ? -rc : rc) & 0xffffffu;
+    const int rc2 = for_members(g, [&](size_t j) -> int {
+      Member& x = *g->m[j]; SlotMember& b = *sl.mb[j];
+      COLTT_TRY(b.d_pack.reserve(per * sizeof(Rec)));
+      if (g->exchange == COLTT_EXCHANGE_RCCL) COLTT_TRY(b.d_gather.reserve((size_t)g->world * per * sizeof(Rec)));
+      pack_status_kernel<<<ceil_div(per, 256), 256, 0, x.stream>>>(per, status ? status : 1u, b.d_pack.as<Rec>());
+      COLTT_HIP(hipGetLastError());
+      COLTT_HIP(hipStreamSynchronize(x.stream));
+      return COLTT_OK;
+    });
+    if (rc2 != COLTT_OK) {
+      std::lock_guard<std::mutex> ql(g->q_mu);
+      g->slot_busy[job->slot] = false; g->slot_cv.notify_all();
+      poison(g);
+      g_last_error = job->local_err;
+      return rc;
+    }
   }
+  std::lock_guard<std::mutex> ql(g->q_mu);
   job->ticket = g->next_ticket++;
   g->jobs[job->ticket] = job;
   g->queue.push_back(job);

@@ -642,17 +642,28 @@ template <int METRIC, int QUANT>
 int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32_t region_base, uint32_t nq, uint32_t k, uint32_t* counter,
                       uint64_t* oi, float* os, uint32_t* oc, unsigned long long* stats) {
   (void)region_base;
-  auto kern = hnsw_search_lat_kernel<METRIC, QUANT>;
-  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   // COLTT_LAT_SEQ=1: the sequential walk (search_level2 + LatEval) also for one-chunk rows — the A/B partner of the pipelined one
-  const bool seq = policy().lat_seq;
-  // the latency kernel reads the index's ONE row array in the layout it has (line-transposed: pieces evaluated out of their registers; natural:
+  const bool seq = policy().lat_seq || x->cfg.m_max0 > 32;
+  // the latency kernel reads the index's ONE row array in the layout it has (line-transposed: lines evaluated out of their registers; natural:
   // staged and transposed through LDS).  COLTT_EV8 chooses between distance cores over the same bytes in the THROUGHPUT kernels; here the layout
-  // alone decides (the A/B partner is an index created with COLTT_ROWS8=0).
+  // alone decides (the A/B partner is an index created with COLTT_ROWS8=0).  One kernel instance per (layout, walk): TP = the row's 128-byte lines
+  // as a compile-time constant for the common shapes (24: 768 x f32; 12: 768 x 2 bytes, 384 x f32), -1 any line-transposed row, 0 natural order.
   GraphView gv = x->view();
-  if (gv.rows8 && QUANT != Q_F8) x->ev8_launches.fetch_add(1);
+  typedef void (*lat_kern_t)(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*);
+  lat_kern_t kern;
+  if constexpr (QUANT == Q_F8) kern = seq ? (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, true> : (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, false>;
+  else {
+    const int lines = gv.rows8 ? (int)(x->stride >> 7) : 0;
+    if (gv.rows8) x->ev8_launches.fetch_add(1);
+    if (!gv.rows8) kern = seq ? (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, true> : (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, false>;
+    else if (seq) kern = hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_R8_ANY, true>;
+    else if (lines == 24) kern = hnsw_search_lat_kernel<METRIC, QUANT, 24, false>;
+    else if (lines == 12) kern = hnsw_search_lat_kernel<METRIC, QUANT, 12, false>;
+    else kern = hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_R8_ANY, false>;
+  }
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
   kern<<<grid, 256, sg.lds, c->stream>>>(gv, x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, seq ? 1 : 0);
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -709,8 +720,10 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
   if (mw) {
     SearchGeom m = sg; m.w2 = -1; m.w2_lds = false; m.bloom_words = 0; m.visg = false;
     // LDS: query + result set + exchange words + the staging area (32 padded rows) + the visited hash
-    const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (size_t)LAT_ROWS * (x->stride + LAT_PAD);
-    if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to stage 32 at a time
+    // (line-transposed rows are evaluated out of the registers they land in: no staging area — hnsw_lat.hpp: lat_eval_chunk, TP != 0)
+    const bool lat_r8 = x->r8 && x->quant != COLTT_Q_F8;
+    const size_t fixed = ((lat_q_floats((int)x->dim) * 4 + 15) & ~(size_t)15) + (size_t)m.ef_pad * 8 + sizeof(LatShared) + (lat_r8 ? (size_t)0 : (size_t)LAT_ROWS * (x->stride + LAT_PAD));
+    if (x->stride > LAT_MAX_STRIDE) mw = false;               // rows too long to hold (or stage) 32 at a time
     else if (x->stride < COLTT_LAT_MIN_STRIDE && !policy().lat_knob_set) mw = false;   // short rows: the one-wave kernel (unless asked for)
     else {
       m.hcap = 32768; while (fixed + (size_t)m.hcap * 4 > 160 * 1024 && m.hcap > 1024) m.hcap /= 2;

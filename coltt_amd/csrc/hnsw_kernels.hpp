@@ -186,13 +186,16 @@ void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
 // Hnsw.Search with a 256-thread workgroup per query (hnsw_lat.hpp): the latency path for small batches — the reference serves one
 // query per RPC (core/core.go:633-667).  One workgroup per CU, queries pulled from a global counter.  Same answers, score bits and
 // counters as the one-wave kernel (the parity tests run both).
-template <int METRIC, int QUANT>
+// TP: how the rows are read (hnsw_lat.hpp: lat_eval_chunk) — > 0 line-transposed rows of TP 128-byte lines, -1 line-transposed of any length, 0 natural order
+// (staged through LDS).  SEQ: hnsw_walk2.hpp's level-0 walk on wave 0 with the chunks evaluated by all four waves (rows of more than one chunk, mMax0 > 32, and
+// the COLTT_LAT_SEQ=1 A/B partner) instead of the walk that is software-pipelined over expansions.  One walk and one evaluation per instance (round 6).
+template <int METRIC, int QUANT, int TP = 0, bool SEQ = false>
 __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32_t entry, int32_t entry_level,
                                                              const float* __restrict__ q_eff, const float* __restrict__ qnorms,
                                                              uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
                                                              uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
                                                              float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                             unsigned long long* __restrict__ stats, int lat_sequential) {
+                                                             unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WaveCtx w;
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   LatShared* xs = reinterpret_cast<LatShared*>(w.res0 + (size_t)ef_pad);
-  uint8_t* stage = reinterpret_cast<uint8_t*>(xs + 1);                                   // [32][stride + pad] rows of the chunk being evaluated
-  w.vis = reinterpret_cast<uint32_t*>(stage + (size_t)LAT_ROWS * (g.stride + LAT_PAD));
+  uint8_t* stage = reinterpret_cast<uint8_t*>(xs + 1);                                   // TP == 0: [32][stride + pad] rows of the chunk being evaluated
+  w.vis = reinterpret_cast<uint32_t*>(stage + (TP == LAT_TP_STAGED ? (size_t)LAT_ROWS * (g.stride + LAT_PAD) : (size_t)0));
   w.ef_pad = ef_pad; w.hcap = hcap; w.hcap_mask = hcap - 1;
   w.visg = nullptr; w.vis_bytes = 0; w.epoch = 0; w.bloom = nullptr; w.bloom_words = 0; w.bloom_shift = 0;
   for (;;) {
@@ -225,29 +228,29 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
     w.qnorm = qnorms[qi];
     // minDistance := Distance(query, entrypoint.vector) (hnsw.go:253): a chunk with one live row
     if (threadIdx.x < LAT_ROWS) { xs->nb[threadIdx.x] = threadIdx.x == 0 ? (uint32_t)entry : NBR_NONE; xs->fresh[threadIdx.x] = threadIdx.x == 0 ? 1u : 0u; }
-    lat_chunk<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+    lat_chunk<METRIC, QUANT, TP>(g, w, xs, stage, wave, lane);
     uint32_t cur = (uint32_t)entry;
     float curd = xs->d[0];
     w.n_dist += 1;
     __syncthreads();   // xs->d[0] has been read by every wave before the next chunk overwrites it
-    for (int l = entry_level; l > 0; l--) greedy_level_lat<METRIC, QUANT>(g, w, xs, stage, cur, curd, l, wave, lane);  // :254-256
+    for (int l = entry_level; l > 0; l--) greedy_level_lat<METRIC, QUANT, TP>(g, w, xs, stage, cur, curd, l, wave, lane);  // :254-256
 #ifdef COLTT_PHASE_TIMING
     if (wave == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); w.pt[6] += t_ - w.t_last; w.t_last = t_; }   // query load + entry + upper levels
 #endif
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    if (g.mMax0 <= 32 && !lat_sequential) {   // rows of one chunk: the walk that is software-pipelined over expansions (hnsw_lat.hpp)
-      search_level_lat3<METRIC, QUANT>(g, w, xs, stage, cur, curd, ef, wave, lane, len);  // :258-259
+    if constexpr (!SEQ) {   // rows of one chunk (mMax0 <= 32: the host checks): the walk that is software-pipelined over expansions (hnsw_lat.hpp)
+      search_level_lat3<METRIC, QUANT, TP>(g, w, xs, stage, cur, curd, ef, wave, lane, len);  // :258-259
     } else if (wave == 0) {   // hnsw_walk2.hpp's level-0 walk on wave 0, the chunks evaluated by all four waves (hnsw_lat.hpp: LatEval)
       if (lane == 0) xs->ctl[0] = 1u;
-      LatEval<METRIC, QUANT> ev{xs, stage};
+      LatEval<METRIC, QUANT, TP> ev{xs, stage};
       search_level2<METRIC, QUANT, PROF_SEARCH_LDS, W2_DELTA, VIS_LDS, true>(g, w, cur, curd, ef, lane, len, ev);  // :258-259
       wave_sync();
       if (lane == 0) xs->ctl[0] = 0u;
       lds_barrier();   // releases the companions
     } else {
       len = 0;
-      lat_companion<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+      lat_companion<METRIC, QUANT, TP>(g, w, xs, stage, wave, lane);
     }
     if (wave == 0) {
       const uint32_t n = len < k ? len : k;

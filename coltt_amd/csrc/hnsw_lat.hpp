@@ -71,176 +71,197 @@ template <int QUANT> __device__ __forceinline__ float lat_elem(const uint8_t* __
 struct LatNoMid { __device__ __forceinline__ void operator()() const {} };
 // MID: called (by every wave) after the row loads have been ISSUED and before they are waited for — wave 0 runs the previous
 // expansion's merge there, under the shadow of the fetch.
-template <int METRIC, int QUANT, bool ADJ, class MID = LatNoMid>
+// TP (round 6): how the kernel instance reads the rows — each instance carries ONE of the two evaluations, not both behind a run-time branch
+// (round 5's single function kept 25 per-piece predicates as live SGPR pairs from the fetch to the LDS store, every piece in its own EXEC
+// region, both evaluations' state at once: 256 VGPRs + 33-42 AGPR spills + 306-386 scalar spills inside the expansion chain):
+//   TP > 0   line-transposed rows (rows8.hpp) of exactly TP 128-byte lines: lane j of a row's group holds chunk j of every line = residue j's
+//            consecutive steps; the pieces are evaluated straight out of the registers they landed in.  The line count is a compile-time
+//            constant: one predicate (`fresh`) around straight-line code.
+//   TP = -1  line-transposed rows of any length (the line count is wave-uniform: a scalar compare per line)
+//   TP = 0   natural-order rows: staged through LDS as they are and read back element-wise
+constexpr int LAT_TP_STAGED = 0, LAT_TP_R8_ANY = -1;
+template <int METRIC, int QUANT, bool ADJ, int TP, class MID = LatNoMid>
 __device__ __forceinline__ void lat_eval_chunk(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane, MID&& mid = MID()) {
   const int r = lane >> 3, j = lane & 7;            // row of this wave's eight, lane within the row
   const int idx = wave * 8 + r;
   const uint32_t nb = xs->nb[idx];
   const bool fresh = xs->fresh[idx] != 0u;
-  const int lds_stride = (int)g.stride + LAT_PAD;
-  uint8_t* srow = stage + (size_t)idx * lds_stride;
-  const int pieces = (int)(g.stride >> 4);          // 16-byte pieces per row (the stride is a multiple of 16)
   const int n8 = g.dim >> 3, n8p = lat_n8p(g.dim);
   float rn = 0.f;
-  const bool r8 = QUANT != Q_F8 && g.rows8 != nullptr;
-  float acc8 = 0.f;
-  if (__ballot(fresh)) {
-    // ---- fetch: every piece of every fresh row of this wave in flight before the first one is stored
-    u32x4v tmp[LAT_MAX_PIECES];
-    u32x4v adj = {NBR_NONE, NBR_NONE, NBR_NONE, NBR_NONE};
-    // Round 4: an index that carries the line-transposed row copy (rows8.hpp) hands lane j of the group, with the very same addresses,
-    // chunk j of every line = residue j's consecutive steps: the pieces are evaluated straight out of the registers they landed in —
-    // no staging through LDS, no element-wise read-back (r8 is wave-uniform).
-    const uint8_t* src = (r8 ? g.rows8 : g.rows) + (size_t)nb * g.stride;
+  float d = 0.f;
+  const bool any = __ballot(fresh) != 0ull;
+  if constexpr (TP != LAT_TP_STAGED) {
+    static_assert(QUANT != Q_F8, "\"f8\" rows are never line-transposed");
+    constexpr int NT = TP > 0 ? TP : LAT_MAX_PIECES;
+    constexpr int S = QUANT == Q_NONE ? 4 : 8;      // steps per 128-byte line
+    const int lines = TP > 0 ? TP : (int)(g.stride >> 7);   // wave-uniform
+    float acc = 0.f;
+    if (any) {
+      // ---- fetch: every line of every fresh row of this wave in flight before the first one is used
+      u32x4v tmp[NT];
+      u32x4v adj = {NBR_NONE, NBR_NONE, NBR_NONE, NBR_NONE};
+      const uint8_t* src = g.rows + (size_t)nb * g.stride + (size_t)j * 16;
+      if (fresh) {
 #pragma unroll
-    for (int t = 0; t < LAT_MAX_PIECES; t++) {
-      const int pc = t * 8 + j;
-      if (fresh && pc < pieces) tmp[t] = *reinterpret_cast<const u32x4v*>(src + (size_t)pc * 16);
-    }
-    if constexpr (ADJ) { if (fresh && (uint32_t)(j * 4) < g.mMax0) adj = *reinterpret_cast<const u32x4v*>(g.adj0 + (size_t)nb * g.mMax0 + j * 4); }
-    if constexpr (METRIC == M_COS) { if (fresh) rn = g.norms[nb]; }
-    mid();
-    if (r8) {
-      if constexpr (QUANT != Q_F8) {
-        constexpr int S = QUANT == Q_NONE ? 4 : 8;      // steps per 128-byte line
+        for (int t = 0; t < NT; t++) { if (TP > 0 || t < lines) tmp[t] = *reinterpret_cast<const u32x4v*>(src + (size_t)t * 128); }
+        if constexpr (ADJ) { if ((uint32_t)(j * 4) < g.mMax0) adj = *reinterpret_cast<const u32x4v*>(g.adj0 + (size_t)nb * g.mMax0 + j * 4); }
+        if constexpr (METRIC == M_COS) rn = g.norms[nb];
+      }
+      mid();
+      if (fresh) {
         const float* qT8 = w.qs + (size_t)j * n8p;
-        if (fresh) {
 #pragma unroll
-          for (int t = 0; t < LAT_MAX_PIECES; t++) {
-            if (t * 8 < pieces) {                        // line t exists (wave-uniform)
-              if constexpr (QUANT == Q_NONE) {
-                const f32x4 x = __builtin_bit_cast(f32x4, tmp[t]);
-                const f32x4 q = *reinterpret_cast<const f32x4*>(qT8 + S * t);
+        for (int t = 0; t < NT; t++) {
+          if (TP > 0 || t < lines) {
+            if constexpr (QUANT == Q_NONE) {
+              const f32x4 x = __builtin_bit_cast(f32x4, tmp[t]);
+              const f32x4 q = *reinterpret_cast<const f32x4*>(qT8 + S * t);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                  if constexpr (METRIC == M_COS) { const float pp = q[u] * x[u]; acc8 = acc8 + pp; }
-                  else { const float df = q[u] - x[u]; const float pp = df * df; acc8 = acc8 + pp; }
-                }
-              } else {
-                const u32x2e lo = {tmp[t].x, tmp[t].y}, hi = {tmp[t].z, tmp[t].w};
-                const f32x4 x0 = __builtin_convertvector(__builtin_bit_cast(f16x4, lo), f32x4);
-                const f32x4 x1 = __builtin_convertvector(__builtin_bit_cast(f16x4, hi), f32x4);
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qT8 + S * t), q1 = *reinterpret_cast<const f32x4*>(qT8 + S * t + 4);
+              for (int u = 0; u < 4; u++) {
+                if constexpr (METRIC == M_COS) { const float pp = q[u] * x[u]; acc = acc + pp; }
+                else { const float df = q[u] - x[u]; const float pp = df * df; acc = acc + pp; }
+              }
+            } else {
+              const u32x2e lo = {tmp[t].x, tmp[t].y}, hi = {tmp[t].z, tmp[t].w};
+              const f32x4 x0 = __builtin_convertvector(__builtin_bit_cast(f16x4, lo), f32x4);
+              const f32x4 x1 = __builtin_convertvector(__builtin_bit_cast(f16x4, hi), f32x4);
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(qT8 + S * t), q1 = *reinterpret_cast<const f32x4*>(qT8 + S * t + 4);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                  if constexpr (METRIC == M_COS) { const float pp = q0[u] * x0[u]; acc8 = acc8 + pp; }
-                  else { const float df = q0[u] - x0[u]; const float pp = df * df; acc8 = acc8 + pp; }
-                }
+              for (int u = 0; u < 4; u++) {
+                if constexpr (METRIC == M_COS) { const float pp = q0[u] * x0[u]; acc = acc + pp; }
+                else { const float df = q0[u] - x0[u]; const float pp = df * df; acc = acc + pp; }
+              }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                  if constexpr (METRIC == M_COS) { const float pp = q1[u] * x1[u]; acc8 = acc8 + pp; }
-                  else { const float df = q1[u] - x1[u]; const float pp = df * df; acc8 = acc8 + pp; }
-                }
+              for (int u = 0; u < 4; u++) {
+                if constexpr (METRIC == M_COS) { const float pp = q1[u] * x1[u]; acc = acc + pp; }
+                else { const float df = q1[u] - x1[u]; const float pp = df * df; acc = acc + pp; }
               }
             }
           }
         }
+        if constexpr (ADJ) *reinterpret_cast<u32x4v*>(&xs->adjn[idx][j * 4]) = adj;
       }
-    } else {
+      COLTT_LT(w, 2)   // fetch issued + landed + evaluated
+      // ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)): butterfly over the 8 lanes of the row (all lanes take part in the DPP moves)
+      float s = acc;
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
+      if (fresh) {   // (a line-transposed row has no scalar tail: its length is a multiple of 128 bytes, i.e. of 8 elements)
+        if constexpr (METRIC == M_COS) d = cos_epilogue(s, w.qnorm, rn);
+        else d = go_sqrt(s);
+      }
+    } else mid();
+    if (j == 0) xs->d[idx] = d;
+    COLTT_LT(w, 3)
+    return;
+  } else {
+    const int lds_stride = (int)g.stride + LAT_PAD;
+    uint8_t* srow = stage + (size_t)idx * lds_stride;
+    const int pieces = (int)(g.stride >> 4);          // 16-byte pieces per row (the stride is a multiple of 16)
+    if (any) {
+      // ---- fetch: every piece of every fresh row of this wave in flight before the first one is stored
+      u32x4v tmp[LAT_MAX_PIECES];
+      u32x4v adj = {NBR_NONE, NBR_NONE, NBR_NONE, NBR_NONE};
+      const uint8_t* src = g.rows + (size_t)nb * g.stride;
+#pragma unroll
+      for (int t = 0; t < LAT_MAX_PIECES; t++) {
+        const int pc = t * 8 + j;
+        if (fresh && pc < pieces) tmp[t] = *reinterpret_cast<const u32x4v*>(src + (size_t)pc * 16);
+      }
+      if constexpr (ADJ) { if (fresh && (uint32_t)(j * 4) < g.mMax0) adj = *reinterpret_cast<const u32x4v*>(g.adj0 + (size_t)nb * g.mMax0 + j * 4); }
+      if constexpr (METRIC == M_COS) { if (fresh) rn = g.norms[nb]; }
+      mid();
 #pragma unroll
       for (int t = 0; t < LAT_MAX_PIECES; t++) {
         const int pc = t * 8 + j;
         if (fresh && pc < pieces) *reinterpret_cast<u32x4v*>(srow + (size_t)pc * 16) = tmp[t];
       }
-    }
-    COLTT_LT(w, 2)   // fetch issued + landed + staged (or, rows8, evaluated)
-    if constexpr (ADJ) { if (fresh) *reinterpret_cast<u32x4v*>(&xs->adjn[idx][j * 4]) = adj; }
-  } else mid();
-  wave_sync();   // the rows of this wave were staged by this wave
-  float d = 0.f;
-  if (__ballot(fresh)) {
-    // ---- evaluate out of LDS: lane j = residue j of the 8-lane accumulator, groups in increasing order.  Blocks of 16 groups:
-    // the 16 row elements and the 16 query elements (4 x ds_read_b128 of the transposed query) are requested together, then
-    // the 16 multiply / add pairs run in order.
-    float acc = acc8;
-    const float* qT = w.qs + (size_t)j * n8p;
-    if (fresh && !r8) {
-      int gq = 0;
-      // The LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run (the adds of a block otherwise wait for
-      // its reads: ~1.1 us per chunk of 32 rows at dim 768 against ~0.4 us of dependent VALU).  A/B at 10 M x 768 f32, ef 128
-      // (profiles/r04_latency_evalpipe_ab.txt): 1 query 1.032 -> 1.015 ms, 16 queries 1.260 -> 1.239, 128 queries 1.444 -> 1.425;
-      // same answers and counters.  Adopted in round 4 (it was the -DCOLTT_LAT_EVAL_PIPE experiment of round 3).
+      COLTT_LT(w, 2)   // fetch issued + landed + staged
+      if constexpr (ADJ) { if (fresh) *reinterpret_cast<u32x4v*>(&xs->adjn[idx][j * 4]) = adj; }
+    } else mid();
+    wave_sync();   // the rows of this wave were staged by this wave
+    if (any) {
+      // ---- evaluate out of LDS: lane j = residue j of the 8-lane accumulator, groups in increasing order.  Blocks of 16 groups:
+      // the 16 row elements and the 16 query elements (4 x ds_read_b128 of the transposed query) are requested together, then
+      // the 16 multiply / add pairs run in order.
+      float acc = 0.f;
+      const float* qT = w.qs + (size_t)j * n8p;
+      if (fresh) {
+        int gq = 0;
+        // The LDS reads of block b + 1 are in flight while block b's 16 multiply / add pairs run (the adds of a block otherwise wait for
+        // its reads: ~1.1 us per chunk of 32 rows at dim 768 against ~0.4 us of dependent VALU).  A/B at 10 M x 768 f32, ef 128
+        // (profiles/r04_latency_evalpipe_ab.txt): 1 query 1.032 -> 1.015 ms, 16 queries 1.260 -> 1.239, 128 queries 1.444 -> 1.425;
+        // same answers and counters.  Adopted in round 4 (it was the -DCOLTT_LAT_EVAL_PIPE experiment of round 3).
 #define COLTT_LAT_LD(G0, RV, QV)                                                                         \
-      {                                                                                                  \
-        _Pragma("unroll") for (int u = 0; u < 16; u++) RV[u] = lat_elem<QUANT>(srow, 8 * ((G0) + u) + j); \
-        _Pragma("unroll") for (int u = 0; u < 4; u++) QV[u] = *reinterpret_cast<const f32x4*>(qT + (G0) + 4 * u); \
-      }
-#define COLTT_LAT_ACC(RV, QV)                                                                            \
-      {                                                                                                  \
-        _Pragma("unroll") for (int u = 0; u < 16; u++) {                                                 \
-          const float qe = QV[u >> 2][u & 3];                                                            \
-          if constexpr (METRIC == M_COS) { const float pp = qe * RV[u]; acc = acc + pp; }                \
-          else { const float df = qe - RV[u]; const float pp = df * df; acc = acc + pp; }                \
-        }                                                                                                \
-      }
-      {
-        const int nblk = n8 >> 4;
-        float rv0[16], rv1[16]; f32x4 qv0[4], qv1[4];
-        if (nblk > 0) COLTT_LAT_LD(0, rv0, qv0)
-        for (int b = 0; b < nblk; b += 2) {
-          if (b + 1 < nblk) COLTT_LAT_LD(16 * (b + 1), rv1, qv1)
-          COLTT_LAT_ACC(rv0, qv0)
-          if (b + 1 < nblk) {
-            if (b + 2 < nblk) COLTT_LAT_LD(16 * (b + 2), rv0, qv0)
-            COLTT_LAT_ACC(rv1, qv1)
-          }
+        {                                                                                                  \
+          _Pragma("unroll") for (int u = 0; u < 16; u++) RV[u] = lat_elem<QUANT>(srow, 8 * ((G0) + u) + j); \
+          _Pragma("unroll") for (int u = 0; u < 4; u++) QV[u] = *reinterpret_cast<const f32x4*>(qT + (G0) + 4 * u); \
         }
-        gq = nblk << 4;
-      }
+#define COLTT_LAT_ACC(RV, QV)                                                                            \
+        {                                                                                                  \
+          _Pragma("unroll") for (int u = 0; u < 16; u++) {                                                 \
+            const float qe = QV[u >> 2][u & 3];                                                            \
+            if constexpr (METRIC == M_COS) { const float pp = qe * RV[u]; acc = acc + pp; }                \
+            else { const float df = qe - RV[u]; const float pp = df * df; acc = acc + pp; }                \
+          }                                                                                                \
+        }
+        {
+          const int nblk = n8 >> 4;
+          float rv0[16], rv1[16]; f32x4 qv0[4], qv1[4];
+          if (nblk > 0) COLTT_LAT_LD(0, rv0, qv0)
+          for (int b = 0; b < nblk; b += 2) {
+            if (b + 1 < nblk) COLTT_LAT_LD(16 * (b + 1), rv1, qv1)
+            COLTT_LAT_ACC(rv0, qv0)
+            if (b + 1 < nblk) {
+              if (b + 2 < nblk) COLTT_LAT_LD(16 * (b + 2), rv0, qv0)
+              COLTT_LAT_ACC(rv1, qv1)
+            }
+          }
+          gq = nblk << 4;
+        }
 #undef COLTT_LAT_LD
 #undef COLTT_LAT_ACC
-      for (; gq + 16 <= n8; gq += 16) {
-        float rv[16]; f32x4 qv[4];
-#pragma unroll
-        for (int u = 0; u < 16; u++) rv[u] = lat_elem<QUANT>(srow, 8 * (gq + u) + j);
-#pragma unroll
-        for (int u = 0; u < 4; u++) qv[u] = *reinterpret_cast<const f32x4*>(qT + gq + 4 * u);
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-          const float qe = qv[u >> 2][u & 3];
-          if constexpr (METRIC == M_COS) { const float p = qe * rv[u]; acc = acc + p; }
-          else { const float df = qe - rv[u]; const float p = df * df; acc = acc + p; }
+        for (; gq < n8; gq++) {
+          const float rv = lat_elem<QUANT>(srow, 8 * gq + j);
+          const float qe = qT[gq];
+          if constexpr (METRIC == M_COS) { const float p = qe * rv; acc = acc + p; }
+          else { const float df = qe - rv; const float p = df * df; acc = acc + p; }
         }
       }
-      for (; gq < n8; gq++) {
-        const float rv = lat_elem<QUANT>(srow, 8 * gq + j);
-        const float qe = qT[gq];
-        if constexpr (METRIC == M_COS) { const float p = qe * rv; acc = acc + p; }
-        else { const float df = qe - rv; const float p = df * df; acc = acc + p; }
+      // ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)): butterfly over the 8 lanes of the row (all lanes take part in the DPP moves)
+      float s = acc;
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+      s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
+      if (fresh) {
+        const float* qtail = w.qs + (size_t)8 * n8p;
+        for (int e = n8 * 8; e < g.dim; e++) {  // scalar tail (avx.cpp:28-31,68-72), the same in every lane of the row
+          const float rv = lat_elem<QUANT>(srow, e);
+          const float qe = qtail[e - n8 * 8];
+          if constexpr (METRIC == M_COS) s += qe * rv;
+          else { const float df = qe - rv; s += df * df; }
+        }
+        if constexpr (METRIC == M_COS) d = cos_epilogue(s, w.qnorm, rn);
+        else d = go_sqrt(s);
       }
     }
-    // ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)): butterfly over the 8 lanes of the row (all lanes take part in the DPP moves)
-    float s = acc;
-    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    s = s + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x141, 0xf, 0xf, true));   // row_half_mirror: lane i <-> 7 - i
-    if (fresh) {
-      const float* qtail = w.qs + (size_t)8 * n8p;
-      for (int e = n8 * 8; e < g.dim; e++) {  // scalar tail (avx.cpp:28-31,68-72), the same in every lane of the row
-        const float rv = lat_elem<QUANT>(srow, e);
-        const float qe = qtail[e - n8 * 8];
-        if constexpr (METRIC == M_COS) s += qe * rv;
-        else { const float df = qe - rv; s += df * df; }
-      }
-      if constexpr (METRIC == M_COS) d = cos_epilogue(s, w.qnorm, rn);
-      else d = go_sqrt(s);
-    }
+    if (j == 0) xs->d[idx] = d;
+    COLTT_LT(w, 3)   // evaluation out of LDS
   }
-  if (j == 0) xs->d[idx] = d;
-  COLTT_LT(w, 3)   // evaluation out of LDS
 }
 
 // Run one chunk through the four waves: wave 0 has written xs->nb / xs->fresh.  Two barriers; afterwards xs->d is valid.
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, int TP>
 __device__ __forceinline__ void lat_chunk(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane) {
   __syncthreads();
-  lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, wave, lane);
+  lat_eval_chunk<METRIC, QUANT, false, TP>(g, w, xs, stage, wave, lane);
   __syncthreads();
 }
 
 // greedyClosestNeighbor (hnsw.go:320-343) on an upper level, all four waves.  cur / curd are meaningful on wave 0 and are
 // handed to the other waves through the exchange words (every wave follows the same hop sequence).
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, int TP>
 __device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w, LatShared* xs, uint8_t* stage, uint32_t& cur, float& curd,
                                                  int level, int wave, int lane_in) {
   for (uint32_t hops = 0;; hops++) {
@@ -258,7 +279,7 @@ __device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w,
         valid = nb != NBR_NONE && !is_deleted(g, nb);
         if ((lane & 1) == 0) { xs->nb[p] = nb; xs->fresh[p] = valid ? 1u : 0u; }
       }
-      lat_chunk<METRIC, QUANT>(g, w, xs, stage, wave, lane);
+      lat_chunk<METRIC, QUANT, TP>(g, w, xs, stage, wave, lane);
       if (wave == 0) {
         const float d = xs->d[p];
         w.n_dist += __popcll(__ballot(valid && (lane & 1) == 0));
@@ -291,7 +312,7 @@ __device__ __forceinline__ void greedy_level_lat(const GraphView& g, WaveCtx& w,
 // fetch and evaluate them (lat_eval_chunk), the distances come back through LDS.  The other waves sit in lat_companion().
 // The chunk's adjacency rows come along with its vectors (xs->adjn), so the next candidate's neighbour list is on chip when it is
 // chosen (search_level2: CHUNK_ADJ); the runner-up's row is requested at pop time.
-template <int METRIC, int QUANT> struct LatEval {
+template <int METRIC, int QUANT, int TP> struct LatEval {
   static constexpr bool CHUNK_ADJ = true;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = true;    // the runner-up's adjacency row is requested at pop time (the chunk's rows come along with its vectors)
@@ -305,21 +326,21 @@ template <int METRIC, int QUANT> struct LatEval {
     if (half == 0) { xs->nb[p] = nb; xs->fresh[p] = fresh ? 1u : 0u; }
     COLTT_LT0(w, 0)   // walk: pop + visited + admission of the previous chunk
     lds_barrier();
-    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, 0, lane);
-    else lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, 0, lane);
+    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true, TP>(g, w, xs, stage, 0, lane);
+    else lat_eval_chunk<METRIC, QUANT, false, TP>(g, w, xs, stage, 0, lane);
     lds_barrier();
     COLTT_LT0(w, 4)   // barrier 2 (the slowest wave)
     return xs->d[p];
   }
 };
 // waves 1-3 while wave 0 walks: one round per published chunk until wave 0 clears ctl[0]
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, int TP>
 __device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx& w, LatShared* xs, uint8_t* stage, int wave, int lane) {
   for (;;) {
     lds_barrier();
     if (xs->ctl[0] == 0u) break;
-    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, wave, lane);
-    else lat_eval_chunk<METRIC, QUANT, false>(g, w, xs, stage, wave, lane);
+    if (g.mMax0 <= 32) lat_eval_chunk<METRIC, QUANT, true, TP>(g, w, xs, stage, wave, lane);
+    else lat_eval_chunk<METRIC, QUANT, false, TP>(g, w, xs, stage, wave, lane);
     lds_barrier();
   }
 }
@@ -336,7 +357,7 @@ __device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx&
 //     member other than the candidate just expanded (the runner-up) and the smallest admitted key;
 //   * if that member does not survive the truncation to ef (it is larger than the new worst member), the canonical loop would find
 //     nothing to expand and stop: the speculative fetch is dropped, nothing of it is counted.
-template <int METRIC, int QUANT>
+template <int METRIC, int QUANT, int TP>
 __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w, LatShared* xs, uint8_t* stage, uint32_t ep, float epd,
                                                   uint32_t ef, int wave, int lane_in, uint32_t& out_len) {
   int lane = lane_in;
@@ -414,7 +435,7 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
     COLTT_LT(w, 0)   // choose + visited + publish (wave 0)
     lds_barrier();
     if (xs->ctl[0] == 0u) break;
-    lat_eval_chunk<METRIC, QUANT, true>(g, w, xs, stage, wave, lane, mid);
+    lat_eval_chunk<METRIC, QUANT, true, TP>(g, w, xs, stage, wave, lane, mid);
     lds_barrier();
     COLTT_LT(w, 4)
     if (wave == 0) {

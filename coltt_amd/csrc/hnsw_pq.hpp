@@ -89,7 +89,10 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // hnsw_walk2.hpp RADJ: the runner-up's adjacency row requested at pop time (it is the next candidate unless this expansion admits a nearer
   // vertex).  On its own, without the speculation above: 1 % slower (profiles/r05s_pq_ab.md) — the exact prefetch at the end of the expansion already
   // flies under the admission and the next pop.
-  static constexpr bool RADJ = SPEC;
+#ifndef COLTT_PQ_RADJ   // A/B knob: 0 = the next candidate's adjacency row + code rows are requested at the END of the expansion only (round 6's first form)
+#define COLTT_PQ_RADJ 1
+#endif
+  static constexpr bool RADJ = SPEC || (NBR && COLTT_PQ_RADJ != 0);
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
   static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
@@ -105,6 +108,9 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // j order), so what can overlap is the reads' latency: left to the scheduler, hipcc 7.2 emits read / wait lgkmcnt(0) / add per lookup (64 x ~64 cycles of
   // exposed LDS latency per expansion; three reads in flight at best in round 5's form).  The block only ever lowers the outstanding-LDS count it raised
   // itself, so the compiler's own wait counts around it stay conservative-correct.
+#ifndef COLTT_PQ_SUM_WAITS   // A/B knob: s_waitcnt instructions per block of eight lookups (8: one in front of every add; 2: one per four adds)
+#define COLTT_PQ_SUM_WAITS 8
+#endif
   template <int J> static __device__ __forceinline__ float sum8(float s, uint32_t v0, uint32_t v1) {
     static_assert(LS != 0, "sum8 needs the table's row length at compile time");
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
@@ -127,6 +133,7 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
         "ds_read_u16 %6, %6 offset:%18\n\t"
         "ds_read_u16 %7, %7 offset:%19\n\t"
         "ds_read_u16 %8, %8 offset:%20\n\t"
+#if COLTT_PQ_SUM_WAITS == 8
         "s_waitcnt lgkmcnt(7)\n\t" "v_fma_mix_f32 %0, %1, %12, %0 op_sel_hi:[1,0,0]\n\t"
         "s_waitcnt lgkmcnt(6)\n\t" "v_fma_mix_f32 %0, %2, %12, %0 op_sel_hi:[1,0,0]\n\t"
         "s_waitcnt lgkmcnt(5)\n\t" "v_fma_mix_f32 %0, %3, %12, %0 op_sel_hi:[1,0,0]\n\t"
@@ -135,6 +142,16 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
         "s_waitcnt lgkmcnt(2)\n\t" "v_fma_mix_f32 %0, %6, %12, %0 op_sel_hi:[1,0,0]\n\t"
         "s_waitcnt lgkmcnt(1)\n\t" "v_fma_mix_f32 %0, %7, %12, %0 op_sel_hi:[1,0,0]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t" "v_fma_mix_f32 %0, %8, %12, %0 op_sel_hi:[1,0,0]"
+#else   // two waits per block: 14 issue slots fewer per 16 lookups, the first add of each half behind four reads instead of one
+        "s_waitcnt lgkmcnt(4)\n\t" "v_fma_mix_f32 %0, %1, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %2, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %3, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %4, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t" "v_fma_mix_f32 %0, %5, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %6, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %7, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %8, %12, %0 op_sel_hi:[1,0,0]"
+#endif
         : "+v"(s), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
         : "v"(v0), "v"(v1), "v"(one), "v"(onef),
           "n"((J + 0) * R), "n"((J + 1) * R), "n"((J + 2) * R), "n"((J + 3) * R), "n"((J + 4) * R), "n"((J + 5) * R), "n"((J + 6) * R), "n"((J + 7) * R)
@@ -182,6 +199,18 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // NBR: the code row of candidate `cand`'s neighbour at position idx of its level-0 row (in_row: idx < mMax0)
   __device__ __forceinline__ void prefetch_at(uint32_t cand, uint32_t idx, bool in_row, int half) {
     if (in_row && half == 0) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, raw);
+  }
+  // RADJ over the neighbourhood blocks: the runner-up's block is requested at POP time into a second set of row registers; if the runner-up is indeed the
+  // next candidate (no nearer vertex admitted meanwhile — the common case once the result set is full) the rows are simply taken over
+  u32x4e spec_raw[NBR ? NR : 1];
+  __device__ __forceinline__ void prefetch_spec(uint32_t cand, uint32_t idx, bool in_row, int half) {
+    if constexpr (NBR) { if (in_row && half == 0) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, spec_raw); }
+  }
+  __device__ __forceinline__ void take_spec() {
+    if constexpr (NBR) {
+#pragma unroll
+      for (int i = 0; i < NR; i++) raw[i] = spec_raw[i];
+    }
   }
   float pre_d;   // EARLY: the table sum of this lane pair's neighbour, computed under the visited probe
   __device__ __forceinline__ void early(bool valid, int half) { pre_d = 0.f; if (valid && half == 0) pre_d = sum(raw); }

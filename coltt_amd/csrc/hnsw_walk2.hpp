@@ -395,6 +395,9 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     uint32_t runner_nb = NBR_NONE;
     if constexpr (eval_t::RADJ && PREF) {
       if (runner_key != ~0ull && (uint32_t)p < g.mMax0) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * g.mMax0 + p];
+      // ... and with it the evaluator's (candidate, position)-addressed inputs of the runner-up's neighbours (AdcEval<.., NBR>: their code rows): a whole
+      // expansion of lead time instead of the pop's
+      if constexpr (eval_t::ROWPF) { if (runner_key != ~0ull && g.mMax0 <= 32) ev.prefetch_spec((uint32_t)runner_key >> 1, (uint32_t)p, (uint32_t)p < g.mMax0, half); }
     }
     int best_src = -1;   // lane of the smallest key admitted in this expansion's (single) chunk
     COLTT_PT(w, 0)  // pop
@@ -425,7 +428,10 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         else if (eval_t::CHUNK_ADJ && width <= 32 && best_src >= 0) pre_nb = (uint32_t)p < width ? ev.chunk_adj(best_src >> 1, p) : NBR_NONE; \
         else pre_nb = (uint32_t)p < width ? g.adj0[(size_t)pre_slot * width + p] : NBR_NONE;        \
         if constexpr (ADJN) pre_nn = (uint32_t)p < width ? g.adj0_n[(size_t)pre_slot * width + p] : 0.f; \
-        if constexpr (eval_t::ROWPF) ev.prefetch_at(pre_slot, (uint32_t)p, (uint32_t)p < width, half); /* the next candidate's neighbours' inputs fly with its adjacency row */ \
+        if constexpr (eval_t::ROWPF) {                                                                 \
+          if (eval_t::RADJ && width <= 32 && runner_key < best_new) ev.take_spec();   /* requested at pop time: the runner-up it is */ \
+          else ev.prefetch_at(pre_slot, (uint32_t)p, (uint32_t)p < width, half);       /* the next candidate's neighbours' inputs fly with its adjacency row */ \
+        }                                                                                              \
         if constexpr (eval_t::SPEC) {                                                                \
           spec_slot = NBR_NONE;                                                                      \
           if (width <= 32 && runner_key < best_new) {   /* pre_nb is in registers (requested at pop time) */ \

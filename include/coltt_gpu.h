@@ -318,8 +318,10 @@ int coltt_group_search_device(coltt_handle_t h, const float* const* d_queries_pe
  * the shape of the reference's local-queue-then-merge scan, edge/none_vectorstore.go:148-178, with the merge taken off the critical
  * path).  _begin returns when every local member has searched the batch and the batch's exchange (pack + ONE all-gather + D2H on the
  * members' comm streams) and host merge have been queued behind the earlier batches'; _end blocks until the merged answers are in the
- * out arrays handed to _begin (they must stay valid until then) and returns that batch's status.  Exactly one of queries (host) /
- * d_queries_per_member (device) is non-NULL.  At most 3 batches may be begun and not ended.  Multi-process groups: every process
+ * out arrays handed to _begin (they must stay valid until then — also when the group is destroyed with the batch in flight: destroy drains
+ * its queue first) and returns that batch's status.  Exactly one of queries (host) /
+ * d_queries_per_member (device) is non-NULL.  At most 3 batches are between their search and the end of their merge (a 4th _begin waits for a slot); a ticket that is never
+ * ended is dropped when the group is destroyed.  Multi-process groups: every process
  * makes the same _begin calls in the same order (the collectives are issued in ticket order). */
 int coltt_group_search_begin(coltt_handle_t h, const float* queries, const float* const* d_queries_per_member, size_t nq, uint32_t k,
                              int select, int mode, uint32_t ef_override, uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
@@ -333,6 +335,14 @@ int coltt_group_timing(coltt_handle_t h, double* out4);
  * largest (edge.PriorityQueue semantics), both returned ascending. */
 int coltt_group_merge_host(const void* recs, int world, size_t nq, uint32_t k, int nearest, uint64_t* out_ids, float* out_scores,
                            uint32_t* out_counts);
+/* Failure of ONE rank's shard search (round 6).  The `valid` word of a packed record carries, above bit 0, the STATUS of the rank that
+ * packed it (bits 8..31; 0 = its shard search succeeded).  A rank whose search fails still takes part in the batch's exchange, with a
+ * block of status records: no peer is left waiting in an all-gather that never comes (the shape of a failing shard goroutine that still
+ * signals its WaitGroup, edge/none_vectorstore.go:148-178), every rank returns an error for THAT batch (coltt_group_search /
+ * _search_end) and the group stays usable.  The RCCL exchange is waited for with a deadline (COLTT_EXCHANGE_TIMEOUT_S, default 120 s):
+ * a peer that died or never made the call turns into an error, and the group refuses further shard searches.
+ * This helper (no device needed) returns the first rank of recs = [world][per] records whose block carries a status, or -1. */
+int coltt_group_first_failed_rank_host(const void* recs, int world, size_t per, uint32_t* out_status);
 /* sharding.ShardVertex on the host (pkg/sharding/shard.go:34-41): the routing rule of a group, no device needed */
 uint64_t coltt_shard_vertex_host(uint64_t id, uint64_t shard_count);
 

@@ -195,17 +195,14 @@ def test_flat_config0_full_size_single_queries(gpu):
                 assert_same_results(gi[0, :gc[0]], gs[0, :gc[0]], wi, ws, f"q{qi} sel{select} mode{mode}")
 
 
-@pytest.mark.parametrize("gen", ["3", "4"])
 @pytest.mark.parametrize("metric,quant", [(O.COSINE, O.Q_F16), (O.L2, O.Q_F16), (O.COSINE, O.Q_NONE)])
-def test_flat_mfma_many_tiles_per_workgroup_smallest_dim(gpu, metric, quant, gen, monkeypatch):
+def test_flat_mfma_many_tiles_per_workgroup_smallest_dim(gpu, metric, quant, monkeypatch):
     """200 k x 128: 782 row tiles over 256 persistent workgroups (three or four tiles each, the raw-norm parity buffers flip with
     every tile) at the SMALLEST dim the matrix-core mode takes (4 K steps per tile: the DMA rings run three tiles ahead of the
-    epilogue).  Ragged batch, batch 256 and a last tile of 64 rows; both kernel generations; == exact mode bit for bit.
+    epilogue).  Ragged batch, batch 256 and a last tile of 64 rows; == exact mode bit for bit.
     (Round 4: dim 96 / 64 / 32 run with K padded to 128 — `Stats()` shows their matrix-core group too; tests/test_gpu_round4.py.)"""
     import subprocess, sys, os, json
-    if gen != "3" and b"+experiments" not in gpu.lib().coltt_version():
-        pytest.skip("generation 4 lives in tools/experiments/: only a -DCOLTT_EXPERIMENTS build carries it")
-    # the generation is read once per process: run the comparison in a child so both generations are really exercised
+    # (a child process: the comparison used to run once per kernel generation, each read once per process)
     code = f"""
 import numpy as np, json, sys
 sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
@@ -226,11 +223,11 @@ small = G.FlatSpace(96, {metric}, {quant}); small.ChangedVertex(ids[:3000], O.fi
 small.VertexSearch(O.fill_normal(44, (8, 96)), 5, G.SELECT_NEAREST, G.MODE_MFMA)
 print(json.dumps({{"ok": ok, "groups": st["mfma_groups"], "fallbacks": st["mfma_fallbacks"], "small_groups": small.Stats()["mfma_groups"]}}))
 """
-    env = dict(os.environ, COLTT_MFMA_GEN=gen)
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    assert r["ok"] and r["groups"] > 0 and r["small_groups"] == (1 if gen == "3" else 0), r
+    assert r["ok"] and r["groups"] > 0 and r["small_groups"] == 1, r
 
 
 @pytest.mark.parametrize("d", [130, 200, 300])

@@ -266,3 +266,75 @@ def test_streamed_shard_search_overlaps_exchange_and_merge_and_answers_identical
         grp.SearchBegin(0, queries=q[:4], ef=ef)
     again = grp.Search(Qs[1], k, ef=ef)
     assert np.array_equal(again[0], plain[1][0])
+
+
+_FAIL_PROC = r'''
+import json, os, sys, time, numpy as np
+sys.path.insert(0, {root!r})
+import coltt_amd as G
+from coltt_amd import group as GG
+from oracle import oracle as O
+rank, world = int(sys.argv[1]), int(sys.argv[2]); uid = bytes.fromhex(sys.argv[3])
+assert G.lib().coltt_init(0) == 0
+n, d, k = 1500, 32, 10
+X = O.fill_normal(1800, (n, d)); ids = np.arange(n, dtype=np.uint64); Q = O.fill_normal(1801, (20, d))
+g = G.Group([0], d, O.L2, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_SHM, world_size=world, rank_base=rank, uid=uid)
+g.ChangedVertex(ids, X)
+a = g.Search(Q, k)                                         # a healthy batch first: both processes answer
+os.environ["COLTT_TEST_FAIL_STAGE_A"] = "1"                # from now on rank 1's shard search fails before it searches anything
+t0 = time.time(); err = None
+try:
+    g.Search(Q, k)
+except G.ColttError as e:
+    err = str(e)
+dt = time.time() - t0
+os.environ.pop("COLTT_TEST_FAIL_STAGE_A")
+b = g.Search(Q, k)                                         # the group is still usable: the failure was that batch's, not the transport's
+print("RESULT " + json.dumps({{"err": err, "dt": dt, "same": bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)))}}))
+g.close()
+'''
+
+
+def test_a_rank_that_fails_before_the_exchange_releases_its_peer_at_once_over_shared_memory(gpu):
+    """VERDICT r5 #4: two processes, rank 1's shard search fails (test hook) — it still contributes a block of status records, BOTH processes return an
+    error for that batch within seconds (nobody waits out the 120 s timeout), and the next batch runs as if nothing had happened."""
+    import json, os, subprocess, sys
+    from coltt_amd import group as GG
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    uid = GG.unique_id().hex()
+    code = _FAIL_PROC.format(root=root)
+    env = dict(os.environ, COLTT_SHM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "2", uid], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    for r in range(2):
+        assert outs[r]["err"] is not None and outs[r]["dt"] < 5.0, outs[r]
+        assert outs[r]["same"], "the batch after the failed one must answer as before"
+    assert "rank 1" in outs[0]["err"], outs[0]["err"]                       # the healthy rank names the one that failed
+    assert "injected stage-A failure" in outs[1]["err"], outs[1]["err"]     # the failing rank reports its own error
+
+
+def test_rccl_exchange_survives_a_failed_shard_search_and_bounds_its_wait(gpu, monkeypatch):
+    """the same on the RCCL transport, one process (world 1): the failing rank still issues its ncclAllGather — of status records — and returns its
+    error; the communicator is intact for the next batch.  (A peer that never issues its all-gather at all is what the deadline on the comm stream is
+    for: COLTT_EXCHANGE_TIMEOUT_S; it cannot be provoked with one rank.)"""
+    from coltt_amd import group as GG
+    n, d, k = 1200, 32, 10
+    X = O.fill_normal(1900, (n, d)); ids = np.arange(n, dtype=np.uint64); Q = O.fill_normal(1901, (16, d))
+    g = gpu.Group([0], d, O.L2, kind=GG.GROUP_FLAT, exchange=GG.EXCHANGE_RCCL)
+    g.ChangedVertex(ids, X)
+    a = g.Search(Q, k)
+    monkeypatch.setenv("COLTT_TEST_FAIL_STAGE_A", "0")
+    with pytest.raises(gpu.ColttError) as ei:
+        g.Search(Q, k)
+    assert "injected stage-A failure" in str(ei.value)
+    t, out = g.SearchBegin(k, queries=Q)                    # streaming form: _begin hands the batch over, _end returns the batch's error
+    with pytest.raises(gpu.ColttError):
+        g.SearchEnd(t)
+    monkeypatch.delenv("COLTT_TEST_FAIL_STAGE_A")
+    b = g.Search(Q, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+    g.close()

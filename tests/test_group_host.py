@@ -77,3 +77,24 @@ def test_normalize_host_is_the_reference_arithmetic_without_a_device():
             assert np.array_equal(out.view(np.uint32), O.normalize(v).view(np.uint32)), (d, scale)
     z = np.zeros(33, np.float32); out = np.ones(33, np.float32)
     assert f(L.vp(z), C.c_uint32(33), L.vp(out)) == 0 and not out.any()
+
+
+def test_first_failed_rank_reads_the_status_every_rank_packs_into_its_records():
+    """Round 6: a rank whose shard search fails still takes part in the exchange with a block of STATUS records (bits 8..31 of `valid`);
+    every rank finds the same failed rank in the gathered block and returns the same error — nobody waits for an all-gather that never comes.  The merge
+    itself only ever looks at bit 0."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    world, nq, k = 4, 6, 10
+    recs = _packed(world, nq, k, rng, False)
+    st = C.c_uint32(123)
+    f = G.lib().coltt_group_first_failed_rank_host
+    assert f(recs.ctypes.data_as(C.c_void_p), world, C.c_size_t(nq * k), C.byref(st)) == -1 and st.value == 0
+    bad = recs.copy()
+    bad[2]["id"] = 0; bad[2]["score"] = 0; bad[2]["valid"] = np.uint32(4 << 8)            # rank 2: no answers, status 4 in every record
+    assert f(bad.ctypes.data_as(C.c_void_p), world, C.c_size_t(nq * k), C.byref(st)) == 2 and st.value == 4
+    bad[1]["valid"] = np.uint32(9 << 8)
+    assert f(bad.ctypes.data_as(C.c_void_p), world, C.c_size_t(nq * k), C.byref(st)) == 1 and st.value == 9   # the FIRST failed rank: the same on every rank
+    ok = recs.copy(); ok["valid"] |= np.uint32(0)                                          # status 0 everywhere: the merge is what it was
+    a = GG.merge_host(ok, world, nq, k, True); b = GG.merge_host(recs, world, nq, k, True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))

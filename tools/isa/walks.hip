@@ -25,11 +25,15 @@ PQK(5, 4, true)
 PQK(8, 2, true)
 #undef PQK
 #endif
-#if WALKS_SET & 8   // single-query latency
-template __global__ void hnsw_search_lat_kernel<0, 0>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, int);
-template __global__ void hnsw_search_lat_kernel<0, 1>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, int);
+#if WALKS_SET & 8   // single-query latency: 768 x f32 (24 lines), 768 x f16 (12 lines), natural-order rows
+#define LATK(Q, TP, SEQ) template __global__ void hnsw_search_lat_kernel<0, Q, TP, SEQ>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, \
+    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*);
+LATK(0, 24, false)
+LATK(1, 12, false)
+LATK(0, -1, false)
+LATK(0, 0, false)
+LATK(0, -1, true)
+#undef LATK
 #endif
 }  // namespace kern
 }  // namespace coltt

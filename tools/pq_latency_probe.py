@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One query at a time on the operating-point collection (10 M x 768 f16, lowrank:32:1.0): latency and recall@10 of the plain walk
 (coltt_hnsw_search_device, the 256-thread latency kernel) and of the product-quantised walk + exact re-rank (coltt_hnsw_pq_search_device)
-per ef.  DESIGN §11.2 asks whether the table walk is the shorter chain for a single query.  `python tools/pq_latency_probe.py [n]`;
+per ef ($PROBE_PLAIN_EFS / $PROBE_PQ_EFS: comma-separated lists).  DESIGN §11.2 asks whether the table walk is the shorter chain for a single query.  `python tools/pq_latency_probe.py [n]`;
 one JSON line per configuration, appended to $PROBE_OUT."""
 import json
 import os
@@ -51,12 +51,12 @@ def main():
         rec = sum(len(set(truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
         return round(rec, 4), round(float(np.median(wall)), 4), round(float(np.median(kern)), 4)
 
-    for ef in (128, 256, 512):
+    for ef in [int(v) for v in os.environ.get("PROBE_PLAIN_EFS", "128,256,512").split(",") if v]:
         r, w, km = run(lambda p: h.SearchDevice(p, 1, k, *o.ptrs(), ef=ef))
         emit({"kind": "plain", "n": n, "ef": ef, "recall": r, "call_wall_ms_median": w, "kernel_ms_median": km})
     sample = h.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
     pq = G.PQSpace(dim, G.PQ_EUCLIDEAN, 64, 32); pq.Fit(sample, iterations=6); h.PqAttach(pq)
-    for ef in (128, 192, 256, 384, 512, 768):
+    for ef in [int(v) for v in os.environ.get("PROBE_PQ_EFS", "128,192,256,384,512,768").split(",") if v]:
         r, w, km = run(lambda p: h.PqSearchDevice(p, 1, k, *o.ptrs(), ef=ef, rerank=0))
         emit({"kind": "pq 64x32", "n": n, "ef": ef, "recall": r, "call_wall_ms_median": w, "kernel_ms_median": km})
     pq.close()
