@@ -82,6 +82,7 @@ Policy read_policy_from_env() {
   v = num("COLTT_PQ_WAVES", set); p.pq_waves = set ? (int)std::max<long long>(1, std::min<long long>(16, v)) : 0;
   p.pq_nbr = !off("COLTT_PQ_NBR");
   { const char* e = getenv("COLTT_LAT_SEQ"); p.lat_seq = e && *e == '1'; }
+  v = num("COLTT_LAT_HELPERS", set); p.lat_helpers = set ? (int)std::max<long long>(0, std::min<long long>(3, v)) : 0;
   v = num("COLTT_LAT_MAX_NQ", set); if (!set) v = num("COLTT_MW_MAX_NQ", set);
   p.lat_knob_set = set; p.lat_max_nq = set ? (uint32_t)std::max<long long>(0, v) : 0;
   v = num("COLTT_VISG_BUDGET_MB", set); p.visg_budget_mb = set ? v : -1;

@@ -112,6 +112,7 @@ struct Policy {
   int pq_waves = 0;            // COLTT_PQ_WAVES: resident traversals per CU of the product-quantised walk, 0 = the default cap
   bool pq_nbr = true;          // COLTT_PQ_NBR=0: the product-quantised walk gathers its code rows by neighbour slot (round 5) instead of reading the neighbourhood blocks
   bool lat_seq = false;        // COLTT_LAT_SEQ=1
+  int lat_helpers = 0;         // COLTT_LAT_HELPERS: cache-warming helper workgroups per walking workgroup of the latency kernel (batches <= 8 queries); 0 = none (default: measured 3-5 % SLOWER, profiles/r06f_latency_helpers_ab.md)
   bool lat_knob_set = false;   // COLTT_LAT_MAX_NQ / COLTT_MW_MAX_NQ present
   uint32_t lat_max_nq = 0;     // ... and its value
   long long visg_budget_mb = -1;  // COLTT_VISG_BUDGET_MB (test knob)

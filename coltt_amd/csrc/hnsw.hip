@@ -197,6 +197,7 @@ struct HCtx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf w_qraw, w_qeff, w_qn, w_out_ids, w_out_sc, w_out_cnt, w_misc, w_pack;
   DevBuf w_surv, w_scnt, w_keys;   // product-quantised walk: survivors (slots), their count, their exact keys
+  DevBuf w_mbox;                   // latency kernel: the walking workgroups' hint mailboxes (hnsw_lat.hpp: cache-warming helper workgroups)
   PinnedBuf h_in, h_out;   // small calls: see PinnedBuf
   int init() {  // the caller has selected the index's device
     COLTT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -649,7 +650,8 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
   // alone decides (the A/B partner is an index created with COLTT_ROWS8=0).  One kernel instance per (layout, walk): TP = the row's 128-byte lines
   // as a compile-time constant for the common shapes (24: 768 x f32; 12: 768 x 2 bytes, 384 x f32), -1 any line-transposed row, 0 natural order.
   GraphView gv = x->view();
-  typedef void (*lat_kern_t)(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*);
+  typedef void (*lat_kern_t)(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*,
+                             unsigned long long*, int);
   lat_kern_t kern;
   if constexpr (QUANT == Q_F8) kern = seq ? (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, true> : (lat_kern_t)hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_STAGED, false>;
   else {
@@ -662,8 +664,20 @@ int launch_search_lat(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uin
     else kern = hnsw_search_lat_kernel<METRIC, QUANT, LAT_TP_R8_ANY, false>;
   }
   COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
+  // Batches of at most LAT_MASTERS queries (the reference's one-query RPC above all) get helper workgroups that warm the XCD's L2 with the rows the walk
+  // will want next (hnsw_lat.hpp).  COLTT_LAT_HELPERS = 1 .. 3 per walking workgroup; OFF by default — exact, but 3-5 % slower than no helpers at all
+  // (profiles/r06f_latency_helpers_ab.md); not with the sequential walk.
+  unsigned long long* mbox = nullptr;
+  const int helpers = seq ? 0 : std::min(policy().lat_helpers, LAT_HELPERS_MAX);
+  if (helpers > 0 && nq <= (uint32_t)LAT_MASTERS) {
+    const size_t mb = (size_t)LAT_MASTERS * (LAT_HELPERS_MAX + 1) * 8;
+    COLTT_TRY(c->w_mbox.reserve(mb));
+    COLTT_HIP(hipMemsetAsync(c->w_mbox.p, 0, mb, c->stream));
+    mbox = c->w_mbox.as<unsigned long long>();
+    grid = (uint32_t)LAT_MASTERS * (uint32_t)(helpers + 1);
+  }
   kern<<<grid, 256, sg.lds, c->stream>>>(gv, x->entry, x->entry_level, c->w_qeff.as<float>(), c->w_qn.as<float>(), nq,
-                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats);
+                                         k, sg.ef, sg.ef_pad, sg.hcap, counter, oi, os, oc, stats, mbox, helpers);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }

@@ -195,9 +195,20 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
                                                              uint32_t nq, uint32_t k, uint32_t ef, uint32_t ef_pad, uint32_t hcap,
                                                              uint32_t* __restrict__ counter, uint64_t* __restrict__ out_ids,
                                                              float* __restrict__ out_scores, uint32_t* __restrict__ out_counts,
-                                                             unsigned long long* __restrict__ stats) {
+                                                             unsigned long long* __restrict__ stats, unsigned long long* __restrict__ mbox, int helpers) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // helped launches (mbox != null; batches of <= LAT_MASTERS queries): blocks 0 .. LAT_MASTERS - 1 walk, block m + 8 (h + 1) is walking block m's helper h
+  unsigned long long* hint_box = nullptr;
+  if (mbox) {
+    const uint32_t m = blockIdx.x & (uint32_t)(LAT_MASTERS - 1);
+    unsigned long long* const box = mbox + (size_t)m * (LAT_HELPERS_MAX + 1);
+    if (blockIdx.x >= (uint32_t)LAT_MASTERS) {
+      lat_helper_loop(g, box, (int)(blockIdx.x / LAT_MASTERS) - 1, reinterpret_cast<LatShared*>(smem));
+      return;
+    }
+    hint_box = box;
+  }
   WaveCtx w;
   size_t off = (lat_q_floats(g.dim) * 4 + 15) & ~(size_t)15;   // the query, residue-major (hnsw_lat.hpp: lat_n8p)
   w.qs = reinterpret_cast<float*>(smem);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
     if constexpr (!SEQ) {   // rows of one chunk (mMax0 <= 32: the host checks): the walk that is software-pipelined over expansions (hnsw_lat.hpp)
-      search_level_lat3<METRIC, QUANT, TP>(g, w, xs, stage, cur, curd, ef, wave, lane, len);  // :258-259
+      search_level_lat3<METRIC, QUANT, TP>(g, w, xs, stage, cur, curd, ef, wave, lane, len, hint_box, helpers);  // :258-259
     } else if (wave == 0) {   // hnsw_walk2.hpp's level-0 walk on wave 0, the chunks evaluated by all four waves (hnsw_lat.hpp: LatEval)
       if (lane == 0) xs->ctl[0] = 1u;
       LatEval<METRIC, QUANT, TP> ev{xs, stage};
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(256) void hnsw_search_lat_kernel(GraphView g, int32
       }
     }
   }
+  if (hint_box && threadIdx.x == 0) __hip_atomic_store(hint_box + LAT_HELPERS_MAX, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases this block's helpers
 }
 
 

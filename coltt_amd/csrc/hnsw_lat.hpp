@@ -345,6 +345,54 @@ __device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx&
   }
 }
 
+// ---- cache-warming helper workgroups (round 6: "more than one CU per query") -------------------------------------------------
+// One query alone leaves 255 CUs idle, and what an expansion waits for is its fetch: ~25 fresh rows of 3 KB through ONE CU's load path (~1.4 us of
+// transfer behind ~1 us of HBM + translation latency; profiles/r06e_latency_kernel_phases.txt: 79 % of the walk).  Handing the rows' EVALUATION to other
+// CUs costs two cross-CU hand-offs per expansion (>= 0.5-1 us each): as much as it saves.  What costs the walk nothing is a HINT: the walking
+// workgroup posts the slots of its best unexpanded candidates (the runner-up and the members behind it — one of them is the next candidate unless
+// the expansion in flight admits a nearer vertex) in a mailbox in HBM; helper workgroups on OTHER CUs of the SAME XCD poll it, read the candidate's
+// adjacency row and simply LOAD every byte of its neighbours' rows.  The rows land in the XCD's L2 (and the translations in its shared TLB level); when
+// the walk gets there, its own fetch is an L2 hit.  Helpers never compute, never write anything the walk reads: the walk's loads, arithmetic, answers
+// and counters are exactly what they are without helpers — a wrong or late hint only wastes a helper's bandwidth.
+// MEASURED (GPU call F, profiles/r06f_latency_helpers_ab.md; 10 M x 768 f32, one index, one process, answers identical in every arm): one query, ef 128:
+// 0.719 ms without helpers, 0.740 / 0.741 / 0.758 ms with 1 / 2 / 3; ef 512: 2.82 against 2.89 / 2.91 / 2.96.  The hint is late by construction — a
+// helper needs the poll, the candidate's adjacency row and then the rows (~2-3 us) while the walk wants the runner-up's rows ~1.5 us after it posted
+// them — and what an expansion waits for is mostly the 75-96 KB moving through the walking CU's own load path, which an L2 hit does not shorten.  OFF by
+// default (COLTT_LAT_HELPERS=0); kept as the A/B partner of that record.
+// Mailbox of walking workgroup m (m = blockIdx.x < LAT_MASTERS): LAT_HELPERS_MAX + 1 8-byte words — word h = (sequence number << 32 | slot) for helper
+// h, the last word = done.  Single 8-byte relaxed agent-scope stores and loads (one granule: untorn); no ordering is needed — a helper acts on whatever
+// slot it sees.  Block b runs on XCD b % 8 (observed placement, used for speed only: a helper on another XCD still warms the Infinity Cache), so walking
+// workgroup m's helpers are the blocks m + 8, m + 16, ...
+constexpr int LAT_MASTERS = 8;        // walking workgroups of a helped launch (one per XCD): batches of at most 8 queries
+constexpr int LAT_HELPERS_MAX = 3;    // helper workgroups per walking workgroup
+__device__ __forceinline__ void lat_post_hint(unsigned long long* box, int helpers, int h, uint32_t seq, uint32_t slot, int lane) {   // wave 0; one lane stores
+  if (h < helpers && lane == 0) __hip_atomic_store(box + h, ((unsigned long long)seq << 32) | slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a helper workgroup: until the walking workgroup is done (or a generous spin budget runs out — nothing waits for a helper)
+__device__ __forceinline__ void lat_helper_loop(const GraphView& g, unsigned long long* box, int h, LatShared* xs) {
+  const int tid = threadIdx.x;
+  unsigned long long last = 0ull; uint32_t sink = 0u;
+  for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+    const unsigned long long v = __hip_atomic_load(box + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long done = __hip_atomic_load(box + LAT_HELPERS_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done) break;
+    if (v == last || v == 0ull) { __builtin_amdgcn_s_sleep(8); continue; }
+    last = v;
+    const uint32_t slot = (uint32_t)v;
+    __syncthreads();   // (everybody is through with the previous hint's neighbour list)
+    if (tid < LAT_ROWS) xs->nb[tid] = (uint32_t)tid < g.mMax0 ? g.adj0[(size_t)slot * g.mMax0 + tid] : NBR_NONE;
+    __syncthreads();
+    const uint32_t pieces = (uint32_t)(g.stride >> 4);
+    for (int i = 0; i < LAT_ROWS; i++) {
+      const uint32_t nb = xs->nb[i];
+      if (nb == NBR_NONE) continue;   // workgroup-uniform
+      const uint8_t* row = g.rows + (size_t)nb * g.stride;
+      for (uint32_t pc = (uint32_t)tid; pc < pieces; pc += 256u) { const u32x4v x = *reinterpret_cast<const u32x4v*>(row + (size_t)pc * 16); sink ^= x.x ^ x.w; }
+    }
+    if (sink == 0x9e3779b9u && spins == 0xffffffffu) box[h] = sink;   // (never true: keeps the loads)
+  }
+}
+
 // searchLevel on level 0 for rows of at most one chunk (mMax0 <= 32), SOFTWARE-PIPELINED over expansions, all four waves.
 // With LatEval an expansion is  pop -> visited -> [fetch -> evaluate] -> admission / eviction  in sequence on wave 0, ~3.4 us of
 // single-wave VALU / LDS work around a ~3.5 us fetch + evaluation (phase timing, profiles/r03_latency.json).  Here the NEXT candidate is
@@ -359,7 +407,7 @@ __device__ __forceinline__ void lat_companion(const GraphView& g, const WaveCtx&
 //     nothing to expand and stop: the speculative fetch is dropped, nothing of it is counted.
 template <int METRIC, int QUANT, int TP>
 __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w, LatShared* xs, uint8_t* stage, uint32_t ep, float epd,
-                                                  uint32_t ef, int wave, int lane_in, uint32_t& out_len) {
+                                                  uint32_t ef, int wave, int lane_in, uint32_t& out_len, unsigned long long* hint_box, int hint_helpers) {
   int lane = lane_in;
   const int tid = wave * 64 + lane;
   unsigned long long* const res = w.res0;
@@ -372,6 +420,7 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
   unsigned long long runner_key = ~0ull; uint32_t runner_nb = NBR_NONE; int runner_idx = -1, runner_dlane = -1;
   uint32_t nb = NBR_NONE; bool fresh = false;       // the expansion in flight (wave 0, lane pair p <-> neighbour p)
   unsigned long long pA = 0, pnext = ~0ull; uint32_t pkhi = 0, pklo = 0, pm = 0; bool locate = false, dead = false;
+  uint32_t hint_seq = 0;   // sequence number of the hints posted to the helper workgroups
 
   auto absorb = [&]() {   // the admitted keys of the previous expansion: into the delta, then keep the ef smallest
     if (!pm) return;
@@ -398,20 +447,33 @@ __device__ __forceinline__ void search_level_lat3(const GraphView& g, WaveCtx& w
     free_slots = ef - (len + dl.n);
     // the runner-up: the smallest unexpanded member of main ∪ delta (the candidate in flight is already marked)
     int ci = -1;
+    unsigned long long more = 0ull; uint32_t more_base = 0;   // the unexpanded main members behind the first one, in its 64-entry chunk (hints)
     for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
       const uint32_t i = base + lane;
       const bool un = i < len && !(res[i] & 1ull);
       const unsigned long long mm = __ballot(un);
-      if (mm) { ci = (int)base + __builtin_ctzll(mm); break; }
+      if (mm) { ci = (int)base + __builtin_ctzll(mm); more = mm & (mm - 1ull); more_base = base; break; }
     }
     scan_lo = ci >= 0 ? (uint32_t)ci : len;
     const unsigned long long kci = ci >= 0 ? res[ci] : ~0ull;
     unsigned long long kd = ~0ull; int dlane = -1;
     { const unsigned long long u = dl.unexpanded(lane); if (u) { dlane = __builtin_ctzll(u); kd = dl.key_at(dlane); } }
-    if (kd < kci) { runner_key = kd; runner_dlane = dlane; runner_idx = -1; }
+    const bool runner_in_delta = kd < kci;
+    if (runner_in_delta) { runner_key = kd; runner_dlane = dlane; runner_idx = -1; }
     else { runner_key = kci; runner_idx = ci; runner_dlane = -1; }
     runner_nb = NBR_NONE;
     if (runner_key != ~0ull && (uint32_t)(lane >> 1) < width) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * width + (lane >> 1)];
+    // hints for the helper workgroups: the runner-up, then the main array's next unexpanded members (the delta's are not looked for: a hint, not a promise)
+    if (hint_box && runner_key != ~0ull) {
+      hint_seq++;
+      lat_post_hint(hint_box, hint_helpers, 0, hint_seq, (uint32_t)runner_key >> 1, lane);
+      int hh = 1;
+      if (runner_in_delta && ci >= 0) { lat_post_hint(hint_box, hint_helpers, hh, hint_seq, (uint32_t)kci >> 1, lane); hh++; }   // the runner-up came from the delta: the main array's first one is next in line
+      while (more && hh < hint_helpers) {
+        const int l1 = __builtin_ctzll(more); more &= more - 1ull;
+        lat_post_hint(hint_box, hint_helpers, hh, hint_seq, (uint32_t)res[more_base + (uint32_t)l1] >> 1, lane); hh++;
+      }
+    }
   };
 
   if (wave == 0) {   // the entrypoint is popped at once (it is the only member)

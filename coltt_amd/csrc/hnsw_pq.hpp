@@ -89,8 +89,12 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // hnsw_walk2.hpp RADJ: the runner-up's adjacency row requested at pop time (it is the next candidate unless this expansion admits a nearer
   // vertex).  On its own, without the speculation above: 1 % slower (profiles/r05s_pq_ab.md) — the exact prefetch at the end of the expansion already
   // flies under the admission and the next pop.
-#ifndef COLTT_PQ_RADJ   // A/B knob: 0 = the next candidate's adjacency row + code rows are requested at the END of the expansion only (round 6's first form)
-#define COLTT_PQ_RADJ 1
+  // Round 6 tried the same over the neighbourhood blocks (-DCOLTT_PQ_RADJ=1: the runner-up's adjacency row AND its 2 KiB block of code rows requested at pop
+  // time into a second set of row registers, taken over when the runner-up is indeed the next candidate): 2.6 % SLOWER in throughput (344.4 against
+  // 353.5 k queries/s on one box, profiles/r06d_pq_radj_ab.md) and no faster for one query alone — 32 more VGPRs and 2 KiB of wasted fetch per misprediction
+  // against a prefetch that the admission, the eviction and the next pop already cover.  Off in the shipped library.
+#ifndef COLTT_PQ_RADJ
+#define COLTT_PQ_RADJ 0
 #endif
   static constexpr bool RADJ = SPEC || (NBR && COLTT_PQ_RADJ != 0);
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
@@ -108,7 +112,7 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // j order), so what can overlap is the reads' latency: left to the scheduler, hipcc 7.2 emits read / wait lgkmcnt(0) / add per lookup (64 x ~64 cycles of
   // exposed LDS latency per expansion; three reads in flight at best in round 5's form).  The block only ever lowers the outstanding-LDS count it raised
   // itself, so the compiler's own wait counts around it stay conservative-correct.
-#ifndef COLTT_PQ_SUM_WAITS   // A/B knob: s_waitcnt instructions per block of eight lookups (8: one in front of every add; 2: one per four adds)
+#ifndef COLTT_PQ_SUM_WAITS   // A/B knob: s_waitcnt instructions per block of eight lookups (8: one in front of every add; 2: one per four adds — measured the same to 0.3 %, r06d)
 #define COLTT_PQ_SUM_WAITS 8
 #endif
   template <int J> static __device__ __forceinline__ float sum8(float s, uint32_t v0, uint32_t v1) {

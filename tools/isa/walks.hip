@@ -27,7 +27,7 @@ PQK(8, 2, true)
 #endif
 #if WALKS_SET & 8   // single-query latency: 768 x f32 (24 lines), 768 x f16 (12 lines), natural-order rows
 #define LATK(Q, TP, SEQ) template __global__ void hnsw_search_lat_kernel<0, Q, TP, SEQ>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, \
-    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*);
+    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, unsigned long long*, int);
 LATK(0, 24, false)
 LATK(1, 12, false)
 LATK(0, -1, false)
