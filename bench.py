@@ -507,6 +507,9 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
              "roofline": {"bound": "latency (resident traversals x dependent round trips; LDS holds the tables)", "achieved": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": pbytes * nq / (float(np.mean(pms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "kernel": "hnsw_pq_search_kernel (hnsw_pq.hpp)",
                           "avg_launch_ms": float(np.mean(pms))}}
+        tr = hnswpq_pmc_traffic(n, dim, pm, pc, pef, nq)
+        if tr[0]:
+            w["roofline"].update({"walk_kernel_traffic": tr[0], "walk_kernel_traffic_over_algorithmic": tr[1], "traffic_source": tr[2]})
         arg = {"cb": pq.Codebooks(), "pq_metric": O.PQ_EUCLIDEAN if O is not None else 1, "ef": pef, "rerank": rr}
         pq.close()
         return w, arg
@@ -1065,6 +1068,7 @@ def compact(res):
                 if isinstance(pw, dict):
                     o[short] = {"error": str(pw["error"])[:120]} if "error" in pw else dict(
                         _pick(pw, "m", "centroids", "ef", "rerank", "recall_at_10", "reached", "value", "over_plain_walk", "gpu_over_cpu"), lat_ms=pw.get("single_query_kernel_ms"),
+                        **({"walk_traffic_ratio": (pw.get("roofline") or {}).get("walk_kernel_traffic_over_algorithmic")} if (pw.get("roofline") or {}).get("walk_kernel_traffic_over_algorithmic") else {}),
                         **({"gpu_equals_oracle": (pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")} if pw.get("cpu_baseline") else {}))
             out["op"] = o
     sec = res.get("secondary") or {}
@@ -1410,6 +1414,17 @@ def pq_pmc_traffic(n, dim, m):
         return rec.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
     except Exception:
         return None, None
+
+
+def hnswpq_pmc_traffic(n, dim, m, centroids, ef, nq):
+    """HBM bytes per launch of the product-quantised WALK kernel from the committed PMC pass (tools/pmc_traffic.py --hnswpq: FETCH_SIZE calibrated per access
+    pattern on known byte counts, tools/micro/fetch_cal.hip), for this very shape and ef only"""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(p)).get(f"hnswpq n={n} dim={dim} m={m} centroids={centroids} ef={ef} queries={nq}", {})
+        return rec.get("hbm_bytes_per_launch"), rec.get("traffic_over_algorithmic"), (f"profiles/{os.path.basename(rec['source'])}" if rec.get("source") else None)
+    except Exception:
+        return None, None, None
 
 
 def flat_pmc_traffic(n, dim, quant, batch):

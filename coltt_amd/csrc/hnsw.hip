@@ -248,7 +248,7 @@ struct Hnsw : Object {
   DevBuf b_head, b_req, b_levels; uint64_t head_cap = 0;  // builder scratch
   // HBM visited set (hnsw_dev.hpp, VISG): vis_regions regions of vis_stride bytes; concurrent searches lease disjoint
   // contiguous runs of regions (vis_busy), the builder (exclusive lock) uses all of them.
-  DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0;
+  DevBuf w_visg, w_vepoch; uint64_t vis_stride = 0; uint32_t vis_regions = 0, vis_want = 0;
   std::mutex vis_mu; std::condition_variable vis_cv; std::vector<uint8_t> vis_busy;
   coltt_hnsw_stats build_stats{};
   ~Hnsw() override {
@@ -326,7 +326,6 @@ int prep_rows_any(Hnsw* x, const float* d_raw, uint64_t n, uint64_t slot_base, b
 
 // derived per-slot data of the slots a writer added (the product quantiser's codes); completes on the device before it returns
 int sync_pq(Hnsw* x);
-int sync_rows8(Hnsw* x) { return sync_pq(x); }
 // stored rows [first, first + m) -> the f32 values the index's distance sees (what the quantiser encodes), packed [m][dim]
 template <int QUANT, bool R8>
 __global__ void rows_to_f32_kernel(const uint8_t* __restrict__ rows, size_t stride, uint64_t first, uint64_t m, int dim, float* __restrict__ out) {
@@ -402,7 +401,8 @@ struct SearchGeom { uint32_t ef, ef_pad, hcap; size_t lds; bool visg; uint32_t m
 #ifndef COLTT_VISG_MIN_EF
 #define COLTT_VISG_MIN_EF 128
 #endif
-constexpr uint32_t VIS_MAX_REGIONS = 3072;  // 12 waves on each of 256 CUs (the row walks keep 8; the product-quantised walk fits 3 per SIMD)
+constexpr uint32_t VIS_MAX_REGIONS = 3072;  // 12 waves on each of 256 CUs: the product-quantised walk (3 per SIMD)
+constexpr uint32_t VIS_ROW_REGIONS = 2048;  // 8 waves per CU: the row walks and the builder
 
 // (Re)allocate the HBM visited set for the current slot capacity: one byte per slot and workgroup, zeroed, epochs reset.
 // Sized against a quarter of the device memory; if that buys fewer than one region per CU the LDS hash is used instead.
@@ -411,14 +411,17 @@ int ensure_visg(Hnsw* x) {
   // search that wants the byte map passes through here first, so a re-allocation can never race a traversal that uses it.
   std::lock_guard<std::mutex> vg(x->vis_mu);
   const uint64_t stride = (std::max<uint64_t>(x->cap, 1) + 1023) & ~1023ull;
-  if (x->vis_stride == stride) return COLTT_OK;
+  // the row walks keep at most 8 traversals per CU (2048 regions); the product-quantised walk fits up to 12 (3072): only an index that carries a
+  // quantiser pays for those (10 M slots x 3072 regions pinned 30 GB instead of 20 for everybody)
+  const uint32_t want_max = x->pq_on ? VIS_MAX_REGIONS : VIS_ROW_REGIONS;
+  if (x->vis_stride == stride && x->vis_want == want_max) return COLTT_OK;
   if (x->w_visg.p) { (void)hipFree(x->w_visg.p); x->w_visg.p = nullptr; x->w_visg.cap = 0; }
   size_t free_b = 0, total_b = 0;
   COLTT_HIP(hipMemGetInfo(&free_b, &total_b));
   uint64_t budget = std::min<uint64_t>(total_b / 4, free_b / 2);
   if (policy().visg_budget_mb >= 0) budget = std::min<uint64_t>(budget, (uint64_t)policy().visg_budget_mb << 20);  // test knob
-  const uint64_t regions = std::min<uint64_t>(VIS_MAX_REGIONS, budget / stride);
-  x->vis_stride = stride;
+  const uint64_t regions = std::min<uint64_t>(want_max, budget / stride);
+  x->vis_stride = stride; x->vis_want = want_max;
   x->vis_regions = 0;
   x->vis_busy.clear();
   if (regions < 256) {
@@ -426,9 +429,9 @@ int ensure_visg(Hnsw* x) {
                     "visited set for ef > %d as well\n", (unsigned long long)regions, (unsigned long long)stride, (unsigned long long)budget, COLTT_VISG_MIN_EF);
     return COLTT_OK;
   }
-  if (regions < VIS_MAX_REGIONS)
+  if (regions < want_max)
     fprintf(stderr, "[coltt_gpu] hnsw: HBM visited workspace capped at %llu of %u regions (%llu B each, budget %llu B): fewer resident "
-                    "traversals per launch\n", (unsigned long long)regions, VIS_MAX_REGIONS, (unsigned long long)stride, (unsigned long long)budget);
+                    "traversals per launch\n", (unsigned long long)regions, want_max, (unsigned long long)stride, (unsigned long long)budget);
   COLTT_TRY(x->w_visg.reserve(regions * stride));
   COLTT_TRY(x->w_vepoch.reserve(VIS_MAX_REGIONS * 4));
   COLTT_HIP(hipMemsetAsync(x->w_visg.p, 0, regions * stride, x->stream));
@@ -982,7 +985,8 @@ int pq_search_once(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_
   // 2 048 waves: every launch as long as its slowest traversal, profiles/r05i_bench_kernel_stats_by_grid.csv); at most 32 768 queries (the re-rank's grid.y)
   const uint32_t lsh = pq_lut_shift(x);
   const size_t lut_q = ((size_t)x->pq_row << lsh) * 2;
-  const size_t group = std::max<size_t>(1, std::min<size_t>({nq, (256ull << 20) / lut_q, (size_t)32768}));
+  // ... and the survivors' slots + exact keys (12 bytes per result-set entry and query) stay under 256 MiB as well (1.5 GB per pooled context at ef 4096)
+  const size_t group = std::max<size_t>(1, std::min<size_t>({nq, (256ull << 20) / lut_q, (256ull << 20) / ((size_t)sg.ef_pad * 12), (size_t)32768}));
   COLTT_TRY(c->w_pack.reserve(group * lut_q + group * 4));   // the tables, then one word per query: its table's maximum (pq.hip: table scale)
   COLTT_TRY(c->w_surv.reserve(group * sg.ef_pad * 4)); COLTT_TRY(c->w_scnt.reserve(group * 4)); COLTT_TRY(c->w_keys.reserve(group * sg.ef_pad * 8));
   COLTT_TRY(c->w_misc.reserve(256));
@@ -1206,7 +1210,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
     x->n += b; x->live += b; x->n_upper += up; i += b;
   }
   COLTT_HIP(hipStreamSynchronize(x->stream));
-  return sync_rows8(x);
+  return sync_pq(x);
 }
 
 // the derived neighbour-norm rows of every slot (bulk installs; Insert / Remove maintain them incrementally in their kernels)
@@ -1404,7 +1408,7 @@ int coltt_hnsw_bulk_load(coltt_handle_t h, uint64_t n, const uint64_t* ids, cons
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_rows8(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_pq(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   return COLTT_OK;
 }
 
@@ -1534,7 +1538,7 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
     }
     return COLTT_OK;
   };
-  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_rows8(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
+  if (n) { int rc = upload_vectors(); if (rc == COLTT_OK) rc = fill_adj_norms(x.get()); if (rc == COLTT_OK) rc = sync_pq(x.get()); if (rc != COLTT_OK) { make_empty(x.get()); return rc; } }
   if (out_n) *out_n = n;
   for (uint64_t i = 0; i < n && i < cap_n; i++) {
     if (out_ids) out_ids[i] = ids[i];
@@ -1909,7 +1913,8 @@ int coltt_hnsw_pq_attach(coltt_handle_t h, coltt_handle_t pq) {
   COLTT_HIP(hipStreamSynchronize(x->stream));
   x->pq_shape = sh; x->pq_row = row; x->pq_done = 0; x->pq_on = true;
   if (x->pq_codes.p) COLTT_HIP(hipMemsetAsync(x->pq_codes.p, 0, x->pq_codes.cap, x->stream));
-  const int rc = sync_pq(x.get());
+  int rc = sync_pq(x.get());
+  if (rc == COLTT_OK && x->vis_stride != 0) rc = ensure_visg(x.get());   // (exclusive lock: no traversal holds a region) 2048 -> 3072 regions for the table walk
   if (rc != COLTT_OK) x->pq_on = false;
   return rc;
 }

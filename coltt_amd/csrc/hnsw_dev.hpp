@@ -132,12 +132,11 @@ __device__ __forceinline__ void vis_clear(WaveCtx& w, int lane) {
 // 22.81 / 47.37 / 174.6, U = 12 22.06 / 43.89 / 165.6, U = 8 23.75 / 46.83 / 176.2.  Hence 12 for f32 rows in every profile.
 // 2-byte rows: the LDS-visited kernel runs 1 wave per SIMD and keeps a WHOLE 768-dim row in flight (U = 48, 13.15 -> 11.88 ms at
 // 2 M x 768); the HBM-visited kernels run 2 waves per SIMD and must stay under 256 registers (U = 24).
-enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_HBM_DEEP = 4, PROF_RERANK = 8 };
+enum { PROF_BUILD = 0, PROF_SEARCH_LDS = 1, PROF_SEARCH_HBM = 2, PROF_SEARCH_HBM_DEEP = 4 };
 #ifndef COLTT_U_F32      // measurement knob: burst depth of f32 rows, all profiles
 #define COLTT_U_F32 12
 #endif
 template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst_depth() {
-  if (PROFILE == PROF_RERANK) return 8;   // hnsw_pq.hpp: a few hundred exact evaluations behind a walk whose occupancy the register count decides
   if (QUANT == Q_NONE) return COLTT_U_F32;
   if (PROFILE == PROF_SEARCH_HBM_DEEP) return 48;   // one wave per SIMD: a whole 2-byte row in flight
   return PROFILE == PROF_SEARCH_LDS ? 48 : 24;

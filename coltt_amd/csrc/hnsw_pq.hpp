@@ -19,7 +19,7 @@
 // centroid pieces have norm <= 1), so its f32 bits order as unsigned integers — the key order of the walk.
 //
 // One wave per query.  LDS: [the query's table | result set | visited hash (small ef; above it the byte map in HBM, no Bloom filter)].  The walk writes its survivors to HBM; the exact re-rank is
-// two kernels of its own (hnsw.hip: hnsw_pq_rerank_kernel — one wave per 32 survivors, deep bursts — and hnsw_pq_select_kernel).
+// two kernels of its own (hnsw_kernels.hpp: hnsw_pq_rerank_kernel — one wave per 32 survivors, the HBM-visited walks' burst profile — and hnsw_pq_select_kernel).
 // The table is what bounds occupancy: mp16 x C' x 2 bytes per resident traversal, C' = the centroid count rounded up to a power of two
 // (m = 32 x 256 centroids: 16 KiB; m = 96 x 256: 48 KiB; m = 64 x 16 — the same 256 bits per row as 32 x 256 — 2 KiB).  Measured with f32 tables
 // (profiles/r05b_hnswpq_probe_10m.jsonl, 10 M x 768 f16): the walk is a chain of dependent round trips (~5 us per expansion), its
@@ -97,6 +97,10 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
 #define COLTT_PQ_RADJ 0
 #endif
   static constexpr bool RADJ = SPEC || (NBR && COLTT_PQ_RADJ != 0);
+#ifndef COLTT_PQ_SETCACHE   // A/B knob: the walk keeps the head / tail windows of its result set's main array in registers (hnsw_walk2.hpp: SETCACHE)
+#define COLTT_PQ_SETCACHE 1
+#endif
+  static constexpr bool SETCACHE = COLTT_PQ_SETCACHE != 0;
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
   static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }

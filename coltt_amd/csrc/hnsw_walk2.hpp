@@ -88,6 +88,25 @@ __device__ __forceinline__ float eval_pair_n(const GraphView& g, const WaveCtx& 
   else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
 }
 
+// a < b for two WAVE-UNIFORM 64-bit keys (d bits << 32 | slot << 1 | expanded), on the scalar unit: the distance words decide unless they are equal
+// (hipcc compares uniform 64-bit integers on the VALU — two v_mov, v_cmp_lt_u64, then s_and / s_cselect behind the VALU's latency — six to eight times
+// per expansion of the large-ef walks)
+// MEASURED (GPU call H, profiles/r06h_setcache_keylt_ab.md): with the scalar form the operating-point row walk lost 11 % (126.1 against 141.6 k queries/s on one
+// box) — the select chains lengthen the scalar dependence of every pop, and the register allocation of the eight-lane walk moved with them.  The
+// compiler's own form is the default; -DCOLTT_KEY_SCALAR=1 is the A/B partner.
+#ifndef COLTT_KEY_SCALAR
+#define COLTT_KEY_SCALAR 0
+#endif
+__device__ __forceinline__ bool key_lt(unsigned long long a, unsigned long long b) {
+#if COLTT_KEY_SCALAR
+  const uint32_t ah = (uint32_t)(a >> 32), bh = (uint32_t)(b >> 32);
+  return ah != bh ? ah < bh : (uint32_t)a < (uint32_t)b;
+#else
+  return a < b;
+#endif
+}
+__device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b) { return key_lt(b, a) ? b : a; }
+
 // The delta: one (hi, lo) key per lane, lanes [0, n) valid and ASCENDING by key (bit 0 of lo = expanded; slots are distinct, so bit 0 never
 // decides an order); lanes >= n hold stale values.  n is wave-uniform.  Every member function is called by all 64 lanes.
 struct Delta {
@@ -163,8 +182,33 @@ __device__ __forceinline__ void delta_flush(unsigned long long* res, uint32_t& l
 }
 
 // Drop the `e` largest members of main ∪ delta ("keep the ef smallest").
-__device__ __forceinline__ void evict_largest(const unsigned long long* res, uint32_t& len, Delta& dl, uint32_t e, int lane) {
+// The main array's TAIL held in registers across expansions (SETCACHE walks): lane t holds res[tb + t] as it was when the window was loaded.  Nothing but
+// a flush adds to or reorders the main array, evictions only shorten it from the end, and the `expanded` bit a pop sets later is masked wherever the
+// window is read — so the window stays usable until a flush (invalidate) or until more than its 64 entries have been evicted (reload).
+struct TailWin {
+  unsigned long long e; uint32_t tb; bool valid;
+  __device__ __forceinline__ void load(const unsigned long long* res, uint32_t len, int lane) {
+    tb = len > 64u ? len - 64u : 0u;
+    e = tb + (uint32_t)lane < len ? res[tb + lane] : 0ull;
+    valid = true;
+  }
+  // the largest main member with the expanded bit cleared (0 when the array is empty)
+  __device__ __forceinline__ unsigned long long last(const unsigned long long* res, uint32_t len, int lane) {
+    if (!len) return 0ull;
+    if (!valid || len <= tb) load(res, len, lane);   // wave-uniform
+    return readlane_u64(e, (int)(len - 1u - tb)) & ~1ull;
+  }
+};
+__device__ __forceinline__ void evict_largest(const unsigned long long* res, uint32_t& len, Delta& dl, uint32_t e, int lane, TailWin* tw = nullptr) {
   // the main array's tail in registers: lane t holds res[tb + t]; at most 32 members leave per call
+  if (tw) {
+    for (uint32_t t = 0; t < e; t++) {
+      const unsigned long long mt = tw->last(res, len, lane);
+      if (dl.n && (!len || key_lt(mt, dl.max_key()))) dl.n--;   // the largest member is the delta's last lane
+      else len--;
+    }
+    return;
+  }
   const uint32_t tb = len > 64u ? len - 64u : 0u;
   const unsigned long long treg = tb + (uint32_t)lane < len ? res[tb + lane] : 0ull;
   for (uint32_t t = 0; t < e; t++) {
@@ -181,6 +225,7 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
   static constexpr bool SPEC = false;        // no speculation on the next expansion's inputs (see AdcEval, hnsw_pq.hpp)
   static constexpr bool RADJ = false;        // the runner-up's adjacency row is not requested at pop time
   static constexpr bool ROWPF = false;       // no per-neighbour input addressed by (candidate, position) (see AdcEval<.., NBR>, hnsw_pq.hpp)
+  static constexpr bool SETCACHE = false;    // the head / tail windows of the main array are not cached in registers (register budget of the row walks)
   static constexpr bool EARLY = false;       // distances are computed for the fresh neighbours only, after the visited test
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
@@ -217,6 +262,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr bool RADJ = false;
   static constexpr bool ROWPF = false;
   static constexpr bool EARLY = false;
+  static constexpr bool SETCACHE = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
@@ -338,6 +384,8 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   uint32_t len = 1;
   uint32_t scan_lo = 0;   // every main-array member before this index is expanded (pop scans start at its 64-entry chunk)
   Delta dl; dl.clear();
+  unsigned long long hwin = 1ull; uint32_t hb = 0; bool hvalid = false;   // SETCACHE: the head window (pop)
+  TailWin twin; twin.e = 0ull; twin.tb = 0; twin.valid = false;           // SETCACHE: the tail window (lowerBound, eviction)
   uint32_t pre_slot = NBR_NONE, pre_nb = NBR_NONE; float pre_nn = 0.f;
   // SPEC evaluators (small per-neighbour inputs: hnsw_pq.hpp): when the next candidate is predicted to be the runner-up — whose adjacency row was
   // requested at pop time and has arrived by the end of the expansion — the visited bytes and the evaluator's inputs of ITS neighbours are requested
@@ -353,18 +401,39 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     const int half = lane & 1, p = lane >> 1;
     // ---- pop: the smallest unexpanded member of main ∪ delta (cj = the unexpanded main member after the first one).  The keys come out of
     // the registers the scan loaded its chunk into (v_readlane), not out of a second, dependent LDS read.
+    typedef typename std::remove_reference<EVAL>::type eval_t;
+    constexpr bool CACHE = DELTA && eval_t::SETCACHE;
     int ci = -1, cj = -1;
     unsigned long long kci = ~0ull, kcj = ~0ull;
-    for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
-      const uint32_t i = base + lane;
-      const unsigned long long e = i < len ? res[i] : 1ull;
-      unsigned long long m = __ballot(!(e & 1ull));
-      if (m) {
-        const int l0 = __builtin_ctzll(m);
-        ci = (int)base + l0; kci = readlane_u64(e, l0);
-        m &= m - 1;
-        if (m) { const int l1 = __builtin_ctzll(m); cj = (int)base + l1; kcj = readlane_u64(e, l1); }
-        break;
+    if constexpr (CACHE) {
+      // SETCACHE: the 64-entry chunk that holds the first unexpanded main member stays in registers from pop to pop (hwin, base hb): only a flush changes
+      // the array's members (it invalidates the window), a pop's `expanded` bit is set in the register too, evictions are a compare against len
+      for (;;) {
+        const uint32_t want = scan_lo & ~63u;
+        if (want >= len) break;
+        if (!hvalid || hb != want) { hb = want; hwin = hb + (uint32_t)lane < len ? res[hb + lane] : 1ull; hvalid = true; }
+        unsigned long long m = __ballot(!(hwin & 1ull) && hb + (uint32_t)lane < len);
+        if (m) {
+          const int l0 = __builtin_ctzll(m);
+          ci = (int)hb + l0; kci = readlane_u64(hwin, l0);
+          m &= m - 1;
+          if (m) { const int l1 = __builtin_ctzll(m); cj = (int)hb + l1; kcj = readlane_u64(hwin, l1); }
+          break;
+        }
+        scan_lo = hb + 64u;   // every member of this chunk is expanded
+      }
+    } else {
+      for (uint32_t base = scan_lo & ~63u; base < len; base += 64) {
+        const uint32_t i = base + lane;
+        const unsigned long long e = i < len ? res[i] : 1ull;
+        unsigned long long m = __ballot(!(e & 1ull));
+        if (m) {
+          const int l0 = __builtin_ctzll(m);
+          ci = (int)base + l0; kci = readlane_u64(e, l0);
+          m &= m - 1;
+          if (m) { const int l1 = __builtin_ctzll(m); cj = (int)base + l1; kcj = readlane_u64(e, l1); }
+          break;
+        }
       }
     }
     unsigned long long kd = ~0ull; int dlane = -1;
@@ -377,21 +446,20 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     if constexpr (VISMODE == VIS_LDS) {
       if (vis_count + 64 > (w.hcap >> 2) * 3) { w.err |= 8u; break; }   // the table would need the reset path: give up, the host re-runs the call on the one-wave kernel
     }
-    const bool from_delta = kd < kci;
+    const bool from_delta = key_lt(kd, kci);
     const unsigned long long ce = from_delta ? kd : kci;
     unsigned long long runner_key = ~0ull;
     if constexpr (PREF) {
       if (from_delta) {
         const unsigned long long u2 = d_un & (d_un - 1ull);   // the delta's second unexpanded member
         const unsigned long long kd2 = u2 ? dl.key_at(__builtin_ctzll(u2)) : ~0ull;
-        runner_key = kci < kd2 ? kci : kd2;
+        runner_key = key_min(kci, kd2);
       } else {
-        runner_key = kcj < kd ? kcj : kd;
+        runner_key = key_min(kcj, kd);
       }
     }
     // evaluators that fetch the chunk's adjacency rows with its vectors (hnsw_lat.hpp): the only adjacency row that can be
     // needed next and is not on chip then is the runner-up's — requested now, it flies during the whole expansion
-    typedef typename std::remove_reference<EVAL>::type eval_t;
     uint32_t runner_nb = NBR_NONE;
     if constexpr (eval_t::RADJ && PREF) {
       if (runner_key != ~0ull && (uint32_t)p < g.mMax0) runner_nb = g.adj0[(size_t)((uint32_t)runner_key >> 1) * g.mMax0 + p];
@@ -402,12 +470,18 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     int best_src = -1;   // lane of the smallest key admitted in this expansion's (single) chunk
     COLTT_PT(w, 0)  // pop
     // lowerBound: the distance of the largest member, sampled once per pop (hnsw.go:357)
-    unsigned long long worst = len ? (res[len - 1] & ~1ull) : 0ull;
-    if constexpr (DELTA) { const unsigned long long dmx = dl.max_key(); worst = dmx > worst ? dmx : worst; }
+    unsigned long long worst;
+    if constexpr (CACHE) worst = twin.last(res, len, lane);
+    else worst = len ? (res[len - 1] & ~1ull) : 0ull;
+    if constexpr (DELTA) { const unsigned long long dmx = dl.max_key(); worst = key_lt(worst, dmx) ? dmx : worst; }
     const float lower_bound = __uint_as_float((uint32_t)(worst >> 32));
     wave_sync();
     if (from_delta) { if (lane == dlane) dl.lo |= 1u; }
-    else { if (lane == 0) res[ci] = ce | 1ull; scan_lo = (uint32_t)ci + 1; }
+    else {
+      if (lane == 0) res[ci] = ce | 1ull;
+      if constexpr (CACHE) { if ((uint32_t)lane == (uint32_t)ci - hb) hwin |= 1ull; }
+      scan_lo = (uint32_t)ci + 1;
+    }
     const uint32_t cslot = (uint32_t)ce >> 1;
     uint32_t free_slots = ef - (len + dl.n);  // the set never exceeds ef
     w.n_exp++;
@@ -421,7 +495,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     unsigned long long best_new = ~0ull;
 #define COLTT_PREFETCH_NEXT2()                                                                       \
     if constexpr (PREF) {                                                                            \
-      const unsigned long long nk_ = runner_key < best_new ? runner_key : best_new;                  \
+      const unsigned long long nk_ = key_min(runner_key, best_new);                                  \
       if (nk_ != ~0ull) {                                                                            \
         pre_slot = (uint32_t)nk_ >> 1;                                                               \
         if (eval_t::RADJ && width <= 32 && runner_key < best_new) pre_nb = runner_nb;                \
@@ -527,15 +601,15 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
               while (am) {
                 const int j = __builtin_ctzll(am); am &= am - 1;
                 const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)khi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
-                if (kj < mn) { mn = kj; bl = j; }
+                if (key_lt(kj, mn)) { mn = kj; bl = j; }
               }
             } else bl = wave_argmin_key(adm, khi, klo, mn);
-            if (mn < best_new) { best_new = mn; best_src = bl; }
+            if (key_lt(mn, best_new)) { best_new = mn; best_src = bl; }
           }
         }
         if (last_chunk) { COLTT_PREFETCH_NEXT2() }
         if (m == 0) continue;
-        if (dl.n + m > 64u) delta_flush(res, len, dl, scan_lo, lane);
+        if (dl.n + m > 64u) { delta_flush(res, len, dl, scan_lo, lane); hvalid = false; twin.valid = false; }
         {
           unsigned long long am = A;
           while (am) {
@@ -544,7 +618,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
           }
         }
         const uint32_t total = len + dl.n;
-        if (total > ef) evict_largest(res, len, dl, total - ef, lane);
+        if (total > ef) { if constexpr (CACHE) evict_largest(res, len, dl, total - ef, lane, &twin); else evict_largest(res, len, dl, total - ef, lane); }
         COLTT_PT(w, 4)  // admission + eviction (+ the occasional flush)
       } else {
         uint32_t myrank = 0;  // rank of my key among the admitted ones (readlane broadcasts: no LDS round trips)

@@ -525,7 +525,7 @@ int launch_scan(Pq* p, PCtx* c, uint64_t b, uint64_t e, int nq, const float* lut
 // one group of <= PQ_GROUP queries: tables, candidate lists and the selection's state are sized by the group, not by the call
 constexpr size_t PQ_GROUP = 256;
 int pq_search_group(Pq* p, PCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
-                    uint32_t* out_counts, bool out_on_device) {
+                    uint32_t* out_counts, bool out_on_device, float* acc_ms) {
   const float* d_q = queries;
   if (!q_on_device) {
     COLTT_TRY(c->w_q.reserve(nq * p->dim * 4));
@@ -594,7 +594,7 @@ int pq_search_group(Pq* p, PCtx* c, const float* queries, bool q_on_device, size
   }
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-  p->last_ms.store(p->last_ms.load() + ms);
+  if (acc_ms) *acc_ms += ms;   // (summed by the call, stored once: concurrent searches share the object under a read lock)
   if (timed_scan) { float sms = 0.f; (void)hipEventElapsedTime(&sms, c->evs0, c->evs1); p->last_scan_ms.store(sms); }
   return COLTT_OK;
 }
@@ -606,11 +606,12 @@ int pq_search_common(Pq* p, PCtx* c, const float* queries, bool q_on_device, siz
   if (k == 0 || k > K_MAX) return fail(COLTT_E_UNSUPPORTED, "pq search: k=%u outside [1,%u]", k, K_MAX);
   if (nq == 0) return COLTT_OK;
   if (!p->trained) return fail(COLTT_E_INVALID, "pq search: the quantiser has no codebooks yet (coltt_pq_set_codebooks / coltt_pq_train)");
-  p->last_ms.store(0.f);
+  float total_ms = 0.f;
   for (size_t q0 = 0; q0 < nq; q0 += PQ_GROUP) {
     const size_t gn = std::min(PQ_GROUP, nq - q0);
-    COLTT_TRY(pq_search_group(p, c, queries + q0 * p->dim, q_on_device, gn, k, out_ids + q0 * k, out_scores + q0 * k, out_counts + q0, out_on_device));
+    COLTT_TRY(pq_search_group(p, c, queries + q0 * p->dim, q_on_device, gn, k, out_ids + q0 * k, out_scores + q0 * k, out_counts + q0, out_on_device, &total_ms));
   }
+  p->last_ms.store(total_ms);
   return COLTT_OK;
 }
 

@@ -1,4 +1,6 @@
-// rows8.hpp — "eight lanes per row": a second, line-transposed copy of the stored vectors and the distance core that walks it.
+// rows8.hpp — "eight lanes per row": the LINE-TRANSPOSED layout of an index's stored vectors and the distance core that walks it.  (Rounds 3-4 kept a
+// second, transposed COPY; since round 5 `rows` itself is stored in this layout for the shapes below — the index's ONE row array — and every host
+// read-back un-permutes through r8_index.  "rows8" below = the row array in that layout.)
 //
 // Why (profiles/r03_gather_*.jsonl, r03_pmc_walk_utcl*.csv): with a row owned by a lane PAIR (exact.hpp) one load
 // instruction of a wave touches 32 rows x 32 bytes — 32 different cache lines and 32 translations, and a line is complete only after
@@ -15,9 +17,9 @@
 // as the pair-owned walk, hence the same bits.  The query is staged in LDS with the same permutation (qp), so lane r reads its S
 // query elements of a line with one (f32 rows) or two (2-byte rows) ds_read_b128.
 //
-// rows8 is DERIVED data (like adj0_n): written by the index's writers right after the canonical rows, never read back by the host,
-// not part of any stream format.  It exists for f32 / 2-byte rows whose byte length is a multiple of 128 (dim % 32 == 0 / dim % 64 == 0:
-// 128, 256, 512, 768, 1024, 1536 ...); other shapes keep the pair-owned walk.
+// The layout is an internal one: writers transpose at ingest (through a natural-order staging block), Commit / Get / fetch and the quantiser's Encode
+// un-permute element indexes, no stream format ever sees it.  It exists for f32 / 2-byte rows whose byte length is a multiple of 128 (dim % 32 == 0 /
+// dim % 64 == 0: 128, 256, 512, 768, 1024, 1536 ...; dim >= 256 by default); other shapes keep natural-order rows and the pair-owned walk.
 #pragma once
 #include "exact.hpp"
 

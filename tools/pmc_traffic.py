@@ -148,15 +148,91 @@ def main_pq(a):
     json.dump(table, open(a.out, "w"), indent=1)
 
 
+def fetch_cal(path, known):
+    """FETCH_SIZE of tools/micro/fetch_cal.hip's three kernels -> {pattern: factor / bytes per load}.  `known` = the JSON line the tool printed."""
+    per = collections.defaultdict(list); per_d = collections.OrderedDict()
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != "FETCH_SIZE":
+                continue
+            key = (r["Dispatch_Id"], r["Kernel_Name"])
+            per_d[key] = per_d.get(key, 0.0) + float(r["Counter_Value"])
+    for (_, name), v in per_d.items():
+        for k in ("block_kernel", "probe_kernel", "stream_kernel"):
+            if k in name:
+                per[k].append(v)
+    out = {}
+    for k, vals in per.items():
+        vals = vals[1:] if len(vals) > 1 else vals      # (the first launch touches cold pages)
+        kib = sum(vals) / len(vals)
+        if k == "block_kernel": out["block_factor"] = known["block_kernel_known_bytes_per_launch"] / (kib * 1024.0)
+        if k == "stream_kernel": out["stream_factor"] = known["stream_kernel_known_bytes_per_launch"] / (kib * 1024.0)
+        if k == "probe_kernel": out["probe_reported_bytes_per_load"] = kib * 1024.0 / known["probe_kernel_loads_per_launch"]
+    return out
+
+
+def main_hnswpq(a):
+    """`--hnswpq bench_full.json --cal-csv fetch_cal.csv --cal-json fetch_cal.out`: HBM bytes of the product-quantised walk's launches (hnsw_pq_search_kernel) in a
+    PMC pass over `bench.py --legs op`, with the counter calibrated PER ACCESS PATTERN on known byte counts (tools/micro/fetch_cal.hip):
+      neighbourhood blocks + adjacency rows   n_exp x (mMax0 x row + mMax0 x 4) bytes, reported at 1 / block_factor
+      visited probes                          the rest of what the kernel reports, at the probe pattern's reported bytes per load — one memory request per
+                                              4-byte probe, i.e. a whole sector of HBM traffic for one useful byte (granularity of random probes, not re-reads)."""
+    full = json.load(open(a.hnswpq))
+    pw = full["operating_point"]["pq_walk"]
+    nq = full["config"]["queries_per_step"]; n = full["config"]["n"]; dim = full["config"]["dim"]
+    pqv = pw["per_query"]; m = pw["m"]; row = (m + 15) // 16 * 16; width = 32
+    cal = fetch_cal(a.cal_csv, json.loads(open(a.cal_json).read().strip().splitlines()[-1]))
+    per_d = collections.OrderedDict()
+    with open(a.csv, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == "FETCH_SIZE" and "hnsw_pq_search_kernel" in r["Kernel_Name"]:
+                key = (r["Dispatch_Id"], int(r["Grid_Size"]))
+                per_d[key] = per_d.get(key, 0.0) + float(r["Counter_Value"])
+    if not per_d:
+        sys.exit("no hnsw_pq_search_kernel dispatches with FETCH_SIZE in " + a.csv)
+    vals = [v for (_, g), v in per_d.items() if g >= 64 * 1024]                 # the 10 000-query launches fill the persistent grid (>= 1024 waves); single-query calls do not
+    best = []
+    for v0 in vals:     # the timed steps: the largest group of launches whose counter values agree within 2 % (the ef sweep uses other ef)
+        grp = [v for v in vals if abs(v - v0) <= 0.02 * v0]
+        if len(grp) > len(best):
+            best = grp
+    raw = sum(best) / len(best) * 1024.0                                       # reported bytes per launch
+    blocks_true = pqv["n_exp"] * (width * row + width * 4) * nq                # what the walk must read of blocks + adjacency rows
+    blocks_raw = blocks_true / cal["block_factor"]
+    probes_raw = max(0.0, raw - blocks_raw)
+    probes = pqv["n_dist"] * nq
+    algorithmic = blocks_true + probes * 4
+    # a probe is ONE request of at least the reported size; taken at what is reported (a lower bound of the bytes moved)
+    traffic = blocks_true + probes_raw
+    table = json.load(open(a.out)) if os.path.exists(a.out) else {}
+    key = f"hnswpq n={n} dim={dim} m={m} centroids={pw['centroids']} ef={pw['ef']} queries={nq}"
+    table[key] = {"hbm_bytes_per_launch": traffic, f"FETCH_SIZE_bytes_reported_mean_of_{len(best)}_launches": raw,
+                  "calibration": dict(cal, source=os.path.basename(a.cal_csv)),
+                  "model": {"blocks_and_adjacency_bytes": blocks_true, "reported_for_them": blocks_raw, "reported_for_probes_and_the_rest": probes_raw,
+                            "probes": probes, "reported_bytes_per_probe": probes_raw / probes},
+                  "algorithmic_bytes_per_launch": algorithmic, "traffic_over_algorithmic": traffic / algorithmic,
+                  "traffic_over_algorithmic_blocks_only": 1.0,
+                  "note": "the walk kernel alone (the re-rank streams rows: x2 as every 16 B/lane stream); blocks are read once each, contiguous; what exceeds the "
+                          "algorithmic bytes is the visited byte map: one memory request per probed byte",
+                  "source": os.path.basename(a.csv), "dispatches_used": len(best)}
+    print(key, "->", json.dumps(table[key], indent=1))
+    json.dump(table, open(a.out, "w"), indent=1)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("csv")
+    ap.add_argument("--hnswpq", help="HNSW-over-PQ mode: bench_full.json of the profiled run (operating_point.pq_walk holds the counters)")
+    ap.add_argument("--cal-csv", help="--hnswpq: counter CSV of a pass over tools/micro/fetch_cal")
+    ap.add_argument("--cal-json", help="--hnswpq: the JSON line fetch_cal printed in that pass")
     ap.add_argument("--pq", help="PQ mode: n,dim,m of the product-quantised store whose single-query scans were profiled")
     ap.add_argument("--bench-json", help="file holding the JSON line bench.py printed in the same run (hnsw mode)")
     ap.add_argument("--leg", default="headline", choices=["headline", "op"], help="which HNSW leg of the bench line (hnsw mode)")
     ap.add_argument("--flat", nargs="*", help="FLAT mode: the n,dim,quant,batch cases of the tools/flat_ab.py run that was profiled")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     a = ap.parse_args(argv)
+    if a.hnswpq:
+        return main_hnswpq(a)
     if a.flat:
         return main_flat(a)
     if a.pq:
