@@ -97,8 +97,11 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
 #define COLTT_PQ_RADJ 0
 #endif
   static constexpr bool RADJ = SPEC || (NBR && COLTT_PQ_RADJ != 0);
-#ifndef COLTT_PQ_SETCACHE   // A/B knob: the walk keeps the head / tail windows of its result set's main array in registers (hnsw_walk2.hpp: SETCACHE)
-#define COLTT_PQ_SETCACHE 1
+  // A/B knob: the walk keeps the head / tail windows of its result set's main array in registers (hnsw_walk2.hpp: SETCACHE) — three LDS round trips
+  // fewer per expansion, exact (154 GPU tests + 460 randomised rounds with it on), and NOT faster: 403.1 against 408.9 k queries/s (call I; separate
+  // processes on one box differ by +-5 % on identical code, so "no gain" is all that can be said).  Off.
+#ifndef COLTT_PQ_SETCACHE
+#define COLTT_PQ_SETCACHE 0
 #endif
   static constexpr bool SETCACHE = COLTT_PQ_SETCACHE != 0;
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row

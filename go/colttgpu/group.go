@@ -8,6 +8,7 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
 	"unsafe"
 )
 
@@ -201,14 +202,31 @@ func (g *Group) SearchBegin(queries []float32, nq int, k uint32, sel, mode int, 
 		p.free()
 		return nil, err
 	}
+	// A batch that is never Ended must not leak its three C blocks — nor free them while the group's exchange thread may still write into them
+	// (ADVICE r5): the finalizer waits for the batch (Close) before it frees.
+	runtime.SetFinalizer(p, func(q *PendingSearch) { q.Close() })
 	return p, nil
 }
 
 func (p *PendingSearch) free() {
+	if p.ids == nil {
+		return
+	}
 	C.free(unsafe.Pointer(p.ids))
 	C.free(unsafe.Pointer(p.scores))
 	C.free(unsafe.Pointer(p.counts))
 	p.ids, p.scores, p.counts = nil, nil, nil
+	runtime.SetFinalizer(p, nil)
+}
+
+// Close abandons a batch: it waits until the library has finished writing the batch's answers (the ticket is consumed, its error ignored) and
+// frees the C blocks.  End calls it implicitly; after End or Close it does nothing.
+func (p *PendingSearch) Close() {
+	if p.ids == nil {
+		return
+	}
+	_ = call(func() C.int { return C.coltt_group_search_end(p.g.h, p.ticket) })
+	p.free()
 }
 
 // End blocks until the batch's merged answers are complete and returns them (rows ascending by (score, id)).

@@ -125,7 +125,10 @@ def main():
         crank[torch.argsort((cent.float() @ cent[0].float()), descending=True).cpu().numpy()] = np.arange(nc)
         return np.argsort(crank[cid], kind="stable")
 
-    for arm, make in (("cluster order", cluster_order), ("bfs order", lambda: bfs_order(raw["adj0"], int(raw["entry"])))):
+    # "same order" = the control: the graph as built, exported and bulk-loaded like the permuted twins (another set of allocations, nothing renumbered)
+    arms = {"same order": lambda: np.arange(n, dtype=np.int64), "cluster order": cluster_order, "bfs order": lambda: bfs_order(raw["adj0"], int(raw["entry"]))}
+    want = [a for a in os.environ.get("SLOT_ARMS", "same order,cluster order,bfs order").split(",") if a in arms]
+    for arm, make in [(a, arms[a]) for a in want]:
         t0 = time.time()
         order = make()                                            # new slot i <- old slot order[i]
         g2 = permute_graph(g, order)
