@@ -222,3 +222,45 @@ def test_one_row_array_serves_every_reader(gpu, monkeypatch):
         assert np.array_equal(a.PqCodes(), b.PqCodes())
         pa = a.PqSearch(Q, 10, ef=64, with_stats=True); pb = b.PqSearch(Q, 10, ef=64, with_stats=True)
         assert np.array_equal(pa[0], pb[0]) and np.array_equal(bits(pa[1]), bits(pb[1])) and pa[3] == pb[3]
+
+
+def test_neighbourhood_blocks_follow_every_mutation_and_equal_the_gathered_walk(gpu, monkeypatch):
+    """Round 6: the product-quantised walk reads NEIGHBOURHOOD BLOCKS — the code rows of a vertex's neighbours beside its adjacency row (derived data,
+    rebuilt lazily by the first search after a mutation).  After the attach, after Removes (tombstones + re-pruned rows) and after Inserts the walk must equal
+    the oracle's definition (ids, exact score bits, all four counters) — and the walk that gathers code rows by neighbour slot (COLTT_PQ_NBR=0) must return the
+    same bits, in the same process, on the same index."""
+    import torch
+    d, m, c, n, k = 64, 16, 32, 3000, 10
+    h, pq, pqm, rows, seen = _pq_case(gpu, n, d, gpu.EUCLIDEAN, gpu.Q_NONE, m, c, 6400)
+    h.PqAttach(pq)
+    cb = pq.Codebooks()
+    Q = O.fill_normal(6477, (32, d))
+
+    def check(tag):
+        codes = h.PqCodes(); g = h.ExportRaw(); rows_now = h.FetchRows(); ex = h.Export()
+        dl = np.packbits(ex["deleted"].astype(np.uint8), bitorder="little")
+        dl = np.concatenate([dl, np.zeros((-len(dl)) % 4, np.uint8)]).view(np.uint32) if ex["deleted"].any() else None
+        for ef, rr in ((300, 0), (300, 40), (200, 0)):     # the byte-map walk (ef > 128): the one that reads the blocks
+            sl, sc, cn, ost, _ = O.csr_search_pq(rows_now, O.Q_NONE, g["adj0"], g["upper_off"], g["adjU"], d, O.L2, g["entry"], g["entry_level"], codes, cb, pqm, Q, k, ef,
+                                                 rerank=rr, del_bits=dl)
+            got = {}
+            for nbr in ("1", "0"):
+                monkeypatch.setenv("COLTT_PQ_NBR", nbr)
+                gi, gs, gc, st = h.PqSearch(Q, k, ef=ef, rerank=rr, with_stats=True)
+                assert np.array_equal(gc, cn.astype(np.uint32)), (tag, ef, rr, nbr)
+                for qi in range(len(Q)):
+                    want_ids = ex["ids"][sl[qi, :cn[qi]]]
+                    assert np.array_equal(gi[qi, :gc[qi]], want_ids), (tag, ef, rr, nbr, qi)
+                    assert np.array_equal(gs[qi, :gc[qi]].view(np.uint32), sc[qi, :cn[qi]].view(np.uint32)), (tag, ef, rr, nbr, qi)
+                assert st == ost, (tag, ef, rr, nbr, st, ost)
+                got[nbr] = (gi.copy(), gs.view(np.uint32).copy())
+            assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1], got["0"][1])
+        monkeypatch.delenv("COLTT_PQ_NBR")
+
+    check("after attach")
+    for i in range(0, 120, 3): h.Remove(i)                                   # tombstones; the neighbours' rows are re-pruned
+    check("after removes")
+    X2 = O.fill_normal(6499, (150, d)); lv2 = O.levels(6500, 150)
+    x2 = torch.from_numpy(X2).to("cuda:0"); torch.cuda.synchronize()
+    h.InsertBatchDevice(x2.data_ptr(), 150, lv2, batch=8, first_id=n)
+    check("after inserts")
