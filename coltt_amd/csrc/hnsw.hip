@@ -46,11 +46,16 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
                                                               uint32_t* __restrict__ counter, uint32_t* __restrict__ req_count,
                                                               BuildReq* __restrict__ req, uint32_t* __restrict__ head,
                                                               unsigned long long* __restrict__ stats, uint8_t* __restrict__ visg,
-                                                              size_t vis_stride, uint32_t* __restrict__ vis_epoch) {
+                                                              size_t vis_stride, uint32_t* __restrict__ vis_epoch,
+                                                              uint32_t diverse /* 0 | 1 | 3 = keepPruned */, uint32_t ext_off) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   WaveCtx w;
   size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  // diverse selection (algo 2): a second query buffer (the candidate's stored row), the chosen and the rejected keys — behind the walk's LDS
+  float* const qs2 = reinterpret_cast<float*>(smem + ext_off);
+  unsigned long long* const sel = reinterpret_cast<unsigned long long*>(smem + ext_off + off);
+  unsigned long long* const prn = sel + 64;
   w.qs = reinterpret_cast<float*>(smem);
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off);
   w.vis = reinterpret_cast<uint32_t*>(w.res0 + (size_t)ef_pad);
@@ -83,8 +88,49 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
       w.n_dist += 1;
       search_level<METRIC, QUANT, VISG, PROF_BUILD, R8>(g, w, cur, curd, efc, l, lane, len, buf);
       const unsigned long long* res = w.res0 + (size_t)buf * ef_pad;
-      const uint32_t m = len < M ? len : M;
-      // the m nearest, re-ordered by slot (canonical row order)
+      uint32_t m = len < M ? len : M;
+      if (diverse) {
+        // algo 2 — NOT reference behaviour; the oracle's select_diverse (coltt_oracle.cpp) is the definition: walk the result set in
+        // ascending (distance, slot) order while fewer than M are chosen; a candidate is chosen iff no already chosen r has
+        // D(candidate as the query, r) < d(new vertex, candidate); every chosen r is evaluated (lane pair per r, side by side).
+        uint32_t ns = 0, np = 0;
+        for (uint32_t ci = 0; ci < len && ns < M; ci++) {
+          const int ln = opaque_lane(lane);
+          const int half = ln & 1, p = ln >> 1;
+          const unsigned long long ce = res[ci];
+          const uint32_t es = (uint32_t)ce >> 1;
+          const float ed = __uint_as_float((uint32_t)(ce >> 32));
+          bool bad = false;
+          if (ns) {
+            const uint8_t* crow = g.rows + (size_t)es * g.stride;
+            for (int t = ln; t < g.dim; t += 64) {
+              if constexpr (R8) qs2[t] = load1<QUANT>(crow, r8_index<QUANT>(t)); else qs2[t] = load1<QUANT>(crow, t);
+            }
+            const float qn2 = METRIC == M_COS ? g.norms[es] : 0.f;
+            wave_sync();
+            for (uint32_t c0 = 0; c0 < ns; c0 += 32) {
+              const uint32_t idx = c0 + (uint32_t)p;
+              const bool valid = idx < ns;
+              float dd = 0.f;
+              if (valid) dd = eval_pair_q<METRIC, QUANT, PROF_BUILD, R8>(g, qs2, qn2, (uint32_t)sel[idx] >> 1, half);
+              bad = bad || (valid && half == 0 && dd < ed);
+            }
+            w.n_dist += ns;
+          }
+          const bool rejected = __ballot(bad) != 0ull;
+          wave_sync();   // every lane is done with qs2 / sel before either is written again
+          if (!rejected) { if (ln == 0) sel[ns] = ce; ns++; }
+          else if (np < 64u) { if (ln == 0) prn[np] = ce; np++; }   // at most M <= 64 rejected ones can ever be re-added
+          wave_sync();
+        }
+        if (diverse & 2u) {   // heuristicKeepPruned: the rejected, nearest first, fill the row up to M
+          for (uint32_t i = 0; i < np && ns < M; i++) { if (lane == 0) sel[ns] = prn[i]; ns++; }
+          wave_sync();
+        }
+        m = ns;
+        res = sel;
+      }
+      // the m nearest (or the m chosen), re-ordered by slot (canonical row order)
       unsigned long long e = (uint32_t)lane < m ? res[lane] : ~0ull;
       uint32_t myslot = (uint32_t)e >> 1;
       float myd = __uint_as_float((uint32_t)(e >> 32));
@@ -106,7 +152,8 @@ __global__ __launch_bounds__(64) void hnsw_build_search_kernel(GraphView g, int3
         uint32_t old = atomicExch(&head[rid], r);
         req[r].rid = rid; req[r].from = vi; req[r].d = myd; req[r].next = old;
       }
-      // next level starts from the nearest result (hnsw.go:145 `entrypoint = neighbor`, last popped = nearest)
+      // next level starts from the nearest result (hnsw.go:145 `entrypoint = neighbor`, last popped = nearest; the nearest candidate is
+      // always chosen first by the diverse selection, so sel[0] == the result set's first member)
       unsigned long long e0 = res[0];
       cur = (uint32_t)e0 >> 1; curd = __uint_as_float((uint32_t)(e0 >> 32));
       wave_sync();
@@ -169,6 +216,144 @@ __global__ void hnsw_link_kernel(GraphView g, uint64_t cap_slots, const BuildReq
   if (lvl0 && g.adj0_n) {
     float* nrow = g.adj0_n + (size_t)rid * g.mMax0;
     for (uint32_t i = 0; i < W; i++) nrow[i] = i < n ? g.norms[s[i]] : 0.f;
+  }
+}
+
+// Phase B of the diverse mode (algo 2 — NOT reference behaviour; definition: the oracle's select_diverse + the batch rule of
+// hnsw_insert_batch): a row receives ALL the batch's links and is pruned ONCE if it overflows — drop the tombstoned neighbours; if the
+// live ones still do not fit, walk them in ascending (stored distance, slot) order and choose a candidate iff no already chosen r has
+// D(candidate's stored row as the query, r's stored row) < the candidate's stored distance, until W are chosen; keepPruned re-adds the
+// rejected, nearest first.  One WAVE per touched row (the owner request's wave; the others leave at once): candidates in LDS, the
+// candidate under test decoded into LDS as a query, the chosen rows evaluated side by side by lane pairs — the builder's own distance code.
+constexpr uint32_t LINKD_CAND = 1024;   // candidates per row (existing + the batch's links); more trips stats[4] |= 16 (lower the batch size)
+template <int METRIC, int QUANT, bool R8>
+__global__ __launch_bounds__(64) void hnsw_link_diverse_kernel(GraphView g, uint64_t cap_slots, const BuildReq* __restrict__ req, uint32_t n_req,
+                                                              uint32_t* __restrict__ head, uint32_t keep_pruned,
+                                                              unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t r = blockIdx.x;
+  if (r >= n_req) return;
+  if (req[r].next != NBR_NONE) return;
+  const int lane_in = threadIdx.x;
+  const size_t off = ((size_t)g.dim * 4 + 15) & ~(size_t)15;
+  float* const qs2 = reinterpret_cast<float*>(smem);
+  unsigned long long* const cand = reinterpret_cast<unsigned long long*>(smem + off);   // [LINKD_CAND] as gathered
+  unsigned long long* const sorted = cand + LINKD_CAND;                                  // [LINKD_CAND] ascending (d bits, slot)
+  unsigned long long* const sel = sorted + LINKD_CAND;                                   // [64] chosen
+  unsigned long long* const prn = sel + 64;                                              // [64] rejected (first W of them)
+  const uint32_t rid = req[r].rid;
+  const bool lvl0 = rid < cap_slots;
+  const uint32_t W = lvl0 ? g.mMax0 : g.mMax;
+  uint32_t* row = lvl0 ? g.adj0 + (size_t)rid * g.mMax0 : g.adjU + (size_t)(rid - cap_slots) * g.mMax;
+  float* drow = lvl0 ? g.adj0_d + (size_t)rid * g.mMax0 : g.adjU_d + (size_t)(rid - cap_slots) * g.mMax;
+  int lane = lane_in;
+  // ---- gather: the row's entries, then the chained requests (the chain is short: one lane walks it)
+  uint32_t n = 0;
+  {
+    const uint32_t sl = (uint32_t)lane < W ? row[lane] : NBR_NONE;
+    const float dl = (uint32_t)lane < W ? drow[lane] : 0.f;
+    const unsigned long long have = __ballot(sl != NBR_NONE);
+    if (sl != NBR_NONE) cand[__popcll(have & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(dl) << 32) | sl;
+    n = (uint32_t)__popcll(have);
+  }
+  uint32_t tot = n;
+  if (lane == 0) {
+    uint32_t cur = head[rid];
+    head[rid] = NBR_NONE;
+    while (cur != NBR_NONE) {
+      if (tot < LINKD_CAND) cand[tot] = ((unsigned long long)__float_as_uint(req[cur].d) << 32) | req[cur].from;
+      tot++;
+      cur = req[cur].next;
+    }
+  }
+  tot = (uint32_t)__shfl((int)tot, 0, 64);
+  if (tot > LINKD_CAND) { if (lane == 0) atomicOr(&stats[4], 16ull); return; }   // the host fails the batch loudly
+  wave_sync();
+  uint32_t ns;            // entries of the new row, in sel[]
+  if (tot <= W) {
+    for (uint32_t i = lane; i < tot; i += 64) sel[i] = cand[i];
+    ns = tot;
+  } else {
+    // drop the tombstoned neighbours (pruneNeighbors skips them, hnsw.go:454-456), rank-sort the live ones by key
+    uint32_t live = 0;
+    for (uint32_t b = 0; b < tot; b += 64) {
+      const uint32_t i = b + lane;
+      const unsigned long long k = i < tot ? cand[i] : ~0ull;
+      const bool ok = i < tot && !is_deleted(g, (uint32_t)k);
+      const unsigned long long mk = __ballot(ok);
+      wave_sync();   // chunk b has been read by every lane before its front part is overwritten (live <= b)
+      if (ok) cand[live + __popcll(mk & ((1ull << lane) - 1ull))] = k;
+      live += (uint32_t)__popcll(mk);
+      wave_sync();
+    }
+    for (uint32_t i = lane; i < live; i += 64) {
+      const unsigned long long k = cand[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < live; j++) rank += cand[j] < k ? 1u : 0u;   // keys are distinct (a slot appears once in a row)
+      sorted[rank] = k;
+    }
+    wave_sync();
+    if (live <= W) {
+      for (uint32_t i = lane; i < live; i += 64) sel[i] = sorted[i];
+      ns = live;
+    } else {
+      uint32_t nsel = 0, np = 0;
+      unsigned long long n_eval = 0;
+      for (uint32_t ci = 0; ci < live && nsel < W; ci++) {
+        lane = opaque_lane(lane_in);
+        const int half = lane & 1, p = lane >> 1;
+        const unsigned long long ce = sorted[ci];
+        const uint32_t es = (uint32_t)ce;
+        const float ed = __uint_as_float((uint32_t)(ce >> 32));
+        bool bad = false;
+        if (nsel) {
+          const uint8_t* crow = g.rows + (size_t)es * g.stride;
+          for (int t = lane; t < g.dim; t += 64) {
+            if constexpr (R8) qs2[t] = load1<QUANT>(crow, r8_index<QUANT>(t)); else qs2[t] = load1<QUANT>(crow, t);
+          }
+          const float qn2 = METRIC == M_COS ? g.norms[es] : 0.f;
+          wave_sync();
+          for (uint32_t c0 = 0; c0 < nsel; c0 += 32) {
+            const uint32_t idx = c0 + (uint32_t)p;
+            const bool valid = idx < nsel;
+            float dd = 0.f;
+            if (valid) dd = eval_pair_q<METRIC, QUANT, PROF_BUILD, R8>(g, qs2, qn2, (uint32_t)sel[idx], half);
+            bad = bad || (valid && half == 0 && dd < ed);
+          }
+          n_eval += nsel;
+        }
+        const bool rejected = __ballot(bad) != 0ull;
+        wave_sync();
+        if (!rejected) { if (lane == 0) sel[nsel] = ce; nsel++; }
+        else if (np < 64u) { if (lane == 0) prn[np] = ce; np++; }
+        wave_sync();
+      }
+      if (keep_pruned) {
+        for (uint32_t i = 0; i < np && nsel < W; i++) { if (lane == 0) sel[nsel] = prn[i]; nsel++; }
+      }
+      if (lane == 0 && n_eval) atomicAdd(&stats[0], n_eval);   // the oracle's n_dist counts these evaluations
+      ns = nsel;
+    }
+  }
+  wave_sync();
+  // ---- the new row, ascending by slot (ns <= W <= 64: one entry per lane, ranked by readlane broadcasts)
+  lane = opaque_lane(lane_in);
+  const unsigned long long mine = (uint32_t)lane < ns ? sel[lane] : ~0ull;
+  const uint32_t myslot = (uint32_t)mine;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < ns; j++) {
+    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)myslot, (int)j);
+    rank += sj < myslot ? 1u : 0u;
+  }
+  wave_sync();
+  float* nrow = (lvl0 && g.adj0_n) ? g.adj0_n + (size_t)rid * g.mMax0 : nullptr;
+  if ((uint32_t)lane < ns) {
+    row[rank] = myslot; drow[rank] = __uint_as_float((uint32_t)(mine >> 32));
+    if (nrow) nrow[rank] = g.norms[myslot];
+  }
+  if ((uint32_t)lane >= ns && (uint32_t)lane < W) {
+    row[lane] = NBR_NONE; drow[lane] = 0.f;
+    if (nrow) nrow[lane] = 0.f;
   }
 }
 
@@ -1087,12 +1272,28 @@ int launch_build(Hnsw* x, const SearchGeom& sg, uint32_t base, uint32_t count, c
                  uint32_t* req_count, BuildReq* req, uint32_t* head, unsigned long long* stats) {
   auto kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true> : hnsw_build_search_kernel<METRIC, QUANT, false>;
   if constexpr (QUANT != Q_F8) { if (x->r8) kern = sg.visg ? hnsw_build_search_kernel<METRIC, QUANT, true, true> : hnsw_build_search_kernel<METRIC, QUANT, false, true>; }
-  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sg.lds));
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / sg.lds));
+  // algo 2 (diverse selection): a second query buffer + the chosen / rejected keys behind the walk's LDS
+  const uint32_t diverse = x->cfg.algo == 2 ? (x->cfg.keep_pruned ? 3u : 1u) : 0u;
+  const size_t ext_off = (sg.lds + 15) & ~(size_t)15;
+  const size_t lds = diverse ? ext_off + (((size_t)x->dim * 4 + 15) & ~(size_t)15) + 2 * 64 * 8 : sg.lds;
+  if (lds > 160 * 1024) return fail(COLTT_E_UNSUPPORTED, "hnsw insert: dim/efConstruction need %zu B of LDS", lds);
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(waves_per_cu_cap(QUANT), (160 * 1024) / lds));
   uint32_t grid = std::min<uint32_t>({count, 256u * per_cu, sg.max_grid});
-  kern<<<grid, 64, sg.lds, x->stream>>>(x->view(), x->entry, x->entry_level, base, count, d_levels, (uint32_t)x->cfg.m,
-                                        sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats,
-                                        x->w_visg.as<uint8_t>(), (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>());
+  kern<<<grid, 64, lds, x->stream>>>(x->view(), x->entry, x->entry_level, base, count, d_levels, (uint32_t)x->cfg.m,
+                                     sg.ef, sg.ef_pad, sg.hcap, x->cap, counter, req_count, req, head, stats,
+                                     x->w_visg.as<uint8_t>(), (size_t)x->vis_stride, x->w_vepoch.as<uint32_t>(), diverse, (uint32_t)ext_off);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
+template <int METRIC, int QUANT>
+int launch_link_diverse(Hnsw* x, const BuildReq* req, uint32_t n_req, uint32_t* head, unsigned long long* stats) {
+  auto kern = hnsw_link_diverse_kernel<METRIC, QUANT, false>;
+  if constexpr (QUANT != Q_F8) { if (x->r8) kern = hnsw_link_diverse_kernel<METRIC, QUANT, true>; }
+  const size_t lds = (((size_t)x->dim * 4 + 15) & ~(size_t)15) + (size_t)(2 * LINKD_CAND + 128) * 8;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<n_req, 64, lds, x->stream>>>(x->view(), x->cap, req, n_req, head, (uint32_t)(x->cfg.keep_pruned ? 1 : 0), stats);
   COLTT_HIP(hipGetLastError());
   return COLTT_OK;
 }
@@ -1199,7 +1400,24 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
       (void)hipStreamSynchronize(x->stream);
       return fail(COLTT_E_DEVICE, "hnsw insert: traversal watchdog tripped (code %llu)", hm.st[4]);
     }
-    if (hm.n_req) {
+    if (hm.n_req && x->cfg.algo == 2) {
+      // diverse mode: one wave per touched row; its evaluations are counted, and a row with more candidates than the kernel holds fails
+      // the batch (the links of THIS batch are then half applied: the index is left for the caller to discard — stated in the error)
+#define COLTT_LD_ARGS x, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>(), d_stats
+#define COLTT_LD(Q) rc = x->metric == COLTT_COSINE ? launch_link_diverse<M_COS, Q>(COLTT_LD_ARGS) : launch_link_diverse<M_L2, Q>(COLTT_LD_ARGS)
+      COLTT_DISPATCH_QUANT(x->quant, COLTT_LD)
+#undef COLTT_LD
+#undef COLTT_LD_ARGS
+      COLTT_TRY(rc);
+      COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
+      COLTT_HIP(hipStreamSynchronize(x->stream));
+      if (hm.st[4]) {
+        fill_u32_kernel<<<ceil_div(x->head_cap, 256), 256, 0, x->stream>>>(x->b_head.as<uint32_t>(), x->head_cap, NBR_NONE);
+        (void)hipStreamSynchronize(x->stream);
+        return fail(COLTT_E_UNSUPPORTED, "hnsw insert (diverse selection): a row received more than %u candidates in one batch — insert in "
+                                         "smaller batches; the rows of this batch are partly linked, rebuild the index", LINKD_CAND);
+      }
+    } else if (hm.n_req) {
       hnsw_link_kernel<<<ceil_div(hm.n_req, 64), 64, 0, x->stream>>>(x->view(), x->cap, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>());
       COLTT_HIP(hipGetLastError());
     }
@@ -1337,8 +1555,8 @@ int coltt::hnsw_create_on(int device, uint32_t dim, int metric, int quant, const
   if (c.level_multiplier == -1.f) c.level_multiplier = 1.0f / (float)std::log((double)(float)c.m);
   if (c.m_max == -1) c.m_max = c.m;
   if (c.m_max0 == -1) c.m_max0 = 2 * c.m;
-  if (c.algo != 0 && c.algo != 1) return fail(COLTT_E_INVALID, "hnsw_create: unknown search algorithm %d", c.algo);
-  if (c.algo == 1 && c.extend_candidates)
+  if (c.algo != 0 && c.algo != 1 && c.algo != COLTT_HNSW_DIVERSE) return fail(COLTT_E_INVALID, "hnsw_create: unknown search algorithm %d", c.algo);
+  if (c.algo != 0 && c.extend_candidates)
     return fail(COLTT_E_UNSUPPORTED, "hnsw_create: HeuristicExtendCandidates is undefined behaviour in the reference "
                                      "(priority_queue.go:109-122 aliases the heap array); rejected");
   if (c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024) return fail(COLTT_E_INVALID, "hnsw_create: need m <= mMax, m <= mMax0 <= 1024");
@@ -1468,7 +1686,7 @@ int coltt_hnsw_load(coltt_handle_t h, int header, const uint8_t* buf, uint64_t l
     if (di != 1 && di != 2) return fail(COLTT_E_INVALID, "Invalid space type");  // InvalidSpaceTypeErr
     if (dim != x->dim) return fail(COLTT_E_INVALID, "hnsw_load: stream dim %u != index dim %u", dim, x->dim);
     if ((di == 1) != (x->metric == COLTT_COSINE)) return fail(COLTT_E_INVALID, "hnsw_load: stream distance differs from the index's");
-    if (c.m <= 0 || c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024 || c.ef <= 0 || c.ef_construction <= 0 || (c.algo != 0 && c.algo != 1))
+    if (c.m <= 0 || c.m_max < c.m || c.m_max0 < c.m || c.m_max0 > 1024 || c.ef <= 0 || c.ef_construction <= 0 || (c.algo != 0 && c.algo != 1 && c.algo != COLTT_HNSW_DIVERSE))
       return fail(COLTT_E_INVALID, "hnsw_load: invalid config in stream");
   }
   std::vector<uint64_t> ids, voff, moff; std::vector<int32_t> levels; std::vector<uint32_t> mlen;

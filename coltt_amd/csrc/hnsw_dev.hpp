@@ -142,13 +142,19 @@ template <int QUANT, int PROFILE> __device__ __forceinline__ constexpr int burst
   return PROFILE == PROF_SEARCH_LDS ? 48 : 24;
 }
 // R8: GraphView::rows is line-transposed (rows8.hpp; the index keeps ONE row array in that layout) — same values, same order, same bits
+// the query given explicitly (natural-order f32 in LDS + its ||q||^2): the traversal's query, or a stored row standing in for one
+// (the diverse neighbour selection compares stored rows with each other, hnsw.hip)
 template <int METRIC, int QUANT, int PROFILE, bool R8 = false>
-__device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
+__device__ __forceinline__ float eval_pair_q(const GraphView& g, const float* __restrict__ qs, float qnorm, uint32_t slot, int half) {
   float rn = 0.f;
   if constexpr (METRIC == M_COS) rn = g.norms[slot];
   constexpr int U = burst_depth<QUANT, PROFILE>();
-  if constexpr (R8) return pair_distance_r8<METRIC, QUANT, U / (QUANT == Q_NONE ? 4 : 8)>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
-  else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, w.qs, g.dim, w.qnorm, rn, half);
+  if constexpr (R8) return pair_distance_r8<METRIC, QUANT, U / (QUANT == Q_NONE ? 4 : 8)>(g.rows + (size_t)slot * g.stride, qs, g.dim, qnorm, rn, half);
+  else return pair_distance<METRIC, QUANT, U>(g.rows + (size_t)slot * g.stride, qs, g.dim, qnorm, rn, half);
+}
+template <int METRIC, int QUANT, int PROFILE, bool R8 = false>
+__device__ __forceinline__ float eval_pair(const GraphView& g, const WaveCtx& w, uint32_t slot, int half) {
+  return eval_pair_q<METRIC, QUANT, PROFILE, R8>(g, w.qs, w.qnorm, slot, half);
 }
 
 // greedyClosestNeighbor (hnsw.go:320-343) on `level`: move to the strict minimum until no neighbour improves.

@@ -161,11 +161,21 @@ typedef struct coltt_hnsw_cfg {       /* hnswConfig defaults: hnsw_config.go:135
   int32_t m_max0;                     /* -1 -> 2m */
   int32_t ef;                         /* 20 */
   int32_t ef_construction;            /* 200 */
-  int32_t algo;                       /* 0 HnswSearchSimple, 1 HnswSearchHeuristic */
+  int32_t algo;                       /* 0 HnswSearchSimple, 1 HnswSearchHeuristic (hnsw_config.go:27-33) — both keep the k nearest —, or
+                                         COLTT_HNSW_DIVERSE (2): NOT reference behaviour, see below */
   float level_multiplier;             /* -1 -> 1/ln(m) */
   int32_t extend_candidates;          /* must be 0: the reference's extend path is undefined */
   int32_t keep_pruned;                /* 1 (dead code in the reference) */
 } coltt_hnsw_cfg;
+
+/* COLTT_HNSW_DIVERSE — an opt-in neighbour selection the reference does NOT have: its selectNeighborsHeuristic (hnsw.go:399-447) never
+ * compares a candidate with the neighbours already chosen, so both of its modes build a plain k-nearest graph.  This mode applies the
+ * diversity test of the HNSW paper (Algorithm 4, as hnswlib runs it) in Insert and in pruneNeighbors-on-overflow: candidates ascending
+ * by (distance, slot); a candidate is chosen iff no already chosen neighbour is closer to it than the base vertex is; keep_pruned re-adds
+ * the rejected ones, nearest first.  Defined in oracle/coltt_oracle.cpp (select_diverse); GPU graph == that definition bit for bit.
+ * Search is unchanged (Hnsw.Search over whatever graph was built).  A graph built this way is NOT the reference's graph: the Go drop-in
+ * refuses the value unless the caller opts in (go/vectorindex). */
+#define COLTT_HNSW_DIVERSE 2
 
 typedef struct coltt_hnsw_stats {     /* per search call, summed over the batch */
   uint64_t n_dist;                    /* distance evaluations */

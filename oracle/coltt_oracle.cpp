@@ -522,7 +522,7 @@ static int flat_search(const Flat* f, const float* query, int topK, int nearest,
 // core/vectorindex HNSW
 // ------------------------------------------------------------------------------------------------
 struct HnswCfg {  // hnsw_config.go:135-162
-  int32_t m, mMax, mMax0, ef, efConstruction, algo /*0 simple,1 heuristic*/;
+  int32_t m, mMax, mMax0, ef, efConstruction, algo /*0 simple, 1 heuristic, 2 DIVERSE (not reference behaviour: a definition, see select_diverse)*/;
   float levelMultiplier;
   int32_t extendCandidates, keepPruned;
 };
@@ -657,12 +657,36 @@ static GoHeap<true> select_heuristic(GoHeap<true>& nb, int k, bool keepPruned) {
   return result;
 }
 
+// algo 2, "diverse" — NOT reference behaviour (the reference's selectNeighborsHeuristic, hnsw.go:399-447, never compares a candidate with
+// the neighbours already chosen: it returns the k nearest).  A DEFINITION, after Algorithm 4 of the HNSW paper as hnswlib runs it
+// (getNeighborsByHeuristic2), fixed here so that the GPU builder and this file agree bit for bit:
+//   candidates `c` ascending by (distance-to-base bits, slot) — the order of the canonical result set;
+//   walk them in that order while fewer than k are chosen: c is chosen iff NO already chosen r has D(c, r) < d(base, c), where
+//   D(c, r) is the index's distance with c's stored vector as the query and r's as the stored row, and d(base, c) is the distance the
+//   candidate list carries (searchLevel's for Insert, the stored edge distance for pruneNeighbors).  EVERY chosen r is evaluated (no
+//   early exit: the GPU evaluates them side by side), so a tested candidate costs |chosen| evaluations;
+//   keepPruned (hnsw_config.go: heuristicKeepPruned): the rejected candidates, nearest first, fill the result up to k.
+// Returns the chosen items in candidate order (chosen first, then the re-added ones).
+static std::vector<RItem> select_diverse(Hnsw* h, const std::vector<RItem>& cand, int k, bool keepPruned) {
+  std::vector<RItem> chosen, pruned;
+  for (const RItem& c : cand) {
+    if ((int)chosen.size() >= k) break;
+    bool good = true;
+    for (const RItem& r : chosen) { float d = h->D(h->v[c.slot].vec, h->v[r.slot].vec); if (d < c.d) good = false; }
+    if (good) chosen.push_back(c); else pruned.push_back(c);
+  }
+  if (keepPruned) for (const RItem& c : pruned) { if ((int)chosen.size() >= k) break; chosen.push_back(c); }
+  return chosen;
+}
+
 // pruneNeighbors (hnsw.go:449-474)
 static void prune(Hnsw* h, int32_t vi, int k, int level) {
   if (h->canon_build) {  // k nearest by (stored distance, slot); Simple == Heuristic(extend=false)
     std::vector<RItem> all;
     for (const Edge& e : h->v[vi].edges[level]) { if (h->v[e.to].deleted) continue; all.push_back({e.d, e.to, false}); }
     std::sort(all.begin(), all.end(), ritem_less);
+    // diverse: the selection runs only when the live neighbours do not fit (hnswlib's rule; Remove's re-prune therefore only drops tombstones)
+    if (h->cfg.algo == 2 && (int)all.size() > k) all = select_diverse(h, all, k, h->cfg.keepPruned != 0);
     if ((int)all.size() > k) all.resize(k);
     std::vector<Edge> ne;
     for (auto& r : all) ne.push_back({r.slot, r.d});
@@ -710,6 +734,7 @@ static int hnsw_insert(Hnsw* h, uint64_t id, const float* value, int vertexLevel
     GoHeap<true> nb;
     if (h->canon_build) {
       std::vector<RItem> r = search_level_canon(h, vec, ep, h->cfg.efConstruction, l);
+      if (h->cfg.algo == 2) r = select_diverse(h, r, h->cfg.m, h->cfg.keepPruned != 0);   // r[0] stays the nearest candidate
       if ((int)r.size() > h->cfg.m) r.resize(h->cfg.m);
       for (auto& x : r) nb.a.push_back({x.d, x.slot});  // ascending array; popped back-to-front below
     } else nb = search_level_literal(h, vec, ep, h->cfg.efConstruction, l);
@@ -826,6 +851,7 @@ static int hnsw_insert_batch(Hnsw* h, const uint64_t* ids, const float* vecs, co
     for (int l = h->v[ep].level; l > levels[i]; l--) greedy(h, vec, ep, minD, l);
     for (int l = std::min(h->v[ep].level, (int)levels[i]); l >= 0; l--) {
       std::vector<RItem> r = search_level_canon(h, vec, ep, h->cfg.efConstruction, l);
+      if (h->cfg.algo == 2) r = select_diverse(h, r, h->cfg.m, h->cfg.keepPruned != 0);
       if ((int)r.size() > h->cfg.m) r.resize(h->cfg.m);
       for (auto& x : r) links.push_back({vi, l, x.slot, x.d});
       ep = r[0].slot;
@@ -833,6 +859,16 @@ static int hnsw_insert_batch(Hnsw* h, const uint64_t* ids, const float* vecs, co
   }
   for (size_t i = i0; i < n; i++) { int32_t vi = base + (int32_t)(i - i0); h->by_id[ids[i]] = vi; h->len++; }
   bool save = h->canon_build; h->canon_build = true;
+  if (h->cfg.algo == 2) {
+    // diverse selection is not associative, so "prune at every overflow" would depend on the order the batch's links arrive in.  The
+    // definition for a batch: a row receives ALL the batch's links, then is pruned ONCE if it overflows (rows are independent of each
+    // other: a prune reads the row's stored edge distances and stored vectors only).  batch == 1 adds one link per row: the sequential Insert.
+    for (auto& k : links) { edge_set(h->v[k.from].edges[k.l], k.to, k.d); edge_set(h->v[k.to].edges[k.l], k.from, k.d); }
+    for (auto& k : links) {
+      int mMax = k.l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
+      if ((int)h->v[k.to].edges[k.l].size() > mMax) prune(h, k.to, mMax, k.l);
+    }
+  } else
   for (auto& k : links) {  // phase B
     int mMax = k.l == 0 ? h->cfg.mMax0 : h->cfg.mMax;
     edge_set(h->v[k.from].edges[k.l], k.to, k.d);
@@ -1297,6 +1333,7 @@ void* orc_hnsw_create(uint32_t dim, int metric, int order, const HnswCfg* cfg) {
   if (h->cfg.levelMultiplier == -1) h->cfg.levelMultiplier = 1.0f / (float)std::log((double)(float)h->cfg.m);
   if (h->cfg.mMax == -1) h->cfg.mMax = h->cfg.m;
   if (h->cfg.mMax0 == -1) h->cfg.mMax0 = 2 * h->cfg.m;
+  if (h->cfg.algo == 2) h->canon_build = true;   // the diverse mode is defined on the canonical forms only (select_diverse)
   return h;
 }
 void orc_hnsw_destroy(void* h) { delete (Hnsw*)h; }
@@ -1306,7 +1343,7 @@ int orc_hnsw_insert(void* h, uint64_t id, const float* vec, int level) {
   if (x->cfg.algo == 1 && x->cfg.extendCandidates) return -4;
   return hnsw_insert(x, id, vec, level, false);
 }
-void orc_hnsw_set_canonical(void* h, int on) { ((Hnsw*)h)->canon_build = on != 0; }
+void orc_hnsw_set_canonical(void* h, int on) { ((Hnsw*)h)->canon_build = on != 0 || ((Hnsw*)h)->cfg.algo == 2; }
 int orc_hnsw_insert_batch(void* h, const uint64_t* ids, const float* vecs, const int32_t* levels, size_t n) {
   return hnsw_insert_batch((Hnsw*)h, ids, vecs, levels, n);
 }

@@ -348,6 +348,79 @@ class Hnsw:
                 "nbr": np.array(nbr, np.int32), "nbr_dist": np.array(nd, np.float32), "entry": -1 if self.entry is None else self.entry.index}
 
 
+# ------------------------------------------------------------------------------------------------ algo 2, "diverse"
+class DiverseHnsw(Hnsw):
+    """COLTT_HNSW_DIVERSE — NOT reference behaviour (the reference's selectNeighborsHeuristic, hnsw.go:399-447, never compares a candidate
+    with the neighbours already chosen).  A DEFINITION, restated here independently of oracle/coltt_oracle.cpp (select_diverse, prune,
+    hnsw_insert): Insert and pruneNeighbors-on-overflow choose neighbours by the diversity test of the HNSW paper (Algorithm 4, as hnswlib
+    runs it).  Everything else — greedy descent, searchLevel (the literal Go-heap form above), Remove, Search — is the class above."""
+
+    def __init__(self, dim, metric, keep_pruned=False, **kw):
+        super().__init__(dim, metric, algo=1, keep_pruned=keep_pruned, **kw)   # algo 1: Search's final selection = the k nearest
+
+    @staticmethod
+    def _order(item):
+        d, vtx = item
+        return (int(np.float32(d).view(np.uint32)), vtx.index)                # (distance bits, slot): the canonical result-set order
+
+    def select_diverse(self, cands, k):
+        """cands: (distance to the base vertex, vertex), any order.  Walk them ascending while fewer than k are chosen; c is chosen iff no
+        already chosen r has dist(c as the query, r) < c's distance; EVERY chosen r is evaluated.  keep_pruned: the rejected, nearest first,
+        fill the result up to k.  Returns the chosen list (chosen first, then the re-added)."""
+        chosen, pruned = [], []
+        for d, c in sorted(cands, key=self._order):
+            if len(chosen) >= k:
+                break
+            good = True
+            for _, r in chosen:
+                if self.dist(c.vector, r.vector) < d:
+                    good = False
+            (chosen if good else pruned).append((d, c))
+        if self.keep_pruned:
+            for it in pruned:
+                if len(chosen) >= k:
+                    break
+                chosen.append(it)
+        return chosen
+
+    def insert(self, id_, value, vertex_level):
+        value = np.asarray(value, f32)
+        if self.metric == self.COSINE:
+            value = normalize(value)
+        if id_ in self.by_id:
+            return "ItemAlreadyExistsError"
+        if self.entry is None:
+            vertex = Vertex(id_, value, 0, len(self.v))
+            self.v.append(vertex); self.by_id[id_] = vertex
+            self.entry = vertex
+            return None
+        vertex = Vertex(id_, value, vertex_level, len(self.v))
+        self.v.append(vertex); self.by_id[id_] = vertex
+        entrypoint = self.entry
+        min_distance = self.dist(vertex.vector, entrypoint.vector)
+        for l in range(entrypoint.level, vertex.level, -1):
+            entrypoint, min_distance = self.greedy(vertex.vector, entrypoint, min_distance, l)
+        for l in range(min(entrypoint.level, vertex.level), -1, -1):
+            found = self.search_level(vertex.vector, entrypoint, self.efc, l)
+            chosen = self.select_diverse(list(found.a), self.m)
+            m_max = self.m_max0 if l == 0 else self.m_max
+            for prio, neighbor in chosen:
+                vertex.edges[l][neighbor.index] = prio
+                neighbor.edges[l][vertex.index] = prio
+                if len(neighbor.edges[l]) > m_max:
+                    self.prune(neighbor, m_max, l)
+            entrypoint = chosen[0][1]                                         # the nearest candidate is always chosen first
+        if self.entry is not None and vertex.level > self.entry.level:
+            self.entry = vertex
+        return None
+
+    def prune(self, vertex, k, level):
+        live = [(d, n) for n, d in self._nbrs(vertex, level) if not n.deleted]
+        if len(live) > k:                                                     # the selection runs on overflow only (hnswlib's rule)
+            live = self.select_diverse(live, k)
+        vertex.edges[level] = {n.index: d for d, n in live}
+
+
 # ------------------------------------------------------------------------------------------------ edge bounded queue
 def edge_queue(scores_ids, max_size):
     """edge.PriorityQueue (edge/priority_queue.go:33-69): Add = push into a MIN-heap, pop the minimum when over capacity (keeps
