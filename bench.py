@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--op-dataset", default="lowrank:32:1.0")
     ap.add_argument("--op-ef-sweep", default="128,256,512,1024,2048")
     ap.add_argument("--op-recall", type=float, default=0.98)
+    ap.add_argument("--no-op-diverse", action="store_true", help="skip op.diverse (a second 10 M build under COLTT_HNSW_DIVERSE, the opt-in NON-reference neighbour selection)")
     ap.add_argument("--no-reserve", dest="reserve", action="store_false", help="let the index arrays grow by halves during the build instead of reserving the known size")
     ap.add_argument("--shard-leg-n", type=int, default=0, help="vectors in the whole sharded collection of the secondary.shard leg (0 = --n)")
     # ranks started by self_launch() get their arguments through the environment: torch.distributed.run's own parser would read
@@ -547,6 +548,55 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
             pqw["gpu_over_cpu"] = pqw["value"] / pqw["cpu_baseline"]["value"]
     op_ev8 = h.Rows8()[0]
     h.close()
+    # ---- the same vectors and level draws under COLTT_HNSW_DIVERSE (opt-in neighbour selection with the HNSW paper's diversity test — NOT reference
+    # behaviour: the reference's selectNeighborsHeuristic, hnsw.go:399-447, keeps the k nearest).  Reported BESIDE `op`, never instead of it.
+    diverse = None
+    if not args.no_op_diverse:
+        try:
+            hd = G.Hnsw(dim, G.COSINE, G.HnswCfg.default(m=args.m, ef=args.ef, ef_construction=args.efc, algo=2, keep_pruned=0), quantization=quant)
+            hd, dbuild_s = build_index(G, torch, dev, ds, n, dim, args, seed, quant, h=hd)
+            defs = sorted({max(k, int(ef_op * f) // 32 * 32) for f in (0.75, 0.8125, 0.875, 0.9375, 1.0)})
+            drec = {}; dqps = {}
+            for ef in defs:
+                hd.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef)
+                dqps[str(ef)] = nq / (hd.last_kernel_ms() / 1e3)
+                ids = out.ids[:rq].cpu().numpy()
+                drec[str(ef)] = sum(len(set(op_truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
+            dok = [ef for ef in defs if drec[str(ef)] >= args.op_recall]
+            def_op = min(dok) if dok else max(defs)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); dms = []; dst = None
+            for _ in range(steps):
+                dst = hd.SearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=def_op); dms.append(hd.last_kernel_ms())
+            torch.cuda.synchronize(); ddt = time.perf_counter() - t0
+            dnd = dst["n_dist"] / nq; dne = dst["n_exp"] / nq
+            dbpq = hnsw_bytes_per_query(dnd, dne, dim, quant, args.m)
+            diverse = {"workload": "the same vectors and level draws built with COLTT_HNSW_DIVERSE (algo 2, keepPruned 0): NOT reference behaviour, opt-in; the search is "
+                                   "the unchanged Hnsw.Search", "ef": def_op, "recall_at_10": drec[str(def_op)], "reached": bool(dok), "value": steps * nq / ddt,
+                       "unit": "queries/s", "over_op": (steps * nq / ddt) / (steps * nq / dt), "recall_vs_ef": drec, "qps_vs_ef": dqps, "build_s": dbuild_s,
+                       "recall_at_op_ef": drec.get(str(ef_op)), "op_recall_at_op_ef": rec[str(ef_op)],
+                       "per_query": {"n_dist": dnd, "n_exp": dne, "bytes": dbpq},
+                       "frac": dbpq * nq / (float(np.mean(dms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(dms))}
+            if isinstance(pqw, dict) and "error" not in pqw:      # and the table walk over the diverse graph, at the plain table walk's own settings
+                sample = hd.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
+                pqd = G.PQSpace(dim, G.PQ_EUCLIDEAN, pqw["m"], pqw["centroids"]); pqd.Fit(sample, iterations=6); hd.PqAttach(pqd)
+                pefs = sorted({int(pqw["ef"] * f) // 64 * 64 for f in (0.8, 0.9, 1.0)}); prec = {}; pq_q = {}
+                for ef in pefs:
+                    hd.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef, rerank=pqw["rerank"])
+                    pq_q[str(ef)] = nq / (hd.last_kernel_ms() / 1e3)
+                    ids = out.ids[:rq].cpu().numpy()
+                    prec[str(ef)] = sum(len(set(op_truth[i].tolist()) & set(ids[i].tolist())) for i in range(rq)) / (rq * k)
+                pok = [ef for ef in pefs if prec[str(ef)] >= args.op_recall]
+                pef = min(pok) if pok else max(pefs)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    hd.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=pef, rerank=pqw["rerank"])
+                torch.cuda.synchronize(); pdt = time.perf_counter() - t0
+                diverse["pq"] = {"ef": pef, "recall_at_10": prec[str(pef)], "reached": bool(pok), "value": steps * nq / pdt, "over_op_pq": (steps * nq / pdt) / pqw["value"],
+                                 "recall_vs_ef": prec, "qps_vs_ef": pq_q}
+                pqd.close()
+            hd.close()
+        except Exception as e:
+            diverse = {"error": str(e)[:300]}
     res = {"workload": f"core/vectorindex HNSW M={args.m} efConstruction={args.efc}, {n}x{dim} f16 codes, cosine, k={k}, dataset {args.op_dataset} "
                        f"(x = mu_c + A z + sigma eps), {nq} queries/step",
            "target_recall_at_10": args.op_recall, "ef": ef_op, "recall_at_10": rec[str(ef_op)], "reached": bool(ok),
@@ -560,7 +610,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
                                   ("; eight lanes per row over rows8)" if op_ev8 > 0 else ")"),
                         "avg_launch_ms": launch_s * 1e3},
            "single_query_kernel_ms": single_ms,
-           "cpu_baseline": cpu, "pq_walk": pqw, "pq_walk_reference_shape": pqw_ref}
+           "cpu_baseline": cpu, "pq_walk": pqw, "pq_walk_reference_shape": pqw_ref, "diverse": diverse}
     if cpu and "value" in cpu:
         res["gpu_over_cpu"] = res["value"] / cpu["value"]
     return res
@@ -810,6 +860,19 @@ def leg_pq(G, torch, dev, O, args, dim, k):
     for i in range(10):
         pq.SearchDevice(q.data_ptr() + (i % nq) * dim * 4, 1, k, *out.ptrs())
     wall1 = (time.perf_counter() - t0) / 10
+    # in-process A/B: the seven-launch segment chain of rounds 4-5 (COLTT_PQ_ONE=0) on the same store, and the answers of both paths
+    one_ids = []; chain_ms = []; chain_ids = []
+    for i in range(4):
+        pq.SearchDevice(q.data_ptr() + i * dim * 4, 1, k, *out.ptrs()); one_ids.append((out.ids[0].cpu().numpy().copy(), out.sc[0].cpu().numpy().copy()))
+    os.environ["COLTT_PQ_ONE"] = "0"
+    try:
+        for i in range(16):
+            pq.SearchDevice(q.data_ptr() + (i % nq) * dim * 4, 1, k, *out.ptrs())
+            if i < 4: chain_ids.append((out.ids[0].cpu().numpy().copy(), out.sc[0].cpu().numpy().copy()))
+            if i >= 4: chain_ms.append(pq.last_kernel_ms()[0])
+    finally:
+        os.environ.pop("COLTT_PQ_ONE", None)
+    one_equals_chain = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) for a, b in zip(one_ids, chain_ids))
     bms = []
     for i in range(4):
         pq.SearchDevice(q.data_ptr(), nq, k, *out.ptrs())
@@ -821,11 +884,14 @@ def leg_pq(G, torch, dev, O, args, dim, k):
                        f"one query per call and one {nq}-query call",
            "value": 1.0 / wall1, "unit": "queries/s (one query per call, device buffers)", "ms_per_batch_kernels": float(np.mean(one_ms)),
            "single_query_scan_launch_ms": scan_s * 1e3, "scan_rows_of_that_launch": int(scan_rows), "batch_64_kernels_ms": float(np.mean(bms)),
+           "search_frac": scan_rows * m / (float(np.mean(one_ms)) / 1e3) / 1e9 / HBM_PEAK_GBS,
+           "search_note": "a single-query search = table + ONE scan launch (per-wave self-tightening lists, pq_scan1_kernel) + one selection",
+           "segment_chain_ms": float(np.mean(chain_ms)), "one_launch_equals_segment_chain": bool(one_equals_chain),
            "batch_64_queries_per_s": nq / (float(np.mean(bms)) / 1e3), "train_s": train_s, "encode_and_ingest_s": ingest_s,
            "roofline": {"bound": "hbm", "achieved": scan_rows * m / scan_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": scan_rows * m / scan_s / 1e9 / HBM_PEAK_GBS, "traffic": pq_pmc_traffic(n, dim, m)[0], "traffic_source": pq_pmc_traffic(n, dim, m)[1],
                         "avg_launch_ms": scan_s * 1e3,
-                        "kernel": "pq_scan_kernel<4,1> (table in LDS, one ds_read_b32 per code byte; tile-interleaved codes, 16 B per lane per load)",
+                        "kernel": "pq_scan1_kernel<4> (table in LDS, one ds_read_b32 per code byte; tile-interleaved codes, 16 B per lane per load; per-wave k-best lists)",
                         "bytes_per_launch": int(scan_rows * m),
                         "lds_note": "one table lookup per code byte: random ds_read_b32 over 32 banks costs 6.29 LDS cycles (2 conflict-free), the LDS array is busy ~92 % of the kernel: its ceiling is ~0.67 of the HBM peak (profiles/r04m_pq_lds.md)"}}
     if O is not None:
@@ -1070,6 +1136,11 @@ def compact(res):
                         _pick(pw, "m", "centroids", "ef", "rerank", "recall_at_10", "reached", "value", "over_plain_walk", "gpu_over_cpu"), lat_ms=pw.get("single_query_kernel_ms"),
                         **({"walk_traffic_ratio": (pw.get("roofline") or {}).get("walk_kernel_traffic_over_algorithmic")} if (pw.get("roofline") or {}).get("walk_kernel_traffic_over_algorithmic") else {}),
                         **({"gpu_equals_oracle": (pw.get("cpu_baseline") or {}).get("gpu_equals_oracle_on_sample")} if pw.get("cpu_baseline") else {}))
+            dv = op.get("diverse")
+            if isinstance(dv, dict):
+                o["diverse"] = {"error": str(dv["error"])[:120]} if "error" in dv else dict(
+                    _pick(dv, "ef", "recall_at_10", "reached", "value", "over_op", "recall_at_op_ef", "build_s"), not_reference_behaviour=True,
+                    **({"pq": _pick(dv["pq"], "ef", "recall_at_10", "reached", "value", "over_op_pq")} if isinstance(dv.get("pq"), dict) else {}))
             out["op"] = o
     sec = res.get("secondary") or {}
     for tag in ("c1", "c2", "c3", "c3f8", "pq"):
@@ -1084,7 +1155,7 @@ def compact(res):
         if r.get("mfma"):
             o["mfma_frac"] = r["mfma"].get("frac")
         o.update(_pick(leg, "identical_to_exact_mode", "exact_mode_ms_per_batch", "equals_oracle", "host_buffer_call_ms_median",
-                       "single_query_scan_launch_ms", "batch_64_queries_per_s"))
+                       "single_query_scan_launch_ms", "batch_64_queries_per_s", "search_frac", "segment_chain_ms", "one_launch_equals_segment_chain"))
         c = leg.get("cpu_baseline")
         if isinstance(c, dict):
             o["cpu_value"] = c.get("value_scaled_to_full_scan", c.get("value"))

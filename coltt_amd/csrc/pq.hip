@@ -343,6 +343,138 @@ __global__ __launch_bounds__(1024) void pq_scan_kernel(const uint8_t* __restrict
 #undef PQ_LOAD
 }
 
+// ---- ONE query, ONE scan launch (round 6; VERDICT r5 #6: a single-query search was a chain of seven launches — table, then three scan + select
+// pairs, each scan behind the threshold the previous selection published — 0.27 ms around a 0.18 ms scan).  Here every WAVE keeps its own
+// self-tightening list: the rows whose key <= the wave's threshold go into a 128-entry LDS list; past 64 entries the list is cut back to the
+// entries <= its k-th smallest key (ties stay) and that key becomes the threshold — after the first tile a wave admits a row with probability
+// ~k / rows seen, so a wave of 2 400 rows compresses two or three times.  At the end the workgroup merges its waves' lists, keeps the entries
+// <= ITS k-th smallest key and appends them to the query's candidate list: ~k per workgroup, a few thousand in all, and the ordinary selection
+// (select.hpp: (score, id) order, ids looked up there) runs once.  Every level keeps ALL keys <= a bound that is >= the collection's k-th
+// smallest key, so the candidate list is a superset of the answer: same answers as the segment chain, bit for bit.  Mass ties that do not fit a
+// wave's list raise the overflow flag and the caller re-runs the bounded-segment chain, as before.
+constexpr uint32_t PQ1_KMAX = 64;     // largest k the one-launch scan serves (a wave's list keeps <= 64 survivors)
+constexpr uint32_t PQ1_WL = 128;      // entries of a wave's list
+static __device__ __forceinline__ void pq_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// cut the wave's list (nl >= k entries, distinct (key << 32 | row) values) back to the entries whose key <= its k-th smallest key
+static __device__ __forceinline__ uint32_t pq1_compress(unsigned long long* __restrict__ wl, uint32_t nl, uint32_t k, uint32_t& thw, int lane, uint32_t* __restrict__ ovf) {
+  const bool h0 = (uint32_t)lane < nl, h1 = 64u + (uint32_t)lane < nl;
+  const unsigned long long e0 = h0 ? wl[lane] : ~0ull, e1 = h1 ? wl[64 + lane] : ~0ull;
+  uint32_t r0 = 0, r1 = 0;
+  for (uint32_t j = 0; j < nl; j++) { const unsigned long long ej = wl[j]; r0 += ej < e0 ? 1u : 0u; r1 += ej < e1 ? 1u : 0u; }
+  const unsigned long long m0 = __ballot(h0 && r0 == k - 1), m1 = __ballot(h1 && r1 == k - 1);   // exactly one entry has rank k - 1
+  const uint32_t kth = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e0 >> 32), __builtin_ctzll(m0))
+                          : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e1 >> 32), __builtin_ctzll(m1 | (1ull << 63)));
+  const bool k0 = h0 && (uint32_t)(e0 >> 32) <= kth, k1 = h1 && (uint32_t)(e1 >> 32) <= kth;
+  const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), lt = (1ull << lane) - 1ull;
+  const uint32_t n0 = (uint32_t)__popcll(b0), p1 = n0 + (uint32_t)__popcll(b1 & lt), tot = n0 + (uint32_t)__popcll(b1);
+  pq_wave_sync();   // every lane holds its entries before the list is rewritten
+  if (k0) wl[__popcll(b0 & lt)] = e0;
+  if (k1 && p1 < PQ1_WL) wl[p1] = e1;
+  pq_wave_sync();
+  thw = kth;
+  if (tot > 64u) { if (lane == 0) atomicOr(ovf, 1u); return 64u; }   // more ties than a list holds: the caller falls back to bounded segments
+  return tot;
+}
+
+template <int W>
+__global__ __launch_bounds__(1024) void pq_scan1_kernel(const uint8_t* __restrict__ codes, int T, int mp, const float* __restrict__ lut_g, uint64_t end, uint32_t k,
+                                                        unsigned long long* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap, uint32_t* __restrict__ ovf) {
+  extern __shared__ __attribute__((aligned(16))) float lut[];
+  __shared__ uint32_t s_wn[16], s_kth;
+  typedef typename PqRaw<W>::type raw_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wpb = (int)(blockDim.x >> 6);
+  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lut + (size_t)mp * 256) + (size_t)wave * PQ1_WL;
+  unsigned long long* const bl = reinterpret_cast<unsigned long long*>(lut + (size_t)mp * 256) + (size_t)wpb * PQ1_WL;   // [wpb * 64] the workgroup's merge list
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(lut_g);
+    f32x4* dst = reinterpret_cast<f32x4*>(lut);
+    for (int i = tid; i < mp * 64; i += blockDim.x) dst[i] = src[i];
+  }
+  if (tid == 0) s_kth = 0xffffffffu;
+  __syncthreads();
+  const uint64_t tile_end = (end + 63) >> 6;
+  const uint64_t tstride = (uint64_t)gridDim.x * wpb;
+  uint64_t ptile = (uint64_t)blockIdx.x * wpb + wave, ctile = ptile;
+  int pt = 0, ct = 0;
+  uint32_t nl = 0, thw = 0xffffffffu;
+  const unsigned long long ltm = (1ull << lane) - 1ull;
+  constexpr int PBYTES = 4 * W;
+#define PQ_LOAD(dst)                                                                                                      \
+  {                                                                                                                       \
+    const uint64_t lt_ = ptile < tile_end ? ptile : tile_end - 1;                                                         \
+    dst = *reinterpret_cast<const raw_t*>(codes + ((lt_ * (uint64_t)T + (uint64_t)pt) * 64 + (uint64_t)lane) * PBYTES);   \
+    if (++pt == T) { pt = 0; ptile += tstride; }                                                                          \
+  }
+  constexpr int R = W == 4 ? PQ_RING : 2 * PQ_RING;
+  if (ctile < tile_end) {
+    raw_t cur[R], nxt[R];
+#pragma unroll
+    for (int u = 0; u < R; u++) PQ_LOAD(cur[u])
+    float acc = 0.f;
+    while (ctile < tile_end) {
+#pragma unroll
+      for (int u = 0; u < R; u++) PQ_LOAD(nxt[u])
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        const raw_t raw = cur[u];
+        const float* lp = lut + (size_t)ct * (PBYTES * 256);
+#pragma unroll
+        for (int d = 0; d < W; d++) {
+          const uint32_t wd = pq_word<W>(raw, d);
+#pragma unroll
+          for (int b = 0; b < 4; b++) acc = acc + lp[(d * 4 + b) * 256 + ((wd >> (8 * b)) & 0xffu)];
+        }
+        if (++ct == T) {
+          const uint64_t row = (ctile << 6) + (uint64_t)lane;
+          const uint32_t key = score_key(acc);
+          const bool pass = ctile < tile_end && row < end && key <= thw;
+          const unsigned long long pm = __ballot(pass);
+          if (pm) {
+            if (pass) wl[nl + (uint32_t)__popcll(pm & ltm)] = ((unsigned long long)key << 32) | (uint32_t)row;   // nl <= 64 here: fits
+            nl += (uint32_t)__popcll(pm);
+            pq_wave_sync();
+            if (nl > 64u) nl = pq1_compress(wl, nl, k, thw, lane, ovf);
+          }
+          acc = 0.f; ct = 0; ctile += tstride;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < R; u++) cur[u] = nxt[u];
+    }
+    if (nl > k) nl = pq1_compress(wl, nl, k, thw, lane, ovf);
+  }
+#undef PQ_LOAD
+  // ---- the workgroup's merge: its waves' survivors, cut back to the entries <= the workgroup's k-th smallest key
+  if (lane == 0) s_wn[wave] = nl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int w = 0; w < wpb; w++) { const uint32_t c = s_wn[w]; base += w < wave ? c : 0u; tot += c; }
+  for (uint32_t i = lane; i < nl; i += 64) bl[base + i] = wl[i];
+  __syncthreads();
+  if (tot >= k) {
+    for (uint32_t i = tid; i < tot; i += blockDim.x) {
+      const unsigned long long e = bl[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < tot; j++) rank += bl[j] < e ? 1u : 0u;
+      if (rank == k - 1) s_kth = (uint32_t)(e >> 32);
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_kth;
+  for (uint32_t i = tid; i < tot; i += blockDim.x) {
+    const unsigned long long e = bl[i];
+    if ((uint32_t)(e >> 32) > kth) continue;
+    const uint32_t idx = atomicAdd(&cnt[0], 1u);
+    if (idx < cap) cand[idx] = e;
+  }
+}
+
 // tables too large for LDS (mp * 1 KiB > PQ_LDS_MAX: more than 152 sub-vectors): the same walk with the table read through the
 // caches — one thread per row, one query per launch row of the grid.  Exact; slow; rare.
 __global__ __launch_bounds__(256) void pq_scan_global_kernel(const uint8_t* __restrict__ codes, int T, int PB, int m, int mp, const float* __restrict__ lut_g,
@@ -522,6 +654,31 @@ int launch_scan(Pq* p, PCtx* c, uint64_t b, uint64_t e, int nq, const float* lut
   return launch_scan_w<1>(p, c, QBq, b, e, nq, lut, thr, cand, cnt, cap);
 }
 
+// the one-launch scan of a single query (pq_scan1_kernel): false = this store / k does not take it
+bool scan1_geometry(const Pq* p, uint32_t k, int* threads_out, size_t* lds_out) {
+  const char* e = getenv("COLTT_PQ_ONE");   // measurement knob (read per call: tests toggle it in-process): 0 = the segment chain
+  const bool off = e && e[0] == '0';
+  if (off || k > PQ1_KMAX) return false;
+  const size_t table = (size_t)p->mp * 1024;
+  const int threads = table > 80 * 1024 ? 1024 : (table > 40 * 1024 ? 512 : 256);
+  const size_t lds = table + (size_t)(threads / 64) * (PQ1_WL + 64) * 8;
+  if (lds > (size_t)PQ_LDS_MAX) return false;
+  *threads_out = threads; *lds_out = lds;
+  return true;
+}
+template <int W>
+int launch_scan1_w(Pq* p, PCtx* c, int threads, size_t lds, uint64_t total, uint32_t k, const float* lut, unsigned long long* cand, uint32_t* cnt, uint32_t cap, uint32_t* ovf) {
+  const int wpb = threads / 64;
+  const int blocks_per_cu = std::max<int>(1, std::min<int>(2048 / threads, (int)((160 * 1024) / lds)));
+  const uint64_t tiles = (total + 63) >> 6;
+  const uint32_t gx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((tiles + wpb - 1) / wpb, (uint64_t)256 * blocks_per_cu));
+  auto kern = pq_scan1_kernel<W>;
+  COLTT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  kern<<<gx, threads, lds, c->stream>>>(p->codes.as<uint8_t>(), p->T, p->mp, lut, total, k, cand, cnt, cap, ovf);
+  COLTT_HIP(hipGetLastError());
+  return COLTT_OK;
+}
+
 // one group of <= PQ_GROUP queries: tables, candidate lists and the selection's state are sized by the group, not by the call
 constexpr size_t PQ_GROUP = 256;
 int pq_search_group(Pq* p, PCtx* c, const float* queries, bool q_on_device, size_t nq, uint32_t k, uint64_t* out_ids, float* out_scores,
@@ -561,8 +718,17 @@ int pq_search_group(Pq* p, PCtx* c, const float* queries, bool q_on_device, size
     flat_select_kernel<<<(uint32_t)nq, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, 1, ids, p->dense_base, ovf, d_oi, d_os, d_oc);
     return COLTT_OK;
   };
+  int t1 = 0; size_t lds1 = 0;
   if (total == 0) {
     flat_select_kernel<<<(uint32_t)nq, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, 1, ids, p->dense_base, ovf, d_oi, d_os, d_oc);
+  } else if (nq == 1 && total > 65536 && scan1_geometry(p, k, &t1, &lds1)) {
+    // ONE query over a large store: table, ONE scan launch (per-wave self-tightening lists, pq_scan1_kernel), ONE selection
+    COLTT_HIP(hipEventRecord(c->evs0, c->stream));
+    if (p->PB == 16) COLTT_TRY(launch_scan1_w<4>(p, c, t1, lds1, total, k, lut, cand, cnt, cap, ovf));
+    else if (p->PB == 8) COLTT_TRY(launch_scan1_w<2>(p, c, t1, lds1, total, k, lut, cand, cnt, cap, ovf));
+    else COLTT_TRY(launch_scan1_w<1>(p, c, t1, lds1, total, k, lut, cand, cnt, cap, ovf));
+    COLTT_HIP(hipEventRecord(c->evs1, c->stream)); timed_scan = true; p->last_scan_rows.store(total);
+    flat_select_kernel<<<1, 256, 0, c->stream>>>(cand, cnt, thr, cap, k, 1, ids, p->dense_base, ovf, d_oi, d_os, d_oc);
   } else {
     // an unfiltered first segment of 4 Ki rows (one radix selection over 4 Ki candidates), then segments 64x what has been seen, each
     // behind the threshold the selection published from everything before it: a row passes with probability ~k / seen, so every

@@ -36,13 +36,17 @@ var (
 )
 
 // ---------------------------------------------------------------------------------------------- config (hnsw_config.go)
-var hnswSearchAlgorithmNames = [...]string{"Simple", "Heuristic"}
+var hnswSearchAlgorithmNames = [...]string{"Simple", "Heuristic", "Diverse"}
 
 type hnswSearchAlgorithm int
 
 const (
 	HnswSearchSimple hnswSearchAlgorithm = iota
 	HnswSearchHeuristic
+	// HnswSearchDiverse is NOT in the reference (COLTT_HNSW_DIVERSE, include/coltt_gpu.h): neighbour selection with the diversity test of
+	// the HNSW paper, which the reference's "heuristic" (hnsw.go:399-447) does not apply.  It builds a DIFFERENT graph than the reference
+	// would: NewHnsw refuses it unless HnswAllowNonReferenceSelection(true) is passed as well.
+	HnswSearchDiverse
 )
 
 func (a hnswSearchAlgorithm) String() string { return hnswSearchAlgorithmNames[a] }
@@ -55,6 +59,7 @@ type hnswConfig struct {
 	heuristicExtendCandidates bool
 	heuristicKeepPruned       bool
 	quantization              int // extension (BASELINE.json configs[4]): 0 none, 1 f16, 2 f8, 3 "bf16" — edgepb.Quantization order
+	allowNonReference         bool // opt-in for HnswSearchDiverse
 }
 
 // HnswOption — functional options, hnsw_config.go:43-109
@@ -79,6 +84,11 @@ func HnswHeuristicExtendCandidates(v bool) HnswOption {
 }
 func HnswHeuristicKeepPruned(v bool) HnswOption {
 	return &hnswOption{func(c *hnswConfig) { c.heuristicKeepPruned = v }}
+}
+
+// HnswAllowNonReferenceSelection opts in to HnswSearchDiverse: without it a drop-in user can never get a graph the reference would not build.
+func HnswAllowNonReferenceSelection(v bool) HnswOption {
+	return &hnswOption{func(c *hnswConfig) { c.allowNonReference = v }}
 }
 
 // HnswQuantization is NOT in the reference: stored rows become 2-/1-byte codes scored as the edge quantised stores do.
@@ -227,6 +237,10 @@ func NewHnsw(dim uint, distancer distance.Space, option ...HnswOption) *Hnsw {
 	x := &Hnsw{dim: dim, distancer: distancer, config: c}
 	for i := range x.meta {
 		x.meta[i] = make(map[uint64]Metadata)
+	}
+	if c.searchAlgorithm == HnswSearchDiverse && !c.allowNonReference {
+		x.err = fmt.Errorf("HnswSearchDiverse is not reference behaviour: pass HnswAllowNonReferenceSelection(true) to opt in")
+		return x
 	}
 	cfg := colttgpu.HnswCfg{M: int32(c.m), MMax: int32(c.mMax), MMax0: int32(c.mMax0), Ef: int32(c.ef), EfConstruction: int32(c.efConstruction),
 		Algo: int32(c.searchAlgorithm), LevelMultiplier: c.levelMultiplier, ExtendCandidates: b2i(c.heuristicExtendCandidates),

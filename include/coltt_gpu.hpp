@@ -138,7 +138,7 @@ struct HnswOptions {
   HnswOptions& M(int v) { c.m = v; return *this; }
   HnswOptions& Mmax(int v) { c.m_max = v; return *this; }
   HnswOptions& Mmax0(int v) { c.m_max0 = v; return *this; }
-  HnswOptions& SearchAlgorithm(int v /*0 HnswSearchSimple, 1 HnswSearchHeuristic*/) { c.algo = v; return *this; }
+  HnswOptions& SearchAlgorithm(int v /*0 HnswSearchSimple, 1 HnswSearchHeuristic; COLTT_HNSW_DIVERSE (2) is NOT reference behaviour, see coltt_gpu.h*/) { c.algo = v; return *this; }
   HnswOptions& HeuristicExtendCandidates(bool v) { c.extend_candidates = v; return *this; }
   HnswOptions& HeuristicKeepPruned(bool v) { c.keep_pruned = v; return *this; }
   HnswOptions& Quantization(int q) { quantization = q; return *this; }   // extension: BASELINE.json configs[4]
@@ -191,7 +191,7 @@ class Hnsw {
   coltt_hnsw_cfg RawConfig() const { coltt_hnsw_cfg c; check(coltt_hnsw_get_cfg(h_, &c)); return c; }
   ProtoConfig Config() const {   // hnsw.go:86-98
     coltt_hnsw_cfg c = RawConfig();
-    return {c.algo == 0 ? "simple" : "heuristic", c.level_multiplier, c.ef, c.ef_construction, c.m, c.m_max, c.m_max0,
+    return {c.algo == 0 ? "simple" : (c.algo == 1 ? "heuristic" : "diverse"), c.level_multiplier, c.ef, c.ef_construction, c.m, c.m_max, c.m_max0,
             c.extend_candidates != 0, c.keep_pruned != 0};
   }
   std::string Distance() const { return distance_ == COLTT_COSINE ? "cosine-dot" : "l2-squared"; }   // Space.Type(), space.go:69,101

@@ -199,3 +199,46 @@ def test_parameters_are_validated(gpu):
     with pytest.raises(ValueError):
         pq.SetCodebooks(np.zeros((8, 16, 7), np.float32))
     pq.close()
+
+
+@pytest.mark.parametrize("dim,m,c", [(768, 96, 256), (96, 16, 256), (384, 48, 256), (64, 8, 32)])
+def test_one_query_takes_one_scan_launch_and_equals_the_oracle_and_the_segment_chain(gpu, monkeypatch, dim, m, c):
+    """Round 6: ONE query over a store of more than 65 536 rows runs table + ONE scan launch (per-wave self-tightening lists,
+    pq_scan1_kernel: 1 024 / 256 / 512 / 256 threads per workgroup for these table sizes) + one selection instead of seven launches.
+    Same ids, same score bits as the oracle — and as the segment chain (COLTT_PQ_ONE=0) in the same process.  k = 65 exceeds what a
+    wave's list keeps: that call takes the chain by itself."""
+    n = 300_000
+    T = O.fill_normal(700 + m, (max(c, 64), dim)); cb = O.pq_train(T, m, c, 1)
+    rng = np.random.default_rng(701 + m)
+    codes = rng.integers(0, c, (n, m), dtype=np.uint8)
+    ids = _ids(n, 13)
+    pq = gpu.PQSpace(dim, gpu.PQ_EUCLIDEAN, m, c); pq.SetCodebooks(cb)
+    pq.InsertCodes(ids, codes)
+    Q = O.fill_normal(702 + m, (3, dim))
+    for k in (1, 10, 64, 65):
+        for qi in range(len(Q)):
+            monkeypatch.setenv("COLTT_PQ_ONE", "1")
+            gi, gs, gc = pq.Search(Q[qi:qi + 1], k)
+            monkeypatch.setenv("COLTT_PQ_ONE", "0")
+            ci, cs, cc = pq.Search(Q[qi:qi + 1], k)
+            assert np.array_equal(gc, cc) and np.array_equal(gi, ci) and np.array_equal(bits(gs), bits(cs)), (k, qi)
+        monkeypatch.setenv("COLTT_PQ_ONE", "1")
+        _check_search(pq, O.PQ_EUCLIDEAN, cb, codes, ids, Q[:1], k)
+    pq.close()
+
+
+def test_one_scan_launch_with_heavy_ties(gpu, monkeypatch):
+    """4 codes x 4 centroids: 256 distinct scores over 150 000 rows — every wave's list fills with ties of its threshold, the overflow
+    flag sends the call to the bounded segments; a milder case (8 x 16) stays on the one-launch path.  Exact (score, id) winners both ways."""
+    for dim, m, c, n in ((16, 4, 4, 150_000), (32, 8, 16, 150_000)):
+        T = O.fill_normal(710 + m, (64, dim)); cb = O.pq_train(T, m, c, 1)
+        rng = np.random.default_rng(711 + m)
+        codes = rng.integers(0, c, (n, m), dtype=np.uint8)
+        ids = _ids(n, 17)
+        pq = gpu.PQSpace(dim, gpu.PQ_EUCLIDEAN, m, c); pq.SetCodebooks(cb)
+        pq.InsertCodes(ids, codes)
+        Q = O.fill_normal(712 + m, (2, dim))
+        for k in (1, 10, 64):
+            _check_search(pq, O.PQ_EUCLIDEAN, cb, codes, ids, Q[:1], k)
+            _check_search(pq, O.PQ_EUCLIDEAN, cb, codes, ids, Q[1:], k)
+        pq.close()
