@@ -343,8 +343,7 @@ def cpu_hnsw(G, torch, O, h, args, dim, quant, ef, q_dev, k, out, m, counts=None
                 pq_res = {"error": str(e)}
         return {"value": best["queries_per_s"], "unit": "queries/s", "cores": best_th, "host_cpus": threads, "kind": "port", "ef": ef, "pq": pq_res,
                 "cpu_model": cpu_model(), "quota_cpus": quota_cpus(threads),
-                "sample_short": f"{sample} of the step's queries on the full {g['n']}x{dim} index, oracle (contiguous arrays, NUMA-interleaved), "
-                                f"best of {sorted(legs)} pinned threads",
+                "sample_short": f"{sample} of the step's queries, full {g['n']}x{dim} index, oracle (NUMA-interleaved arrays), best of {sorted(legs)} pinned threads",
                 "sample": f"{sample} of the step's queries on the full {g['n']}x{dim} index ({QNAME[quant]}{'' if quant == 0 else ', both operands decoded per pair as the reference does'}), "
                           f"oracle contiguous variant, BEST of {sorted(legs)} native threads (pinned 1:1 to the allowed CPUs, 1 query per thread) = {best_th}; rows and level-0 adjacency in "
                           f"NUMA-interleaved memory ({O.lib().orc_numa_nodes()} node(s), mbind={'ok' if rows.flags & 1 else 'refused -> parallel first touch'}, THP advised={bool(rows.flags & 2)})",
@@ -579,7 +578,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
             if isinstance(pqw, dict) and "error" not in pqw:      # and the table walk over the diverse graph, at the plain table walk's own settings
                 sample = hd.FetchRows(0, min(n, 65536)).view(np.float16).astype(np.float32)
                 pqd = G.PQSpace(dim, G.PQ_EUCLIDEAN, pqw["m"], pqw["centroids"]); pqd.Fit(sample, iterations=6); hd.PqAttach(pqd)
-                pefs = sorted({int(pqw["ef"] * f) // 64 * 64 for f in (0.8, 0.9, 1.0)}); prec = {}; pq_q = {}
+                pefs = sorted({int(pqw["ef"] * f) // 64 * 64 for f in (0.77, 0.86, 0.91, 0.96, 1.0)}); prec = {}; pq_q = {}
                 for ef in pefs:
                     hd.PqSearchDevice(q.data_ptr(), nq, k, *out.ptrs(), ef=ef, rerank=pqw["rerank"])
                     pq_q[str(ef)] = nq / (hd.last_kernel_ms() / 1e3)
@@ -1139,8 +1138,8 @@ def compact(res):
             dv = op.get("diverse")
             if isinstance(dv, dict):
                 o["diverse"] = {"error": str(dv["error"])[:120]} if "error" in dv else dict(
-                    _pick(dv, "ef", "recall_at_10", "reached", "value", "over_op", "recall_at_op_ef", "build_s"), not_reference_behaviour=True,
-                    **({"pq": _pick(dv["pq"], "ef", "recall_at_10", "reached", "value", "over_op_pq")} if isinstance(dv.get("pq"), dict) else {}))
+                    _pick(dv, "ef", "recall_at_10", "value", "over_op", "recall_at_op_ef"), reference_behaviour=False,
+                    **({"pq": _pick(dv["pq"], "ef", "recall_at_10", "value", "over_op_pq")} if isinstance(dv.get("pq"), dict) else {}))
             out["op"] = o
     sec = res.get("secondary") or {}
     for tag in ("c1", "c2", "c3", "c3f8", "pq"):
@@ -1155,7 +1154,9 @@ def compact(res):
         if r.get("mfma"):
             o["mfma_frac"] = r["mfma"].get("frac")
         o.update(_pick(leg, "identical_to_exact_mode", "exact_mode_ms_per_batch", "equals_oracle", "host_buffer_call_ms_median",
-                       "single_query_scan_launch_ms", "batch_64_queries_per_s", "search_frac", "segment_chain_ms", "one_launch_equals_segment_chain"))
+                       "single_query_scan_launch_ms", "batch_64_queries_per_s", "search_frac", "segment_chain_ms"))
+        if "one_launch_equals_segment_chain" in leg:
+            o["eq_chain"] = leg["one_launch_equals_segment_chain"]
         c = leg.get("cpu_baseline")
         if isinstance(c, dict):
             o["cpu_value"] = c.get("value_scaled_to_full_scan", c.get("value"))
@@ -1348,7 +1349,7 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": tr, "traffic_source": tr_src, "avg_launch_ms": launch_s * 1e3,
                     "kernel": "hnsw_search_kernel (hnsw_dev.hpp:search_level)" if os.environ.get("COLTT_WALK2_LDS", "") == "off" else
-                              ("hnsw_search2_kernel<.., VIS_LDS, EV8> (hnsw_walk2.hpp over the LDS visited hash; level-0 distances by eight lanes per row over the line-transposed row copy, rows8.hpp)"
+                              ("hnsw_search2_kernel<.., VIS_LDS, EV8> (hnsw_walk2.hpp: LDS visited hash; eight lanes per line-transposed row, rows8.hpp)"
                                if ev8_launches > 0 else "hnsw_search2_kernel<.., VIS_LDS> (hnsw_walk2.hpp over the LDS visited hash: adjacency-carried norms)"),
                     "eight_lane_launches": ev8_launches}
         h.close()

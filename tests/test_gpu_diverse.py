@@ -134,7 +134,7 @@ def test_diverse_commit_load_and_config(gpu):
     blob = gh.Commit()
     g2 = gpu.Hnsw(d, O.L2); g2.Load(blob)
     assert g2.Config().algo == DIVERSE   # (the reference's stream carries no keepPruned / extendCandidates: hnsw_config.go:179-203)
-    _graph_equal(gh.Export(), g2.Export())
+    assert g2.Len() == n and g2.Commit() == blob            # (slots are renumbered in stream order: the stream is the fixed point)
     with pytest.raises(gpu.ColttError):
         gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(algo=DIVERSE, extend_candidates=1))
     with pytest.raises(gpu.ColttError):
