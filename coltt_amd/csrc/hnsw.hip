@@ -1063,7 +1063,7 @@ struct PqGeom { uint32_t ef, ef_pad, vis_words; size_t lds; int variant; /* 0: L
 bool pq_geom(Hnsw* x, uint32_t ef, bool force_hbm, PqGeom& out) {
   PqGeom s{};
   s.ef = ef; s.ef_pad = (ef + 63) & ~63u;
-  const size_t fixed = (size_t)s.ef_pad * 8 + ((size_t)x->pq_row << pq_lut_shift(x)) * 2;   // result set | binary16 table (the query stays in HBM: only the re-rank reads it)
+  const size_t fixed = (size_t)s.ef_pad * 8 + ((size_t)pq_walk_table_rows(x->pq_row >> 4) << pq_lut_shift(x)) * 2;   // result set | binary16 table, pair-interleaved (the query stays in HBM: only the re-rank reads it)
   if (fixed > 160 * 1024) return false;
   const bool hbm_ok = x->vis_stride != 0 && x->vis_regions > 0;
   // LDS hash: as search_geom sizes it; it must never need the reset path (err 8 -> the call is re-run over the byte map)

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
   if constexpr (LS != 0) {   // AdcEval<LS> addresses the table by absolute LDS offsets: this kernel has no static LDS, so its dynamic LDS starts at 0
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem != 0u) { if (lane == 0) atomicOr(&stats[4], 128ull); return; }
   }
-  size_t off = ((size_t)row_bytes << lut_shift) * 2;   // a multiple of 512
+  size_t off = ((size_t)pq_walk_table_rows(row_bytes >> 4) << lut_shift) * 2;   // the pair-interleaved table (hnsw_pq.hpp); a multiple of 512
   w.qs = nullptr; w.qp = nullptr; w.scr = nullptr;
   w.res0 = reinterpret_cast<unsigned long long*>(smem + off); off += (size_t)ef_pad * 8;
   w.ef_pad = ef_pad;
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     w.visg = visg + (size_t)blockIdx.x * vis_stride; w.vis_bytes = vis_stride; w.epoch = vis_epoch[blockIdx.x];
   }
   AdcEval<LS, NP, NBR> ev; ev.codes = codes; ev.row_bytes = row_bytes; ev.lut = lut; ev.lut_shift = lut_shift; ev.nbrc = nbrc; ev.nbr_stride = g.mMax0 * row_bytes;
+  ev.hsel = (uint32_t)lane & 1u;
   for (;;) {
     const uint32_t qt = atomicAdd(counter, lane == 0 ? 1u : 0u);  // branch-free work fetch, see hnsw_search_kernel
     const uint32_t qi = (uint32_t)__shfl((int)qt, 0, 64);
@@ -338,11 +339,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hn
     w.t_last = __builtin_amdgcn_s_memtime();
 #endif
     wave_sync();
-    {  // the query's table as pq_lut16_kernel wrote it: row_bytes rows of (1 << lut_shift) binary16 entries, copied 16 bytes per lane and step
+    {  // the query's table as pq_lut16_kernel wrote it — row_bytes rows of (1 << lut_shift) binary16 entries — copied 16 bytes per lane and step into the
+      // PAIR-INTERLEAVED layout the lane pairs read (hnsw_pq.hpp): table row j -> LDS row 2 (j mod JS) + (j div JS), JS = 16 * ceil(pieces / 2)
       const u32x4v* src = reinterpret_cast<const u32x4v*>(lut_g + ((size_t)qi * row_bytes << lut_shift));
       u32x4v* dst = reinterpret_cast<u32x4v*>(lut);
-      const uint32_t total = row_bytes << (lut_shift - 3);   // 16-byte pieces (row_bytes is a multiple of 16, lut_shift >= 4)
-      for (uint32_t i = (uint32_t)lane; i < total; i += 64) dst[i] = src[i];
+      const uint32_t psh = lut_shift - 3;                    // log2 of the 16-byte pieces per table row (lut_shift >= 4)
+      const uint32_t total = row_bytes << psh;               // 16-byte pieces (row_bytes is a multiple of 16)
+      const uint32_t js = 16u * (((row_bytes >> 4) + 1u) >> 1);
+      for (uint32_t i = (uint32_t)lane; i < total; i += 64) {
+        const uint32_t j = i >> psh, within = i & ((1u << psh) - 1u);
+        const uint32_t r = j < js ? 2u * j : 2u * (j - js) + 1u;
+        dst[(r << psh) + within] = src[i];
+      }
     }
     w.qnorm = 0.f;
     wave_sync();

@@ -10,7 +10,9 @@
 //             quantiser's table entry (pq.hip) ROUNDED TO BINARY16 (round to nearest even, compresshelper.Fromfloat32's rounding,
 //             float16.go:276-321) — d only ranks candidates, the answers carry exact distances, and half the table bytes are twice the
 //             resident traversals (the table is what bounds this kernel's occupancy, see below)
-//   distance  d(q, v) = sum over j = 0..m-1 of float32(lut[j][code_v[j]]), f32 adds, in j order
+//   distance  d(q, v) = S_lo + S_hi (one f32 add), S_lo = the f32 sum, in j order from +0.0, of float32(lut[j][code_v[j]]) over j < JS, S_hi the same over
+//             JS <= j < m; JS = 16 * ceil(P / 2), P = ceil(m / 16) the row's 16-byte pieces (round 6: each lane of the pair that owns a neighbour sums
+//             half the code row — rounds 4-5 summed all of it in j order in ONE lane while its partner idled; a definition either way)
 //   walk      Hnsw.Search with d in place of Distance(): entrypoint, greedyClosestNeighbor on the upper levels, searchLevel(ef) on
 //             level 0 — same admission rule, same canonical neighbour order, ties by (d bits, slot)
 //   re-rank   the r = min(max(rerank, k), len) nearest survivors by d (rerank = 0: all of them) get the index's EXACT distance
@@ -44,12 +46,29 @@ namespace dev {
 // mMax0 x row_bytes block (2 KiB for 32 x 64) instead of 32 gathers of 64 bytes (each a whole 128-byte line of HBM traffic) behind the adjacency row's
 // own round trip; the table sums of ALL listed neighbours then run under the visited probe's round trip (EARLY) instead of behind it.  One dependent
 // round trip per expansion (the probe) instead of three.  Derived data like adj0_n (hnsw.hip: sync_pq_nbr); the upper levels gather from `codes`.
+// Round 6 — BOTH lanes of a pair work: the even lane owns the row's first PH = ceil(P / 2) pieces (table rows j < JS = 16 PH), the odd lane the rest; each sums its
+// half in j order from +0.0 and the pair adds the two partial sums (one DPP swap + one add: the definition above).  Half the issue slots per expansion for the
+// table sums, half the row registers.  So that ONE instruction stream serves both lanes, the table sits in LDS PAIR-INTERLEAVED — row j of the table at LDS row
+// 2 (j mod JS) + (j div JS) — and lookup t of a lane addresses `t * 2R + (code + h * C') * 2` (R = bytes per table row, C' = its entries, h = the lane's half): the
+// immediate offset is shared, and the lane's half rides in the CODE BYTE — one packed add of h * C' to every dword of the row when C' <= 128 (no carries: a code
+// is < C'), one v_add per lookup for 256-entry rows.  For an odd P the odd lane owns one piece less and the interleaved table has unused rows (one piece's worth).
+__host__ __device__ __forceinline__ constexpr uint32_t pq_walk_table_rows(uint32_t pieces) { return 2u * ((pieces + 1u) / 2u) * 16u; }   // LDS rows of the interleaved table
 template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   const uint8_t* codes; uint32_t row_bytes;   // [n][row_bytes], row_bytes = mp16 (a multiple of 16, <= 128); bytes j >= m are 0
-  const unsigned short* lut;                   // LDS: [row_bytes][1 << lut_shift] binary16, rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
+  const unsigned short* lut;                   // LDS: [pq_walk_table_rows][1 << lut_shift] binary16, pair-interleaved; rows j >= m are +0.0 (d + 0.0 keeps d's bits: d is never -0)
   uint32_t lut_shift;                          // log2 of the table's row length = the number of centroids rounded up to a power of two (4 .. 8)
   const uint8_t* nbrc; uint32_t nbr_stride;    // NBR: [n][mMax0][row_bytes], nbr_stride = mMax0 * row_bytes
-  static constexpr int NR = NP ? NP : 8;       // row registers (16-byte pieces)
+  uint32_t hsel;                               // this lane's half of its pair: 0 = the row's first PH pieces, 1 = the rest
+  static constexpr int NR = NP ? (NP + 1) / 2 : 4;   // row registers (16-byte pieces) of ONE lane
+  static constexpr bool BIAS = LS != 0 && LS <= 7;   // the lane's half rides in the code bytes (packed add per dword); LS 8: one add per lookup
+  __device__ __forceinline__ int pieces() const { return NP ? NP : (int)(row_bytes >> 4); }
+  __device__ __forceinline__ int first_piece() const { return hsel ? (pieces() + 1) >> 1 : 0; }
+  __device__ __forceinline__ int my_pieces() const { const int np = pieces(), ph = (np + 1) >> 1; return hsel ? np - ph : ph; }
+  // the pair's total: both lanes end up with S_lo + S_hi (f32 addition commutes bit for bit)
+  static __device__ __forceinline__ float pair_total(float part) {
+    const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, part), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    return part + other;
+  }
   // s + float32(h), h = a binary16 in the low half of a register.  v_fma_mix_f32 computes fma(float32(h), 1.0f, s) with ONE rounding; float32(h) * 1.0f
   // is exact, so the result is the IEEE sum of the converted entry — the bits of v_cvt_f32_f16 + v_add_f32 (the definition) in one issue slot.
   static __device__ __forceinline__ float acc(float s, uint32_t h) {
@@ -69,15 +88,11 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   // table entry (row j, code byte B of v), as the 16 bits the LDS read returns.  LS != 0: the table starts at LDS address 0 (the kernel checks it), so
   // the read is addressed by the shifted code byte alone, the row in the instruction's offset field — through the generic pointer the compiler adds
   // the (zero) base symbol to every address: one v_add per lookup.
-  template <int B> __device__ __forceinline__ uint32_t entry(uint32_t j, uint32_t sh, uint32_t v) const {
-    if constexpr (LS != 0) {
-      typedef __attribute__((address_space(3))) const unsigned short lds_u16;
-      return *reinterpret_cast<lds_u16*>((uint32_t)((j << (LS + 1)) + byte2<B>(v)));
-    } else {
-      return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)j << (sh + 1)) + byte2<B>(v));
-    }
+  // jl = the lookup's index within this lane's half; the LDS row is 2 jl + hsel (pair-interleaved table)
+  template <int B> __device__ __forceinline__ uint32_t entry(uint32_t jl, uint32_t sh, uint32_t v) const {
+    return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const uint8_t*>(lut) + ((size_t)(2u * jl + hsel) << (sh + 1)) + byte2<B>(v));
   }
-  u32x4e raw[NR];                              // the code row requested by prefetch() / prefetch_at() for this lane pair's neighbour
+  u32x4e raw[NR];                              // this lane's half of the code row requested by prefetch() / prefetch_at() for the pair's neighbour
   static constexpr bool CHUNK_ADJ = false;
   // hnsw_walk2.hpp SPEC: visited bytes + code rows of the predicted next candidate's (the runner-up's) neighbours requested one expansion ahead.
   // Exact (tests + 246 randomised rounds with it on), but measured SLOWER — an A/B knob (-DCOLTT_PQ_SPEC=1), off in the shipped library
@@ -108,10 +123,15 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
   static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void load_from(const uint8_t* row, u32x4e (&r)[NR]) const {
-    const u32x4e* p = reinterpret_cast<const u32x4e*>(row);
-    const int np = NP ? NP : (int)(row_bytes >> 4);
+    const u32x4e* p = reinterpret_cast<const u32x4e*>(row) + first_piece();
+    if constexpr (NP != 0 && NP % 2 == 0) {
 #pragma unroll
-    for (int i = 0; i < NR; i++) if (i < np) r[i] = p[i];
+      for (int i = 0; i < NR; i++) r[i] = p[i];
+    } else {
+      const int cnt = my_pieces();
+#pragma unroll
+      for (int i = 0; i < NR; i++) if (i < cnt) r[i] = p[i];
+    }
   }
   __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[NR]) const { load_from(codes + (size_t)slot * row_bytes, r); }
   // Eight lookups at a time, as ONE instruction block (LS known): the eight byte extractions, then the eight LDS reads, then the eight adds — each add
@@ -122,11 +142,47 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
 #ifndef COLTT_PQ_SUM_WAITS   // A/B knob: s_waitcnt instructions per block of eight lookups (8: one in front of every add; 2: one per four adds — measured the same to 0.3 %, r06d)
 #define COLTT_PQ_SUM_WAITS 8
 #endif
-  template <int J> static __device__ __forceinline__ float sum8(float s, uint32_t v0, uint32_t v1) {
+  // J = the first lookup's index within the lane's half; kadd: the lane's byte offset into the pair of interleaved rows (ADDK form: 256-entry rows, the half does
+  // not fit beside the code in a byte) — 0 in the BIAS form, where v0 / v1 already carry code + h * C' in every byte
+  template <int J> static __device__ __forceinline__ float sum8(float s, uint32_t v0, uint32_t v1, uint32_t kadd) {
     static_assert(LS != 0, "sum8 needs the table's row length at compile time");
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7;
     const uint32_t one = 1u; const float onef = 1.0f;
-    constexpr int R = 1 << (LS + 1);   // bytes per table row
+    constexpr int R = 2 << (LS + 1);   // bytes per PAIR of interleaved table rows
+    if constexpr (!BIAS) {
+      asm volatile(
+        "v_lshlrev_b32_sdwa %1, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %2, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %3, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %4, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_lshlrev_b32_sdwa %5, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+        "v_lshlrev_b32_sdwa %6, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+        "v_lshlrev_b32_sdwa %7, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+        "v_lshlrev_b32_sdwa %8, %11, %10 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+        "v_add_u32 %1, %21, %1\n\t" "v_add_u32 %2, %21, %2\n\t" "v_add_u32 %3, %21, %3\n\t" "v_add_u32 %4, %21, %4\n\t"
+        "v_add_u32 %5, %21, %5\n\t" "v_add_u32 %6, %21, %6\n\t" "v_add_u32 %7, %21, %7\n\t" "v_add_u32 %8, %21, %8\n\t"
+        "ds_read_u16 %1, %1 offset:%13\n\t"
+        "ds_read_u16 %2, %2 offset:%14\n\t"
+        "ds_read_u16 %3, %3 offset:%15\n\t"
+        "ds_read_u16 %4, %4 offset:%16\n\t"
+        "ds_read_u16 %5, %5 offset:%17\n\t"
+        "ds_read_u16 %6, %6 offset:%18\n\t"
+        "ds_read_u16 %7, %7 offset:%19\n\t"
+        "ds_read_u16 %8, %8 offset:%20\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t" "v_fma_mix_f32 %0, %1, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t" "v_fma_mix_f32 %0, %2, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(5)\n\t" "v_fma_mix_f32 %0, %3, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t" "v_fma_mix_f32 %0, %4, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t" "v_fma_mix_f32 %0, %5, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t" "v_fma_mix_f32 %0, %6, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t" "v_fma_mix_f32 %0, %7, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t" "v_fma_mix_f32 %0, %8, %12, %0 op_sel_hi:[1,0,0]"
+        : "+v"(s), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(v0), "v"(v1), "v"(one), "v"(onef),
+          "n"((J + 0) * R), "n"((J + 1) * R), "n"((J + 2) * R), "n"((J + 3) * R), "n"((J + 4) * R), "n"((J + 5) * R), "n"((J + 6) * R), "n"((J + 7) * R), "v"(kadd)
+        : "memory");
+      return s;
+    }
     asm volatile(
         "v_lshlrev_b32_sdwa %1, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
         "v_lshlrev_b32_sdwa %2, %11, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
@@ -169,28 +225,28 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
         : "memory");
     return s;
   }
-  template <int I> __device__ __forceinline__ float sum_piece(float s, const u32x4e& r) const {   // the 16 lookups of piece I
-    s = sum8<I * 16>(s, r[0], r[1]);
-    return sum8<I * 16 + 8>(s, r[2], r[3]);
+  template <int I> __device__ __forceinline__ float sum_piece(float s, const u32x4e& r, uint32_t bias, uint32_t kadd) const {   // the 16 lookups of this lane's piece I
+    s = sum8<I * 16>(s, r[0] + bias, r[1] + bias, kadd);
+    return sum8<I * 16 + 8>(s, r[2] + bias, r[3] + bias, kadd);
   }
+  // this lane's PARTIAL sum (its half of the row, in j order from +0.0); pair_total() makes the distance
   __device__ __forceinline__ float sum(const u32x4e (&r)[NR]) const {
-    const int np = NP ? NP : (int)(row_bytes >> 4);
+    const int cnt = my_pieces();
     float s = 0.f;
     if constexpr (LS != 0) {
-      if (0 < np) s = sum_piece<0>(s, r[0]);
-      if constexpr (NR > 1) { if (1 < np) s = sum_piece<1>(s, r[1]); }
-      if constexpr (NR > 2) { if (2 < np) s = sum_piece<2>(s, r[2]); }
-      if constexpr (NR > 3) { if (3 < np) s = sum_piece<3>(s, r[3]); }
-      if constexpr (NR > 4) { if (4 < np) s = sum_piece<4>(s, r[4]); }
-      if constexpr (NR > 5) { if (5 < np) s = sum_piece<5>(s, r[5]); }
-      if constexpr (NR > 6) { if (6 < np) s = sum_piece<6>(s, r[6]); }
-      if constexpr (NR > 7) { if (7 < np) s = sum_piece<7>(s, r[7]); }
+      const uint32_t bias = BIAS ? (hsel ? (uint32_t)(1u << LS) * 0x01010101u : 0u) : 0u;   // h * C' in every byte (BIAS form)
+      const uint32_t kadd = BIAS ? 0u : (hsel << (LS + 1));                                 // h * R bytes (ADDK form)
+      constexpr bool EVEN = NP != 0 && NP % 2 == 0;   // both lanes own NR pieces: no per-lane test
+      if (EVEN || 0 < cnt) s = sum_piece<0>(s, r[0], bias, kadd);
+      if constexpr (NR > 1) { if (EVEN || 1 < cnt) s = sum_piece<1>(s, r[1], bias, kadd); }
+      if constexpr (NR > 2) { if (EVEN || 2 < cnt) s = sum_piece<2>(s, r[2], bias, kadd); }
+      if constexpr (NR > 3) { if (EVEN || 3 < cnt) s = sum_piece<3>(s, r[3], bias, kadd); }
       return s;
     } else {
       const uint32_t sh = lut_shift;
 #pragma unroll
       for (int i = 0; i < NR; i++) {
-        if (i < np) {
+        if (i < cnt) {
 #pragma unroll
           for (int wd = 0; wd < 4; wd++) {
             const uint32_t v = r[i][wd];
@@ -202,20 +258,21 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
       return s;
     }
   }
-  __device__ __forceinline__ float adc(uint32_t slot) const { u32x4e r[NR]; load(slot, r); return sum(r); }
+  // d(query, slot) in every lane of the pair (every lane of the wave when they all pass the same slot: the entrypoint)
+  __device__ __forceinline__ float adc(uint32_t slot) const { u32x4e r[NR]; load(slot, r); return pair_total(sum(r)); }
   // The code row of every LISTED neighbour is requested before the walk knows which of them are fresh: 32-128 bytes each, in flight
   // under the visited test's own dependent HBM probe instead of behind it (one round trip less per expansion; rows of already visited
   // neighbours are fetched for nothing — a few KB per expansion against a dependent ~2 us).
-  __device__ __forceinline__ void prefetch(uint32_t nb, bool valid, int half) { if (valid && half == 0) load(nb, raw); }
+  __device__ __forceinline__ void prefetch(uint32_t nb, bool valid, int /*half*/) { if (valid) load(nb, raw); }   // both lanes: each its half of the row
   // NBR: the code row of candidate `cand`'s neighbour at position idx of its level-0 row (in_row: idx < mMax0)
-  __device__ __forceinline__ void prefetch_at(uint32_t cand, uint32_t idx, bool in_row, int half) {
-    if (in_row && half == 0) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, raw);
+  __device__ __forceinline__ void prefetch_at(uint32_t cand, uint32_t idx, bool in_row, int /*half*/) {
+    if (in_row) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, raw);
   }
   // RADJ over the neighbourhood blocks: the runner-up's block is requested at POP time into a second set of row registers; if the runner-up is indeed the
   // next candidate (no nearer vertex admitted meanwhile — the common case once the result set is full) the rows are simply taken over
   u32x4e spec_raw[NBR ? NR : 1];
-  __device__ __forceinline__ void prefetch_spec(uint32_t cand, uint32_t idx, bool in_row, int half) {
-    if constexpr (NBR) { if (in_row && half == 0) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, spec_raw); }
+  __device__ __forceinline__ void prefetch_spec(uint32_t cand, uint32_t idx, bool in_row, int /*half*/) {
+    if constexpr (NBR) { if (in_row) load_from(nbrc + (size_t)cand * nbr_stride + (size_t)idx * row_bytes, spec_raw); }
   }
   __device__ __forceinline__ void take_spec() {
     if constexpr (NBR) {
@@ -223,21 +280,19 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
       for (int i = 0; i < NR; i++) raw[i] = spec_raw[i];
     }
   }
-  float pre_d;   // EARLY: the table sum of this lane pair's neighbour, computed under the visited probe
-  __device__ __forceinline__ void early(bool valid, int half) { pre_d = 0.f; if (valid && half == 0) pre_d = sum(raw); }
+  float pre_d;   // EARLY: the table sum of this lane pair's neighbour, computed under the visited probe (both lanes hold it)
+  __device__ __forceinline__ void early(bool valid, int /*half*/) { float part = 0.f; if (valid) part = sum(raw); pre_d = pair_total(part); }
   // ties a value loaded before early() to early()'s result: the compiler may not use (hence wait for) it before the sums are computed
   __device__ __forceinline__ void after_early(uint32_t& x) { asm volatile("" : "+v"(x), "+v"(pre_d)); }
   // the table sum over the code row prefetch() requested (greedy descent: every valid neighbour is evaluated at once)
-  __device__ __forceinline__ float eval_now(bool fresh, int half) const {
-    float r = 0.f;
-    if (fresh && half == 0) r = sum(raw);
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));   // even lane's value to its pair: quad_perm [0,0,2,2]
+  __device__ __forceinline__ float eval_now(bool fresh, int /*half*/) const {
+    float part = 0.f;
+    if (fresh) part = sum(raw);
+    return pair_total(part);   // both lanes of the pair
   }
   __device__ __forceinline__ float operator()(const GraphView&, const WaveCtx&, uint32_t, bool fresh, float, int half, int) const {
-    if constexpr (EARLY) {
-      const float r = fresh ? pre_d : 0.f;   // (pre_d lives in the even lanes)
-      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, r), 0xA0, 0xf, 0xf, true));
-    } else return eval_now(fresh, half);
+    if constexpr (EARLY) return fresh ? pre_d : 0.f;
+    else return eval_now(fresh, half);
   }
 };
 

@@ -1721,6 +1721,17 @@ static inline float pq_adc(const float* lut, int m, int C, const uint8_t* code) 
   for (int j = 0; j < m; j++) dist += lut[(size_t)j * C + code[j]];
   return dist;
 }
+// The table distance of the product-quantised WALK (a definition of ours, like the walk itself — "Product-quantised HNSW" below): the code row is
+// P = ceil(m / 16) 16-byte pieces; S_lo sums the entries of the first ceil(P / 2) pieces (j < JS = 16 ceil(P / 2)) in j order from +0.0, S_hi the
+// entries of the rest (JS <= j < m) in j order from +0.0; d = S_lo + S_hi, one f32 add.  (Round 6: on the GPU a neighbour is owned by a LANE PAIR, and
+// each lane now sums half the row; rounds 4-5 had one lane sum the whole row in j order while its partner idled — a different, equally arbitrary order.)
+static inline float pq_adc_walk(const float* lut, int m, int C, const uint8_t* code) {
+  const int P = (m + 15) / 16, JS = 16 * ((P + 1) / 2);
+  float lo = 0.f, hi = 0.f;
+  for (int j = 0; j < m && j < JS; j++) lo += lut[(size_t)j * C + code[j]];
+  for (int j = JS; j < m; j++) hi += lut[(size_t)j * C + code[j]];
+  return lo + hi;
+}
 
 extern "C" {
 
@@ -1789,7 +1800,7 @@ int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub,
 // closed form of csr_search above, and the quantiser's Encode / table / score of "Product quantiser" above
 // (pkg/distancepq/distance.go:30-42):
 //   codes    code_v = Encode(stored row of v as the index's distance sees it: normalised for cosine, lowered and raised for 2-byte rows)
-//   d(q, v)  = pq_adc(lut16(q'), code_v), q' = the query as the index's distance sees it, lut16 = the quantiser's table (its distancepq
+//   d(q, v)  = pq_adc_walk(lut16(q'), code_v) (two half-row sums added: see pq_adc_walk), q' = the query as the index's distance sees it, lut16 = the quantiser's table (its distancepq
 //            function) with every entry rounded to binary16 (round to nearest even — the f16 codec's own rounding) and read back as f32:
 //            d only ranks, the answers carry exact distances, and a 2-byte table doubles the GPU kernel's resident traversals.  Before the
 //            rounding every entry is multiplied by 2^-k, k = the smallest integer >= 0 with (largest entry) * 2^-k <= 32768 (exact; k = 0 for
@@ -1820,7 +1831,7 @@ static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* c
   }
   for (float& v : lut) v = u2f(f16bits_to_f32bits(f32bits_to_f16bits(f2u(v))));   // the walk's table entries are binary16 (round to nearest even)
   uint64_t n_dist = 0, n_exp = 0, n_hops = 0, n_exact = 0;
-  auto D = [&](uint32_t s) { n_dist++; return pq_adc(lut.data(), m, C, codes + (size_t)s * m); };
+  auto D = [&](uint32_t s) { n_dist++; return pq_adc_walk(lut.data(), m, C, codes + (size_t)s * m); };
   const size_t rb = (size_t)g.dim * quant_bytes(g.quant);
   auto X = [&](uint32_t s) {
     n_exact++;

@@ -557,7 +557,7 @@ def pq_search(metric, codebooks, vectors, ids, query, k):
 def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level, codes, codebooks, pq_metric, query_seen, k, ef, rerank=0):
     """Product-quantised Hnsw.Search as DEFINED in oracle/coltt_oracle.cpp ("Product-quantised HNSW"), restated independently in plain
     Python over the padded-array graph (adj0 [n][w0], upper_off [n], adj_u [rows][wu], 0xffffffff padded): table distance
-    d = sum_j float32(binary16(lut[j][code[j]])) (f32 adds, j order) in place of Distance() for the entrypoint (hnsw.go:253), greedyClosestNeighbor (:320-343)
+    d = S_lo + S_hi, the two half-row sums of float32(binary16(lut[j][code[j]])) (f32 adds, j order within a half) in place of Distance() for the entrypoint (hnsw.go:253), greedyClosestNeighbor (:320-343)
     and searchLevel(ef) (:345-389, canonical closed form: stale lowerBound per pop, ascending-slot neighbour order, ties by (d, slot));
     then the r = min(max(rerank, k), len) nearest (rerank = 0: all) re-scored with the exact distance (AVX order) and the k smallest by
     (score bits, slot) returned.  rows_seen / query_seen: the f32 values the index's distance sees.  Returns slots, scores, counters."""
@@ -574,12 +574,16 @@ def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level,
     cnt = {"n_dist": 0, "n_exp": 0, "n_hops": 0, "n_exact": 0}
     NONE = 0xFFFFFFFF
 
+    js = 16 * (((m + 15) // 16 + 1) // 2)     # the first ceil(P / 2) of the row's P = ceil(m / 16) 16-byte pieces
+
     def d_of(s):
         cnt["n_dist"] += 1
-        acc = f32(0)
-        for j in range(m):
-            acc = f32(acc + lut[j][int(codes[s][j])])
-        return acc
+        lo = f32(0); hi = f32(0)               # two half-row sums, each in j order from +0.0, added once (coltt_oracle.cpp: pq_adc_walk)
+        for j in range(min(m, js)):
+            lo = f32(lo + lut[j][int(codes[s][j])])
+        for j in range(js, m):
+            hi = f32(hi + lut[j][int(codes[s][j])])
+        return f32(lo + hi)
 
     def bits(x):
         return int(f32(x).view(np.uint32))

@@ -134,7 +134,12 @@ def test_diverse_commit_load_and_config(gpu):
     blob = gh.Commit()
     g2 = gpu.Hnsw(d, O.L2); g2.Load(blob)
     assert g2.Config().algo == DIVERSE   # (the reference's stream carries no keepPruned / extendCandidates: hnsw_config.go:179-203)
-    assert g2.Len() == n and g2.Commit() == blob            # (slots are renumbered in stream order: the stream is the fixed point)
+    assert g2.Len() == n
+    Q = O.fill_normal(9113, (16, d))                         # (slots are renumbered in stream order: compare what a caller sees)
+    a = gh.Search(Q, 10, ef=64); b = g2.Search(Q, 10, ef=64)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+    c1 = g2.Commit(); g3 = gpu.Hnsw(d, O.L2); g3.Load(c1)
+    assert g3.Commit() == c1 and g3.Config().algo == DIVERSE   # the stream is a fixed point of Commit(Load(.))
     with pytest.raises(gpu.ColttError):
         gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(algo=DIVERSE, extend_candidates=1))
     with pytest.raises(gpu.ColttError):

@@ -42,6 +42,8 @@ def read_counter(path, counter="FETCH_SIZE"):
         elif "hnsw_search_kernel" in name:   # the two visited-set variants are different kernels: <.., false> LDS hash, <.., true> HBM byte map
             q = name.split("hnsw_search_kernel<")[1].split(",")[1].strip() if "hnsw_search_kernel<" in name else "0"   # <METRIC, QUANT, VISG>
             short = ("hnsw_search_kernel/hbm" if "true>" in name else "hnsw_search_kernel/lds") + ("" if q == "0" else f"/q{q}")
+        elif "pq_scan1_kernel" in name:  # pq.hip, round 6: ONE scan launch per single-query search (all rows of the store)
+            short = "pq_scan1_kernel"
         elif "pq_scan_kernel" in name:   # pq.hip: the ADC scan (every query-group / piece-width instance)
             short = "pq_scan_kernel"
         elif "flat_scan_kernel" in name:   # flat_scan_kernel<METRIC, QUANT, ...>: the calibration launches of each row format apart
@@ -120,7 +122,9 @@ def main_pq(a):
     cluster of dispatches whose counter values agree within 3 % among the values above half the maximum of the one-pass launches
     (the 64-query call streams the codes 64 times in one dispatch and is excluded by its size)."""
     n, dim, m = (int(v) for v in a.pq.split(","))
-    c = read_counter(a.csv).get("pq_scan_kernel", [])
+    counters = read_counter(a.csv)
+    one_launch = bool(counters.get("pq_scan1_kernel"))     # round 6: a single-query search is ONE scan launch over all n rows (pq_scan1_kernel)
+    c = counters.get("pq_scan1_kernel") or counters.get("pq_scan_kernel", [])
     if not c:
         sys.exit("no pq_scan_kernel dispatches with FETCH_SIZE in " + a.csv)
     one_pass_cap = 1.5 * n * m / 1024.0 / 2.0           # KiB a one-pass launch can report at most (the counter halves 16 B/lane streams)
@@ -135,7 +139,7 @@ def main_pq(a):
     s0 = 4096
     while s0 * 64 < n:
         s0 *= 64
-    rows = n - s0                                          # pq.hip: segments 4 Ki, x64, ... — the last one starts at the largest 4096 * 64^i below n
+    rows = n if one_launch else n - s0                     # pq.hip: segments 4 Ki, x64, ... — the last one starts at the largest 4096 * 64^i below n
     algorithmic = rows * m
     traffic = mean_kib * 1024.0 * 2.0
     table = json.load(open(a.out)) if os.path.exists(a.out) else {}
@@ -143,7 +147,7 @@ def main_pq(a):
     table[key] = {"hbm_bytes_per_launch": traffic, f"FETCH_SIZE_KiB_mean_of_{len(best)}_launches": mean_kib,
                   "correction": "x2: gfx950 FETCH_SIZE under-counts 16 B/lane streams (factor 1.997 calibrated on flat_scan_kernel in the hnsw passes; the code pieces are 16 B/lane loads)",
                   "algorithmic_bytes_per_launch": algorithmic, "rows_of_the_launch": rows, "traffic_over_algorithmic": traffic / algorithmic,
-                  "source": os.path.basename(a.csv), "dispatches_used": len(best)}
+                  "source": os.path.basename(a.csv), "dispatches_used": len(best), "kernel": "pq_scan1_kernel" if one_launch else "pq_scan_kernel"}
     print(key, "->", json.dumps(table[key], indent=1))
     json.dump(table, open(a.out, "w"), indent=1)
 
@@ -214,7 +218,7 @@ def main_hnswpq(a):
                   "traffic_over_algorithmic_blocks_only": 1.0,
                   "note": "the walk kernel alone (the re-rank streams rows: x2 as every 16 B/lane stream); blocks are read once each, contiguous; what exceeds the "
                           "algorithmic bytes is the visited byte map: one memory request per probed byte",
-                  "source": os.path.basename(a.csv), "dispatches_used": len(best)}
+                  "source": os.path.basename(a.csv), "dispatches_used": len(best), "kernel": "pq_scan1_kernel" if one_launch else "pq_scan_kernel"}
     print(key, "->", json.dumps(table[key], indent=1))
     json.dump(table, open(a.out, "w"), indent=1)
 
