@@ -318,6 +318,7 @@ template <int METRIC, int QUANT, int TP> struct LatEval {
   static constexpr bool RADJ = true;    // the runner-up's adjacency row is requested at pop time (the chunk's rows come along with its vectors)
   static constexpr bool ROWPF = false;
   static constexpr bool EARLY = false;
+  static constexpr bool BOUNDED = false;
   static constexpr bool SETCACHE = false;
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }

@@ -119,6 +119,8 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
 #define COLTT_PQ_SETCACHE 0
 #endif
   static constexpr bool SETCACHE = COLTT_PQ_SETCACHE != 0;
+  static constexpr bool BOUNDED = true;   // hnsw_walk2.hpp: once the set is full, a neighbour whose table distance is not below lowerBound is neither marked nor counted,
+                                          // and the result set itself answers "visited?" (no byte-map probe, no mark)
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
   static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }

@@ -218,6 +218,43 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
   }
 }
 
+#ifndef COLTT_PQ_BYSET
+#define COLTT_PQ_BYSET 0
+#endif
+// Is the lane's key (khi = distance bits, klo = slot << 1) a CURRENT member of main ∪ delta?  (COLTT_PQ_BYSET, see search_level2; EVERY lane must call — never
+// behind a per-lane `want && ...` short circuit: the delta's keys sit one per lane, an inactive lane's key is not compared — that bug cost three GPU calls.)  Called by every lane of the wave; the lanes with `want` test.
+// The main array is sorted by key and a member's key differs from the probe in the `expanded` bit at most: a binary search; the delta's <= 64 keys sit one
+// per lane: one broadcast + compare per lane that the array did not settle.  LDS and registers only — no memory request.
+__device__ __forceinline__ bool set_member(const unsigned long long* res, uint32_t len, const Delta& dl, bool want, uint32_t khi, uint32_t klo, uint32_t rej_slot, int lane) {
+  // lower bound of the key in the main array, the SAME number of steps in every lane (a lane without a key searches for ~0): no divergent loop in front of
+  // the cross-lane operations below
+  const unsigned long long key = want ? ((((unsigned long long)khi) << 32) | klo) : ~0ull;
+  uint32_t base = 0;
+  for (uint32_t sz = len; sz > 1u;) {   // wave-uniform trip count
+    const uint32_t h = sz >> 1;
+    base = res[base + h - 1u] < key ? base + h : base;
+    sz -= h;
+  }
+  bool member = false;
+  if (len) {
+    const unsigned long long e0 = res[base];
+    const uint32_t pos = base + (e0 < key ? 1u : 0u);
+    const unsigned long long e = pos < len ? res[pos] : ~0ull;
+    member = want && pos < len && ((e ^ key) >> 1) == 0ull;
+  }
+  // the delta's keys (one per lane) and the vertices the walk REJECTED in the expansion that filled the set (rej_slot, one per lane or NBR_NONE): they were
+  // tested against a lowerBound sampled before that expansion's unconditional admissions raised the worst member, so they may lie under a later bound
+  // without being members — the only visited non-members that can
+  unsigned long long cand = __ballot(want && !member);
+  while (cand) {
+    const int j = __builtin_ctzll(cand); cand &= cand - 1;
+    const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j), kl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j);
+    const unsigned long long hit = __ballot(((uint32_t)lane < dl.n && dl.hi == kh && ((dl.lo ^ kl) >> 1) == 0u) || rej_slot == (kl >> 1));
+    if (hit && lane == j) member = true;
+  }
+  return member;
+}
+
 // Where the distances of a chunk come from.  The throughput kernels evaluate them in place (one lane pair per row, exact.hpp); the
 // latency kernel (hnsw_lat.hpp) hands the chunk to all four waves of its workgroup.  Called by every lane of the walking wave.
 template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct PairEval {
@@ -227,6 +264,7 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
   static constexpr bool ROWPF = false;       // no per-neighbour input addressed by (candidate, position) (see AdcEval<.., NBR>, hnsw_pq.hpp)
   static constexpr bool SETCACHE = false;    // the head / tail windows of the main array are not cached in registers (register budget of the row walks)
   static constexpr bool EARLY = false;       // distances are computed for the fresh neighbours only, after the visited test
+  static constexpr bool BOUNDED = false;     // the reference's order: visited test first, every fresh neighbour evaluated (hnsw.go:366-373)
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
@@ -262,6 +300,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr bool RADJ = false;
   static constexpr bool ROWPF = false;
   static constexpr bool EARLY = false;
+  static constexpr bool BOUNDED = false;
   static constexpr bool SETCACHE = false;
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
@@ -393,6 +432,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
   // expansion (program order, agent-scope accesses served by L2) and nothing marks in between, so the values are exactly what the probe of the
   // next expansion would read.
   uint32_t spec_slot = NBR_NONE; uint32_t spec_vis = 0;
+  uint32_t rej_slot = NBR_NONE;   // BOUNDED: the fresh neighbour this lane pair rejected in the expansion that filled the set (see set_member)
   const uint32_t width = g.mMax0;
   wave_sync();
   for (uint32_t iters = 0;; iters++) {
@@ -484,6 +524,20 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
     }
     const uint32_t cslot = (uint32_t)ce >> 1;
     uint32_t free_slots = ef - (len + dl.n);  // the set never exceeds ef
+    // BOUNDED evaluators (the walk over product-quantiser codes — a definition of ours, coltt_oracle.cpp: csr_search_pq): once the result set is full at a pop
+    // it stays full and its worst member only ever improves, so a neighbour whose table distance is not below lowerBound can never be admitted, now or later:
+    // it is neither marked visited nor counted (its distance costs a table sum, not a row).  The sequence of result sets — hence ids, scores, n_exp — is
+    // exactly that of the unbounded walk; n_dist counts the evaluations that passed the bound and were fresh.
+    // What this buys is the visited MARKS: a byte store into the map is a read-modify-write in HBM, and 22 of them per expansion became ~3.4 — 412.6 -> 467.8 k
+    // queries/s at 10 M x 768, ef 1 344 (profiles/r06o_*).
+    // -DCOLTT_PQ_BYSET=1 (A/B knob, exact, measured SLOWER, off): THE RESULT SET AS THE VISITED SET.  A vertex under the bound that was met before was admitted (it
+    // was under the bound then, too: the bound only falls) and is still a member — had it been evicted, it would be above the bound now; the one exception are the
+    // neighbours REJECTED by the expansion that filled the set (rej_slot, see set_member).  So in a full set "visited" == "is a current member", and the byte map
+    // need not be read or written again.  But the membership test — a binary search of 11 dependent LDS reads + the delta's registers — costs more than the probe
+    // it replaces, which flies under the table sums: 467.8 -> 403.9 k queries/s, one query 2.75 -> 3.66 ms (profiles/r06s_*).
+    // (Rows wider than one chunk keep the byte map in any case: the set changes between the chunks of one expansion, the oracle's visited set does not.)
+    const bool full_at_pop = free_slots == 0;
+    const bool by_set = COLTT_PQ_BYSET != 0 && full_at_pop && width <= 32;
     w.n_exp++;
     wave_sync();
     const uint32_t* row = g.adj0 + (size_t)cslot * width;
@@ -518,6 +572,8 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       }                                                                                              \
     }
     for (uint32_t c0 = 0; c0 < width; c0 += 32) {
+      float bounded_d = 0.f;   // BOUNDED, not EARLY: the chunk's table distances, computed before the visited test
+      (void)bounded_d;
       const uint32_t idx = c0 + p;
       const bool pre_hit = use_pre && c0 == 0;
       const uint32_t nb = idx < width ? (pre_hit ? pre_now : row[idx]) : NBR_NONE;
@@ -539,6 +595,15 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         // ~200 issue slots of table lookups instead of in front of them.  Test-and-set as below.
         static_assert(!eval_t::SPEC, "EARLY evaluators take no speculative visited bytes");
         const bool probe = valid && half == 0;
+        if (eval_t::BOUNDED && by_set) {
+          // full set: the table sums, the bound, then membership in the result set (no probe, no mark)
+          ev.early(valid, half);
+          const bool want = probe && ev.pre_d < lower_bound;
+          if (__ballot(want)) {   // (every lane calls: the delta's keys sit one per lane)
+            const bool member = set_member(res, len, dl, want, __float_as_uint(ev.pre_d), nb << 1, rej_slot, lane);
+            fresh_i = (want && !member) ? 1 : 0;
+          }
+        } else {
         // The aligned 32-bit word around the byte is loaded (no zero-extension for the compiler to place — with its s_waitcnt vmcnt — right behind the
         // load) and the byte is taken out of it after early().  The region is this wave's own and its size a multiple of 16; agent scope: served by L2.
         // EVERY lane loads (the others word 0 of the region: one more address in the same request): a load under a divergent branch would leave the
@@ -548,10 +613,22 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         ev.after_early(vw);   // the probe's value is not looked at (no s_waitcnt vmcnt for it) before the table sums are there
         const uint32_t v = (vw >> ((nb & 3u) * 8u)) & 0xffu;
         fresh_i = probe && v != (w.epoch & 0xffu) ? 1 : 0;
+        if constexpr (eval_t::BOUNDED) { if (full_at_pop && !(ev.pre_d < lower_bound)) fresh_i = 0; }   // (wide rows) the bound: not marked, not counted
         if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       } else {
         if constexpr (eval_t::EARLY) ev.early(valid, half);
-        if (valid && half == 0) {
+        bool want = valid && half == 0;
+        if constexpr (eval_t::BOUNDED) {   // full set (see full_at_pop): the table sums of ALL listed neighbours, the bound, then membership in the result set
+          if (full_at_pop) {
+            bounded_d = ev.eval_now(valid, half); want = want && bounded_d < lower_bound;
+            if (by_set && __ballot(want)) {   // (every lane calls: the delta's keys sit one per lane)
+              const bool member = set_member(res, len, dl, want, __float_as_uint(bounded_d), nb << 1, rej_slot, lane);
+              fresh_i = (want && !member) ? 1 : 0;
+            }
+          }
+        }
+        if (want && !(eval_t::BOUNDED && by_set)) {
           // Test-and-set.  No two lanes hold the same slot (a row lists a neighbour once), so load + store on the byte map is
           // race-free; agent-scope atomics are served by L2, never by a stale L1 line.
           bool maybe = true;
@@ -578,10 +655,13 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       COLTT_PT(w, 2)  // visited test-and-set
       const bool last_chunk = c0 + 32 >= width;
       if (nfresh == 0) { if (last_chunk) { COLTT_PREFETCH_NEXT2() } continue; }
-      w.n_dist += nfresh; vis_count += nfresh;
-      const float d = ev(g, w, nb, fresh, nrm, half, lane);
+      w.n_dist += nfresh; vis_count += (eval_t::BOUNDED && by_set) ? 0u : nfresh;   // (vis_count: entries of the LDS hash)
+      float d;
+      if constexpr (eval_t::BOUNDED && !eval_t::EARLY) { if (full_at_pop) d = fresh ? bounded_d : 0.f; else d = ev(g, w, nb, fresh, nrm, half, lane); }
+      else d = ev(g, w, nb, fresh, nrm, half, lane);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u));   // fresh neighbours in front of this lane
       const bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);
+      if constexpr (eval_t::BOUNDED) { if (!full_at_pop && fresh && half == 0 && !adm) rej_slot = nb; }   // only the expansion that fills the set rejects while filling
 #ifdef COLTT_PHASE_TIMING
       if (__ballot(adm) == 0xdeadbeefcafeull) w.err |= 64u;  // forces the distances
 #endif

@@ -1809,7 +1809,8 @@ int orc_pq_search_mt(int metric, const float* codebooks, int m, int C, int dsub,
 //            searchLevel(ef) on level 0 (:345-389) — admission rule, canonical neighbour order and (d, slot) ties unchanged
 //   re-rank  r = min(max(rerank, k), |result set|) (rerank = 0: the whole set): the r nearest by d are re-scored with the index's
 //            exact distance; the k smallest by (exact score bits, slot) are returned with the exact scores.
-// Counters: st[0] table-distance evaluations, st[1] expansions, st[2] greedy hops, st[3] exact evaluations.
+// Counters: st[0] table-distance evaluations (level 0: those that passed the bound and the visited test — see BOUNDED VISITING), st[1] expansions,
+// st[2] greedy hops, st[3] exact evaluations.
 // ------------------------------------------------------------------------------------------------
 static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* cb, int m, int C, int dsub, int pq_metric, const float* query, int k, int ef,
                          int rerank, int32_t* out_slots, float* out_scores, uint64_t* st) {
@@ -1864,9 +1865,22 @@ static int csr_search_pq(const CsrGraph& g, const uint8_t* codes, const float* c
     float lowerBound = res.back().d; int free_slots = ef - (int)res.size(); uint32_t c = (uint32_t)res[ci].slot;
     n_exp++; adm.clear();
     uint32_t w; const uint32_t* row = csr_row(g, c, 0, w);
+    // BOUNDED VISITING (round 6; part of this definition, not of the reference): a table distance costs a few lookups, a visited test a memory request.  Once the
+    // result set is full at a pop it stays full and its worst member only ever improves, so a neighbour with d >= lowerBound can never be admitted, now or at
+    // any later encounter: it is skipped BEFORE the visited test — neither marked nor counted.  The sequence of result sets (hence ids, scores, n_exp) is
+    // exactly that of the unbounded walk; st[0] counts the evaluations that passed the bound and the visited test (every fresh one while the set fills up).
+    const bool full_at_pop = free_slots == 0;
     for (uint32_t j = 0; j < w && row[j] != 0xffffffffu; j++) {
       uint32_t nb = row[j];
       if (csr_deleted(g, nb)) continue;
+      if (full_at_pop) {
+        float d = pq_adc_walk(lut.data(), m, C, codes + (size_t)nb * m);   // not counted
+        if (!(d < lowerBound)) continue;
+        if (!visited.insert(nb)) continue;
+        n_dist++;
+        adm.push_back({d, (int32_t)nb, false});
+        continue;
+      }
       if (!visited.insert(nb)) continue;
       float d = D(nb);
       if (free_slots > 0) { adm.push_back({d, (int32_t)nb, false}); free_slots--; }

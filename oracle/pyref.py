@@ -576,8 +576,9 @@ def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level,
 
     js = 16 * (((m + 15) // 16 + 1) // 2)     # the first ceil(P / 2) of the row's P = ceil(m / 16) 16-byte pieces
 
-    def d_of(s):
-        cnt["n_dist"] += 1
+    def d_of(s, count=True):
+        if count:
+            cnt["n_dist"] += 1
         lo = f32(0); hi = f32(0)               # two half-row sums, each in j order from +0.0, added once (coltt_oracle.cpp: pq_adc_walk)
         for j in range(min(m, js)):
             lo = f32(lo + lut[j][int(codes[s][j])])
@@ -616,11 +617,21 @@ def csr_search_pq(rows_seen, adj0, upper_off, adj_u, metric, entry, entry_level,
             break
         res[ci][2] = True
         lower_bound = res[-1][0]; free = ef - len(res); cnt["n_exp"] += 1
+        full_at_pop = free == 0                 # bounded visiting (coltt_oracle.cpp: csr_search_pq): the set stays full, its worst member only improves
         adm = []
         for nb in row(res[ci][1], 0):
             nb = int(nb)
             if nb == NONE:
                 break
+            if full_at_pop:
+                dd = d_of(nb, count=False)      # a table sum is cheaper than a visited test: the bound first
+                if not dd < lower_bound:
+                    continue                    # can never be admitted, now or later: neither marked nor counted
+                if nb in visited:
+                    continue
+                visited.add(nb); cnt["n_dist"] += 1
+                adm.append([dd, nb, False])
+                continue
             if nb in visited:
                 continue
             visited.add(nb)
