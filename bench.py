@@ -496,8 +496,11 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
         torch.cuda.synchronize(); pdt = time.perf_counter() - t0
         pnd = pst["n_dist"] / nq; pnx = pst["n_exact"] / nq; pne = pst["n_exp"] / nq
         row = (pm + 15) // 16 * 16
-        # algorithmic bytes: one code row + one visited byte per table distance, the adjacency row per expansion, the stored row per exact distance
-        pbytes = pnd * row + pne * (2 * args.m) * 4 + pnd * 4 + pnx * dim * 2
+        # algorithmic bytes: per expansion the candidate's neighbourhood block (mMax0 code rows), its adjacency row and one visited byte per listed neighbour;
+        # one visited mark per counted evaluation (round 6: n_dist counts the evaluations that passed the bound of a full set and were fresh); the stored row
+        # per exact distance
+        w0 = 2 * args.m
+        pbytes = pne * (w0 * row + w0 * 4 + w0) + pnd + pnx * dim * 2
         w = {"workload": f"the same index walked on product-quantiser codes (m = {pm} sub-vectors x {pc} centroids, {row} B per row, binary16 tables in LDS; code rows read from "
                          f"neighbourhood blocks beside the adjacency rows) + exact re-rank of {'every survivor' if rr == 0 else 'the ' + str(rr) + ' nearest survivors'}",
              "m": pm, "centroids": pc, "rerank": rr, "ef": pef, "recall_at_10": pcurve[str(pef)], "reached": bool(pok),

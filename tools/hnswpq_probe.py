@@ -71,7 +71,7 @@ def main():
                         h.PqSearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef, rerank=rr)
                         t0 = time.time(); st = h.PqSearchDevice(q.data_ptr(), nq, k, *o.ptrs(), ef=ef, rerank=rr); dt = time.time() - t0
                         nd, nx = st["n_dist"] / nq, st["n_exact"] / nq
-                        bytes_q = nd * ((m + 15) // 16 * 16) + st["n_exp"] / nq * 32 * 4 + nd * 4 + nx * dim * 2
+                        bytes_q = st["n_exp"] / nq * (32 * ((m + 15) // 16 * 16) + 32 * 4 + 32) + nd + nx * dim * 2   # block + adjacency row + probes per expansion, marks, exact rows
                         emit({"kind": "pq", "knobs": knobs, "n": n, "m": m, "C": nc, "pq_metric": pname, "ef": ef, "rerank": rr, "recall": round(recall(o.ids.cpu().numpy()), 4),
                               "qps": round(nq / dt), "kernel_ms": round(h.last_kernel_ms(), 3), "n_dist": round(nd, 1), "n_exact": round(nx, 1),
                               "MB_per_query": round(bytes_q / 1e6, 3), "GBps": round(bytes_q * nq / max(h.last_kernel_ms(), 1e-9) / 1e6, 1),

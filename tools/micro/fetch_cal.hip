@@ -1,7 +1,7 @@
 // fetch_cal.hip — what rocprofv3's FETCH_SIZE reports for the two access patterns of the product-quantised walk (hnsw_pq.hpp, round 6), on known
 // byte counts (MI355X_MICROARCH.md: "FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read ... other access widths are
 // uncalibrated: calibrate on a known byte count in your own access pattern"):
-//   block_kernel   the neighbourhood blocks: a wave reads random 2 KiB blocks, EVEN lanes only, lane 2p its 64 bytes at p * 64 as four 16-byte loads
+//   block_kernel   the neighbourhood blocks: a wave reads random 2 KiB blocks, lane pair p the 64 bytes at p * 64: each lane its half as two 16-byte loads
 //                  (exactly AdcEval<.., NBR>::prefetch_at) — known bytes = blocks x 2048
 //   probe_kernel   the visited byte map: every EVEN lane loads ONE aligned 32-bit word at a random address of a large table (the probe of
 //                  search_level2's EARLY path) — algorithmic bytes = loads x 4; what HBM moves is a sector per load
@@ -26,10 +26,10 @@ __global__ __launch_bounds__(64) void block_kernel(const uint8_t* __restrict__ t
   u32x4 acc = {0, 0, 0, 0};
   for (uint32_t i = 0; i < passes; i++) {
     const uint64_t b = mix(((uint64_t)blockIdx.x << 32) ^ i) % nblocks;   // wave-uniform: one block per pass
-    if ((lane & 1) == 0) {
-      const u32x4* r = reinterpret_cast<const u32x4*>(table + b * 2048ull + (uint64_t)p * 64ull);
-      const u32x4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
-      acc ^= a0 ^ a1 ^ a2 ^ a3;
+    {   // (round 6, call N: BOTH lanes of a pair load — each its half of the 64-byte row, two 16-byte loads)
+      const u32x4* r = reinterpret_cast<const u32x4*>(table + b * 2048ull + (uint64_t)p * 64ull + (uint64_t)(lane & 1) * 32ull);
+      const u32x4 a0 = r[0], a1 = r[1];
+      acc ^= a0 ^ a1;
     }
   }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x] = 1;

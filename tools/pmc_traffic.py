@@ -204,8 +204,8 @@ def main_hnswpq(a):
     blocks_true = pqv["n_exp"] * (width * row + width * 4) * nq                # what the walk must read of blocks + adjacency rows
     blocks_raw = blocks_true / cal["block_factor"]
     probes_raw = max(0.0, raw - blocks_raw)
-    probes = pqv["n_dist"] * nq
-    algorithmic = blocks_true + probes * 4
+    probes = pqv["n_exp"] * width * nq                                          # one per LISTED neighbour (upper bound: rows are not all full); round 6: n_dist counts marks, not probes
+    algorithmic = blocks_true + probes * 1 + pqv["n_dist"] * nq
     # a probe is ONE request of at least the reported size; taken at what is reported (a lower bound of the bytes moved)
     traffic = blocks_true + probes_raw
     table = json.load(open(a.out)) if os.path.exists(a.out) else {}
@@ -218,7 +218,7 @@ def main_hnswpq(a):
                   "traffic_over_algorithmic_blocks_only": 1.0,
                   "note": "the walk kernel alone (the re-rank streams rows: x2 as every 16 B/lane stream); blocks are read once each, contiguous; what exceeds the "
                           "algorithmic bytes is the visited byte map: one memory request per probed byte",
-                  "source": os.path.basename(a.csv), "dispatches_used": len(best), "kernel": "pq_scan1_kernel" if one_launch else "pq_scan_kernel"}
+                  "source": os.path.basename(a.csv), "dispatches_used": len(best)}
     print(key, "->", json.dumps(table[key], indent=1))
     json.dump(table, open(a.out, "w"), indent=1)
 
