@@ -1178,7 +1178,9 @@ def compact(res):
                         o[f"{short}_b{key.split('_')[1]}_{key.split('_')[-1]}"] = [v.get("kernels_ms"), v.get("frac_of_hbm_peak"), v.get("equals_exact_mode")]
             out["f3"] = {"ms_frac_equal": o}
     if isinstance(sec.get("h1"), dict):
-        out["h1"] = _pick(sec["h1"], "single_query_call_ms_median", "single_query_kernel_ms_median", "batch_of_10000_queries_per_s", "error")
+        h1 = sec["h1"]
+        out["h1"] = {"error": h1["error"]} if "error" in h1 else {"call_ms": h1.get("single_query_call_ms_median"), "kernel_ms": h1.get("single_query_kernel_ms_median"),
+                                                                   "batch_qps": h1.get("batch_of_10000_queries_per_s")}
     if isinstance(sec.get("lat"), dict):
         out["lat"] = _pick(sec["lat"], "kernel_ms_1", "call_ms_1", "kernel_ms_16", "ef", "error")
     if isinstance(sec.get("g8"), dict):
@@ -1188,7 +1190,7 @@ def compact(res):
     if res.get("pcie_inclusive"):
         out["pcie_inclusive_qps"] = res["pcie_inclusive"].get("queries_per_s")
     out["wall_s"] = res.get("wall_s")
-    out["full"] = "bench_full.json (also the previous stdout line)"
+    out["full"] = "bench_full.json"
     return _r(out)
 
 

@@ -406,10 +406,12 @@ int coltt_pq_last_kernel_ms(coltt_handle_t h, float* out_search_ms, float* out_s
  * (oracle/coltt_oracle.cpp "Product-quantised HNSW"), assembled from the pinned pieces: the graph and traversal of
  * core/vectorindex/hnsw.go:243-278,320-389 and the quantiser above (pkg/distancepq/distance.go:30-42):
  *   codes    Encode(stored row as the index's distance sees it), one row-major code per slot, kept up to date by Insert / Load
- *   d(q, v)  = sum over j of float32(binary16(lut[j][code_v[j]])) (f32 adds, j order): the quantiser's table over the query the index's
- *            distance sees (normalised / lowered), every entry rounded to binary16 (nearest even) — d only ranks, and a 2-byte table
- *            doubles the walk's resident traversals
- *   walk     Hnsw.Search with d in place of Distance() (entrypoint, upper levels, searchLevel(ef)); ties by (d bits, slot)
+ *   d(q, v)  = S_lo + S_hi, the f32 sums (j order, from +0.0) of float32(binary16(lut[j][code_v[j]])) over the first ceil(P / 2) and the remaining
+ *            16-byte pieces of the code row (P = ceil(m / 16)): the quantiser's table over the query the index's distance sees (normalised /
+ *            lowered), every entry rounded to binary16 (nearest even) — d only ranks, and a 2-byte table doubles the walk's resident traversals
+ *   walk     Hnsw.Search with d in place of Distance() (entrypoint, upper levels, searchLevel(ef)); ties by (d bits, slot).  Bounded visiting:
+ *            once the result set is full, a neighbour whose d is not below lowerBound is skipped before the visited test (it can never be
+ *            admitted: the bound only falls) — the result sets are exactly the unbounded walk's, n_dist counts what passed the bound and was fresh
  *   re-rank  the min(max(rerank, k), |result set|) nearest by d (rerank = 0: the whole result set) are re-scored with the index's
  *            exact-order distance; the k smallest by (exact score, slot) are returned with their exact scores.
  * attach snapshots the (trained) quantiser's codebooks — later changes to `pq` do not reach the index — and encodes every stored row.
@@ -418,7 +420,8 @@ int coltt_hnsw_pq_attach(coltt_handle_t hnsw, coltt_handle_t pq);
 int coltt_hnsw_pq_info(coltt_handle_t hnsw, uint32_t* out_num_subvectors, uint32_t* out_num_centroids, int32_t* out_pq_metric, uint64_t* out_coded_slots);
 /* codes of slots [first_slot, first_slot + n): out_codes [n][num_subvectors] */
 int coltt_hnsw_pq_fetch_codes(coltt_handle_t hnsw, uint64_t first_slot, uint64_t n, uint8_t* out_codes);
-/* stats: n_dist = table-distance evaluations, n_exp / n_hops as Hnsw.Search; *out_n_exact (may be NULL) = exact re-rank evaluations */
+/* stats: n_dist = table-distance evaluations that counted (entrypoint, upper levels, every fresh neighbour while the set fills, afterwards the fresh
+ * neighbours under the bound), n_exp / n_hops as Hnsw.Search; *out_n_exact (may be NULL) = exact re-rank evaluations */
 int coltt_hnsw_pq_search(coltt_handle_t hnsw, const float* queries, size_t nq, uint32_t k, uint32_t ef_override_or_0, uint32_t rerank,
                          uint64_t* out_ids, float* out_scores, uint32_t* out_counts, coltt_hnsw_stats* stats, uint64_t* out_n_exact);
 int coltt_hnsw_pq_search_device(coltt_handle_t hnsw, const float* d_queries, size_t nq, uint32_t k, uint32_t ef_override_or_0, uint32_t rerank,
