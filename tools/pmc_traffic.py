@@ -259,7 +259,11 @@ def main(argv=None):
     hs = c.get(("hnsw_search_kernel/hbm" if ef > 128 else "hnsw_search_kernel/lds") + ("" if quant == 0 else f"/q{quant}"), [])
     if not hs:
         sys.exit("no hnsw_search_kernel dispatches with FETCH_SIZE in " + a.csv)
-    full = collections.Counter(g for g, _ in hs).most_common(1)[0][0]
+    # (the grid that moved the most bytes: single-query latency probes — grid 64 — can outnumber the timed steps)
+    by_grid = collections.defaultdict(float)
+    for g, v in hs:
+        by_grid[g] += v
+    full = max(by_grid, key=by_grid.get)
     vals = [v for g, v in hs if g == full]
     # launches of the same grid may still differ in efSearch (the ef sweeps use the persistent grid too): the timed steps are the
     # largest group of launches whose counter values agree within 3 %
