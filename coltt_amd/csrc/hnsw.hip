@@ -357,6 +357,18 @@ __global__ __launch_bounds__(64) void hnsw_link_diverse_kernel(GraphView g, uint
   }
 }
 
+// Before the diverse link pass: the longest request chain of the batch (+ the widest row) -> stats[5].  A row that would receive more candidates than the link
+// kernel holds makes the host retry the batch in halves BEFORE anything was applied (insert_core): the index stays exactly as it was.
+__global__ void hnsw_link_count_kernel(const BuildReq* __restrict__ req, uint32_t n_req, const uint32_t* __restrict__ head, uint64_t cap_slots,
+                                       uint32_t mMax0, uint32_t mMax, unsigned long long* __restrict__ stats) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_req || req[r].next != NBR_NONE) return;
+  const uint32_t rid = req[r].rid;
+  uint32_t c = 0;
+  for (uint32_t cur = head[rid]; cur != NBR_NONE; cur = req[cur].next) c++;
+  atomicMax(&stats[5], (unsigned long long)(c + (rid < cap_slots ? mMax0 : mMax)));
+}
+
 // adj0_n[slot][j] = norms[adj0[slot][j]] for the level-0 rows of slots [first, first + n): after a bulk install of the topology
 __global__ void adj_norms_kernel(GraphView g, uint64_t first, uint64_t n) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1323,11 +1335,13 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
   uint32_t* req_count = counter + 1;
   unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(x->w_misc.as<uint8_t>() + 16);
   size_t i = 0;
+  uint32_t shrink = 0;   // diverse mode: a batch that would overflow a row's candidate list is retried at half the size (nothing was applied)
   while (i < n) {
     // nil entrypoint (empty index, or Remove left no successor: hnsw.go:197-217 may CAS the entrypoint to nil): the vertex is
     // stored at level 0 and becomes the entrypoint, nothing is linked (hnsw.go:108-116)
     const bool first = x->entry < 0;
     uint32_t b = first ? 1u : (uint32_t)std::min<size_t>(batch, n - i);
+    if (shrink) b = std::min(b, shrink);
     uint64_t up = 0;
     for (uint32_t j = 0; j < b; j++) up += first ? 0 : (uint64_t)levels[i + j];
     const uint64_t base = x->n;
@@ -1392,7 +1406,7 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
 #undef COLTT_LB
 #undef COLTT_LB_ARGS
     COLTT_TRY(rc);
-    struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[5]; } hm;
+    struct { uint32_t counter, n_req, pad0, pad1; unsigned long long st[6]; } hm;
     COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
     COLTT_HIP(hipStreamSynchronize(x->stream));
     if (hm.st[4]) {  // phase A queued link requests on head[] before tripping: drop them so the next batch starts clean
@@ -1401,8 +1415,19 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
       return fail(COLTT_E_DEVICE, "hnsw insert: traversal watchdog tripped (code %llu)", hm.st[4]);
     }
     if (hm.n_req && x->cfg.algo == 2) {
-      // diverse mode: one wave per touched row; its evaluations are counted, and a row with more candidates than the kernel holds fails
-      // the batch (the links of THIS batch are then half applied: the index is left for the caller to discard — stated in the error)
+      // diverse mode: one wave per touched row; its evaluations are counted.  A row that would receive more candidates than the link kernel holds (a hub
+      // chosen by > ~1 000 vertices of ONE batch) is found BEFORE anything is applied, and the batch is retried in halves: a smaller batch is another
+      // legal schedule of the same Inserts, and the index is untouched by the attempt (the new slots' own rows are rewritten by the retry)
+      hnsw_link_count_kernel<<<ceil_div(hm.n_req, 256), 256, 0, x->stream>>>(x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>(), x->cap, (uint32_t)x->cfg.m_max0,
+                                                                            (uint32_t)x->cfg.m_max, d_stats);
+      COLTT_HIP(hipMemcpyAsync(&hm, x->w_misc.p, sizeof(hm), hipMemcpyDeviceToHost, x->stream));
+      COLTT_HIP(hipStreamSynchronize(x->stream));
+      if (hm.st[5] > LINKD_CAND && b > 1) {
+        fill_u32_kernel<<<ceil_div(x->head_cap, 256), 256, 0, x->stream>>>(x->b_head.as<uint32_t>(), x->head_cap, NBR_NONE);
+        COLTT_HIP(hipStreamSynchronize(x->stream));
+        shrink = std::max(1u, b / 2);
+        continue;
+      }
 #define COLTT_LD_ARGS x, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>(), d_stats
 #define COLTT_LD(Q) rc = x->metric == COLTT_COSINE ? launch_link_diverse<M_COS, Q>(COLTT_LD_ARGS) : launch_link_diverse<M_L2, Q>(COLTT_LD_ARGS)
       COLTT_DISPATCH_QUANT(x->quant, COLTT_LD)
@@ -1414,9 +1439,9 @@ int insert_core(Hnsw* x, const uint64_t* ids, uint64_t first_id, const float* d_
       if (hm.st[4]) {
         fill_u32_kernel<<<ceil_div(x->head_cap, 256), 256, 0, x->stream>>>(x->b_head.as<uint32_t>(), x->head_cap, NBR_NONE);
         (void)hipStreamSynchronize(x->stream);
-        return fail(COLTT_E_UNSUPPORTED, "hnsw insert (diverse selection): a row received more than %u candidates in one batch — insert in "
-                                         "smaller batches; the rows of this batch are partly linked, rebuild the index", LINKD_CAND);
+        return fail(COLTT_E_DEVICE, "hnsw insert (diverse selection): a row overflowed the link kernel's %u candidates behind the pre-check", LINKD_CAND);   // (cannot happen)
       }
+      shrink = 0;
     } else if (hm.n_req) {
       hnsw_link_kernel<<<ceil_div(hm.n_req, 64), 64, 0, x->stream>>>(x->view(), x->cap, x->b_req.as<BuildReq>(), hm.n_req, x->b_head.as<uint32_t>());
       COLTT_HIP(hipGetLastError());

@@ -146,13 +146,16 @@ def test_diverse_commit_load_and_config(gpu):
         gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(algo=3))
 
 
-def test_diverse_row_with_too_many_links_in_one_batch_fails_loudly(gpu):
-    """One vertex in the graph, 1 100 new ones in ONE batch: all of them link to it — more candidates than the link kernel holds
-    (1 024).  The batch is refused with an error, never silently truncated."""
+def test_diverse_batch_that_would_overflow_a_row_is_retried_in_halves(gpu):
+    """One vertex in the graph, 1 100 new ones in ONE batch: all of them link to it — more candidates than the link kernel holds (1 024).  The builder finds
+    that BEFORE anything is applied and retries the batch in halves (a smaller batch is another legal schedule of the same Inserts): the graph equals the
+    oracle's for the schedule 1, 550, 550 — never a truncated candidate list, never a half-applied batch."""
     d = 16
-    X = O.fill_normal(9121, (1101, d)); lv = np.zeros(1101, np.int32)
+    X = O.fill_normal(9121, (1101, d)); lv = np.zeros(1101, np.int32); ids = np.arange(1101, dtype=np.uint64)
     gh = gpu.Hnsw(d, O.L2, gpu.HnswCfg.default(algo=DIVERSE, keep_pruned=0))
     _gpu_build(gpu, gh, X[:1], lv[:1], lambda i: 1)
-    with pytest.raises(gpu.ColttError) as e:
-        _gpu_build(gpu, gh, X[1:], lv[1:], lambda i: 1100, first_id=1)
-    assert "smaller batches" in str(e.value)
+    _gpu_build(gpu, gh, X[1:], lv[1:], lambda i: 1100, first_id=1)
+    assert gh.Len() == 1101
+    oh = O.Hnsw(d, O.L2, O.default_cfg(algo=DIVERSE, keepPruned=0))
+    oh.insert_batched(ids, X, lv, 0, schedule=lambda i: 1 if i == 0 else 550)
+    _graph_equal(gh.Export(), oh.export(with_vectors=False))
