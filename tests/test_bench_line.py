@@ -164,3 +164,21 @@ def test_last_record_of_round_5_is_the_last_library():
     assert pq["value"] > 2.0 * op["value"] and committed["op"]["pq"]["value"] == pq["value"]
     g8 = c["g8"]
     assert g8["streamed_equals_serial"] is True and g8["exposed_frac_of_a_streamed_batch"] < 0.05
+
+
+def test_final_line_of_round_6_record_fits_and_carries_the_new_legs():
+    """round 6's record (call T: op.pq, op.pq_ref, op.diverse — marked as not reference behaviour —, the one-launch PQ scan beside the segment chain): under the
+    4 KB target, nothing trimmed, the fields the round's claims rest on present"""
+    res = json.load(open(os.path.join(ROOT, "profiles", "r06t_bench_10m_full.json")))
+    line = bench.final_line(res)
+    assert len(line) <= bench.LINE_TARGET, len(line)
+    c = json.loads(line)
+    for k in REQUIRED:
+        assert k in c, k
+    assert "trimmed" not in c
+    op = c["op"]
+    assert op["recall_at_10"] >= 0.98 and op["pq"]["recall_at_10"] >= 0.98 and op["pq"]["value"] > 4e5 and op["pq"]["gpu_equals_oracle"] is True
+    assert op["pq_ref"]["m"] == 32 and op["pq_ref"]["centroids"] == 256
+    assert op["diverse"]["reference_behaviour"] is False and op["diverse"]["recall_at_10"] >= 0.98 and op["diverse"]["ef"] < op["ef"]
+    assert c["pq"]["eq_chain"] is True and c["pq"]["ms"] < c["pq"]["segment_chain_ms"] and 0 < c["pq"]["search_frac"] < c["pq"]["frac"] < 1
+    assert c["roofline"]["frac"] == pytest.approx(res["roofline"]["achieved"] / res["roofline"]["peak"], rel=1e-4)

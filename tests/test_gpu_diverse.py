@@ -159,3 +159,24 @@ def test_diverse_batch_that_would_overflow_a_row_is_retried_in_halves(gpu):
     oh = O.Hnsw(d, O.L2, O.default_cfg(algo=DIVERSE, keepPruned=0))
     oh.insert_batched(ids, X, lv, 0, schedule=lambda i: 1 if i == 0 else 550)
     _graph_equal(gh.Export(), oh.export(with_vectors=False))
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_diverse_graph_equals_the_committed_golden_vectors(gpu, ci):
+    """tests/golden/round6_definitions.npz (written by oracle/pyref.py: DiverseHnsw, pure Python): inserts with interleaved Removes, cosine + narrow rows and
+    Euclidean + keepPruned — the GPU builder (batch = 1) must end at the committed graph: levels, tombstones, edge lists, stored edge distances, entrypoint."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round6_definitions.npz"))
+    g = lambda k: z[f"d{ci}_{k}"]
+    d, metric, m, mmax0, efc, keep = (int(v) for v in g("cfg"))
+    gh = gpu.Hnsw(d, O.COSINE if metric == 0 else O.L2, gpu.HnswCfg.default(m=m, m_max0=mmax0, ef_construction=efc, algo=DIVERSE, keep_pruned=keep))
+    X, ids, lv = g("X"), g("ids"), g("levels")
+    rem = {int(a): int(b) for a, b in g("removes")}
+    for i in range(len(X)):
+        gh.Insert(ids[i], X[i], lv[i])
+        if i in rem:
+            gh.Remove(ids[rem[i]])
+    e = gh.Export()
+    for k in ("levels", "deleted", "row_offsets", "nbr"):
+        assert np.array_equal(e[k], g("g_" + k)), k
+    assert np.array_equal(e["nbr_dist"].view(np.uint32), g("g_nbr_dist").view(np.uint32)) and e["entry"] == int(g("g_entry"))

@@ -264,3 +264,28 @@ def test_neighbourhood_blocks_follow_every_mutation_and_equal_the_gathered_walk(
     x2 = torch.from_numpy(X2).to("cuda:0"); torch.cuda.synchronize()
     h.InsertBatchDevice(x2.data_ptr(), 150, lv2, batch=8, first_id=n)
     check("after inserts")
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_pq_walk_equals_the_committed_golden_vectors(gpu, ci):
+    """tests/golden/round6_definitions.npz (written by oracle/pyref.py: csr_search_pq, pure Python): the walk over product-quantiser codes as DEFINED in round 6 —
+    table distance = two half-row sums (8 codes: one piece; 24 codes: 16 + 8), bounded visiting once the result set is full (ef 40 / 30 of 300 / 260
+    vertices) — slots, exact score bits and all four counters, on the graph, codebooks and codes the fixture carries."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "round6_definitions.npz"))
+    g = lambda k: z[f"p{ci}_{k}"]
+    d, metric, m, c, ef, k, rr = (int(v) for v in g("cfg"))
+    h = gpu.Hnsw(d, gpu.COSINE if metric == 0 else gpu.EUCLIDEAN, gpu.HnswCfg.default(m=6, ef=16, ef_construction=30))
+    h.BulkLoad({"ids": g("g_ids"), "levels": g("g_levels"), "deleted": g("g_deleted"), "row_offsets": g("g_row_offsets"), "nbr": g("g_nbr"),
+                "nbr_dist": g("g_nbr_dist"), "entry": int(g("entry"))}, g("X"))
+    pq = gpu.PQSpace(d, gpu.PQ_EUCLIDEAN, m, c); pq.SetCodebooks(g("cb"))
+    h.PqAttach(pq)
+    assert np.array_equal(h.PqCodes(), g("codes"))
+    gi, gs, gc, st = h.PqSearch(g("Q"), k, ef=ef, rerank=rr, with_stats=True)
+    assert np.array_equal(gc.astype(np.int64), g("counts").astype(np.int64))
+    for qi in range(len(gc)):
+        n_ = int(gc[qi])
+        assert np.array_equal(gi[qi, :n_].astype(np.int64), g("g_ids")[g("slots")[qi, :n_]].astype(np.int64)), qi
+        assert np.array_equal(bits(gs[qi, :n_]), bits(g("scores")[qi, :n_])), qi
+    assert [st["n_dist"], st["n_exp"], st["n_hops"], st["n_exact"]] == [int(v) for v in g("counters")]
+    pq.close()
