@@ -576,6 +576,7 @@ def leg_operating_point(G, torch, dev, O, args, dim, k):
                                    "the unchanged Hnsw.Search", "ef": def_op, "recall_at_10": drec[str(def_op)], "reached": bool(dok), "value": steps * nq / ddt,
                        "unit": "queries/s", "over_op": (steps * nq / ddt) / (steps * nq / dt), "recall_vs_ef": drec, "qps_vs_ef": dqps, "build_s": dbuild_s,
                        "recall_at_op_ef": drec.get(str(ef_op)), "op_recall_at_op_ef": rec[str(ef_op)],
+                       "n_dist_over_op": dnd / nd,      # evaluations per query at the recall point against op's: the box-independent reading (two index instances differ by +-10 % in queries/s)
                        "per_query": {"n_dist": dnd, "n_exp": dne, "bytes": dbpq},
                        "frac": dbpq * nq / (float(np.mean(dms)) / 1e3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": float(np.mean(dms))}
             if isinstance(pqw, dict) and "error" not in pqw:      # and the table walk over the diverse graph, at the plain table walk's own settings
@@ -1141,7 +1142,7 @@ def compact(res):
             dv = op.get("diverse")
             if isinstance(dv, dict):
                 o["diverse"] = {"error": str(dv["error"])[:120]} if "error" in dv else dict(
-                    _pick(dv, "ef", "recall_at_10", "value", "over_op", "recall_at_op_ef"), reference_behaviour=False,
+                    _pick(dv, "ef", "recall_at_10", "value", "over_op", "n_dist_over_op", "recall_at_op_ef"), reference_behaviour=False,
                     **({"pq": _pick(dv["pq"], "ef", "recall_at_10", "value", "over_op_pq")} if isinstance(dv.get("pq"), dict) else {}))
             out["op"] = o
     sec = res.get("secondary") or {}
