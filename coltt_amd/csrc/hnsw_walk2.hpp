@@ -181,6 +181,9 @@ __device__ __forceinline__ void delta_flush(unsigned long long* res, uint32_t& l
   wave_sync();
 }
 
+#ifndef COLTT_EVICT_BULK   // A/B knob: evictions of more than two members by one merge-path step (below)
+#define COLTT_EVICT_BULK 1
+#endif
 // Drop the `e` largest members of main ∪ delta ("keep the ef smallest").
 // The main array's TAIL held in registers across expansions (SETCACHE walks): lane t holds res[tb + t] as it was when the window was loaded.  Nothing but
 // a flush adds to or reorders the main array, evictions only shorten it from the end, and the `expanded` bit a pop sets later is masked wherever the
@@ -209,6 +212,25 @@ __device__ __forceinline__ void evict_largest(const unsigned long long* res, uin
     }
     return;
   }
+#if COLTT_EVICT_BULK
+  if (e > 2u && e <= 64u) {
+    // MERGE PATH (round 6): the e largest of main ∪ delta in one step instead of e dependent rounds of four v_readlane + a 64-bit compare.  Both are sorted; with
+    // D_i = the delta's i-th largest key and M_j = the main array's j-th largest (expanded bits cleared), D_i is among the e largest of the union iff fewer than
+    // e - i main members exceed it, i.e. iff M_{e-1-i} < D_i (or the array has no such member) — true for a prefix of i: their count leaves the delta, the rest
+    // of e leaves the array.  Lane i tests D_i (ds_bpermute from lane n - 1 - i) against M_{e-1-i} (one LDS read).  Keys are distinct.
+    const uint32_t i = (uint32_t)lane;
+    const bool in = i < e && i < dl.n;
+    const int src = (int)((dl.n - 1u - i) & 63u) << 2;
+    const uint32_t dh = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dl.hi), dlo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dl.lo) & ~1u;
+    const uint32_t j = e - 1u - i;                       // (meaningful for i < e)
+    const bool mj = in && j < len;
+    const unsigned long long M = mj ? (res[len - 1u - j] & ~1ull) : 0ull;
+    const unsigned long long D = (((unsigned long long)dh) << 32) | dlo;
+    const uint32_t x = (uint32_t)__popcll(__ballot(in && (!mj || D > M)));
+    dl.n -= x; len -= e - x;
+    return;
+  }
+#endif
   const uint32_t tb = len > 64u ? len - 64u : 0u;
   const unsigned long long treg = tb + (uint32_t)lane < len ? res[tb + lane] : 0ull;
   for (uint32_t t = 0; t < e; t++) {
