@@ -14,7 +14,7 @@ _env_seen = None
 # the knobs the library snapshots (coltt_amd/csrc/common.hpp: Policy); when the test / tool changes one of them in os.environ the
 # binding asks the library to re-read them before the next call
 _KNOBS = ("COLTT_FLAT_ONE", "COLTT_STAGING", "COLTT_EV8", "COLTT_ROWS8", "COLTT_F8_MFMA", "COLTT_VISG", "COLTT_WALK2", "COLTT_WALK2_LDS", "COLTT_BLOOM_KB",
-          "COLTT_WAVES_PER_CU", "COLTT_PQ_WAVES", "COLTT_PQ_NBR", "COLTT_LAT_SEQ", "COLTT_LAT_HELPERS", "COLTT_LAT_MAX_NQ", "COLTT_MW_MAX_NQ", "COLTT_VISG_BUDGET_MB")
+          "COLTT_WAVES_PER_CU", "COLTT_ROWS_NT", "COLTT_ROWS_NT_MIN_MB", "COLTT_PQ_WAVES", "COLTT_PQ_NBR", "COLTT_LAT_SEQ", "COLTT_LAT_HELPERS", "COLTT_LAT_MAX_NQ", "COLTT_MW_MAX_NQ", "COLTT_VISG_BUDGET_MB")
 
 
 class ColttError(RuntimeError):

@@ -79,6 +79,8 @@ Policy read_policy_from_env() {
   { const char* e = getenv("COLTT_WALK2_LDS"); if (!e || !*e) p.walk2_lds = 4; else if (!strcmp(e, "off")) p.walk2_lds = -1; else { const int w = atoi(e) & 6; p.walk2_lds = w ? w : -1; } }
   v = num("COLTT_BLOOM_KB", set); p.bloom_kb = set ? (int)std::max<long long>(1, std::min<long long>(64, v)) : 0;
   v = num("COLTT_WAVES_PER_CU", set); p.waves_per_cu = set ? (int)std::max<long long>(1, std::min<long long>(12, v)) : 0;
+  v = num("COLTT_ROWS_NT", set); p.rows_nt = set ? (v > 0 ? 1 : (v < 0 ? -1 : 0)) : -1;
+  v = num("COLTT_ROWS_NT_MIN_MB", set); p.rows_nt_min_mb = set ? std::max<long long>(0, v) : 12288;
   v = num("COLTT_PQ_WAVES", set); p.pq_waves = set ? (int)std::max<long long>(1, std::min<long long>(16, v)) : 0;
   p.pq_nbr = !off("COLTT_PQ_NBR");
   { const char* e = getenv("COLTT_LAT_SEQ"); p.lat_seq = e && *e == '1'; }

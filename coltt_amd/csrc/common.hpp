@@ -109,6 +109,8 @@ struct Policy {
   int walk2_lds = 4;           // COLTT_WALK2_LDS: -1 off, 2 / 4 / 6
   int bloom_kb = 0;            // COLTT_BLOOM_KB: 0 = sized by the occupancy budget
   int waves_per_cu = 0;        // COLTT_WAVES_PER_CU: 0 = per row format
+  int rows_nt = -1;            // COLTT_ROWS_NT: non-temporal row loads in the eight-lane walks: -1 = by the size of the row array (default), 0 never, 1 always
+  long long rows_nt_min_mb = 12288;  // COLTT_ROWS_NT_MIN_MB: ... row arrays of at least this many MiB (see exact.hpp: row_ld; measured crossover: profiles/r06ag_nt_rows_ab.md)
   int pq_waves = 0;            // COLTT_PQ_WAVES: resident traversals per CU of the product-quantised walk, 0 = the default cap
   bool pq_nbr = true;          // COLTT_PQ_NBR=0: the product-quantised walk gathers its code rows by neighbour slot (round 5) instead of reading the neighbourhood blocks
   bool lat_seq = false;        // COLTT_LAT_SEQ=1

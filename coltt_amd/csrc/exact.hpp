@@ -199,6 +199,16 @@ __device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
 }
 typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+// Stored rows are read ONCE per evaluation by ONE compute unit.  On a collection far larger than the caches (10 M x 768: 15-30 GB against 32 MB of L2 + 256 MB of
+// MALL) a non-temporal hint on the row loads (`global_load_dwordx4 ... nt`) is worth +4.5 % on the headline walk (0.769 -> 0.804 of HBM peak) and +7 % on the
+// operating-point walk, same box (GPU call AG, profiles/r06ag_nt_rows_ab.md; MI355X_MICROARCH.md "nt-weights"); on a SMALL collection whose rows are re-read out of
+// L2 / MALL by the next queries (2 M x 768 x 2 B in eight shards, 10 000 queries per batch) the same hint costs 28 %.  So it is a template argument of the
+// eight-lane kernels, chosen per launch from the size of the row array (hnsw.hip: rows_nt).  The product quantiser's neighbourhood blocks lose with it at any
+// size measured (-7.5 %: hub vertices' blocks are re-read by other traversals): no hint there.
+template <bool NT, class T> __device__ __forceinline__ T row_ld(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 typedef uint32_t u32x2e __attribute__((ext_vector_type(2)));
 template <int METRIC>
 __device__ __forceinline__ void h2_consume(f32x4& acc, u32x4e raw, const float* __restrict__ q, int s, int half) {

@@ -762,6 +762,15 @@ uint32_t resident_waves(const SearchGeom& sg, int quant) {
   return 256u * (uint32_t)std::max<size_t>(1, std::min<size_t>(cap, (160 * 1024) / sg.lds));
 }
 
+// Non-temporal row loads for the eight-lane walks (exact.hpp: row_ld): worth it when the row array is far larger than L2 + MALL, costly when later queries
+// would have found the rows there.  COLTT_ROWS_NT = 0 / 1 forces, COLTT_ROWS_NT_MIN_MB moves the threshold (default 12 GiB of rows: 768-d rows, same box — f16 0.5 M -24 %, 1 M -10 %,
+// 2 M -2 %, 4 M +0.8 %, 10 M +-0; f32 1 M -4 %, 3 M +0.7 %, 10 M +4.5 %: profiles/r06ag_nt_rows_ab.md).
+bool rows_nt(const Hnsw* x) {
+  const Policy p = policy();
+  if (p.rows_nt >= 0) return p.rows_nt != 0;
+  return (unsigned long long)x->n * (unsigned long long)x->stride >= (unsigned long long)p.rows_nt_min_mb << 20;
+}
+
 // hnsw_walk2.hpp kernels.  The default build carries the shipped variant (and its Bloom-less twin for geometries whose LDS
 // has no room for the filter); -DCOLTT_WALK_EXPERIMENTS adds every OPT x profile combination for A/B runs (tools/walk_sweep.py).
 template <int METRIC, int QUANT>
@@ -770,6 +779,7 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
   typedef void (*kern_t)(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*,
                          uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
   kern_t kern = nullptr;
+  const bool nt = rows_nt(x);   // non-temporal row loads (eight-lane kernels): see exact.hpp: row_ld
 #define COLTT_W2(V, PROF, OPT) case V: kern = hnsw_search2_kernel<METRIC, QUANT, PROF, OPT>; break;
   if (sg.w2_lds) {
     switch (sg.w2) {
@@ -780,7 +790,7 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
       case 4:
         kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS>;
         if constexpr (QUANT != Q_F8) {
-          if (sg.ev8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true>;
+          if (sg.ev8) kern = nt ? hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true, false, true> : hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, true>;
           else if (x->r8) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_LDS, 4, VIS_LDS, false, false, true>;   // the pair-owned core over the line-transposed rows
         }
         break;   // (adjacency prefetch for f32 rows in small batches: measured, no gain — 1 M x 128, ef 20, one query 105 vs 111 us)
@@ -804,8 +814,8 @@ int launch_search2(Hnsw* x, HCtx* c, const SearchGeom& sg, uint32_t grid, uint32
       default: break;
     }
     if constexpr (QUANT != Q_F8) {
-      if (sg.ev8 && sg.w2 == 6) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, true>;
-      if (sg.ev8 && sg.w2 == 7) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, true>;
+      if (sg.ev8 && sg.w2 == 6) kern = nt ? hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, true, false, true> : hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, true>;
+      if (sg.ev8 && sg.w2 == 7) kern = nt ? hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, true, false, true> : hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, true>;
       if (!sg.ev8 && x->r8 && sg.w2 == 6) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 6, VIS_HBM, false, false, true>;
       if (!sg.ev8 && x->r8 && sg.w2 == 7) kern = hnsw_search2_kernel<METRIC, QUANT, PROF_SEARCH_HBM, 7, VIS_HBM, false, false, true>;
     }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(GraphView g, int32_t en
 // of the byte map, neighbour norms riding with the adjacency rows (OPT bits) — at two register/occupancy profiles.
 // EV8: the level-0 distances come from the eight-lanes-per-row core over GraphView::rows8 (rows8.hpp); the upper levels and the
 // entrypoint (a few dozen evaluations) stay on the pair-owned rows.
-template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false, bool EV8 = false, bool R8 = false>   // APREF: adjacency prefetch for f32 rows too (small batches); R8 (without EV8): the pair-owned core over line-transposed rows
+template <int METRIC, int QUANT, int PROFILE, int OPT, int VISMODE = VIS_HBM, bool APREF = false, bool EV8 = false, bool R8 = false, bool NT = false>   // NT (EV8 only): non-temporal row loads, for collections far larger than the caches (exact.hpp: row_ld); APREF: adjacency prefetch for f32 rows too (small batches); R8 (without EV8): the pair-owned core over line-transposed rows
 #ifndef COLTT_OP_WAVES_PER_EU   // experiment knob: minimum waves per SIMD the register allocator must leave room for in the HBM-visited eight-lane 2-byte walk (the operating point)
 #define COLTT_OP_WAVES_PER_EU 1
 #endif
@@ -147,18 +147,18 @@ void hnsw_search2_kernel(GraphView g, int32_t entry, int32_t entry_level,
     uint32_t cur = (uint32_t)entry;
     float curd;
     constexpr bool H16 = EV8 && QUANT != Q_NONE && VISMODE == VIS_HBM;   // Group8Eval: rows x burst depth of the HBM-visited 2-byte kernels
-    if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false, H16>().one(g, w, cur, lane);
+    if constexpr (EV8) curd = Group8Eval<METRIC, QUANT, false, H16, NT>().one(g, w, cur, lane);
     else curd = eval_pair<METRIC, QUANT, PROFILE, R8>(g, w, cur, lane & 1);  // hnsw.go:253
     curd = __shfl(curd, 0, 64);
     w.n_dist += 1;
     for (int l = entry_level; l > 0; l--) {  // :254-256
-      if constexpr (EV8) greedy_level8<METRIC, QUANT, H16>(g, w, cur, curd, l, lane);
+      if constexpr (EV8) greedy_level8<METRIC, QUANT, H16, NT>(g, w, cur, curd, l, lane);
       else greedy_level<METRIC, QUANT, PROFILE, R8>(g, w, cur, curd, l, lane);
     }
     COLTT_PT(w, 5)
     w.n_dist += 1;  // searchLevel re-evaluates the entrypoint distance (hnsw.go:346)
     uint32_t len;
-    if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS, H16>());
+    if constexpr (EV8) search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, Group8Eval<METRIC, QUANT, (OPT & W2_ADJN) != 0 && METRIC == M_COS, H16, NT>());
     else search_level2<METRIC, QUANT, PROFILE, OPT, VISMODE, APREF>(g, w, cur, curd, ef, lane, len, PairEval<METRIC, QUANT, PROFILE, (OPT & W2_ADJN) != 0 && METRIC == M_COS, R8>());  // :258-259
     const uint32_t n = len < k ? len : k;  // selectNeighbors + pop (:261-277) == the k smallest, ascending
     for (uint32_t i = lane; i < n; i += 64) {

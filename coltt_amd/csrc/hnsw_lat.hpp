@@ -319,6 +319,7 @@ template <int METRIC, int QUANT, int TP> struct LatEval {
   static constexpr bool ROWPF = false;
   static constexpr bool EARLY = false;
   static constexpr bool BOUNDED = false;
+  static constexpr bool SPLIT = false;
   static constexpr bool SETCACHE = false;
   LatShared* xs; uint8_t* stage;
   __device__ __forceinline__ uint32_t chunk_adj(int idx, int p) const { return xs->adjn[idx][p]; }

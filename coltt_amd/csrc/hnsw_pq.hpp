@@ -119,20 +119,31 @@ template <int LS = 0, int NP = 0, bool NBR = false> struct AdcEval {
 #define COLTT_PQ_SETCACHE 0
 #endif
   static constexpr bool SETCACHE = COLTT_PQ_SETCACHE != 0;
+  static constexpr bool SPLIT = false;
   static constexpr bool BOUNDED = true;   // hnsw_walk2.hpp: once the set is full, a neighbour whose table distance is not below lowerBound is neither marked nor counted,
                                           // and the result set itself answers "visited?" (no byte-map probe, no mark)
   static constexpr bool ROWPF = NBR;   // per-neighbour inputs addressed by (candidate, position): requested with the candidate's adjacency row
   static constexpr bool EARLY = NBR;   // the distances of all listed neighbours are computed under the visited probe (early())
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
+#ifndef COLTT_PQ_NT   // A/B knob: non-temporal hint on the code rows / neighbourhood blocks — measured SLOWER (475.6 -> 440.0 k queries/s at ef 1 344, GPU call AG: hub vertices' blocks are re-read by other traversals out of L2 / MALL), off
+#define COLTT_PQ_NT 0
+#endif
+  static __device__ __forceinline__ u32x4e pq_ld(const u32x4e* p) {
+#if COLTT_PQ_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+  }
   __device__ __forceinline__ void load_from(const uint8_t* row, u32x4e (&r)[NR]) const {
     const u32x4e* p = reinterpret_cast<const u32x4e*>(row) + first_piece();
     if constexpr (NP != 0 && NP % 2 == 0) {
 #pragma unroll
-      for (int i = 0; i < NR; i++) r[i] = p[i];
+      for (int i = 0; i < NR; i++) r[i] = pq_ld(p + i);
     } else {
       const int cnt = my_pieces();
 #pragma unroll
-      for (int i = 0; i < NR; i++) if (i < cnt) r[i] = p[i];
+      for (int i = 0; i < NR; i++) if (i < cnt) r[i] = pq_ld(p + i);
     }
   }
   __device__ __forceinline__ void load(uint32_t slot, u32x4e (&r)[NR]) const { load_from(codes + (size_t)slot * row_bytes, r); }

@@ -287,6 +287,7 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
   static constexpr bool SETCACHE = false;    // the head / tail windows of the main array are not cached in registers (register budget of the row walks)
   static constexpr bool EARLY = false;       // distances are computed for the fresh neighbours only, after the visited test
   static constexpr bool BOUNDED = false;     // the reference's order: visited test first, every fresh neighbour evaluated (hnsw.go:366-373)
+  static constexpr bool SPLIT = false;       // no evaluation pass in front of the visited probe's answer (see Group8Eval)
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}   // nothing worth requesting before the visited test (a row is 1.5-3 KB)
   __device__ __forceinline__ float operator()(const GraphView& g, const WaveCtx& w, uint32_t nb, bool fresh, float nrm, int half, int /*lane*/) const {
@@ -315,8 +316,24 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
 #ifndef COLTT_G8_U_H16
 #define COLTT_G8_U_H16 12
 #endif
-template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eval {
-  static constexpr int G8R = HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS, G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
+// SPLIT (round 6, third session; A/B knob, exact, measured SLOWER, off): behind the Bloom filter a listed neighbour is either DEFINITELY fresh (a negative
+// answer) or needs the dependent probe of the HBM byte map, and the walk waits for that probe before it requests a single row.  With the knob the probe is
+// issued, the first full pass of definitely-fresh rows (8 x ROWS of them: two thirds of a listed row are Bloom negatives) is requested and evaluated under it,
+// and the probe's answer is looked at only then; the remaining fresh neighbours follow in the usual passes.  Every neighbour's distance is the same function of
+// the same row whichever pass computes it and admission sees all of them at once: ids, score bits and counters are unchanged (GPU call AE: same answers'
+// hash from both libraries).  But the walk under load is bound by the memory system's row gather, not by one wave's dependent chain: 10 M x 768 f16, ef 1 024,
+// same box: 79.5 ms per 10 000 queries without, 80.9 ms with (ef 256 and f32 rows: +-0) — profiles/r06ae_split_pass_ab.md.
+#ifndef COLTT_G8_SPLIT
+#define COLTT_G8_SPLIT 0
+#endif
+// ONEBURST (HBM-visited 2-byte kernels): rows of exactly U lines are read in one burst without a second buffer (rows8.hpp), and the registers that frees
+// carry a second row per lane group — 16 rows per pass instead of 8, i.e. one dependent round trip less per expansion of ~21 fresh neighbours.
+#ifndef COLTT_G8_ONEBURST_H16
+#define COLTT_G8_ONEBURST_H16 0
+#endif
+template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false, bool NT = false> struct Group8Eval {   // NT: exact.hpp row_ld
+  static constexpr bool ONEB = HBM16 && COLTT_G8_ONEBURST_H16 != 0;
+  static constexpr int G8R = ONEB ? 2 : (HBM16 ? COLTT_G8_ROWS_H16 : COLTT_G8_ROWS), G8U = HBM16 ? COLTT_G8_U_H16 : COLTT_G8_U;
   static constexpr bool CHUNK_ADJ = false;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = false;
@@ -324,6 +341,8 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
   static constexpr bool EARLY = false;
   static constexpr bool BOUNDED = false;
   static constexpr bool SETCACHE = false;
+  static constexpr bool SPLIT = COLTT_G8_SPLIT != 0;
+  static constexpr int PASS_ROWS = 8 * G8R;   // rows one pass evaluates
   __device__ __forceinline__ uint32_t chunk_adj(int, int) const { return NBR_NONE; }
   __device__ __forceinline__ void prefetch(uint32_t, bool, int) const {}
   // distances of the chunk's `fresh` neighbours (one per lane pair, held by both lanes); the result is valid in BOTH lanes of a pair
@@ -349,7 +368,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
         rn[i] = 0.f;
         if constexpr (METRIC == M_COS) { if constexpr (ADJN) rn[i] = s_nr[live[i] ? idx[i] : 0]; else rn[i] = g.norms[slot]; }
       }
-      group8_distance<METRIC, QUANT, ROWS, G8U>(rp, live, w.qp, nl, w.qnorm, rn, rj, d);
+      group8_distance<METRIC, QUANT, ROWS, G8U, ONEB, NT>(rp, live, w.qp, nl, w.qnorm, rn, rj, d);
 #pragma unroll
       for (int i = 0; i < ROWS; i++) if (rj == 0 && live[i]) s_d[idx[i]] = d[i];
     }
@@ -365,16 +384,16 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false> struct Group8Eva
     const bool live[1] = {true};
     float rn[1] = {0.f}, d[1];
     if constexpr (METRIC == M_COS) rn[0] = g.norms[slot];
-    group8_distance<METRIC, QUANT, 1, G8U>(rp, live, w.qp, (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7, w.qnorm, rn, lane & 7, d);
+    group8_distance<METRIC, QUANT, 1, G8U, ONEB, NT>(rp, live, w.qp, (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7, w.qnorm, rn, lane & 7, d);
     return d[0];
   }
 };
 
 // greedyClosestNeighbor (hnsw.go:320-343) with the eight-lane core: hnsw_dev.hpp:greedy_level with the distances of a chunk coming
 // from Group8Eval (the upper rows carry no norms: the 4-byte gather serves the handful of evaluations up here)
-template <int METRIC, int QUANT, bool HBM16>
+template <int METRIC, int QUANT, bool HBM16, bool NT = false>
 __device__ __forceinline__ void greedy_level8(const GraphView& g, WaveCtx& w, uint32_t& cur, float& curd, int level, int lane_in) {
-  const Group8Eval<METRIC, QUANT, false, HBM16> ev;
+  const Group8Eval<METRIC, QUANT, false, HBM16, NT> ev;
   for (uint32_t hops = 0;; hops++) {
     const int lane = opaque_lane(lane_in);
     const int half = lane & 1, p = lane >> 1;
@@ -403,6 +422,20 @@ __device__ __forceinline__ void greedy_level8(const GraphView& g, WaveCtx& w, ui
     if (best != ~0ull && bd < curd) { cur = best_slot; curd = bd; }
     else break;
   }
+}
+// Probe of the HBM byte map.  The region is this wave's own for the whole launch; the load must not be served by a stale L1 line (the wave's own marks went
+// to L2): the agent-scope atomic load (`sc1`) bypasses L1 — and so does a non-temporal load (`nt`, MI355X_MICROARCH.md), which in addition tells L2 / MALL that
+// the line will not be used again: a random probe pulls in a whole line for one byte, and what it displaces are the neighbourhood blocks and adjacency rows of hub
+// vertices that other traversals do re-read.  COLTT_VIS_NT: 0 = `sc1` (rounds 2-6), 1 = `nt` (A/B knob).
+#ifndef COLTT_VIS_NT
+#define COLTT_VIS_NT 0
+#endif
+template <class T> __device__ __forceinline__ T vis_probe(const T* p) {
+#if COLTT_VIS_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 enum { VIS_HBM = 0, VIS_LDS = 1 };   // visited set of search_level2: HBM byte map (behind the Bloom filter) | LDS hash that is never reset (err 8)
 
@@ -611,6 +644,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
 #endif
       COLTT_PT(w, 1)  // adjacency row
       int fresh_i = 0;
+      bool split_done = false; float split_d = 0.f;   // SPLIT evaluators: this pair's row went through the pass in front of the probe's answer
       if constexpr (eval_t::EARLY && VISMODE == VIS_HBM && !BLOOM) {
         // The probe of the byte map is ISSUED, the evaluator computes the distances of all listed neighbours out of inputs that are already on chip
         // (AdcEval<.., NBR>: the code rows came with the adjacency row), and only then is the probe's answer looked at: its round trip runs under
@@ -630,7 +664,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         // load) and the byte is taken out of it after early().  The region is this wave's own and its size a multiple of 16; agent scope: served by L2.
         // EVERY lane loads (the others word 0 of the region: one more address in the same request): a load under a divergent branch would leave the
         // compiler two paths with different numbers of loads in flight, and it then waits for all of them (vmcnt(0)) in front of the sums.
-        uint32_t vw = __hip_atomic_load(reinterpret_cast<const uint32_t*>(w.visg + (probe ? (nb & ~3u) : 0u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t vw = vis_probe(reinterpret_cast<const uint32_t*>(w.visg + (probe ? (nb & ~3u) : 0u)));
         ev.early(valid, half);
         ev.after_early(vw);   // the probe's value is not looked at (no s_waitcnt vmcnt for it) before the table sums are there
         const uint32_t v = (vw >> ((nb & 3u) * 8u)) & 0xffu;
@@ -638,6 +672,29 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
         if constexpr (eval_t::BOUNDED) { if (full_at_pop && !(ev.pre_d < lower_bound)) fresh_i = 0; }   // (wide rows) the bound: not marked, not counted
         if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      } else if constexpr (eval_t::SPLIT && BLOOM && VISMODE == VIS_HBM && !eval_t::EARLY && !eval_t::BOUNDED && !eval_t::SPEC) {
+        // Bloom filter, then the byte-map probe of the positives ISSUED and the first full pass of definitely-fresh rows evaluated under it (see COLTT_G8_SPLIT)
+        const bool want = valid && half == 0;
+        bool maybe = false;
+        if (want) {
+          const uint32_t h = nb * 0x9E3779B1u;
+          const uint32_t bits = (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+          const uint32_t old = atomicOr(&w.bloom[h >> w.bloom_shift], bits);
+          maybe = (old & bits) == bits;
+        }
+        const bool sure = want && !maybe;
+        const unsigned long long S = __ballot(sure);
+        // every lane loads (the others byte 0 of the region: one more address in the same request) — no divergent branch around a load in flight
+        const uint8_t pv = vis_probe(w.visg + (maybe ? nb : 0u));
+        if ((uint32_t)__popcll(S) >= (uint32_t)eval_t::PASS_ROWS && __ballot(maybe)) {   // wave-uniform: a full pass of negatives and a probe to hide
+          const uint32_t srank = __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
+          int first_i = (sure && srank < (uint32_t)eval_t::PASS_ROWS) ? 1 : 0;
+          first_i = __builtin_amdgcn_mov_dpp(first_i, 0xA0, 0xf, 0xf, true);   // to the odd lane of the pair
+          split_done = first_i != 0;
+          split_d = ev(g, w, nb, split_done, nrm, half, lane);
+        }
+        fresh_i = (sure || (maybe && pv != (uint8_t)w.epoch)) ? 1 : 0;
+        if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         if constexpr (eval_t::EARLY) ev.early(valid, half);
         bool want = valid && half == 0;
@@ -663,7 +720,7 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
           if constexpr (VISMODE == VIS_LDS) fresh_i = vis_insert(w.vis, w.hcap_mask, nb) ? 1 : 0;
           else {
             if (maybe) {
-              const uint8_t v = spec_hit ? (uint8_t)spec_vis_now : __hip_atomic_load(w.visg + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint8_t v = spec_hit ? (uint8_t)spec_vis_now : vis_probe(w.visg + nb);
               fresh_i = v != (uint8_t)w.epoch ? 1 : 0;
             } else fresh_i = 1;
             if (fresh_i) __hip_atomic_store(w.visg + nb, (uint8_t)w.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -680,6 +737,11 @@ __device__ __forceinline__ void search_level2(const GraphView& g, WaveCtx& w, ui
       w.n_dist += nfresh; vis_count += (eval_t::BOUNDED && by_set) ? 0u : nfresh;   // (vis_count: entries of the LDS hash)
       float d;
       if constexpr (eval_t::BOUNDED && !eval_t::EARLY) { if (full_at_pop) d = fresh ? bounded_d : 0.f; else d = ev(g, w, nb, fresh, nrm, half, lane); }
+      else if constexpr (eval_t::SPLIT) {
+        const bool rest = fresh && !split_done;
+        d = split_d;
+        if (__ballot(rest)) { const float d2 = ev(g, w, nb, rest, nrm, half, lane); d = split_done ? split_d : d2; }
+      }
       else d = ev(g, w, nb, fresh, nrm, half, lane);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0u));   // fresh neighbours in front of this lane
       const bool adm = fresh && half == 0 && (rank < free_slots || d < lower_bound);

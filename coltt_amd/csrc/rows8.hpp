@@ -21,6 +21,7 @@
 // un-permute element indexes, no stream format ever sees it.  It exists for f32 / 2-byte rows whose byte length is a multiple of 128 (dim % 32 == 0 /
 // dim % 64 == 0: 128, 256, 512, 768, 1024, 1536 ...; dim >= 256 by default); other shapes keep natural-order rows and the pair-owned walk.
 #pragma once
+#include <type_traits>
 #include "exact.hpp"
 
 namespace coltt {
@@ -74,7 +75,7 @@ __device__ __forceinline__ float group8_hsum(float a) {
 // Distance(query, row) of ROWS rows per 8-lane group at once (ROWS x U..2U 16-byte loads per lane in flight); rj = this lane's
 // residue (lane & 7).  row8[i] -> the rows8 copy of row i, qp -> the permuted query in LDS, nl = 128-byte lines per row.
 // live[i] == false: this group has no i-th row in this pass — row8[i] then points at some live row, the result is dropped by the caller.
-template <int METRIC, int QUANT, int ROWS, int U>
+template <int METRIC, int QUANT, int ROWS, int U, bool ONEBURST = false, bool NT = false>
 __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROWS], const bool (&live)[ROWS], const float* __restrict__ qp, int nl,
                                                 float qnorm, const float (&rnorm)[ROWS], int rj, float (&out)[ROWS]) {
   constexpr int S = rows8_steps<QUANT>();
@@ -85,7 +86,7 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
   struct Raw { u32x4e v[ROWS]; };
   // (the loads are NOT predicated on `live`: wrapping each of them in its own EXEC save / restore broke the back-to-back issue of a burst —
   //  10 M x 768 f32, ef 128: 19.9 -> 27.3 ms per 10 k queries, profiles/r04d_ev8_variants.md; an idle group re-reads a live row instead)
-#define COLTT_G8_LD(L, DST) { _Pragma("unroll") for (int i = 0; i < ROWS; i++) DST.v[i] = *reinterpret_cast<const u32x4e*>(row8[i] + (size_t)(L) * 128 + rj * 16); }
+#define COLTT_G8_LD(L, DST) { _Pragma("unroll") for (int i = 0; i < ROWS; i++) DST.v[i] = row_ld<NT>(reinterpret_cast<const u32x4e*>(row8[i] + (size_t)(L) * 128 + rj * 16)); }
 #define COLTT_G8_CS(RAW, L)                                                                                                   \
   {                                                                                                                           \
     if constexpr (QUANT == Q_NONE) {                                                                                          \
@@ -114,34 +115,47 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
       }                                                                                                                       \
     }                                                                                                                         \
   }
-  {
-    const int nb = nl / U;
-    Raw cur[U], nxt[U];
+  // bursts of UU lines, the next burst requested before the current one is consumed (2 x ROWS x UU 16-byte loads per lane in flight at most)
+  auto bursts = [&](auto uc) {
+    constexpr int UU = decltype(uc)::value;
+    const int nb = nl / UU;
+    Raw cur[UU], nxt[UU];
     if (nb > 0) {
 #pragma unroll
-      for (int u = 0; u < U; u++) COLTT_G8_LD(u, cur[u])
+      for (int u = 0; u < UU; u++) COLTT_G8_LD(u, cur[u])
     }
     for (int b = 0; b < nb; b++) {
       if (b + 1 < nb) {
 #pragma unroll
-        for (int u = 0; u < U; u++) COLTT_G8_LD((b + 1) * U + u, nxt[u])
+        for (int u = 0; u < UU; u++) COLTT_G8_LD((b + 1) * UU + u, nxt[u])
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) COLTT_G8_CS(cur[u], b * U + u)
+      for (int u = 0; u < UU; u++) COLTT_G8_CS(cur[u], b * UU + u)
 #pragma unroll
-      for (int u = 0; u < U; u++) cur[u] = nxt[u];
+      for (int u = 0; u < UU; u++) cur[u] = nxt[u];
     }
-    // lines beyond whole bursts (nl % U; the whole row when nl < U — 128-d f32 rows are 4 lines): ONE predicated burst, every load
+    // lines beyond whole bursts (nl % UU; the whole row when nl < UU — 128-d f32 rows are 4 lines): ONE predicated burst, every load
     // in flight before the first is consumed (a line-by-line loop here made a short row cost nl dependent round trips: 1 M x 128 f32,
     // one query, 0.111 -> 0.191 ms in the first bench run of this core)
-    const int l0 = nb * U;
+    const int l0 = nb * UU;
     if (l0 < nl) {
 #pragma unroll
-      for (int u = 0; u < U; u++) if (l0 + u < nl) COLTT_G8_LD(l0 + u, cur[u])
+      for (int u = 0; u < UU; u++) if (l0 + u < nl) COLTT_G8_LD(l0 + u, cur[u])
 #pragma unroll
-      for (int u = 0; u < U; u++) if (l0 + u < nl) COLTT_G8_CS(cur[u], l0 + u)
+      for (int u = 0; u < UU; u++) if (l0 + u < nl) COLTT_G8_CS(cur[u], l0 + u)
     }
-  }
+  };
+  if constexpr (ONEBURST) {
+    // rows of exactly U lines (768 x 2-byte with U = 12): the WHOLE row of every one of the ROWS rows in flight at once, no second buffer — the registers the
+    // double-buffered form spends on `nxt` carry a second row instead (ROWS = 2: 16 rows per pass at the register cost of 8).  Any other length: bursts of U / 2.
+    if (nl == U) {
+      Raw cur[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) COLTT_G8_LD(u, cur[u])
+#pragma unroll
+      for (int u = 0; u < U; u++) COLTT_G8_CS(cur[u], u)
+    } else bursts(std::integral_constant<int, (U / 2 > 0 ? U / 2 : 1)>());
+  } else bursts(std::integral_constant<int, U>());
 #undef COLTT_G8_LD
 #undef COLTT_G8_CS
 #pragma unroll

@@ -113,3 +113,23 @@ def test_shapes_without_a_copy_and_the_create_time_switch(gpu, monkeypatch):
     monkeypatch.delenv("COLTT_ROWS8")
     gh.Search(O.fill_normal(9207, (4, 128)), 5, ef=32)
     assert gh.Rows8() == (1, True)
+
+
+@pytest.mark.parametrize("quant,d", [(O.Q_NONE, 768), (O.Q_F16, 768), (O.Q_BF16, 256)])
+def test_non_temporal_twins_equal_the_oracle_and_the_default_kernels(gpu, monkeypatch, quant, d):
+    """Round 6: collections far larger than the caches run the eight-lane kernels with non-temporal row loads (exact.hpp: row_ld; chosen per launch from the
+    size of the row array, hnsw.hip: rows_nt).  A cache hint cannot change a value: with the hint forced on (COLTT_ROWS_NT=1) ids, score bits and counters
+    equal the oracle's and those of the default kernels (COLTT_ROWS_NT=0), for the LDS-visited and the HBM-visited walk."""
+    monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
+    n = 3000
+    X = O.fill_normal(9300 + d, (n, d)); lv = O.levels(9301 + d, n)
+    gh = _build(gpu, X, lv, O.COSINE, quant, gpu.HnswCfg.default(ef_construction=60))
+    assert gh.Rows8()[1]
+    Q = O.fill_normal(9302 + d, (50, d))
+    for ef, k in ((64, 10), (128, 10), (300, 10), (1024, 50)):
+        monkeypatch.setenv("COLTT_ROWS_NT", "1")
+        gi, gs, gc, st = _oracle_check(gh, Q, quant, O.COSINE, ef, k)
+        monkeypatch.setenv("COLTT_ROWS_NT", "0")
+        pi, ps, pc, pst = gh.Search(Q, k, ef=ef, with_stats=True)
+        monkeypatch.delenv("COLTT_ROWS_NT")
+        assert np.array_equal(gi, pi) and np.array_equal(bits(gs), bits(ps)) and np.array_equal(gc, pc) and st == pst, ef

@@ -35,5 +35,11 @@ LATK(0, 0, false)
 LATK(0, -1, true)
 #undef LATK
 #endif
+#if WALKS_SET & 16  // the non-temporal twins of the headline and the operating-point walks (collections far larger than the caches)
+template __global__ void hnsw_search2_kernel<0, 0, 1, 4, 1, false, true, false, true>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
+template __global__ void hnsw_search2_kernel<0, 1, 2, 7, 0, false, true, false, true>(GraphView, int32_t, int32_t, const float*, const float*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+    uint32_t*, uint64_t*, float*, uint32_t*, unsigned long long*, uint8_t*, size_t, uint32_t*);
+#endif
 }  // namespace kern
 }  // namespace coltt

@@ -48,7 +48,10 @@ def main():
         same = bool(np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1].view(np.uint32), ref[1].view(np.uint32)) and cur[2] == ref[2])
         bpq = B.hnsw_bytes_per_query(st["n_dist"] / nq, st["n_exp"] / nq, dim, quant, 16)
         t = float(np.median(ms)) / 1e3
-        row = {"setting": s, "ms": t * 1e3, "min_ms": float(min(ms)), "frac_of_hbm_peak": bpq * nq / t / 8e12, "identical_to_first": same}
+        import hashlib
+        sha = hashlib.sha256(cur[0].tobytes() + cur[1].tobytes() + json.dumps(cur[2], sort_keys=True).encode()).hexdigest()[:16]   # compare across libraries (COLTT_LIB)
+        row = {"setting": s, "ms": t * 1e3, "min_ms": float(min(ms)), "qps": nq / t, "frac_of_hbm_peak": bpq * nq / t / 8e12, "identical_to_first": same, "answers_sha16": sha,
+               "lib": os.path.basename(os.environ.get("COLTT_LIB", "libcoltt_gpu.so"))}
         res["rows"].append(row)
         print(json.dumps(row), file=sys.stderr, flush=True)
     print(json.dumps(res))
