@@ -579,12 +579,12 @@ bool rows8_shape(uint32_t dim, int quant) {
   return ((size_t)dim * quant_bytes(quant)) % 128 == 0;
 }
 
-int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq) {
+int prep_queries_any(Hnsw* x, HCtx* c, const float* d_qraw, size_t nq, uint32_t* zero64 = nullptr) {
   COLTT_TRY(c->w_qeff.reserve(nq * x->dim * 4));
   COLTT_TRY(c->w_qn.reserve(nq * 4));
   int norm = x->metric == COLTT_COSINE;
   float* qe = c->w_qeff.as<float>();
-#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)x->dim, norm, qe, c->w_qn.as<float>())
+#define COLTT_PQ(Q) launch_prep_queries<Q>(c->stream, d_qraw, nq, (int)x->dim, norm, qe, c->w_qn.as<float>(), zero64)
   COLTT_DISPATCH_QUANT(x->quant, COLTT_PQ)
 #undef COLTT_PQ
   COLTT_HIP(hipGetLastError());
@@ -967,12 +967,12 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
     COLTT_HIP(hipMemcpyAsync(c->w_qraw.p, src, nq * x->dim * 4, hipMemcpyHostToDevice, c->stream));
     d_q = c->w_qraw.as<float>();
   }
-  COLTT_TRY(prep_queries_any(x, c, d_q, nq));
   COLTT_TRY(c->w_misc.reserve(256));
+  if (!packed) COLTT_TRY(c->h_out.reserve(256));   // the traversal counters come back through page-locked memory (a pageable target makes the copy a blocking, staged one)
   uint8_t* misc = packed ? c->w_pack.as<uint8_t>() : c->w_misc.as<uint8_t>();
   uint32_t* counter = reinterpret_cast<uint32_t*>(misc);
   unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(misc + 16);
-  COLTT_HIP(hipMemsetAsync(misc, 0, 256, c->stream));
+  COLTT_TRY(prep_queries_any(x, c, d_q, nq, reinterpret_cast<uint32_t*>(misc)));   // ... which also clears the 256 bytes of counters (no memset of their own)
   COLTT_HIP(hipEventRecord(c->ev0, c->stream));
   int rc;
 #define COLTT_LS_ARGS x, c, sg, grid, lease.base, (uint32_t)nq, k, counter, d_oi, d_os, d_oc, d_stats
@@ -993,13 +993,14 @@ int search_common(Hnsw* x, HCtx* c, const float* queries, bool on_device, size_t
       COLTT_HIP(hipMemcpyAsync(out_scores, d_os, nq * k * 4, hipMemcpyDeviceToHost, c->stream));
       COLTT_HIP(hipMemcpyAsync(out_counts, d_oc, nq * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    COLTT_HIP(hipMemcpyAsync(h_stats, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
+    COLTT_HIP(hipMemcpyAsync(c->h_out.p, d_stats, 40, hipMemcpyDeviceToHost, c->stream));
   }
 #ifdef COLTT_PHASE_TIMING
   unsigned long long h_pt[8] = {0};
   COLTT_HIP(hipMemcpyAsync(h_pt, d_stats + 8, 64, hipMemcpyDeviceToHost, c->stream));
 #endif
   COLTT_HIP(hipStreamSynchronize(c->stream));  // the lease (destructor) outlives the kernel
+  if (!packed) std::memcpy(h_stats, c->h_out.p, 40);
   if (packed) {
     const uint8_t* hb = c->h_out.as<uint8_t>();
     std::memcpy(h_stats, hb + 16, 40);

@@ -106,7 +106,8 @@ __global__ void row_norms_kernel(const uint8_t* __restrict__ rows, size_t stride
 // written — one launch less on the single-query path, where every launch is ~10 us of a ~100 us search.
 template <int QUANT>
 __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ raw, uint64_t nq, int dim, int normalize,
-                                                          float* __restrict__ q_eff, float* __restrict__ qn) {
+                                                          float* __restrict__ q_eff, float* __restrict__ qn, uint32_t* __restrict__ zero64) {
+  if (zero64 && blockIdx.x == 0) zero64[threadIdx.x] = 0u;   // the search's work counter + traversal counters (256 bytes): one stream operation less per call
   __shared__ __attribute__((aligned(16))) float buf[PQ_CHUNK];
   __shared__ float s_norm;
   const uint64_t i = blockIdx.x;
@@ -157,11 +158,12 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
 }
 static __global__ void query_norms_kernel(const float* __restrict__ q_eff, uint64_t nq, int dim, float* __restrict__ qn);
 // q_eff <- Normalize / Lower / decode of the raw queries; qn (may be null) <- their AVX-order squared norms
+// zero64 (may be null): 64 words the first workgroup clears — the caller's counters, so that they need no memset of their own
 template <int QUANT>
-inline void launch_prep_queries(hipStream_t st, const float* raw, uint64_t nq, int dim, int normalize, float* q_eff, float* qn = nullptr) {
+inline void launch_prep_queries(hipStream_t st, const float* raw, uint64_t nq, int dim, int normalize, float* q_eff, float* qn = nullptr, uint32_t* zero64 = nullptr) {
   if (!nq) return;
   const bool fused = qn && dim <= PQ_CHUNK;
-  prep_queries_kernel<QUANT><<<(unsigned)nq, 64, 0, st>>>(raw, nq, dim, normalize, q_eff, fused ? qn : nullptr);
+  prep_queries_kernel<QUANT><<<(unsigned)nq, 64, 0, st>>>(raw, nq, dim, normalize, q_eff, fused ? qn : nullptr, zero64);
   if (qn && !fused) query_norms_kernel<<<(unsigned)((nq * 2 + 255) / 256), 256, 0, st>>>(q_eff, nq, dim, qn);
 }
 static __global__ void query_norms_kernel(const float* __restrict__ q_eff, uint64_t nq, int dim, float* __restrict__ qn) {

@@ -163,7 +163,7 @@ def test_pmc_traffic_tool_flat_mode_on_the_committed_csv(tmp_path):
 
 
 def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path):
-    """The committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op,pq` (round 6: profiles/r06u_*, taken on the round's final kernels;
+    """The committed raw `rocprofv3 --pmc FETCH_SIZE` pass over `bench.py --legs op,pq` (round 6: profiles/r06ak_* and r06u_*, taken on the round's final kernels;
     earlier rounds' passes stay in profiles/ as history) -> the HBM traffic bench.py reports for the headline kernel (`hnsw_search2_kernel<.., VIS_LDS, .., EV8>`: the
     eight-lane core over the line-transposed rows), for the recall-0.98 kernel (HBM visited map) and for the ONE scan launch of a single-query
     product-quantiser search (pq_scan1_kernel: all rows).  Re-derived here from the raw CSV and compared with profiles/pmc_traffic.json."""
@@ -172,12 +172,15 @@ def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import pmc_traffic as T
-    src = os.path.join(root, "profiles", "r06u_pmc_fetch_size_raw.csv")
-    bj = os.path.join(root, "profiles", "r06u_bench_10m_under_pmc.json")
+    # the two walks: call AK (the library with the non-temporal twins of the eight-lane kernels — rows no longer linger in L2 / MALL, so the few re-reads of hub
+    # rows come from HBM: 1.008 -> 1.021 and 1.040 -> 1.056 x the algorithmic bytes, for +4.5 % and +-0 queries/s); the PQ scan: call U (unchanged kernel)
+    src = os.path.join(root, "profiles", "r06ak_pmc_fetch_size_raw.csv")
+    bj = os.path.join(root, "profiles", "r06ak_bench_10m_under_pmc.json")
+    src_pq = os.path.join(root, "profiles", "r06u_pmc_fetch_size_raw.csv")
     out = tmp_path / "t.json"
     T.main([src, "--bench-json", bj, "--out", str(out)])
     T.main([src, "--bench-json", bj, "--leg", "op", "--out", str(out)])
-    T.main([src, "--pq", "10000000,768,96", "--out", str(out)])
+    T.main([src_pq, "--pq", "10000000,768,96", "--out", str(out)])
     t = json.load(open(out))
     committed = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
     head = "hnsw n=10000000 dim=768 quant=0 ef=128 m=16 queries=10000 dataset=normal"
@@ -186,7 +189,7 @@ def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path
     assert set(t) == {head, op, pq}
     assert 0.98 <= t[pq]["traffic_over_algorithmic"] <= 1.03 and t[pq]["dispatches_used"] >= 20 and t[pq]["rows_of_the_launch"] == 10_000_000 and t[pq]["kernel"] == "pq_scan1_kernel"
     assert abs(committed[pq]["hbm_bytes_per_launch"] - t[pq]["hbm_bytes_per_launch"]) < 1.0
-    for key, lo, hi in ((head, 0.97, 1.03), (op, 1.0, 1.05)):
+    for key, lo, hi in ((head, 0.97, 1.04), (op, 1.0, 1.08)):
         r = t[key]
         assert lo <= r["traffic_over_algorithmic"] <= hi, (key, r)
         assert r["dispatches_used"] >= 5 and "x1.99" in r["correction"], r
