@@ -119,8 +119,17 @@ template <int QUANT> struct Raw4 { typedef f32x4 type; };
 template <> struct Raw4<Q_F16> { typedef f16x4 type; };
 template <> struct Raw4<Q_BF16> { typedef f16x4 type; };
 template <> struct Raw4<Q_F8> { typedef uint32_t type; };
+#ifndef COLTT_PAIR_NT   // A/B knob: the non-temporal hint (row_ld below) on the PAIR-owned row loads too (FLAT exact scans, filtered scans, the PQ re-rank, the builder) — compile-time, every size.
+                        // Measured SLOWER everywhere (GPU call AM: FLAT scans -40 %, C3 -12 %, PQ walk -7.5 %, build +20-40 %: these kernels re-read rows through L2), off
+#define COLTT_PAIR_NT 0
+#endif
 template <int QUANT> __device__ __forceinline__ typename Raw4<QUANT>::type load_raw4(const uint8_t* __restrict__ row, int e) {
-  return *reinterpret_cast<const typename Raw4<QUANT>::type*>(row + (size_t)e * elem_bytes<QUANT>());
+  typedef typename Raw4<QUANT>::type raw_t;
+#if COLTT_PAIR_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(row + (size_t)e * elem_bytes<QUANT>()));
+#else
+  return *reinterpret_cast<const raw_t*>(row + (size_t)e * elem_bytes<QUANT>());
+#endif
 }
 template <int QUANT> __device__ __forceinline__ f32x4 decode4(typename Raw4<QUANT>::type v) {
   if constexpr (QUANT == Q_NONE) return v;
@@ -271,7 +280,7 @@ __device__ __forceinline__ float pair_distance(const uint8_t* __restrict__ row, 
   const int n8 = dim >> 3;
   if constexpr ((QUANT == Q_F16 || QUANT == Q_BF16) && U >= 2) {
     // wide walk over pairs of groups (every store keeps rows 16-byte aligned: row strides are rounded up to 16 B)
-#define COLTT_LD_(S) (*reinterpret_cast<const u32x4e*>(row + (size_t)(16 * (S) + 8 * half) * 2))
+#define COLTT_LD_(S) (row_ld<COLTT_PAIR_NT != 0>(reinterpret_cast<const u32x4e*>(row + (size_t)(16 * (S) + 8 * half) * 2)))
 #define COLTT_CS_(RAW, S) h2_consume<METRIC>(acc, RAW, q, S, half)
     COLTT_BURST_WALK(U / 2, u32x4e, n8 >> 1, COLTT_LD_, COLTT_CS_)
 #undef COLTT_LD_
@@ -327,7 +336,7 @@ __device__ __forceinline__ void r8_consume(f32x4& acc, const Line4& ln, const fl
 __device__ __forceinline__ Line4 r8_load(const uint8_t* __restrict__ row, int L, int half) {
   const u32x4e* p = reinterpret_cast<const u32x4e*>(row + (size_t)L * 128 + (size_t)half * 64);
   Line4 ln;
-  ln.c[0] = p[0]; ln.c[1] = p[1]; ln.c[2] = p[2]; ln.c[3] = p[3];
+  ln.c[0] = row_ld<COLTT_PAIR_NT != 0>(p); ln.c[1] = row_ld<COLTT_PAIR_NT != 0>(p + 1); ln.c[2] = row_ld<COLTT_PAIR_NT != 0>(p + 2); ln.c[3] = row_ld<COLTT_PAIR_NT != 0>(p + 3);
   return ln;
 }
 template <int METRIC, int QUANT, int U = 3>
