@@ -115,13 +115,13 @@ def test_shapes_without_a_copy_and_the_create_time_switch(gpu, monkeypatch):
     assert gh.Rows8() == (1, True)
 
 
-@pytest.mark.parametrize("quant,d", [(O.Q_NONE, 768), (O.Q_F16, 768), (O.Q_BF16, 256)])
+@pytest.mark.parametrize("quant,d", [(O.Q_NONE, 768), (O.Q_NONE, 256), (O.Q_NONE, 1536), (O.Q_F16, 768), (O.Q_BF16, 256)])
 def test_non_temporal_twins_equal_the_oracle_and_the_default_kernels(gpu, monkeypatch, quant, d):
     """Round 6: collections far larger than the caches run the eight-lane kernels with non-temporal row loads (exact.hpp: row_ld; chosen per launch from the
     size of the row array, hnsw.hip: rows_nt).  A cache hint cannot change a value: with the hint forced on (COLTT_ROWS_NT=1) ids, score bits and counters
     equal the oracle's and those of the default kernels (COLTT_ROWS_NT=0), for the LDS-visited and the HBM-visited walk."""
     monkeypatch.setenv("COLTT_MW_MAX_NQ", "0")
-    n = 3000
+    n = 3000 if d <= 768 else 1500   # (f32 twins: one row x 12 lines per lane group — 8 lines: the tail burst alone; 24 and 48 lines: two and four bursts)
     X = O.fill_normal(9300 + d, (n, d)); lv = O.levels(9301 + d, n)
     gh = _build(gpu, X, lv, O.COSINE, quant, gpu.HnswCfg.default(ef_construction=60))
     assert gh.Rows8()[1]
