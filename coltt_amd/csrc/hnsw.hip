@@ -767,8 +767,11 @@ uint32_t resident_waves(const SearchGeom& sg, int quant) {
 // 2 M -2 %, 4 M +0.8 %, 10 M +-0; f32 1 M -4 %, 3 M +0.7 %, 10 M +4.5 %: profiles/r06ag_nt_rows_ab.md).
 bool rows_nt(const Hnsw* x) {
   const Policy p = policy();
-  if (p.rows_nt >= 0) return p.rows_nt != 0;
-  return (unsigned long long)x->n * (unsigned long long)x->stride >= (unsigned long long)p.rows_nt_min_mb << 20;
+  const unsigned long long bytes = (unsigned long long)x->n * (unsigned long long)x->stride, least = (unsigned long long)p.rows_nt_min_mb << 20;
+  const bool on = p.rows_nt >= 0 ? p.rows_nt != 0 : bytes >= least;
+  static const bool dbg = [] { const char* e = getenv("COLTT_DEBUG_ROWS_NT"); return e && *e == '1'; }();   // diagnostics: which twin a launch takes, and why
+  if (dbg) fprintf(stderr, "[rows_nt] slots=%llu stride=%zu row bytes=%llu threshold=%llu knob=%d -> %s\n", (unsigned long long)x->n, (size_t)x->stride, bytes, least, p.rows_nt, on ? "nt" : "default");
+  return on;
 }
 
 // hnsw_walk2.hpp kernels.  The default build carries the shipped variant (and its Bloom-less twin for geometries whose LDS
