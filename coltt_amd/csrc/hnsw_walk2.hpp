@@ -337,6 +337,9 @@ template <int METRIC, int QUANT, int PROFILE, bool ADJN, bool R8 = false> struct
 #ifndef COLTT_G8_ONEBURST_H16
 #define COLTT_G8_ONEBURST_H16 0
 #endif
+#ifndef COLTT_G8_STREAM
+#define COLTT_G8_STREAM 1
+#endif
 #ifndef COLTT_G8_ONEBURST   // the same for the other eight-lane kernels (f32 rows; 2-byte rows behind the LDS hash): rows of exactly COLTT_G8_U lines in one burst
 #define COLTT_G8_ONEBURST 0
 #endif
@@ -348,6 +351,9 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false, bool NT = false>
   static constexpr bool F32NT = NT && QUANT == Q_NONE && !HBM16;
   static constexpr int G8R = (ONEB && HBM16) ? 2 : (HBM16 ? COLTT_G8_ROWS_H16 : (F32NT ? COLTT_G8_ROWS_NT32 : COLTT_G8_ROWS)),
                        G8U = HBM16 ? COLTT_G8_U_H16 : (F32NT ? COLTT_G8_U_NT32 : COLTT_G8_U);
+  // COLTT_G8_STREAM (bit 0: the f32 non-temporal twins, bit 1: the HBM-visited 2-byte walk): rows of a whole number of bursts are evaluated as one stream of
+  // bursts over all passes of the chunk — no bubble at the pass boundaries (rows8.hpp: group8_stream)
+  static constexpr bool STREAM = G8R == 1 && !ONEB && ((F32NT && (COLTT_G8_STREAM & 1)) || (HBM16 && (COLTT_G8_STREAM & 2)));
   static constexpr bool CHUNK_ADJ = false;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = false;
@@ -371,6 +377,14 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false, bool NT = false>
     wave_sync();
     const int grp = lane >> 3, rj = lane & 7;
     const int nl = (g.dim * (QUANT == Q_NONE ? 4 : 2)) >> 7;
+    bool streamed = false;
+    if constexpr (STREAM) {   // one row per lane group: all passes as ONE stream of bursts (rows8.hpp: group8_stream)
+      if (nl >= G8U && nl % G8U == 0) {
+        group8_stream<METRIC, QUANT, G8U, NT, ADJN>(g.rows8, g.stride, g.norms, s_nb, s_nr, s_d, nf, grp, rj, w.qp, nl, w.qnorm);
+        streamed = true;
+      }
+    }
+    if (!streamed)
     for (uint32_t base = 0; base < nf; base += 8 * ROWS) {          // wave-uniform
       const uint8_t* rp[ROWS]; float rn[ROWS], d[ROWS]; uint32_t idx[ROWS]; bool live[ROWS];
 #pragma unroll

@@ -75,6 +75,9 @@ __device__ __forceinline__ float group8_hsum(float a) {
 // Distance(query, row) of ROWS rows per 8-lane group at once (ROWS x U..2U 16-byte loads per lane in flight); rj = this lane's
 // residue (lane & 7).  row8[i] -> the rows8 copy of row i, qp -> the permuted query in LDS, nl = 128-byte lines per row.
 // live[i] == false: this group has no i-th row in this pass — row8[i] then points at some live row, the result is dropped by the caller.
+#ifndef COLTT_G8_PEEL   // A/B knob: see the burst loop below
+#define COLTT_G8_PEEL 0
+#endif
 template <int METRIC, int QUANT, int ROWS, int U, bool ONEBURST = false, bool NT = false>
 __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROWS], const bool (&live)[ROWS], const float* __restrict__ qp, int nl,
                                                 float qnorm, const float (&rnorm)[ROWS], int rj, float (&out)[ROWS]) {
@@ -124,6 +127,22 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
 #pragma unroll
       for (int u = 0; u < UU; u++) COLTT_G8_LD(u, cur[u])
     }
+#if COLTT_G8_PEEL
+    // the last burst peeled off: inside the loop the next burst is requested UNCONDITIONALLY (a branch around loads in flight makes the compiler wait for all of
+    // them — vmcnt(0) — in front of the first use of the current burst: see group8_stream)
+    for (int b = 0; b + 1 < nb; b++) {
+#pragma unroll
+      for (int u = 0; u < UU; u++) COLTT_G8_LD((b + 1) * UU + u, nxt[u])
+#pragma unroll
+      for (int u = 0; u < UU; u++) COLTT_G8_CS(cur[u], b * UU + u)
+#pragma unroll
+      for (int u = 0; u < UU; u++) cur[u] = nxt[u];
+    }
+    if (nb > 0) {
+#pragma unroll
+      for (int u = 0; u < UU; u++) COLTT_G8_CS(cur[u], (nb - 1) * UU + u)
+    }
+#else
     for (int b = 0; b < nb; b++) {
       if (b + 1 < nb) {
 #pragma unroll
@@ -134,6 +153,7 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
 #pragma unroll
       for (int u = 0; u < UU; u++) cur[u] = nxt[u];
     }
+#endif
     // lines beyond whole bursts (nl % UU; the whole row when nl < UU — 128-d f32 rows are 4 lines): ONE predicated burst, every load
     // in flight before the first is consumed (a line-by-line loop here made a short row cost nl dependent round trips: 1 M x 128 f32,
     // one query, 0.111 -> 0.191 ms in the first bench run of this core)
@@ -164,6 +184,87 @@ __device__ __forceinline__ void group8_distance(const uint8_t* const (&row8)[ROW
     if constexpr (METRIC == M_COS) out[i] = cos_epilogue(s, qnorm, rnorm[i]);
     else out[i] = go_sqrt(s);
   }
+}
+
+// ONE row per lane group, the rows of ALL passes as one stream of bursts (COLTT_G8_STREAM): group8_distance leaves a bubble at every pass boundary — the last
+// burst of a row is consumed with nothing in flight, and the first burst of the next pass's row is requested only after the distance has been reduced and
+// handed over.  Here the next burst is ALWAYS in flight while the current one is consumed, across row boundaries too (its row pointer comes from the compacted
+// list in LDS).  Ping-pong buffers: no register moves.  Same lines, same order per row, same reduction: same bits.  Requires nl % U == 0, nl >= U.
+// s_nb / s_nr: the compacted fresh neighbours (slot, norm) of the chunk; s_d: their distances, written by lane 0 of the group that evaluated the row.
+template <int METRIC, int QUANT, int U, bool NT, bool ADJN>
+__device__ __forceinline__ void group8_stream(const uint8_t* __restrict__ rows8, size_t stride, const float* __restrict__ norms, const uint32_t* s_nb, const float* s_nr,
+                                              float* s_d, uint32_t nf, int grp, int rj, const float* __restrict__ qp, int nl, float qnorm) {
+  constexpr int S = rows8_steps<QUANT>();
+  const float* qb = qp + rj * S;
+  const int nbur = nl / U;
+  const uint32_t total = ((nf + 7u) >> 3) * (uint32_t)nbur;
+  u32x4e A[U], B[U];
+  auto row_of = [&](uint32_t pass) -> const uint8_t* {
+    const uint32_t idx = pass * 8u + (uint32_t)grp;
+    return rows8 + (size_t)s_nb[idx < nf ? idx : 0u] * stride + rj * 16;   // an idle group re-reads a live row (see group8_distance)
+  };
+  const uint8_t* rp = row_of(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) A[u] = row_ld<NT>(reinterpret_cast<const u32x4e*>(rp + (size_t)u * 128));
+  float acc = 0.f;
+  uint32_t pass = 0; int b = 0;
+  // LOADNEXT is a literal: the step that has a successor issues its loads UNCONDITIONALLY (a branch around loads in flight makes the compiler's wait-count
+  // insertion give up at the merge and wait for everything — vmcnt(0) — in front of the first use: no overlap at all; seen in the first build of this function)
+#define COLTT_G8S_STEP(CUR, NXT, LOADNEXT)                                                                                   \
+  {                                                                                                                         \
+    int nb_ = b + 1; uint32_t np_ = pass; const uint8_t* nrp = rp;                                                          \
+    if (nb_ == nbur) { nb_ = 0; np_ = pass + 1u; }                                                                          \
+    if (LOADNEXT) {                                                                                                         \
+      if (nb_ == 0) nrp = row_of(np_);                                                                                      \
+      _Pragma("unroll") for (int u = 0; u < U; u++) NXT[u] = row_ld<NT>(reinterpret_cast<const u32x4e*>(nrp + (size_t)(nb_ * U + u) * 128)); \
+    }                                                                                                                       \
+    _Pragma("unroll") for (int u = 0; u < U; u++) {                                                                         \
+      const int L = b * U + u;                                                                                              \
+      if constexpr (QUANT == Q_NONE) {                                                                                      \
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + L * 32);                                                      \
+        const f32x4 x = __builtin_bit_cast(f32x4, CUR[u]);                                                                  \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) {                                                                  \
+          if constexpr (METRIC == M_COS) { const float p = q0[s_] * x[s_]; acc = acc + p; }                                 \
+          else { const float d = q0[s_] - x[s_]; const float p = d * d; acc = acc + p; }                                    \
+        }                                                                                                                   \
+      } else {                                                                                                              \
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qb + L * 64), q1 = *reinterpret_cast<const f32x4*>(qb + L * 64 + 4); \
+        const u32x2e lo = {CUR[u].x, CUR[u].y}, hi = {CUR[u].z, CUR[u].w};                                                  \
+        const f32x4 x0 = __builtin_convertvector(__builtin_bit_cast(f16x4, lo), f32x4);                                     \
+        const f32x4 x1 = __builtin_convertvector(__builtin_bit_cast(f16x4, hi), f32x4);                                     \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) {                                                                  \
+          if constexpr (METRIC == M_COS) { const float p = q0[s_] * x0[s_]; acc = acc + p; }                                \
+          else { const float d = q0[s_] - x0[s_]; const float p = d * d; acc = acc + p; }                                   \
+        }                                                                                                                   \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; s_++) {                                                                  \
+          if constexpr (METRIC == M_COS) { const float p = q1[s_] * x1[s_]; acc = acc + p; }                                \
+          else { const float d = q1[s_] - x1[s_]; const float p = d * d; acc = acc + p; }                                   \
+        }                                                                                                                   \
+      }                                                                                                                     \
+    }                                                                                                                       \
+    if (b == nbur - 1) {   /* wave-uniform: every group is at the same burst of its row */                                   \
+      const float sum = group8_hsum(acc);                                                                                   \
+      const uint32_t idx = pass * 8u + (uint32_t)grp;                                                                       \
+      const bool live = idx < nf;                                                                                           \
+      float out;                                                                                                            \
+      if constexpr (METRIC == M_COS) {                                                                                      \
+        float rn;                                                                                                           \
+        if constexpr (ADJN) rn = s_nr[live ? idx : 0u]; else rn = norms[s_nb[live ? idx : 0u]];                             \
+        out = cos_epilogue(sum, qnorm, rn);                                                                                 \
+      } else out = go_sqrt(sum);                                                                                            \
+      if (rj == 0 && live) s_d[idx] = out;                                                                                  \
+      acc = 0.f;                                                                                                            \
+    }                                                                                                                       \
+    b = nb_; pass = np_; rp = nrp;                                                                                          \
+  }
+  uint32_t t = 0;
+  for (; t + 3u <= total; t += 2) {   // both steps have a successor
+    COLTT_G8S_STEP(A, B, 1)
+    COLTT_G8S_STEP(B, A, 1)
+  }
+  if (total - t == 2u) { COLTT_G8S_STEP(A, B, 1) COLTT_G8S_STEP(B, A, 0) }
+  else if (total - t == 1u) { COLTT_G8S_STEP(A, B, 0) }
+#undef COLTT_G8S_STEP
 }
 
 }  // namespace dev
