@@ -167,9 +167,9 @@ def test_last_record_of_round_5_is_the_last_library():
 
 
 def test_final_line_of_round_6_record_fits_and_carries_the_new_legs():
-    """round 6's final record (call AR: op.pq, op.pq_ref, op.diverse — marked as not reference behaviour —, the one-launch PQ scan beside the segment chain): under the
+    """round 6's final record (call AX: op.pq, op.pq_ref, op.diverse — marked as not reference behaviour —, the one-launch PQ scan beside the segment chain): under the
     4 KB target, nothing trimmed, the fields the round's claims rest on present"""
-    res = json.load(open(os.path.join(ROOT, "profiles", "r06ar_bench_10m_full.json")))
+    res = json.load(open(os.path.join(ROOT, "profiles", "r06ax_bench_10m_full.json")))
     line = bench.final_line(res)
     assert len(line) <= bench.LINE_TARGET, len(line)
     c = json.loads(line)
