@@ -353,7 +353,7 @@ template <int METRIC, int QUANT, bool ADJN, bool HBM16 = false, bool NT = false>
                        G8U = HBM16 ? COLTT_G8_U_H16 : (F32NT ? COLTT_G8_U_NT32 : COLTT_G8_U);
   // COLTT_G8_STREAM (bit 0: the f32 non-temporal twins, bit 1: the HBM-visited 2-byte walk): rows of a whole number of bursts are evaluated as one stream of
   // bursts over all passes of the chunk — no bubble at the pass boundaries (rows8.hpp: group8_stream)
-  static constexpr bool STREAM = G8R == 1 && !ONEB && ((F32NT && (COLTT_G8_STREAM & 1)) || (HBM16 && (COLTT_G8_STREAM & 2)));
+  static constexpr bool STREAM = G8R == 1 && !ONEB && ((F32NT && (COLTT_G8_STREAM & 1)) || (HBM16 && (COLTT_G8_STREAM & 2)) || (!HBM16 && (COLTT_G8_STREAM & 4)));   // bit 2: every other eight-lane kernel built with one row per group (A/B)
   static constexpr bool CHUNK_ADJ = false;
   static constexpr bool SPEC = false;
   static constexpr bool RADJ = false;
