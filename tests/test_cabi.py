@@ -174,11 +174,14 @@ def test_pmc_traffic_of_the_shipped_walk_kernels_from_the_committed_csv(tmp_path
     import pmc_traffic as T
     # the two walks: call AK (the library with the non-temporal twins of the eight-lane kernels — rows no longer linger in L2 / MALL, so the few re-reads of hub
     # rows come from HBM: 1.008 -> 1.021 and 1.040 -> 1.056 x the algorithmic bytes, for +4.5 % and +-0 queries/s); the PQ scan: call U (unchanged kernel)
+    # (the headline kernel once more after its last change — one row x 12 lines as a stream of bursts: call BA, 1.022 x)
     src = os.path.join(root, "profiles", "r06ak_pmc_fetch_size_raw.csv")
     bj = os.path.join(root, "profiles", "r06ak_bench_10m_under_pmc.json")
+    src_head = os.path.join(root, "profiles", "r06ba_pmc_fetch_size_raw.csv")
+    bj_head = os.path.join(root, "profiles", "r06ba_bench_10m_under_pmc.json")
     src_pq = os.path.join(root, "profiles", "r06u_pmc_fetch_size_raw.csv")
     out = tmp_path / "t.json"
-    T.main([src, "--bench-json", bj, "--out", str(out)])
+    T.main([src_head, "--bench-json", bj_head, "--out", str(out)])
     T.main([src, "--bench-json", bj, "--leg", "op", "--out", str(out)])
     T.main([src_pq, "--pq", "10000000,768,96", "--out", str(out)])
     t = json.load(open(out))
